@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- Falcon-1024 verify-with-ntt R1CS witnesses per second on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path (falcon-r1cs/src/circuits/falcon_ntt.rs:26-123 of the reference) over one batch
+of synthetic signatures per GPU: BASELINE.json configs[2], "Falcon-1024 batch=65536 sigs, full verify-with-ntt
+witness".  65,536 witnesses are 329 GB, more than one GPU's 288 GB, so a step streams the batch through one reused
+HBM witness buffer in chunks (default 4,096 signatures = 20.5 GB per launch); inputs are resident in HBM before the
+timed region and outputs stay in HBM (the boundary a GPU prover or a peer would consume them from).
+Multi-GPU: signatures shard by index, every rank processes its own 65,536 (weak scaling), no data-path collective.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream; `cpu_baseline`
+times the oracle (oracle/frw_oracle.c, a restatement -- the Rust reference cannot run here) on this host's cores
+over a bounded sample of the same inputs and checks the GPU's witnesses against it by digest.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import falcon_r1cs_amd as frw  # noqa: E402
+from falcon_r1cs_amd import sharding  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+SEED = 0x46414C434F4E31        # recorded in the output
+
+
+def synth(logn, count, first_index, threads):
+    """count synthetic triples starting at global index first_index (bit-identical on every host/rank)."""
+    n = 1 << logn
+    out = [np.empty((count, n), dtype=np.uint16) for _ in range(3)]
+    step = max(1, (count + threads - 1) // threads)
+
+    def work(lo):
+        s, p, h = frw.synth_triples(logn, min(step, count - lo), SEED, first_index + lo)
+        out[0][lo:lo + len(s)], out[1][lo:lo + len(s)], out[2][lo:lo + len(s)] = s, p, h
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(0, count, step)))
+    return out
+
+
+def cpu_baseline(logn, sig, pk, hm, gpu_digests, threads):
+    """Oracle ("port") on the host cores over a bounded sample; also the parity check of the GPU run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import frw_testlib                      # the ONLY place bench.py touches oracle/: as the timed CPU baseline + checker
+    oracle = frw_testlib.load_oracle()
+    sub = 256                               # 1.3 GB of host witness at a time
+    # single thread: the analogue of the reference's one-threaded generate_constraints
+    n1 = 1024
+    t0 = time.perf_counter()
+    for lo in range(0, n1, sub):
+        oracle.witness_ntt_verify(logn, sig[lo:lo + sub], pk[lo:lo + sub], hm[lo:lo + sub], 1, threads=1)
+    one = n1 / (time.perf_counter() - t0)
+    # all cores, and digest parity with the GPU on the same signatures
+    nall = min(len(sig), 4096)
+    checked, t_all = 0, 0.0
+    for lo in range(0, nall, sub):
+        t0 = time.perf_counter()
+        wit, _, st = oracle.witness_ntt_verify(logn, sig[lo:lo + sub], pk[lo:lo + sub], hm[lo:lo + sub], 1,
+                                               threads=threads)
+        t_all += time.perf_counter() - t0
+        if lo < 512:                        # digest a few hundred on the host (python loop over ctypes calls)
+            for i in range(len(wit)):
+                assert oracle.digest(wit[i]) == gpu_digests[lo + i], "GPU witness %d differs from the oracle" % (lo + i)
+                checked += 1
+    return {"value": round(nall / t_all, 1), "unit": "signatures/s", "cores": threads, "kind": "port",
+            "sample": "%d Falcon-1024 signatures of the same synthetic batch, %d threads (oracle/frw_oracle.c, "
+                      "a C restatement; the Rust reference cannot be built here)" % (nall, threads),
+            "single_thread": round(one, 1), "single_thread_sample": n1,
+            "gpu_witnesses_checked_by_digest": checked}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--logn", type=int, default=10, choices=[9, 10])
+    ap.add_argument("--batch", type=int, default=65536, help="signatures per GPU per step")
+    ap.add_argument("--chunk", type=int, default=4096, help="signatures per kernel launch (HBM witness buffer)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    logn, batch, chunk = args.logn, args.batch, min(args.chunk, args.batch)
+    L = frw.layout(logn)
+    eng = frw.WitnessEngine(local_rank)
+    threads = min(os.cpu_count() or 1, 16)
+
+    # ---- inputs resident in HBM -------------------------------------------------------------
+    lo, hi = sharding.shard_range(batch * world, rank, world)      # this rank's global signature indices
+    sig, pk, hm = synth(logn, hi - lo, lo, threads)
+    d_sig, d_pk, d_hm = (torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm))
+    d_wit = torch.empty((chunk, L.num_witness, 4), dtype=torch.int64, device=dev)
+    d_inst = torch.empty((chunk, L.num_instance, 4), dtype=torch.int64, device=dev)
+    d_st = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    nchunks = (batch + chunk - 1) // chunk
+    n = L.n
+
+    def step(events=None):
+        for c in range(nchunks):
+            a = c * chunk
+            cnt = min(chunk, batch - a)
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            eng.witness_ntt_verify_dev(logn, cnt, d_sig[a:a + cnt], d_pk[a:a + cnt], d_hm[a:a + cnt], d_wit, d_inst,
+                                       d_st[a:a + cnt], frw.ENC_MONTGOMERY, stream.cuda_stream)
+            if events is not None:
+                e1.record(stream)
+                events.append((e0, e1, cnt))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # ---- control-plane exchange (untimed): global status vector ---------------------------------
+    status = sharding.gather_per_signature(d_st, batch * world, rank, world)
+    n_bad = int((status != 0).sum().item())
+
+    # ---- roofline of the dominant (only) kernel, from HIP events on the launch stream ------------------
+    full = [(e0.elapsed_time(e1), cnt) for e0, e1, cnt in events if cnt == chunk]
+    launch_ms = sum(t for t, _ in full) / max(1, len(full))
+    bytes_per_sig = 32 * (L.num_witness + 2 * n) + 3 * 2 * n          # 5,086,848 B for Falcon-1024
+    achieved = chunk * bytes_per_sig / (launch_ms * 1e-3) / 1e9
+
+    result = None
+    if rank == 0:
+        value = world * batch * args.steps / elapsed
+        result = {
+            "metric": "falcon%d_verify_with_ntt_r1cs_witnesses_per_sec" % n, "value": round(value, 1),
+            "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "falcon-%d full verify-with-ntt witness (NTT ladder + mod_q + pointwise + l2-norm), "
+                                   "batch=%d signatures per GPU per step" % (n, batch),
+                       "logn": logn, "batch_per_gpu": batch, "chunk": chunk, "launches_per_step": nchunks,
+                       "encoding": "bls12-381-fr montgomery (arkworks witness_assignment bytes)",
+                       "seed": hex(SEED), "sharding": "by signature index, no data-path collective",
+                       "signatures_failing_range_checks": n_bad},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "witness_ntt_verify_kernel<%d,1>" % logn,
+                         "algorithmic_bytes_per_launch": chunk * bytes_per_sig,
+                         "avg_launch_ms": round(launch_ms, 4), "launches_timed": len(full)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # digests of the first launch's witnesses (recomputed: the buffer holds the last chunk now)
+            k = min(512, chunk)
+            dig = torch.zeros(k, dtype=torch.int64, device=dev)
+            eng.witness_ntt_verify_dev(logn, k, d_sig[:k], d_pk[:k], d_hm[:k], d_wit, d_inst, d_st[:k],
+                                       frw.ENC_MONTGOMERY, stream.cuda_stream)
+            eng.digest_dev(d_wit, L.num_witness * 4, k, dig, stream.cuda_stream)
+            torch.cuda.synchronize()
+            gpu_digests = [int(x) & (2 ** 64 - 1) for x in dig.cpu().numpy()]
+            result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, gpu_digests, threads)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

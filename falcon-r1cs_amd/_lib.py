@@ -1,0 +1,83 @@
+"""ctypes binding of libfrw.so (the C ABI declared in include/frw.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C falcon-r1cs_amd/csrc``.
+There is no fallback: if the shared object is missing or no HIP device is usable, callers get
+an exception, never a CPU-computed result.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class FrwError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__("%s failed: %d %s" % (where, code, detail))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfrw.so")
+
+
+class LayoutStruct(C.Structure):
+    _fields_ = [("logn", C.c_int32), ("n", C.c_int32), ("num_witness", C.c_int32),
+                ("num_instance", C.c_int32), ("num_constraints", C.c_int32),
+                ("seg_off", C.c_int32 * 8), ("seg_len", C.c_int32 * 8)]
+
+
+# name -> (restype, argtypes); must list every symbol include/frw.h declares
+PROTOTYPES = {
+    "frw_layout": (C.c_int, [C.c_int, C.POINTER(LayoutStruct)]),
+    "frw_strerror": (C.c_char_p, [C.c_int]),
+    "frw_last_error": (C.c_char_p, []),
+    "frw_device_count": (C.c_int, []),
+    "frw_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "frw_ctx_destroy": (None, [C.c_void_p]),
+    "frw_witness_ntt_verify_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_ntt_modq_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "frw_witness_ntt_verify": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "frw_ntt_modq": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_void_p]),
+    "frw_digest_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "frw_synth_triples": (C.c_int, [C.c_int, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "frw_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "frw_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "frw_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "frw_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
+
+
+def load_library():
+    """Load libfrw.so; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise FrwError(-2, "load_library", "%s not built; run __graft_entry__.build()" % path)
+        # One HIP runtime per process: torch wheels bundle their own libamdhip64.so.7.  If torch is going to
+        # be used for device memory / streams / torch.distributed in this process, its runtime must be the one
+        # already mapped when libfrw.so (NEEDED libamdhip64.so.7) is loaded, or torch later finds no GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        lib = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def check(code, where):
+    if code != 0:
+        lib = load_library()
+        detail = "%s; %s" % (lib.frw_strerror(code).decode(), lib.frw_last_error().decode())
+        raise FrwError(code, where, detail)

@@ -1,0 +1,303 @@
+// frw_capi.cpp -- the C ABI of include/frw.h over the gfx950 kernels of frw_kernels.hip.
+// Host-side only: contexts, table construction, argument checking, chunked host-buffer variants.
+// There is deliberately no CPU compute path here: without a HIP device every entry point that
+// would produce a witness returns FRW_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "../../include/frw.h"
+#include "frw_device.h"
+
+struct frw_ctx {
+    int device;
+    int num_cu;
+    frw::Tables *d_tables;
+};
+
+namespace {
+
+thread_local char g_last_error[256] = "";
+
+int hip_fail(hipError_t e, const char *what)
+{
+    snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? FRW_E_OUT_OF_MEMORY : FRW_E_HIP;
+}
+
+#define FRW_HIP(call)                                     \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+uint32_t powmod(uint32_t b, uint32_t e)
+{
+    uint64_t r = 1, x = b;
+    while (e) {
+        if (e & 1) r = r * x % frw::Q;
+        x = x * x % frw::Q;
+        e >>= 1;
+    }
+    return (uint32_t)r;
+}
+
+// falcon-rust NTT_TABLE[i] = 7^bitrev10(i) mod q (script/ntt_param.sage:3-132: Falcon's GMb / R);
+// C_k = 2^k q^(k+1) (falcon_ntt.rs:31-39).
+void build_tables(frw::Tables &t)
+{
+    for (uint32_t i = 0; i < 1024; i++) {
+        uint32_t r = 0;
+        for (int b = 0; b < 10; b++)
+            if (i & (1u << b)) r |= 1u << (9 - b);
+        t.tw[i] = (uint16_t)powmod(7, r);
+        t.itw[i] = (uint16_t)powmod(7, (2048 - r) % 2048);
+    }
+    uint32_t c[5] = {frw::Q, 0, 0, 0, 0};
+    memcpy(t.ck[0], c, sizeof c);
+    for (int k = 1; k <= 10; k++) {
+        uint64_t carry = 0;
+        for (int i = 0; i < 5; i++) {
+            carry += (uint64_t)c[i] * (2 * frw::Q);
+            c[i] = (uint32_t)carry;
+            carry >>= 32;
+        }
+        memcpy(t.ck[k], c, sizeof c);
+    }
+}
+
+bool bad_common(const frw_ctx *ctx, int logn, int encoding)
+{
+    return !ctx || (logn != 9 && logn != 10) || (encoding != FRW_ENC_CANONICAL && encoding != FRW_ENC_MONTGOMERY);
+}
+
+}  // namespace
+
+extern "C" {
+
+int frw_layout(int logn, frw_layout_t *out)
+{
+    if (!out || (logn != 9 && logn != 10)) return FRW_E_INVALID_ARG;
+    const int n = 1 << logn, nb = logn == 9 ? 50 : 52;
+    const int len[FRW_NUM_SEGMENTS] = {n, n, 27 * n, 29 * n, 29 * n, 30 * n, 36 * n, nb};
+    int off = 0;
+    out->logn = logn;
+    out->n = n;
+    for (int i = 0; i < FRW_NUM_SEGMENTS; i++) {
+        out->seg_off[i] = off;
+        out->seg_len[i] = len[i];
+        off += len[i];
+    }
+    out->num_witness = off;
+    out->num_instance = 2 * n + 1;
+    out->num_constraints = 159 * n + nb + 2;
+    return FRW_OK;
+}
+
+const char *frw_strerror(int code)
+{
+    switch (code) {
+    case FRW_OK: return "ok";
+    case FRW_E_INVALID_ARG: return "invalid argument";
+    case FRW_E_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+    case FRW_E_HIP: return "HIP runtime error (see frw_last_error)";
+    case FRW_E_OUT_OF_MEMORY: return "out of device memory";
+    case FRW_E_RANGE: return "strict mode: a signature failed its range checks";
+    default: return "unknown error";
+    }
+}
+
+const char *frw_last_error(void) { return g_last_error; }
+
+int frw_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int frw_ctx_create(int device, frw_ctx **out)
+{
+    if (!out) return FRW_E_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        snprintf(g_last_error, sizeof g_last_error, "no HIP device %d (%d visible)", device, n);
+        return FRW_E_NO_DEVICE;
+    }
+    FRW_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FRW_HIP(hipGetDeviceProperties(&prop, device));
+    frw_ctx *ctx = new (std::nothrow) frw_ctx;
+    if (!ctx) return FRW_E_OUT_OF_MEMORY;
+    ctx->device = device;
+    ctx->num_cu = prop.multiProcessorCount;
+    ctx->d_tables = nullptr;
+    frw::Tables host;
+    build_tables(host);
+    hipError_t e = hipMalloc((void **)&ctx->d_tables, sizeof(frw::Tables));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tables, &host, sizeof host, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+        delete ctx;
+        return hip_fail(e, "table upload");
+    }
+    *out = ctx;
+    return FRW_OK;
+}
+
+void frw_ctx_destroy(frw_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    delete ctx;
+}
+
+int frw_witness_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_sig, const uint16_t *d_pk,
+                               const uint16_t *d_hm, int encoding, uint64_t *d_witness, uint64_t *d_instance,
+                               int32_t *d_status, void *stream)
+{
+    if (bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, batch, d_sig, d_pk, d_hm,
+                                           d_witness, d_instance, d_status, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+int frw_ntt_modq_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_poly, int encoding, uint64_t *d_witness,
+                     uint16_t *d_ntt_out, int32_t *d_status, void *stream)
+{
+    if (bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!d_poly || !d_witness || !d_ntt_out || !d_status) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, ctx->num_cu, logn, encoding, batch, d_poly, d_witness, d_ntt_out,
+                                 d_status, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+};
+}  // namespace
+
+int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch, const uint16_t *sig, const uint16_t *pk,
+                           const uint16_t *hm, int encoding, uint64_t *witness, uint64_t *instance, int32_t *status,
+                           int strict)
+{
+    if (bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!sig || !pk || !hm || !witness || !instance || !status) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    frw_layout_t L;
+    frw_layout(logn, &L);
+    const size_t n = (size_t)L.n, wbytes = (size_t)L.num_witness * 32, ibytes = (size_t)L.num_instance * 32;
+    const size_t chunk = std::min<size_t>(batch, 512);            // <= 2.6 GB of witness per chunk
+    DevBuf d_in[3], d_wit, d_inst, d_st;
+    for (auto &b : d_in) FRW_HIP(b.alloc(chunk * n * 2));
+    FRW_HIP(d_wit.alloc(chunk * wbytes));
+    FRW_HIP(d_inst.alloc(chunk * ibytes));
+    FRW_HIP(d_st.alloc(chunk * sizeof(int32_t)));
+    const uint16_t *src[3] = {sig, pk, hm};
+    bool any_bad = false;
+    for (size_t lo = 0; lo < batch; lo += chunk) {
+        const size_t cnt = std::min(chunk, batch - lo);
+        for (int k = 0; k < 3; k++) FRW_HIP(hipMemcpy(d_in[k].p, src[k] + lo * n, cnt * n * 2, hipMemcpyHostToDevice));
+        FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, cnt,
+                                               (const uint16_t *)d_in[0].p, (const uint16_t *)d_in[1].p,
+                                               (const uint16_t *)d_in[2].p, (uint64_t *)d_wit.p, (uint64_t *)d_inst.p,
+                                               (int32_t *)d_st.p, nullptr));
+        FRW_HIP(hipMemcpy(status + lo, d_st.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+        FRW_HIP(hipMemcpy((char *)witness + lo * wbytes, d_wit.p, cnt * wbytes, hipMemcpyDeviceToHost));
+        FRW_HIP(hipMemcpy((char *)instance + lo * ibytes, d_inst.p, cnt * ibytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; i++) any_bad |= status[lo + i] != FRW_ST_OK;
+    }
+    return strict && any_bad ? FRW_E_RANGE : FRW_OK;
+}
+
+int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int encoding, uint64_t *witness,
+                 uint16_t *ntt_out, int32_t *status)
+{
+    if (bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!poly || !witness || !ntt_out || !status) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << logn, wbytes = 29 * n * 32;
+    const size_t chunk = std::min<size_t>(batch, 2048);
+    DevBuf d_in, d_wit, d_out, d_st;
+    FRW_HIP(d_in.alloc(chunk * n * 2));
+    FRW_HIP(d_wit.alloc(chunk * wbytes));
+    FRW_HIP(d_out.alloc(chunk * n * 2));
+    FRW_HIP(d_st.alloc(chunk * sizeof(int32_t)));
+    for (size_t lo = 0; lo < batch; lo += chunk) {
+        const size_t cnt = std::min(chunk, batch - lo);
+        FRW_HIP(hipMemcpy(d_in.p, poly + lo * n, cnt * n * 2, hipMemcpyHostToDevice));
+        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in.p,
+                                     (uint64_t *)d_wit.p, (uint16_t *)d_out.p, (int32_t *)d_st.p, nullptr));
+        FRW_HIP(hipMemcpy(status + lo, d_st.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+        FRW_HIP(hipMemcpy((char *)witness + lo * wbytes, d_wit.p, cnt * wbytes, hipMemcpyDeviceToHost));
+        FRW_HIP(hipMemcpy(ntt_out + lo * n, d_out.p, cnt * n * 2, hipMemcpyDeviceToHost));
+    }
+    return FRW_OK;
+}
+
+int frw_digest_dev(frw_ctx *ctx, const uint64_t *d_buf, size_t words_per_item, size_t items, uint64_t *d_out,
+                   void *stream)
+{
+    if (!ctx || !d_buf || !d_out) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_digest(d_buf, words_per_item, items, d_out, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+int frw_malloc(frw_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(hipMalloc(d_ptr, bytes));
+    return FRW_OK;
+}
+
+int frw_free(frw_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(hipFree(d_ptr));
+    return FRW_OK;
+}
+
+int frw_memcpy_h2d(frw_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (!ctx) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return FRW_OK;
+}
+
+int frw_memcpy_d2h(frw_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (!ctx) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return FRW_OK;
+}
+
+int frw_synchronize(frw_ctx *ctx, void *stream)
+{
+    if (!ctx) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return FRW_OK;
+}
+
+}  // extern "C"

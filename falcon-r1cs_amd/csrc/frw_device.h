@@ -1,0 +1,30 @@
+// frw_device.h -- constants and launcher prototypes shared by frw_kernels.hip and frw_capi.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace frw {
+
+constexpr uint32_t Q = 12289;          // falcon-rust MODULUS (gadgets/arithmetics.rs:5)
+constexpr int WAVE = 64;               // CDNA wavefront
+constexpr int BLOCK = 256;             // one workgroup = 4 wavefronts = one signature
+constexpr int WAVES = BLOCK / WAVE;
+
+constexpr int ST_OK = 0, ST_COEFF_RANGE = 1, ST_NORM_BOUND = 2;    // == FRW_ST_* of include/frw.h
+
+// Per-device constant tables, built by frw_ctx_create.
+struct Tables {
+    uint16_t tw[1024];      // falcon-rust NTT_TABLE: 7^bitrev10(i) mod q   (misc.rs:72; script/ntt_param.sage:3-132)
+    uint16_t itw[1024];     // 7^-bitrev10(i) mod q
+    uint32_t ck[11][5];     // C_k = 2^k q^(k+1), 32-bit limbs (falcon_ntt.rs:31-39)
+};
+
+hipError_t launch_witness_ntt_verify(const Tables *tab, int num_cu, int logn, int enc, size_t batch,
+                                     const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
+                                     uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st);
+hipError_t launch_ntt_modq(const Tables *tab, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
+                           uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st);
+hipError_t launch_digest(const uint64_t *buf, size_t words, size_t items, uint64_t *out, hipStream_t st);
+
+}  // namespace frw

@@ -1,0 +1,700 @@
+// frw_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the Falcon-verification R1CS witness engine.
+//
+// What the path is (reference citations relative to /root/reference/):
+//   FalconNTTVerificationCircuit::generate_constraints, falcon-r1cs/src/circuits/falcon_ntt.rs:26-123,
+//   with the gadgets it drives (poly.rs:104-159, arithmetics.rs:105-149,214-262,
+//   range_proofs.rs:42-94,100-186,192-272,289-333, misc.rs:9-51).
+// The circuit is the same for every signature, so the witness is a closed-form function of
+// (sig, pk, hm); this file evaluates it for a batch, one workgroup (4 wavefronts) per signature.
+//
+// Shape of the work: 6 KB of input becomes 5.0 MB of output per Falcon-1024 signature, 91 % of it
+// field elements that are 0 or 1.  The kernel is an HBM write stream; the integer work (mod-q NTTs,
+// the un-reduced 160-bit butterfly ladder, short divisions, Montgomery conversions) is a few
+// percent of the time and lives in LDS/registers.  No MFMA: nothing here is GEMM-shaped.
+//
+// Data flow of one workgroup
+//   1. inputs -> LDS (u16), range check
+//   2. mod-q NTT of sig, pk, hm; v_ntt = hm_ntt - sig_ntt*pk_ntt; v = INTT(v_ntt)        (falcon_ntt.rs:44-51)
+//   3. "small" segments S0,S1,S2,S5,S6,S7 + instance vector, written tile by tile
+//   4. ladder(sig) in LDS (limb-major u32[5][N])  -> S3 tiles  (poly.rs:113-156)
+//   5. ladder(v)   in the same LDS                -> S4 tiles
+// A tile = 64 gadget blocks = one wavefront: lane k computes block k's few non-boolean elements
+// (converted to the field encoding, parked in a per-wave LDS slab) and a <=30-bit mask of its
+// boolean elements; the wave then walks the tile's bytes in order, every lane producing 16 B per
+// store instruction, so each global_store_dwordx4 writes 1 KiB of contiguous HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "frw_device.h"
+
+namespace frw {
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));     // 16 B = one lane's share of a store instruction
+__device__ __forceinline__ v4u mk4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { v4u r = {a, b, c, d}; return r; }
+
+// ------------------------------------------------------------------------------------------------
+// BLS12-381 scalar field, 32-bit little-endian limbs (ark-ff Fp256; gadgets/poly.rs:244)
+// ------------------------------------------------------------------------------------------------
+#define FRW_P32  {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u}
+// R  = 2^256 mod p  (Montgomery form of 1)
+#define FRW_R32  {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau, 0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u}
+// K1 = 2^288 mod p: REDC_1(x * K1) = x * 2^256 mod p for a one-limb x
+#define FRW_K1   {0xcaaf6b13u, 0x355094eau, 0x69a568efu, 0xf6b10cb3u, 0x40cc3869u, 0xe2c926a6u, 0xed269aadu, 0x736a6d3bu}
+// K5 = 2^416 mod p: REDC_5(x * K5) = x * 2^256 mod p for a five-limb x
+#define FRW_K5   {0x9afbc14cu, 0x5d23afe0u, 0x2b0e40d0u, 0x1deef9adu, 0x203ba106u, 0xe07e784du, 0xa251b319u, 0x562ca75au}
+// -p^-1 mod 2^32 = 0xffffffff, i.e. the Montgomery quotient digit is simply -T[0].
+
+// One CIOS round: T (9 limbs) <- (T + x*K + m*p) / 2^32.
+template <typename KArr>
+__device__ __forceinline__ void cios_round(uint32_t (&T)[9], uint32_t x, const KArr &K)
+{
+    constexpr uint32_t P[8] = FRW_P32;
+    uint64_t acc;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        acc = (uint64_t)x * K[j] + T[j] + c;
+        T[j] = (uint32_t)acc;
+        c = (uint32_t)(acc >> 32);
+    }
+    acc = (uint64_t)T[8] + c;
+    T[8] = (uint32_t)acc;
+    uint32_t t9 = (uint32_t)(acc >> 32);
+    uint32_t m = 0u - T[0];
+    acc = (uint64_t)m * P[0] + T[0];
+    c = (uint32_t)(acc >> 32);
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+        acc = (uint64_t)m * P[j] + T[j] + c;
+        T[j - 1] = (uint32_t)acc;
+        c = (uint32_t)(acc >> 32);
+    }
+    acc = (uint64_t)T[8] + c;
+    T[7] = (uint32_t)acc;
+    T[8] = t9 + (uint32_t)(acc >> 32);
+}
+
+// T < 2p on entry (T[8] == 0); subtract p once if T >= p.
+__device__ __forceinline__ void cond_sub_p(uint32_t (&T)[9], uint32_t (&out)[8])
+{
+    constexpr uint32_t P[8] = FRW_P32;
+    uint32_t d[8];
+    uint32_t bw = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint64_t x = (uint64_t)T[j] - P[j] - bw;
+        d[j] = (uint32_t)x;
+        bw = (uint32_t)(x >> 63);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[j] = bw ? T[j] : d[j];
+}
+
+// integer < 2^32  ->  field element in the requested encoding
+template <int ENC>
+__device__ __forceinline__ void encode_u32(uint32_t x, uint32_t (&out)[8])
+{
+    if (ENC == 0) {
+        out[0] = x;
+#pragma unroll
+        for (int j = 1; j < 8; j++) out[j] = 0;
+    } else {
+        constexpr uint32_t K[8] = FRW_K1;
+        uint32_t T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        cios_round(T, x, K);
+        cond_sub_p(T, out);
+    }
+}
+
+// integer < 2^160 (five limbs)  ->  field element
+template <int ENC>
+__device__ __forceinline__ void encode_u160(const uint32_t (&x)[5], uint32_t (&out)[8])
+{
+    if (ENC == 0) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) out[j] = x[j];
+        out[5] = out[6] = out[7] = 0;
+    } else {
+        constexpr uint32_t K[8] = FRW_K5;
+        uint32_t T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 5; i++) cios_round(T, x[i], K);
+        cond_sub_p(T, out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mod_q_u32(uint32_t x) { return x % Q; }   // constant divisor: mul_hi + fixups
+
+// a (five limbs) = t*q + b: schoolbook short division in 16-bit steps (arithmetics.rs:127-134)
+__device__ __forceinline__ uint32_t divmod_q_u160(const uint32_t (&a)[5], uint32_t (&t)[5])
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 4; i >= 0; i--) {
+        uint32_t cur = (r << 16) | (a[i] >> 16);          // r < q < 2^14  ->  cur < 2^30
+        uint32_t qh = cur / Q;
+        r = cur - qh * Q;
+        cur = (r << 16) | (a[i] & 0xffffu);
+        uint32_t ql = cur / Q;
+        r = cur - ql * Q;
+        t[i] = (qh << 16) | ql;
+    }
+    return r;
+}
+
+// enforce_less_than_q's 27 booleans as a bit mask (range_proofs.rs:62-89):
+//   bits 0..13 a0..a13 | bits 14..24 w0..w10 = fold-left OR of a0..a11 | bit 25 w10&a12 | bit 26 bit25&a13
+__device__ __forceinline__ uint32_t ltq_mask(uint32_t a)
+{
+    uint32_t p = a & 0xfffu;
+    p |= p << 1; p |= p << 2; p |= p << 4; p |= p << 8;       // bit i = OR(a0..ai)
+    uint32_t w = (p >> 1) & 0x7ffu;                            // w0..w10
+    uint32_t w11 = (w >> 10) & (a >> 12) & 1u;
+    uint32_t w12 = w11 & (a >> 13) & 1u;
+    return (a & 0x3fffu) | (w << 14) | (w11 << 25) | (w12 << 26);
+}
+
+// is_less_than_6144's 16 booleans (range_proofs.rs:304-328): a0..a13, w0 = a11&a12, w1 = nor(a13, w0)
+__device__ __forceinline__ uint32_t lt6144_mask(uint32_t a)
+{
+    uint32_t w0 = (a >> 11) & (a >> 12) & 1u;
+    uint32_t w1 = (~(a >> 13)) & (~w0) & 1u;
+    return (a & 0x3fffu) | (w0 << 14) | (w1 << 15);
+}
+
+// enforce_less_than_norm_bound_{512,1024}: bits then gates in allocation order (range_proofs.rs:100-186, 192-272)
+__device__ uint64_t norm_mask_512(uint64_t a)
+{
+    auto b = [a](int i) -> uint32_t { return (uint32_t)(a >> i) & 1u; };
+    uint32_t g[24];
+    g[0] = b(19) | b(20); g[1] = g[0] | b(21); g[2] = g[1] | b(22); g[3] = g[2] | b(23); g[4] = g[3] | b(24);
+    g[5] = b(16) & b(17); g[6] = g[5] & b(18);
+    g[7] = b(6) | b(7); g[8] = g[7] | b(8); g[9] = g[8] | b(9);
+    g[10] = b(3) | b(4);
+    g[11] = b(1) & b(2);
+    g[12] = (g[10] | g[11]) ^ 1u;
+    g[13] = b(5) & (g[12] ^ 1u);
+    g[14] = (g[9] | g[13]) ^ 1u;
+    g[15] = b(10) & (g[14] ^ 1u);
+    g[16] = (b(11) | g[15]) ^ 1u;
+    g[17] = b(12) & (g[16] ^ 1u);
+    g[18] = (b(13) | g[17]) ^ 1u;
+    g[19] = b(14) & (g[18] ^ 1u);
+    g[20] = (b(15) | g[19]) ^ 1u;
+    g[21] = g[6] & (g[20] ^ 1u);
+    g[22] = (g[4] | g[21]) ^ 1u;
+    g[23] = b(25) & (g[22] ^ 1u);
+    uint64_t m = a & ((1ull << 26) - 1);
+#pragma unroll
+    for (int i = 0; i < 24; i++) m |= (uint64_t)g[i] << (26 + i);
+    return m;
+}
+
+__device__ uint64_t norm_mask_1024(uint64_t a)
+{
+    auto b = [a](int i) -> uint32_t { return (uint32_t)(a >> i) & 1u; };
+    uint32_t g[25];
+    g[0] = b(22) | b(23); g[1] = g[0] | b(24); g[2] = g[1] | b(25);
+    g[3] = b(20) & b(21);
+    g[4] = b(14) | b(15); g[5] = g[4] | b(16); g[6] = g[5] | b(17); g[7] = g[6] | b(18); g[8] = g[7] | b(19);
+    g[9] = b(9) | b(10);
+    g[10] = b(7) & b(8);
+    g[11] = b(5) | b(6);
+    g[12] = b(3) & b(4);
+    g[13] = b(1) | b(2);
+    g[14] = g[13] & g[12];
+    g[15] = (g[11] | g[14]) ^ 1u;
+    g[16] = g[10] & (g[15] ^ 1u);
+    g[17] = (g[9] | g[16]) ^ 1u;
+    g[18] = b(11) & (g[17] ^ 1u);
+    g[19] = (b(12) | g[18]) ^ 1u;
+    g[20] = b(13) & (g[19] ^ 1u);
+    g[21] = (g[8] | g[20]) ^ 1u;
+    g[22] = g[3] & (g[21] ^ 1u);
+    g[23] = (g[2] | g[22]) ^ 1u;
+    g[24] = b(26) & (g[23] ^ 1u);
+    uint64_t m = a & ((1ull << 27) - 1);
+#pragma unroll
+    for (int i = 0; i < 25; i++) m |= (uint64_t)g[i] << (27 + i);
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mod-q NTT / inverse NTT on u16 arrays in LDS, whole workgroup (Falcon mq_NTT schedule == poly.rs:115-149)
+// ------------------------------------------------------------------------------------------------
+template <int LOGN, int NPOLY>
+__device__ __forceinline__ void ntt_modq_lds(uint16_t *const (&a)[NPOLY], const uint16_t *tw, int tid)
+{
+    constexpr int N = 1 << LOGN;
+#pragma unroll 1
+    for (int l = 0; l < LOGN; l++) {
+        const int sh = LOGN - 1 - l;            // log2(ht)
+        const int ht = 1 << sh;
+        for (int bf = tid; bf < N / 2; bf += BLOCK) {
+            const int i = bf >> sh;
+            const int j = ((i << sh) << 1) + (bf & (ht - 1));
+            const uint32_t s = tw[(1 << l) + i];
+#pragma unroll
+            for (int p = 0; p < NPOLY; p++) {
+                uint32_t u = a[p][j];
+                uint32_t v = mod_q_u32(a[p][j + ht] * s);
+                uint32_t x = u + v;
+                uint32_t y = u + Q - v;
+                a[p][j] = (uint16_t)(x >= Q ? x - Q : x);
+                a[p][j + ht] = (uint16_t)(y >= Q ? y - Q : y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int LOGN>
+__device__ __forceinline__ void intt_modq_lds(uint16_t *a, const uint16_t *itw, int tid)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr uint32_t NINV = LOGN == 9 ? 12265u : 12277u;     // N^-1 mod q
+#pragma unroll 1
+    for (int l = LOGN - 1; l >= 0; l--) {
+        const int sh = LOGN - 1 - l;
+        const int ht = 1 << sh;
+        for (int bf = tid; bf < N / 2; bf += BLOCK) {
+            const int i = bf >> sh;
+            const int j = ((i << sh) << 1) + (bf & (ht - 1));
+            const uint32_t s = itw[(1 << l) + i];
+            uint32_t x = a[j], y = a[j + ht];
+            uint32_t u = x + y;
+            uint32_t w = mod_q_u32((x + Q - y) * s);
+            a[j] = (uint16_t)(u >= Q ? u - Q : u);
+            a[j + ht] = (uint16_t)w;
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < N; j += BLOCK) a[j] = (uint16_t)mod_q_u32(a[j] * NINV);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// the un-reduced butterfly ladder over the integers (poly.rs:113-149), limb-major u32[5][N] in LDS.
+// Round l reads LIN limbs and writes LOUT: values entering round l are < B_l, B_0 = q,
+// B_{l+1} = B_l + C_{l+1}, C_k = 2^k q^(k+1) (falcon_ntt.rs:31-39): 29,43,58,72,87,102,116,131,145,160 bits.
+// ------------------------------------------------------------------------------------------------
+template <int LOGN, int L, int LIN, int LOUT>
+__device__ __forceinline__ void ladder_round(uint32_t *lad, const uint16_t *tw, const uint32_t *ck, int tid)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int sh = LOGN - 1 - L;
+    constexpr int ht = 1 << sh;
+    uint32_t c[LOUT];
+#pragma unroll
+    for (int k = 0; k < LOUT; k++) c[k] = ck[(L + 1) * 5 + k];
+    for (int bf = tid; bf < N / 2; bf += BLOCK) {
+        const int i = bf >> sh;
+        const int j = ((i << sh) << 1) + (bf & (ht - 1));
+        const uint32_t s = tw[(1 << L) + i];
+        uint32_t u[LOUT], v[LOUT];
+#pragma unroll
+        for (int k = 0; k < LOUT; k++) u[k] = k < LIN ? lad[k * N + j] : 0u;
+        // v = out[j+ht] * s                                                   poly.rs:136
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < LIN; k++) {
+            uint64_t acc = (uint64_t)lad[k * N + j + ht] * s + carry;
+            v[k] = (uint32_t)acc;
+            carry = (uint32_t)(acc >> 32);
+        }
+        if constexpr (LOUT > LIN) v[LIN] = carry;
+        // out[j] = u + v ; out[j+ht] = u + (C_{l+1} - v)                      poly.rs:137-142
+        uint32_t cy = 0, bw = 0, cy2 = 0;
+#pragma unroll
+        for (int k = 0; k < LOUT; k++) {
+            uint64_t x = (uint64_t)u[k] + v[k] + cy;
+            cy = (uint32_t)(x >> 32);
+            uint64_t d = (uint64_t)c[k] - v[k] - bw;
+            bw = (uint32_t)(d >> 63);
+            uint64_t y = (uint64_t)u[k] + (uint32_t)d + cy2;
+            cy2 = (uint32_t)(y >> 32);
+            lad[k * N + j] = (uint32_t)x;
+            lad[k * N + j + ht] = (uint32_t)y;
+        }
+    }
+    __syncthreads();
+}
+
+template <int LOGN>
+__device__ __forceinline__ void ladder_lds(uint32_t *lad, const uint16_t *in, const uint16_t *tw, const uint32_t *ck, int tid)
+{
+    constexpr int N = 1 << LOGN;
+    for (int j = tid; j < N; j += BLOCK) lad[j] = in[j];
+    __syncthreads();
+    ladder_round<LOGN, 0, 1, 1>(lad, tw, ck, tid);
+    ladder_round<LOGN, 1, 1, 2>(lad, tw, ck, tid);
+    ladder_round<LOGN, 2, 2, 2>(lad, tw, ck, tid);
+    ladder_round<LOGN, 3, 2, 3>(lad, tw, ck, tid);
+    ladder_round<LOGN, 4, 3, 3>(lad, tw, ck, tid);
+    ladder_round<LOGN, 5, 3, 4>(lad, tw, ck, tid);
+    ladder_round<LOGN, 6, 4, 4>(lad, tw, ck, tid);
+    ladder_round<LOGN, 7, 4, 5>(lad, tw, ck, tid);
+    ladder_round<LOGN, 8, 5, 5>(lad, tw, ck, tid);
+    if constexpr (LOGN == 10) ladder_round<LOGN, 9, 5, 5>(lad, tw, ck, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile writer.  A tile is 64 consecutive gadget blocks of BLK field elements; block k belongs to
+// lane k.  Element `pos` of a block is either one of the block's NVAL non-boolean values (parked
+// in the wave's LDS slab, 32 B each, as [slot][half][lane] v4u) or a boolean taken from bit
+// `pos` of lane k's mask.  VFIRST = position of the first value (values are contiguous).
+// The wave emits the tile's 64*BLK*32 bytes in address order, 1 KiB per store instruction.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slab_put(v4u *slab, int slot, int lane, const uint32_t (&e)[8])
+{
+    slab[(slot * 2 + 0) * WAVE + lane] = mk4(e[0], e[1], e[2], e[3]);
+    slab[(slot * 2 + 1) * WAVE + lane] = mk4(e[4], e[5], e[6], e[7]);
+}
+
+template <int ENC, int BLK, int NVAL, int VFIRST>
+__device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab, uint32_t mask, int lane)
+{
+    constexpr uint32_t R[8] = FRW_R32;
+    const int half = lane & 1;
+    // this lane's half of the field element "1"
+    v4u one;
+    if (ENC == 0) one = half ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0);
+    else one = half ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]);
+    // make sure the slab writes of all lanes have landed (same wave: a wait on LDS ops is enough)
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+    for (int it = 0; it < 2 * BLK; it++) {
+        const int e = it * 32 + (lane >> 1);          // element index inside the tile
+        const int k = e / BLK;                        // owning block == owning lane
+        const int pos = e - k * BLK;
+        const uint32_t mk = (uint32_t)__shfl((int)mask, k, WAVE);
+        const uint32_t bit = (mk >> pos) & 1u;
+        v4u val = bit ? one : mk4(0, 0, 0, 0);
+        if (NVAL > 0) {
+            const int slot = pos - VFIRST;
+            const bool isval = (unsigned)slot < (unsigned)NVAL;
+            const v4u lv = slab[((isval ? slot : 0) * 2 + half) * WAVE + k];
+            if (isval) val = lv;
+        }
+        __builtin_nontemporal_store(val, &out[it * WAVE + lane]);
+    }
+    // the slab is rewritten by the next tile: all lanes must have finished reading it
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS carve-up of one workgroup
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+struct Smem {
+    static constexpr int N = 1 << LOGN;
+    v4u slab[WAVES][3 * 2 * WAVE];     // per-wave value slab: 3 slots x 2 halves x 64 lanes x 16 B = 6 KB
+    uint32_t lad[5 * N];                 // ladder integers, limb-major
+    uint16_t tw[1024], itw[1024];
+    uint16_t sig[N], v[N];               // coefficient domain
+    uint16_t nsig[N], npk[N], nhm[N], nv[N];   // NTT domain, all reduced mod q
+    unsigned long long norm;
+    int bad;
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernel: full verify-with-ntt witness (falcon_ntt.rs:26-123)
+// ------------------------------------------------------------------------------------------------
+template <int LOGN, int ENC>
+__global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
+    const Tables *__restrict__ tab, size_t batch,
+    const uint16_t *__restrict__ g_sig, const uint16_t *__restrict__ g_pk, const uint16_t *__restrict__ g_hm,
+    v4u *__restrict__ g_wit, v4u *__restrict__ g_inst, int32_t *__restrict__ g_status)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int NB = LOGN == 9 ? 50 : 52;
+    constexpr size_t W = 153 * (size_t)N + NB;
+    constexpr size_t I = 2 * (size_t)N + 1;
+    constexpr int TILES = N / WAVE;
+    __shared__ Smem<LOGN> sm;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = tid >> 6;
+    v4u *slab = sm.slab[wave];
+
+    for (int j = tid; j < 1024; j += BLOCK) { sm.tw[j] = tab->tw[j]; sm.itw[j] = tab->itw[j]; }
+
+    for (size_t s = blockIdx.x; s < batch; s += gridDim.x) {
+        // ---- 1. load + range check ----------------------------------------------------------
+        if (tid == 0) { sm.norm = 0; sm.bad = 0; }
+        __syncthreads();
+        int bad = 0;
+        for (int j = tid; j < N; j += BLOCK) {
+            uint32_t a = g_sig[s * N + j], b = g_pk[s * N + j], c = g_hm[s * N + j];
+            bad |= (a >= Q) | (b >= Q) | (c >= Q);
+            sm.sig[j] = (uint16_t)a; sm.nsig[j] = (uint16_t)a; sm.npk[j] = (uint16_t)b; sm.nhm[j] = (uint16_t)c;
+        }
+        if (bad) sm.bad = 1;
+        __syncthreads();
+        if (sm.bad) {                                    // uniform across the workgroup
+            if (tid == 0) g_status[s] = ST_COEFF_RANGE;
+            __syncthreads();
+            continue;
+        }
+        // ---- 2. clear arithmetic -------------------------------------------------------------
+        {
+            uint16_t *const polys[3] = {sm.nsig, sm.npk, sm.nhm};
+            ntt_modq_lds<LOGN, 3>(polys, sm.tw, tid);                          // falcon_ntt.rs:45,51
+        }
+        for (int j = tid; j < N; j += BLOCK) {
+            uint32_t x = sm.nhm[j] + Q - mod_q_u32((uint32_t)sm.nsig[j] * sm.npk[j]);
+            x = x >= Q ? x - Q : x;
+            sm.nv[j] = (uint16_t)x; sm.v[j] = (uint16_t)x;
+        }
+        __syncthreads();
+        intt_modq_lds<LOGN>(sm.v, sm.itw, tid);                                // v = hm - sig*pk   :48-49
+
+        v4u *wit = g_wit + s * W * 2;
+        v4u *inst = g_inst + s * I * 2;
+
+        // ---- 3. small segments ---------------------------------------------------------------
+        uint32_t e8[8];
+        // instance_assignment[0] = 1; then pk_ntt, hm_ntt                                   :63,:67
+        if (tid < 2) {
+            constexpr uint32_t R[8] = FRW_R32;
+            v4u one = ENC == 0 ? (tid ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0))
+                                 : (tid ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]));
+            inst[tid] = one;
+        }
+        for (int t = wave; t < TILES; t += WAVES) {
+            const int k = t * WAVE + lane;
+            encode_u32<ENC>(sm.npk[k], e8); slab_put(slab, 0, lane, e8);
+            emit_tile<ENC, 1, 1, 0>(inst + 2 + (size_t)t * WAVE * 2, slab, 0, lane);
+            encode_u32<ENC>(sm.nhm[k], e8); slab_put(slab, 0, lane, e8);
+            emit_tile<ENC, 1, 1, 0>(inst + 2 + (size_t)(N + t * WAVE) * 2, slab, 0, lane);
+            // S0 sig, S1 v                                                                  :58-59,:71
+            encode_u32<ENC>(sm.sig[k], e8); slab_put(slab, 0, lane, e8);
+            emit_tile<ENC, 1, 1, 0>(wit + (size_t)(t * WAVE) * 2, slab, 0, lane);
+            const uint32_t vk = sm.v[k];
+            encode_u32<ENC>(vk, e8); slab_put(slab, 0, lane, e8);
+            emit_tile<ENC, 1, 1, 0>(wit + (size_t)(N + t * WAVE) * 2, slab, 0, lane);
+            // S2 enforce_less_than_q(v[k])                                                  :73-77
+            emit_tile<ENC, 27, 0, 0>(wit + ((size_t)2 * N + (size_t)t * WAVE * 27) * 2, slab, ltq_mask(vk), lane);
+            // S5 pointwise: [prod, t, c, ltq(c)]                                            :94-111
+            {
+                const uint32_t prod = (uint32_t)sm.nsig[k] * sm.npk[k];
+                const uint32_t ab = sm.nv[k] + prod;                      // arithmetics.rs:238
+                const uint32_t tq = ab / Q, c = ab - tq * Q;              // :242-243
+                encode_u32<ENC>(prod, e8); slab_put(slab, 0, lane, e8);
+                encode_u32<ENC>(tq, e8);   slab_put(slab, 1, lane, e8);
+                encode_u32<ENC>(c, e8);    slab_put(slab, 2, lane, e8);
+                emit_tile<ENC, 30, 3, 0>(wit + ((size_t)87 * N + (size_t)t * WAVE * 30) * 2, slab, ltq_mask(c) << 3, lane);
+            }
+        }
+        // S6 l2_norm_var over v || sig: [a0..a13, w0, w1, r, sq]                             :116-120
+        unsigned long long nrm = 0;
+        for (int t = wave; t < 2 * TILES; t += WAVES) {
+            const int k = t * WAVE + lane;
+            const uint32_t a = k < N ? sm.v[k] : sm.sig[k - N];
+            const uint32_t m = lt6144_mask(a);
+            const uint32_t r = (m >> 15) & 1u ? a : Q - a;                // misc.rs:35-46
+            const uint32_t sq = r * r;
+            nrm += sq;
+            encode_u32<ENC>(r, e8);  slab_put(slab, 0, lane, e8);
+            encode_u32<ENC>(sq, e8); slab_put(slab, 1, lane, e8);
+            emit_tile<ENC, 18, 2, 16>(wit + ((size_t)117 * N + (size_t)t * WAVE * 18) * 2, slab, m, lane);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor((unsigned long long)nrm, off, WAVE);
+        if (lane == 0) atomicAdd(&sm.norm, nrm);
+        __syncthreads();
+        // S7 enforce_less_than_norm_bound                                                   :122
+        if (wave == 0) {
+            const unsigned long long norm = sm.norm;
+            const unsigned long long nm = LOGN == 9 ? norm_mask_512(norm) : norm_mask_1024(norm);
+            constexpr uint32_t R[8] = FRW_R32;
+            const int half = lane & 1;
+            v4u one = ENC == 0 ? (half ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0))
+                                 : (half ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]));
+            v4u *o = wit + (size_t)153 * N * 2;
+            for (int c = lane; c < NB * 2; c += WAVE) {
+                const int pos = c >> 1;
+                o[c] = (nm >> pos) & 1ull ? one : mk4(0, 0, 0, 0);
+            }
+            if (lane == 0) g_status[s] = norm >= (LOGN == 9 ? 34034726ull : 70265242ull) ? ST_NORM_BOUND : ST_OK;
+        }
+
+        // ---- 4./5. ladders: S3 = mod_q blocks of NTT(sig), S4 = of NTT(v)                   :88-91
+#pragma unroll 1
+        for (int which = 0; which < 2; which++) {
+            ladder_lds<LOGN>(sm.lad, which ? sm.v : sm.sig, sm.tw, &tab->ck[0][0], tid);
+            v4u *seg = wit + (size_t)(which ? 58 : 29) * N * 2;
+            for (int t = wave; t < TILES; t += WAVES) {
+                const int k = t * WAVE + lane;
+                uint32_t a[5], q5[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) a[i] = sm.lad[i * N + k];
+                const uint32_t b = divmod_q_u160(a, q5);                  // arithmetics.rs:127-134
+                encode_u160<ENC>(q5, e8); slab_put(slab, 0, lane, e8);    // t_var :137
+                encode_u32<ENC>(b, e8);   slab_put(slab, 1, lane, e8);    // b_var :138
+                emit_tile<ENC, 29, 2, 0>(seg + (size_t)t * WAVE * 29 * 2, slab, ltq_mask(b) << 2, lane);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel: NTTPolyVar::ntt_circuit alone (poly.rs:104-159): N mod_q blocks + the reduced NTT
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+struct SmemNtt {
+    static constexpr int N = 1 << LOGN;
+    v4u slab[WAVES][2 * 2 * WAVE];
+    uint32_t lad[5 * N];
+    uint16_t tw[1024];
+    uint16_t in[N];
+    int bad;
+};
+
+template <int LOGN, int ENC>
+__global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
+    const Tables *__restrict__ tab, size_t batch, const uint16_t *__restrict__ g_poly,
+    v4u *__restrict__ g_wit, uint16_t *__restrict__ g_ntt, int32_t *__restrict__ g_status)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int TILES = N / WAVE;
+    __shared__ SmemNtt<LOGN> sm;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    v4u *slab = sm.slab[wave];
+    for (int j = tid; j < 1024; j += BLOCK) sm.tw[j] = tab->tw[j];
+
+    for (size_t s = blockIdx.x; s < batch; s += gridDim.x) {
+        if (tid == 0) sm.bad = 0;
+        __syncthreads();
+        int bad = 0;
+        for (int j = tid; j < N; j += BLOCK) {
+            uint32_t a = g_poly[s * N + j];
+            bad |= a >= Q;
+            sm.in[j] = (uint16_t)a;
+        }
+        if (bad) sm.bad = 1;
+        __syncthreads();
+        if (tid == 0) g_status[s] = sm.bad ? ST_COEFF_RANGE : ST_OK;
+        if (sm.bad) { __syncthreads(); continue; }
+        ladder_lds<LOGN>(sm.lad, sm.in, sm.tw, &tab->ck[0][0], tid);
+        v4u *seg = g_wit + s * (size_t)29 * N * 2;
+        for (int t = wave; t < TILES; t += WAVES) {
+            const int k = t * WAVE + lane;
+            uint32_t a[5], q5[5], e8[8];
+#pragma unroll
+            for (int i = 0; i < 5; i++) a[i] = sm.lad[i * N + k];
+            const uint32_t b = divmod_q_u160(a, q5);
+            g_ntt[s * N + k] = (uint16_t)b;
+            encode_u160<ENC>(q5, e8); slab_put(slab, 0, lane, e8);
+            encode_u32<ENC>(b, e8);   slab_put(slab, 1, lane, e8);
+            emit_tile<ENC, 29, 2, 0>(seg + (size_t)t * WAVE * 29 * 2, slab, ltq_mask(b) << 2, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-item digest: out[i] = sum_j splitmix64(buf[i][j] + j*golden)  (order independent)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(BLOCK) void digest_kernel(const uint64_t *__restrict__ buf, size_t words, size_t items,
+                                                       unsigned long long *__restrict__ out, int blocks_per_item)
+{
+    const size_t item = blockIdx.x / blocks_per_item;
+    const int part = blockIdx.x % blocks_per_item;
+    if (item >= items) return;
+    const uint64_t *p = buf + item * words;
+    uint64_t h = 0;
+    for (size_t j = (size_t)part * BLOCK + threadIdx.x; j < words; j += (size_t)blocks_per_item * BLOCK)
+        h += splitmix64(p[j] + j * 0x9E3779B97F4A7C15ull);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_xor((unsigned long long)h, off, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&out[item], (unsigned long long)h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from frw_capi.cpp)
+// ------------------------------------------------------------------------------------------------
+// Persistent grid: as many workgroups as the device keeps resident (LDS-limited: 2-3 per CU), each
+// striding over the batch.  Residency is asked from the runtime once per kernel instantiation.
+template <typename K>
+static int resident_grid(K kernel, size_t batch, int num_cu, int &cache)
+{
+    if (cache == 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        cache = per_cu;
+    }
+    const size_t cap = (size_t)cache * (size_t)num_cu;
+    return (int)(batch < cap ? batch : cap);
+}
+
+hipError_t launch_witness_ntt_verify(const Tables *tab, int num_cu, int logn, int enc, size_t batch,
+                                     const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
+                                     uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    static int occ[4] = {0, 0, 0, 0};
+#define FRW_LAUNCH(LOGN, ENC)                                                                                  \
+    do {                                                                                                       \
+        const int grid = resident_grid(witness_ntt_verify_kernel<LOGN, ENC>, batch, num_cu,                    \
+                                       occ[(LOGN - 9) * 2 + ENC]);                                             \
+        hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, batch, \
+                           sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                                      \
+    } while (0)
+    if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);
+    else if (logn == 9) FRW_LAUNCH(9, 1);
+    else if (enc == 0) FRW_LAUNCH(10, 0);
+    else FRW_LAUNCH(10, 1);
+#undef FRW_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_modq(const Tables *tab, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
+                           uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    static int occ[4] = {0, 0, 0, 0};
+#define FRW_LAUNCH(LOGN, ENC)                                                                                  \
+    do {                                                                                                       \
+        const int grid = resident_grid(ntt_modq_kernel<LOGN, ENC>, batch, num_cu, occ[(LOGN - 9) * 2 + ENC]);  \
+        hipLaunchKernelGGL((ntt_modq_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, batch, poly,     \
+                           (v4u *)wit, ntt_out, status);                                                       \
+    } while (0)
+    if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);
+    else if (logn == 9) FRW_LAUNCH(9, 1);
+    else if (enc == 0) FRW_LAUNCH(10, 0);
+    else FRW_LAUNCH(10, 1);
+#undef FRW_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_digest(const uint64_t *buf, size_t words, size_t items, uint64_t *out, hipStream_t st)
+{
+    if (items == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(out, 0, items * sizeof(uint64_t), st);
+    if (e != hipSuccess) return e;
+    int bpi = (int)((words + (size_t)BLOCK * 64 - 1) / ((size_t)BLOCK * 64));
+    if (bpi < 1) bpi = 1;
+    if (bpi > 64) bpi = 64;
+    const size_t grid = items * (size_t)bpi;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(digest_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, st, buf, words, items,
+                       (unsigned long long *)out, bpi);
+    return hipGetLastError();
+}
+
+}  // namespace frw

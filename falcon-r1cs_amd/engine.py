@@ -1,0 +1,124 @@
+"""Host-side driver of the witness engine (Python face of the C ABI in include/frw.h).
+
+Mirrors what a caller of the reference does around
+``FalconNTTVerificationCircuit::generate_constraints`` (falcon-r1cs/src/circuits/falcon_ntt.rs:26-123):
+hand over (sig, pk, hm) coefficient vectors, receive ``witness_assignment`` / ``instance_assignment``
+of every signature in arkworks order.  torch is used only to own device memory and streams.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._lib import FrwError, LayoutStruct, check, load_library
+
+ENC_CANONICAL, ENC_MONTGOMERY = 0, 1
+ST_OK, ST_COEFF_RANGE, ST_NORM_BOUND = 0, 1, 2
+E_RANGE = -5
+
+
+@dataclass(frozen=True)
+class Layout:
+    logn: int
+    n: int
+    num_witness: int
+    num_instance: int
+    num_constraints: int
+    seg_off: tuple
+    seg_len: tuple
+
+
+def layout(logn) -> Layout:
+    s = LayoutStruct()
+    check(load_library().frw_layout(int(logn), C.byref(s)), "frw_layout")
+    return Layout(s.logn, s.n, s.num_witness, s.num_instance, s.num_constraints, tuple(s.seg_off), tuple(s.seg_len))
+
+
+def synth_triples(logn, batch, seed=0x46414C434F4E, first_index=0):
+    """Synthetic valid (sig, pk, hm) -- frw_synth_triples; uint16 arrays of shape [batch, N]."""
+    n = 1 << logn
+    out = [np.empty((batch, n), dtype=np.uint16) for _ in range(3)]
+    check(load_library().frw_synth_triples(int(logn), batch, seed, first_index,
+                                           *[a.ctypes.data_as(C.c_void_p) for a in out]), "frw_synth_triples")
+    return tuple(out)
+
+
+def _u16(a, n):
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.ndim != 2 or a.shape[1] != n:
+        raise ValueError("input length %s is not N=%d" % (a.shape, n))   # poly.rs:110-112 panics likewise
+    return a
+
+
+class WitnessEngine:
+    """One context on one HIP device.  Raises FrwError when no device is usable."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        check(self._lib.frw_ctx_create(int(device), C.byref(h)), "frw_ctx_create")
+        self._ctx = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.frw_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    # ---- host buffers ------------------------------------------------------------------
+    def witness_ntt_verify(self, logn, sig, pk, hm, encoding=ENC_MONTGOMERY, strict=True):
+        """-> (witness u64[batch, W, 4], instance u64[batch, I, 4], status i32[batch])."""
+        L = layout(logn)
+        sig, pk, hm = (_u16(a, L.n) for a in (sig, pk, hm))
+        batch = sig.shape[0]
+        if pk.shape[0] != batch or hm.shape[0] != batch:
+            raise ValueError("batch mismatch")
+        wit = np.zeros((batch, L.num_witness, 4), dtype=np.uint64)
+        inst = np.zeros((batch, L.num_instance, 4), dtype=np.uint64)
+        st = np.zeros(batch, dtype=np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = self._lib.frw_witness_ntt_verify(self._ctx, logn, batch, p(sig), p(pk), p(hm), encoding,
+                                              p(wit), p(inst), p(st), 1 if strict else 0)
+        if rc == E_RANGE:
+            bad = np.nonzero(st)[0]
+            raise FrwError(rc, "frw_witness_ntt_verify",
+                           "Invalid input: signature(s) %s failed range checks (status %s)" % (bad[:8], st[bad][:8]))
+        check(rc, "frw_witness_ntt_verify")
+        return wit, inst, st
+
+    def ntt_modq(self, logn, poly, encoding=ENC_MONTGOMERY):
+        """NTTPolyVar::ntt_circuit alone -> (witness u64[batch, 29N, 4], ntt u16[batch, N], status)."""
+        n = 1 << logn
+        poly = _u16(poly, n)
+        batch = poly.shape[0]
+        wit = np.zeros((batch, 29 * n, 4), dtype=np.uint64)
+        out = np.zeros((batch, n), dtype=np.uint16)
+        st = np.zeros(batch, dtype=np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(self._lib.frw_ntt_modq(self._ctx, logn, batch, p(poly), encoding, p(wit), p(out), p(st)), "frw_ntt_modq")
+        return wit, out, st
+
+    # ---- device buffers (torch tensors or raw pointers) ---------------------------------
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t if isinstance(t, int) else t.data_ptr())
+
+    def witness_ntt_verify_dev(self, logn, batch, d_sig, d_pk, d_hm, d_wit, d_inst, d_status,
+                               encoding=ENC_MONTGOMERY, stream=0):
+        check(self._lib.frw_witness_ntt_verify_dev(self._ctx, logn, batch, self._ptr(d_sig), self._ptr(d_pk),
+                                                   self._ptr(d_hm), encoding, self._ptr(d_wit), self._ptr(d_inst),
+                                                   self._ptr(d_status), C.c_void_p(stream)),
+              "frw_witness_ntt_verify_dev")
+
+    def ntt_modq_dev(self, logn, batch, d_poly, d_wit, d_ntt, d_status, encoding=ENC_MONTGOMERY, stream=0):
+        check(self._lib.frw_ntt_modq_dev(self._ctx, logn, batch, self._ptr(d_poly), encoding, self._ptr(d_wit),
+                                         self._ptr(d_ntt), self._ptr(d_status), C.c_void_p(stream)),
+              "frw_ntt_modq_dev")
+
+    def digest_dev(self, d_buf, words_per_item, items, d_out, stream=0):
+        check(self._lib.frw_digest_dev(self._ctx, self._ptr(d_buf), words_per_item, items, self._ptr(d_out),
+                                       C.c_void_p(stream)), "frw_digest_dev")

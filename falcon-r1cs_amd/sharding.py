@@ -1,0 +1,56 @@
+"""Multi-GPU partitioning of a batch of signatures (one process per GPU).
+
+Signatures are independent (each reference ``generate_constraints`` call builds its own constraint system,
+falcon-r1cs/src/circuits/falcon_ntt.rs:143-151), so the path shards by signature index with no data-path
+collective: rank r owns a contiguous block of the global index range and keeps its witnesses in its own HBM.
+The only cross-rank traffic is control plane: a barrier around the timed region, a MAX-reduce of the elapsed time
+and an all-gather of the per-signature status words / digests (a few bytes per signature), over whatever backend
+the process group uses (``nccl`` == RCCL over xGMI on the GPU box, ``gloo`` in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """Contiguous block of [0, total) owned by ``rank``; blocks differ by at most one item."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def barrier():
+    if is_dist():
+        dist.barrier()
+
+
+def max_over_ranks(seconds, device):
+    """Every rank gets the slowest rank's time."""
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device):
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def gather_per_signature(local, total, rank, world):
+    """All-gather a per-signature 1-D tensor (status words, digests) sharded by ``shard_range`` into the global
+    vector, on every rank.  Shards may be ragged, so they are padded to the largest shard for the collective."""
+    if not is_dist() or world == 1:
+        return local.clone()
+    sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    width = max(sizes)
+    padded = torch.zeros(width, dtype=local.dtype, device=local.device)
+    padded[: local.numel()] = local
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded)
+    return torch.cat([o[:n] for o, n in zip(out, sizes)])

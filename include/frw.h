@@ -1,0 +1,155 @@
+/*
+ * frw.h -- C ABI of the MI355X Falcon-verification R1CS witness engine (libfrw.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (zhenfeizhang/falcon-r1cs, all citations relative to its root) has no FFI of its own; the
+ * path is the Rust generic API
+ *     FalconNTTVerificationCircuit::generate_constraints   falcon-r1cs/src/circuits/falcon_ntt.rs:26-123
+ *     NTTPolyVar::ntt_circuit                              falcon-r1cs/src/gadgets/poly.rs:104-159
+ *     mod_q / add_mod                                      falcon-r1cs/src/gadgets/arithmetics.rs:105-149, :214-262
+ *     enforce_less_than_q / is_less_than_6144 / enforce_less_than_norm_bound
+ *                                                          falcon-r1cs/src/gadgets/range_proofs.rs:42-94, :289-333, :274-284
+ *     l2_norm_var / enforce_decompose                      falcon-r1cs/src/gadgets/misc.rs:30-51, :9-24
+ * whose only observable product is the pair of assignment vectors of the arkworks
+ * ConstraintSystem (witness_assignment, instance_assignment).  Because the circuit is the same
+ * for every signature of one parameter set, the replacement is a batch witness filler: a Rust
+ * host keeps allocating variables and emitting constraints exactly as today and takes the
+ * VALUES of all W witnesses and I instance variables of `batch` signatures from one call
+ * (binding shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain C types only; all buffers are caller-owned; no callbacks.
+ *   - `logn` is 9 (Falcon-512) or 10 (Falcon-1024); the reference selects it with a cargo
+ *     feature (falcon-r1cs/Cargo.toml:28-32), here it is a run-time argument.
+ *   - polynomials are `uint16_t[batch][N]`, row-major, coefficients in [0, q), q = 12289
+ *     (what falcon-rust's Polynomial::coeff() returns; falcon_ntt.rs:27-28,44).
+ *   - a field element is 4 x uint64_t little-endian limbs (ark-ff Fp256 over the BLS12-381
+ *     scalar field).  encoding FRW_ENC_MONTGOMERY stores x*2^256 mod p -- byte-identical to
+ *     what arkworks keeps in witness_assignment; FRW_ENC_CANONICAL stores x itself.
+ *   - witness:  uint64_t[batch][W][4] in arkworks allocation order (layout: frw_layout()).
+ *     instance: uint64_t[batch][I][4], I = 2N+1: [1, pk_ntt[0..N), hm_ntt[0..N)]
+ *     (falcon_ntt.rs:63,67; public-input order as in examples/pok_sig.rs:38-45).
+ *   - status:   int32_t[batch]: FRW_ST_OK, FRW_ST_COEFF_RANGE (an input coefficient >= q; nothing is
+ *     written for that signature), FRW_ST_NORM_BOUND (l2 norm >= SIG_L2_BOUND; the witness IS written,
+ *     with the truncated bit decomposition the reference assigns when its `#[cfg(not(test))]`
+ *     panic is compiled out (range_proofs.rs:112-117,203-208), so the system is unsatisfied).
+ *   - every function returns FRW_OK (0) or a negative FRW_E_* code; frw_strerror() names it.
+ *     There is NO CPU fallback: without a usable HIP device every compute entry point fails
+ *     with FRW_E_NO_DEVICE.
+ *   - a context is bound to one HIP device and may be used by one host thread at a time;
+ *     independent contexts may be used concurrently (the reference's ConstraintSystemRef is an
+ *     Rc<RefCell<..>>, i.e. one circuit per thread as well).
+ */
+#ifndef FRW_H
+#define FRW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRW_OK               0
+#define FRW_E_INVALID_ARG   -1   /* bad logn / encoding / null pointer */
+#define FRW_E_NO_DEVICE     -2   /* no HIP device, or device ordinal out of range */
+#define FRW_E_HIP           -3   /* a HIP runtime call failed; see frw_last_error() */
+#define FRW_E_OUT_OF_MEMORY -4
+#define FRW_E_RANGE         -5   /* strict mode: at least one signature has status != FRW_ST_OK (the reference panics) */
+
+#define FRW_ENC_CANONICAL   0
+#define FRW_ENC_MONTGOMERY  1
+
+#define FRW_ST_OK           0
+#define FRW_ST_COEFF_RANGE  1
+#define FRW_ST_NORM_BOUND   2
+
+#define FRW_NUM_SEGMENTS    8
+
+/* Witness layout = allocation order of falcon_ntt.rs:58-122, in units of field elements. */
+typedef struct frw_layout {
+    int32_t logn;
+    int32_t n;                 /* N = 1 << logn */
+    int32_t num_witness;       /* W = 153 N + {50 | 52}        (README.md:44,55: 156,724 / 78,386) */
+    int32_t num_instance;      /* I = 2 N + 1                  (README.md:44,55: 2,049 / 1,025)   */
+    int32_t num_constraints;   /* C = 159 N + {52 | 54}        (README.md:44,55: 162,870 / 81,460) */
+    /* S0 sig[i]                          falcon_ntt.rs:58-59       N
+     * S1 v[i]                            falcon_ntt.rs:71          N
+     * S2 enforce_less_than_q(v[i])       falcon_ntt.rs:73-77       27 N
+     * S3 mod_q blocks of ntt_circuit(sig) falcon_ntt.rs:88-89      29 N
+     * S4 mod_q blocks of ntt_circuit(v)  falcon_ntt.rs:90-91       29 N
+     * S5 pointwise product + add_mod     falcon_ntt.rs:94-111      30 N
+     * S6 l2_norm_var over v || sig       falcon_ntt.rs:116-120     18 * 2N
+     * S7 enforce_less_than_norm_bound    falcon_ntt.rs:122         50 | 52 */
+    int32_t seg_off[FRW_NUM_SEGMENTS];
+    int32_t seg_len[FRW_NUM_SEGMENTS];
+} frw_layout_t;
+
+typedef struct frw_ctx frw_ctx;
+
+/* ---- structure --------------------------------------------------------------------------- */
+int frw_layout(int logn, frw_layout_t *out);
+const char *frw_strerror(int code);
+/* text of the last failing HIP call on this thread ("" if none) */
+const char *frw_last_error(void);
+
+/* ---- device context ---------------------------------------------------------------------- */
+int frw_device_count(void);
+/* device = HIP ordinal >= 0.  Builds the twiddle / offset tables on that device. */
+int frw_ctx_create(int device, frw_ctx **out);
+void frw_ctx_destroy(frw_ctx *ctx);
+
+/* ---- hot path, device-resident buffers (hipStream_t passed as void*; NULL = default stream) ----
+ * Replaces one generate_constraints() call per signature (falcon_ntt.rs:26-123): fills the
+ * witness and instance assignment of `batch` signatures.  All pointers are device pointers.
+ * Asynchronous w.r.t. the host: returns after enqueueing on `stream`. */
+int frw_witness_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch,
+                               const uint16_t *d_sig, const uint16_t *d_pk, const uint16_t *d_hm,
+                               int encoding, uint64_t *d_witness, uint64_t *d_instance,
+                               int32_t *d_status, void *stream);
+
+/* Replaces NTTPolyVar::ntt_circuit alone (poly.rs:104-159; the "ntt conversion" row of
+ * examples/constraint_counts.rs:74-113): d_witness = uint64_t[batch][29 N][4] (the N mod_q
+ * blocks [t, b, ltq(b)]), d_ntt_out = uint16_t[batch][N] (the b values == NTTPolynomial::from).
+ * d_status: FRW_ST_OK or FRW_ST_COEFF_RANGE. */
+int frw_ntt_modq_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_poly, int encoding,
+                     uint64_t *d_witness, uint16_t *d_ntt_out, int32_t *d_status, void *stream);
+
+/* ---- hot path, host buffers ----------------------------------------------------------------
+ * Same results through pageable host memory: H2D of the inputs, the kernels, D2H of the outputs,
+ * chunked so that any batch fits the device.  strict != 0 mirrors the reference's non-test
+ * build: returns FRW_E_RANGE if any status != FRW_ST_OK (outputs of those signatures must not
+ * be used).  strict == 0 mirrors its cfg(test) build (see FRW_ST_NORM_BOUND above). */
+int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
+                           const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
+                           int encoding, uint64_t *witness, uint64_t *instance,
+                           int32_t *status, int strict);
+
+int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int encoding,
+                 uint64_t *witness, uint16_t *ntt_out, int32_t *status);
+
+/* ---- utilities ---------------------------------------------------------------------------- */
+/* Per-item digest of a device buffer of `items` x `words_per_item` uint64_t:
+ * d_out[i] = sum_j splitmix64(buf[i][j] + j * 0x9E3779B97F4A7C15) mod 2^64.
+ * Lets a host compare whole HBM-resident witness batches without copying them back. */
+int frw_digest_dev(frw_ctx *ctx, const uint64_t *d_buf, size_t words_per_item, size_t items,
+                   uint64_t *d_out, void *stream);
+
+/* Synthetic, always-valid inputs (host side; stands where the reference's tests call
+ * KeyPair::keygen + sign, falcon_ntt.rs:134-138): sig, v ~ rounded Gaussian(sigma_logn),
+ * pk uniform in [0,q), hm := v + sig*pk mod (x^N+1, q); triples whose norm reaches the bound are
+ * redrawn.  Counter-based: triple i depends only on (seed, first_index + i). */
+int frw_synth_triples(int logn, size_t batch, uint64_t seed, uint64_t first_index,
+                      uint16_t *sig, uint16_t *pk, uint16_t *hm);
+
+/* thin wrappers so that a host without a HIP binding can own device memory */
+int frw_malloc(frw_ctx *ctx, size_t bytes, void **d_ptr);
+int frw_free(frw_ctx *ctx, void *d_ptr);
+int frw_memcpy_h2d(frw_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int frw_memcpy_d2h(frw_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int frw_synchronize(frw_ctx *ctx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRW_H */

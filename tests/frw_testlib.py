@@ -1,0 +1,115 @@
+"""Shared helpers of the test-suite: loading the ORACLE (oracle/) and drawing inputs.
+
+The oracle is the checker.  Nothing here is imported by the product package.
+"""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+Q = 12289
+SIGMA = {9: 165.7366, 10: 168.3886}
+SIG_L2_BOUND = {9: 34034726, 10: 70265242}
+
+
+class OracleLayout(C.Structure):
+    _fields_ = [("logn", C.c_int32), ("n", C.c_int32), ("num_witness", C.c_int32), ("num_instance", C.c_int32),
+                ("num_constraints", C.c_int32), ("seg_off", C.c_int32 * 8), ("seg_len", C.c_int32 * 8)]
+
+
+class Oracle:
+    """ctypes face of oracle/libfrw_oracle.so (plain-C closed-form restatement)."""
+
+    def __init__(self, path):
+        lib = C.CDLL(path)
+        lib.frw_oracle_layout.argtypes = [C.c_int, C.POINTER(OracleLayout)]
+        lib.frw_oracle_witness_ntt_verify.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int] + \
+            [C.c_void_p] * 3 + [C.c_int]
+        lib.frw_oracle_ntt_modq.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        lib.frw_oracle_ntt_clear.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        lib.frw_oracle_digest.argtypes = [C.c_void_p, C.c_size_t]
+        lib.frw_oracle_digest.restype = C.c_uint64
+        self.lib = lib
+
+    def layout(self, logn):
+        L = OracleLayout()
+        assert self.lib.frw_oracle_layout(logn, C.byref(L)) == 0
+        return L
+
+    def witness_ntt_verify(self, logn, sig, pk, hm, encoding=1, threads=1):
+        L = self.layout(logn)
+        sig, pk, hm = (np.ascontiguousarray(a, dtype=np.uint16).reshape(-1, L.n) for a in (sig, pk, hm))
+        batch = sig.shape[0]
+        wit = np.zeros((batch, L.num_witness, 4), dtype=np.uint64)
+        inst = np.zeros((batch, L.num_instance, 4), dtype=np.uint64)
+        st = np.zeros(batch, dtype=np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = self.lib.frw_oracle_witness_ntt_verify(logn, batch, p(sig), p(pk), p(hm), encoding, p(wit), p(inst),
+                                                    p(st), threads)
+        assert rc == 0
+        return wit, inst, st
+
+    def ntt_modq(self, logn, poly, encoding=1):
+        n = 1 << logn
+        poly = np.ascontiguousarray(poly, dtype=np.uint16).reshape(-1, n)
+        batch = poly.shape[0]
+        wit = np.zeros((batch, 29 * n, 4), dtype=np.uint64)
+        out = np.zeros((batch, n), dtype=np.uint16)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert self.lib.frw_oracle_ntt_modq(logn, batch, p(poly), encoding, p(wit), p(out)) == 0
+        return wit, out
+
+    def ntt_clear(self, logn, poly, inverse=False):
+        poly = np.ascontiguousarray(poly, dtype=np.uint16)
+        out = np.zeros_like(poly)
+        assert self.lib.frw_oracle_ntt_clear(logn, poly.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                             1 if inverse else 0) == 0
+        return out
+
+    def digest(self, words):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        return int(self.lib.frw_oracle_digest(words.ctypes.data_as(C.c_void_p), words.size))
+
+
+def load_oracle():
+    so = os.path.join(ORACLE_DIR, "libfrw_oracle.so")
+    src = os.path.join(ORACLE_DIR, "frw_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libfrw_oracle.so"])
+    return Oracle(so)
+
+
+def negacyclic_mul(a, b):
+    """Schoolbook product mod (x^N + 1, q) with numpy -- independent of every NTT in the repo."""
+    n = len(a)
+    a = np.asarray(a, dtype=np.int64)
+    b = np.asarray(b, dtype=np.int64)
+    full = np.convolve(a, b)                       # < 1024 * q^2 < 2^38
+    res = full[:n].copy()
+    res[: n - 1] -= full[n:]
+    return np.mod(res, Q)
+
+
+def random_triple(logn, rng: random.Random, scale=1.0):
+    """Python-side synthetic (sig, pk, hm); scale > 1 inflates the norm (for the bound tests)."""
+    n = 1 << logn
+    s = SIGMA[logn] * scale
+    sig = [round(rng.gauss(0, s)) % Q for _ in range(n)]
+    v = [round(rng.gauss(0, s)) % Q for _ in range(n)]
+    pk = [rng.randrange(Q) for _ in range(n)]
+    hm = (np.array(v, dtype=np.int64) + negacyclic_mul(sig, pk)) % Q
+    return (np.array(sig, dtype=np.uint16), np.array(pk, dtype=np.uint16), hm.astype(np.uint16),
+            np.array(v, dtype=np.uint16))
+
+
+def centred_norm(*polys):
+    tot = 0
+    for p in polys:
+        x = np.asarray(p, dtype=np.int64)
+        x = np.where(x < 6144, x, Q - x)
+        tot += int((x * x).sum())
+    return tot
