@@ -32,6 +32,22 @@ sys.path.insert(0, ROOT)
 import falcon_r1cs_amd as frw  # noqa: E402
 from falcon_r1cs_amd import sharding  # noqa: E402
 
+def measured_traffic(logn, chunk):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/*_hbm_traffic.json, written by
+    tools/summarize_profiles.py from separate --pmc WRITE_SIZE / FETCH_SIZE passes of this same command);
+    None when no summary matches this configuration."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        try:
+            j = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if j.get("logn") == logn and j.get("signatures_per_launch") == chunk:
+            best = (j["hbm_bytes_per_launch"], os.path.basename(path))
+    return best
+
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 SEED = 0x46414C434F4E31        # recorded in the output
 
@@ -159,6 +175,7 @@ def main():
     achieved = chunk * bytes_per_sig / (launch_ms * 1e-3) / 1e9
 
     result = None
+    traffic = measured_traffic(logn, chunk)
     if rank == 0:
         value = world * batch * args.steps / elapsed
         result = {
@@ -173,7 +190,9 @@ def main():
                        "seed": hex(SEED), "sharding": "by signature index, no data-path collective",
                        "signatures_failing_range_checks": n_bad},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
                          "kernel": "witness_ntt_verify_kernel<%d,1>" % logn,
                          "algorithmic_bytes_per_launch": chunk * bytes_per_sig,
                          "avg_launch_ms": round(launch_ms, 4), "launches_timed": len(full)},

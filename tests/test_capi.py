@@ -1,0 +1,82 @@
+"""CPU tests of the drop-in boundary: libfrw.so loads, exports every symbol include/frw.h declares, answers the
+structural questions, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import falcon_r1cs_amd as frw
+from falcon_r1cs_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "frw.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(frw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = frw.load_library()
+    names = declared_symbols()
+    assert len(names) >= 17
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.PROTOTYPES) == names          # the Python binding covers the whole header
+
+
+def test_layout_matches_reference_counts():
+    for logn, (i, w, c) in {9: (1025, 78386, 81460), 10: (2049, 156724, 162870)}.items():   # README.md:44,55
+        L = frw.layout(logn)
+        assert (L.num_instance, L.num_witness, L.num_constraints) == (i, w, c)
+        n = L.n
+        assert L.seg_len == (n, n, 27 * n, 29 * n, 29 * n, 30 * n, 36 * n, 50 if logn == 9 else 52)
+        assert L.seg_off[0] == 0 and all(L.seg_off[k + 1] == L.seg_off[k] + L.seg_len[k] for k in range(7))
+        assert L.seg_off[7] + L.seg_len[7] == w
+    with pytest.raises(frw.FrwError):
+        frw.layout(8)
+
+
+def test_product_layout_equals_oracle_layout(oracle):
+    for logn in (9, 10):
+        a, b = frw.layout(logn), oracle.layout(logn)
+        assert a.seg_off == tuple(b.seg_off) and a.seg_len == tuple(b.seg_len)
+
+
+def test_no_device_means_error_not_fallback():
+    lib = frw.load_library()
+    if lib.frw_device_count() > 0:
+        pytest.skip("a GPU is present; the refusal path is exercised on the CPU box")
+    h = C.c_void_p()
+    assert lib.frw_ctx_create(0, C.byref(h)) == -2                       # FRW_E_NO_DEVICE
+    assert not h.value
+    assert b"no CPU path" in lib.frw_strerror(-2)
+    with pytest.raises(frw.FrwError) as ei:
+        frw.WitnessEngine(0)
+    assert ei.value.code == -2
+    # compute entry points reject a null context instead of computing anything
+    assert lib.frw_witness_ntt_verify(None, 10, 1, None, None, None, 1, None, None, None, 1) == -1
+    assert lib.frw_ntt_modq_dev(None, 9, 1, None, 1, None, None, None, None) == -1
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product sources must not include, import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "falcon-r1cs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+    needed = os.popen("readelf -d %s" % frw.lib_path()).read()
+    assert "frw_oracle" not in needed
+
+
+def test_synth_rejects_bad_arguments():
+    lib = frw.load_library()
+    buf = np.zeros(512, dtype=np.uint16)
+    p = buf.ctypes.data_as(C.c_void_p)
+    assert lib.frw_synth_triples(8, 1, 0, 0, p, p, p) == -1
+    assert lib.frw_synth_triples(9, 1, 0, 0, None, p, p) == -1
