@@ -347,6 +347,20 @@ __device__ __forceinline__ void ladder_lds(uint32_t *lad, const uint16_t *in, co
 // `pos` of lane k's mask.  VFIRST = position of the first value (values are contiguous).
 // The wave emits the tile's 64*BLK*32 bytes in address order, 1 KiB per store instruction.
 // ------------------------------------------------------------------------------------------------
+// Output store.  Measured on MI355X (tools/hbm_write_ceiling.hip, 20 GB pure write stream): plain stores
+// 5.67 TB/s, non-temporal 5.39 TB/s; FRW_NT_STORE selects the flavour for A/B runs (tools/ab_variants.py).
+#ifndef FRW_NT_STORE
+#define FRW_NT_STORE 0
+#endif
+__device__ __forceinline__ void stream_store(v4u val, v4u *p)
+{
+#if FRW_NT_STORE
+    __builtin_nontemporal_store(val, p);
+#else
+    *p = val;
+#endif
+}
+
 __device__ __forceinline__ void slab_put(v4u *slab, int slot, int lane, const uint32_t (&e)[8])
 {
     slab[(slot * 2 + 0) * WAVE + lane] = mk4(e[0], e[1], e[2], e[3]);
@@ -379,7 +393,7 @@ __device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab
             const v4u lv = slab[((isval ? slot : 0) * 2 + half) * WAVE + k];
             if (isval) val = lv;
         }
-        __builtin_nontemporal_store(val, &out[it * WAVE + lane]);
+        stream_store(val, &out[it * WAVE + lane]);
     }
     // the slab is rewritten by the next tile: all lanes must have finished reading it
     __builtin_amdgcn_s_waitcnt(0xc07f);
