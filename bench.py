@@ -98,6 +98,50 @@ def cpu_baseline(logn, sig, pk, hm, gpu_digests, threads):
             "gpu_witnesses_checked_by_digest": checked}
 
 
+def bench_ntt_modq(args, world, rank, dev):
+    """NTTPolyVar::ntt_circuit alone (poly.rs:104-159): uniform random polynomials -> N mod_q witness blocks."""
+    logn, batch = args.logn, args.batch
+    n = 1 << logn
+    eng = frw.WitnessEngine(dev.index)
+    rng = np.random.default_rng(SEED + rank)
+    poly = torch.from_numpy(rng.integers(0, 12289, size=(batch, n), dtype=np.uint16).view(np.int16)).to(dev)
+    wit = torch.empty((batch, 29 * n, 4), dtype=torch.int64, device=dev)
+    out = torch.empty((batch, n), dtype=torch.int16, device=dev)
+    st = torch.empty(batch, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    run = lambda: eng.ntt_modq_dev(logn, batch, poly, wit, out, st, frw.ENC_MONTGOMERY, stream.cuda_stream)
+    for _ in range(max(1, args.warmup)):
+        run()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    ev = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        run()
+        e1.record(stream)
+        ev.append((e0, e1))
+    torch.cuda.synchronize()
+    sharding.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev if args.backend == "nccl" else torch.device("cpu"))
+    ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    bytes_per = 32 * 29 * n + 2 * n                               # SURVEY 8(d): 476,160 / 952,320 B per polynomial
+    achieved = batch * bytes_per / (ms * 1e-3) / 1e9
+    if rank == 0:
+        print(json.dumps({
+            "metric": "falcon%d_ntt_modq_witness_polys_per_sec" % n, "value": round(world * batch * args.steps / elapsed, 1),
+            "unit": "polynomials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "falcon-%d NTT + mod_q witness kernel, batch=%d polynomials" % (n, batch), "logn": logn,
+                       "batch_per_gpu": batch},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "ntt_modq_kernel<%d,1>" % logn, "algorithmic_bytes_per_launch": batch * bytes_per,
+                         "avg_launch_ms": round(ms, 4), "launches_timed": len(ev)}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +151,12 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="signatures per GPU per step")
     ap.add_argument("--chunk", type=int, default=4096, help="signatures per kernel launch (HBM witness buffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1: nccl (= RCCL over xGMI, the default) or gloo (rehearsal of "
+                         "the N > 1 code path with several ranks sharing one GPU)")
+    ap.add_argument("--workload", default="verify", choices=["verify", "ntt_modq"],
+                    help="verify = full verify-with-ntt witness (default, BASELINE configs[2]); ntt_modq = the "
+                         "NTT + mod_q witness kernel alone (BASELINE configs[1]: --logn 9 --batch 4096 --chunk 4096)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,16 +165,27 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("no HIP device visible: this benchmark has no CPU path")
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
+    dev_index = local_rank % ndev                       # gloo rehearsal: ranks may share a GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
+    if args.workload == "ntt_modq":
+        return bench_ntt_modq(args, world, rank, dev)
     logn, batch, chunk = args.logn, args.batch, min(args.chunk, args.batch)
     L = frw.layout(logn)
-    eng = frw.WitnessEngine(local_rank)
-    threads = min(os.cpu_count() or 1, 16)
+    eng = frw.WitnessEngine(dev_index)
+    threads = max(1, min(os.cpu_count() or 1, 16) // world)
 
     # ---- inputs resident in HBM -------------------------------------------------------------
     lo, hi = sharding.shard_range(batch * world, rank, world)      # this rank's global signature indices
@@ -162,10 +223,11 @@ def main():
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
-    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where control-plane tensors live
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, cdev)
 
     # ---- control-plane exchange (untimed): global status vector ---------------------------------
-    status = sharding.gather_per_signature(d_st, batch * world, rank, world)
+    status = sharding.gather_per_signature(d_st.to(cdev), batch * world, rank, world)
     n_bad = int((status != 0).sum().item())
 
     # ---- roofline of the dominant (only) kernel, from HIP events on the launch stream ------------------

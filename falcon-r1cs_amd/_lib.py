@@ -43,6 +43,11 @@ PROTOTYPES = {
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "frw_ntt_modq": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
+    "frw_gadget_block_len": (C.c_int, [C.c_int]),
+    "frw_gadget_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "frw_gadget": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                             C.c_void_p]),
     "frw_digest_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "frw_synth_triples": (C.c_int, [C.c_int, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -251,6 +251,48 @@ int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int
     return FRW_OK;
 }
 
+int frw_gadget_block_len(int kind)
+{
+    static const int len[6] = {27, 29, 29, 18, 50, 52};
+    return kind >= 0 && kind < 6 ? len[kind] : FRW_E_INVALID_ARG;
+}
+
+int frw_gadget_dev(frw_ctx *ctx, int kind, size_t count, const void *d_a, const uint64_t *d_b, int encoding,
+                   uint64_t *d_out, int32_t *d_status, void *stream)
+{
+    if (bad_common(ctx, 10, encoding) || frw_gadget_block_len(kind) < 0) return FRW_E_INVALID_ARG;
+    if (count == 0) return FRW_OK;
+    if (!d_a || !d_out || (kind == FRW_G_ADD_MOD && !d_b)) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_gadget(kind, encoding, count, d_a, d_b, d_out, d_status, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+int frw_gadget(frw_ctx *ctx, int kind, size_t count, const void *a, const uint64_t *b, int encoding, uint64_t *out,
+               int32_t *status)
+{
+    if (bad_common(ctx, 10, encoding) || frw_gadget_block_len(kind) < 0) return FRW_E_INVALID_ARG;
+    if (count == 0) return FRW_OK;
+    if (!a || !out || (kind == FRW_G_ADD_MOD && !b)) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    const size_t in_bytes = count * (kind == FRW_G_MOD_Q ? 20 : 8);
+    const size_t out_bytes = count * (size_t)frw_gadget_block_len(kind) * 32;
+    DevBuf d_a, d_b, d_out, d_st;
+    FRW_HIP(d_a.alloc(in_bytes));
+    FRW_HIP(d_out.alloc(out_bytes));
+    FRW_HIP(d_st.alloc(count * sizeof(int32_t)));
+    FRW_HIP(hipMemcpy(d_a.p, a, in_bytes, hipMemcpyHostToDevice));
+    if (kind == FRW_G_ADD_MOD) {
+        FRW_HIP(d_b.alloc(count * 8));
+        FRW_HIP(hipMemcpy(d_b.p, b, count * 8, hipMemcpyHostToDevice));
+    }
+    FRW_HIP(frw::launch_gadget(kind, encoding, count, d_a.p, (const uint64_t *)d_b.p, (uint64_t *)d_out.p,
+                               (int32_t *)d_st.p, nullptr));
+    FRW_HIP(hipMemcpy(out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
+    if (status) FRW_HIP(hipMemcpy(status, d_st.p, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FRW_OK;
+}
+
 int frw_digest_dev(frw_ctx *ctx, const uint64_t *d_buf, size_t words_per_item, size_t items, uint64_t *d_out,
                    void *stream)
 {

@@ -13,6 +13,9 @@ constexpr int WAVES = BLOCK / WAVE;
 
 constexpr int ST_OK = 0, ST_COEFF_RANGE = 1, ST_NORM_BOUND = 2;    // == FRW_ST_* of include/frw.h
 
+// stand-alone gadget kinds == FRW_G_* of include/frw.h
+constexpr int G_LESS_THAN_Q = 0, G_MOD_Q = 1, G_ADD_MOD = 2, G_L2_ELEM = 3, G_NORM_512 = 4, G_NORM_1024 = 5;
+
 // Per-device constant tables, built by frw_ctx_create.
 struct Tables {
     uint16_t tw[1024];      // falcon-rust NTT_TABLE: 7^bitrev10(i) mod q   (misc.rs:72; script/ntt_param.sage:3-132)
@@ -25,6 +28,8 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, int num_cu, int logn, in
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st);
 hipError_t launch_ntt_modq(const Tables *tab, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
                            uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st);
+hipError_t launch_gadget(int kind, int enc, size_t count, const void *a, const uint64_t *b, uint64_t *out,
+                         int32_t *status, hipStream_t st);
 hipError_t launch_digest(const uint64_t *buf, size_t words, size_t items, uint64_t *out, hipStream_t st);
 
 }  // namespace frw

@@ -367,8 +367,17 @@ __device__ __forceinline__ void slab_put(v4u *slab, int slot, int lane, const ui
     slab[(slot * 2 + 1) * WAVE + lane] = mk4(e[4], e[5], e[6], e[7]);
 }
 
-template <int ENC, int BLK, int NVAL, int VFIRST>
-__device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab, uint32_t mask, int lane)
+template <typename M>
+__device__ __forceinline__ M lane_read(M v, int k)
+{
+    if constexpr (sizeof(M) == 4) return (M)__shfl((int)v, k, WAVE);
+    else return (M)__shfl((unsigned long long)v, k, WAVE);
+}
+
+// LIMIT = false: the tile is complete (64 blocks).  LIMIT = true: only the first `nchunks` 16-byte chunks exist
+// (last, partial tile of a ragged gadget batch).
+template <int ENC, int BLK, int NVAL, int VFIRST, bool LIMIT = false, typename MASK = uint32_t>
+__device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab, MASK mask, int lane, int nchunks = 0)
 {
     constexpr uint32_t R[8] = FRW_R32;
     const int half = lane & 1;
@@ -384,8 +393,8 @@ __device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab
         const int e = it * 32 + (lane >> 1);          // element index inside the tile
         const int k = e / BLK;                        // owning block == owning lane
         const int pos = e - k * BLK;
-        const uint32_t mk = (uint32_t)__shfl((int)mask, k, WAVE);
-        const uint32_t bit = (mk >> pos) & 1u;
+        const MASK mk = lane_read(mask, k);
+        const uint32_t bit = (uint32_t)(mk >> pos) & 1u;
         v4u val = bit ? one : mk4(0, 0, 0, 0);
         if (NVAL > 0) {
             const int slot = pos - VFIRST;
@@ -393,7 +402,7 @@ __device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab
             const v4u lv = slab[((isval ? slot : 0) * 2 + half) * WAVE + k];
             if (isval) val = lv;
         }
-        stream_store(val, &out[it * WAVE + lane]);
+        if (!LIMIT || it * WAVE + lane < nchunks) stream_store(val, &out[it * WAVE + lane]);
     }
     // the slab is rewritten by the next tile: all lanes must have finished reading it
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -614,6 +623,83 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// kernel: stand-alone gadget blocks (the reference's gadget API called outside the full circuit, as its unit tests
+// do): one block of BLK field elements per item, 64 items per wavefront tile.
+//   G_LESS_THAN_Q   a:u64            -> ltq block, 27            range_proofs.rs:42-94
+//   G_MOD_Q         a:5 x u32 limbs  -> [t, b, ltq(b)], 29       arithmetics.rs:105-149
+//   G_ADD_MOD       a:u64, b:u64     -> [t, c, ltq(c)], 29       arithmetics.rs:214-262
+//   G_L2_ELEM       a:u64            -> [a0..a13, w0, w1, r, sq], 18   misc.rs:35-47 + range_proofs.rs:289-333
+//   G_NORM_512/1024 a:u64            -> bits + gates, 50 / 52    range_proofs.rs:100-186 / 192-272
+// status: 0, or ST_COEFF_RANGE when an input is outside what the path can produce (see include/frw.h).
+// ------------------------------------------------------------------------------------------------
+template <int KIND> struct GadgetShape;
+template <> struct GadgetShape<G_LESS_THAN_Q> { static constexpr int BLK = 27, NVAL = 0, VFIRST = 0; using mask_t = uint32_t; };
+template <> struct GadgetShape<G_MOD_Q>       { static constexpr int BLK = 29, NVAL = 2, VFIRST = 0; using mask_t = uint32_t; };
+template <> struct GadgetShape<G_ADD_MOD>     { static constexpr int BLK = 29, NVAL = 2, VFIRST = 0; using mask_t = uint32_t; };
+template <> struct GadgetShape<G_L2_ELEM>     { static constexpr int BLK = 18, NVAL = 2, VFIRST = 16; using mask_t = uint32_t; };
+template <> struct GadgetShape<G_NORM_512>    { static constexpr int BLK = 50, NVAL = 0, VFIRST = 0; using mask_t = uint64_t; };
+template <> struct GadgetShape<G_NORM_1024>   { static constexpr int BLK = 52, NVAL = 0, VFIRST = 0; using mask_t = uint64_t; };
+
+template <int KIND, int ENC>
+__global__ __launch_bounds__(BLOCK) void gadget_kernel(size_t count, const void *__restrict__ in_a,
+                                                       const uint64_t *__restrict__ in_b, v4u *__restrict__ out,
+                                                       int32_t *__restrict__ status)
+{
+    using S = GadgetShape<KIND>;
+    using mask_t = typename S::mask_t;
+    __shared__ v4u slab_all[WAVES][2 * 2 * WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    v4u *slab = slab_all[wave];
+    const size_t tiles = (count + WAVE - 1) / WAVE;
+    for (size_t t = (size_t)blockIdx.x * WAVES + wave; t < tiles; t += (size_t)gridDim.x * WAVES) {
+        const size_t item = t * WAVE + lane;
+        const bool live = item < count;
+        mask_t mask = 0;
+        int st = ST_OK;
+        uint32_t e8[8];
+        if (KIND == G_LESS_THAN_Q) {
+            const uint64_t a = live ? ((const uint64_t *)in_a)[item] : 0;
+            mask = ltq_mask((uint32_t)a & 0x3fffu);                  // to_bits_le().take(14): range_proofs.rs:62-69
+        } else if (KIND == G_MOD_Q) {
+            uint32_t a[5], q5[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) a[i] = live ? ((const uint32_t *)in_a)[item * 5 + i] : 0;
+            const uint32_t b = divmod_q_u160(a, q5);
+            encode_u160<ENC>(q5, e8); slab_put(slab, 0, lane, e8);
+            encode_u32<ENC>(b, e8);   slab_put(slab, 1, lane, e8);
+            mask = ltq_mask(b) << 2;
+        } else if (KIND == G_ADD_MOD) {
+            const uint64_t a = live ? ((const uint64_t *)in_a)[item] : 0, b = live ? in_b[item] : 0;
+            const uint64_t ab = a + b;                                // arithmetics.rs:238
+            if (ab < a) st = ST_COEFF_RANGE;                          // beyond 64 bits: not representable here
+            const uint64_t tq = ab / Q;
+            const uint32_t c = (uint32_t)(ab - tq * Q);               // :242-243
+            const uint32_t t5[5] = {(uint32_t)tq, (uint32_t)(tq >> 32), 0, 0, 0};
+            encode_u160<ENC>(t5, e8); slab_put(slab, 0, lane, e8);
+            encode_u32<ENC>(c, e8);   slab_put(slab, 1, lane, e8);
+            mask = ltq_mask(c) << 2;
+        } else if (KIND == G_L2_ELEM) {
+            const uint64_t a = live ? ((const uint64_t *)in_a)[item] : 0;
+            if (a > Q) st = ST_COEFF_RANGE;                           // q - e would wrap in the field
+            const uint32_t e = (uint32_t)a;
+            mask = lt6144_mask(e & 0x3fffu);
+            const uint32_t r = (mask >> 15) & 1u ? e : Q - e;
+            encode_u32<ENC>(r, e8); slab_put(slab, 0, lane, e8);
+            const uint64_t sq = (uint64_t)r * r;
+            const uint32_t s5[5] = {(uint32_t)sq, (uint32_t)(sq >> 32), 0, 0, 0};
+            encode_u160<ENC>(s5, e8); slab_put(slab, 1, lane, e8);
+        } else {
+            const uint64_t a = live ? ((const uint64_t *)in_a)[item] : 0;
+            mask = KIND == G_NORM_512 ? norm_mask_512(a) : norm_mask_1024(a);
+        }
+        if (live && status) status[item] = st;
+        const size_t remaining = count - t * WAVE;
+        const int nchunks = (int)(remaining >= WAVE ? WAVE : remaining) * S::BLK * 2;
+        emit_tile<ENC, S::BLK, S::NVAL, S::VFIRST, true, mask_t>(out + t * WAVE * S::BLK * 2, slab, mask, lane, nchunks);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-item digest: out[i] = sum_j splitmix64(buf[i][j] + j*golden)  (order independent)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
@@ -692,6 +778,31 @@ hipError_t launch_ntt_modq(const Tables *tab, int num_cu, int logn, int enc, siz
     else if (logn == 9) FRW_LAUNCH(9, 1);
     else if (enc == 0) FRW_LAUNCH(10, 0);
     else FRW_LAUNCH(10, 1);
+#undef FRW_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_gadget(int kind, int enc, size_t count, const void *a, const uint64_t *b, uint64_t *out,
+                         int32_t *status, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    size_t tiles = (count + WAVE - 1) / WAVE;
+    size_t grid = (tiles + WAVES - 1) / WAVES;
+    if (grid > 8192) grid = 8192;
+#define FRW_LAUNCH(KIND)                                                                                         \
+    case KIND:                                                                                                   \
+        if (enc == 0) hipLaunchKernelGGL((gadget_kernel<KIND, 0>), dim3((unsigned)grid), dim3(BLOCK), 0, st, count, a, b, (v4u *)out, status); \
+        else hipLaunchKernelGGL((gadget_kernel<KIND, 1>), dim3((unsigned)grid), dim3(BLOCK), 0, st, count, a, b, (v4u *)out, status);          \
+        break
+    switch (kind) {
+        FRW_LAUNCH(G_LESS_THAN_Q);
+        FRW_LAUNCH(G_MOD_Q);
+        FRW_LAUNCH(G_ADD_MOD);
+        FRW_LAUNCH(G_L2_ELEM);
+        FRW_LAUNCH(G_NORM_512);
+        FRW_LAUNCH(G_NORM_1024);
+    default: return hipErrorInvalidValue;
+    }
 #undef FRW_LAUNCH
     return hipGetLastError();
 }

@@ -15,6 +15,7 @@ from ._lib import FrwError, LayoutStruct, check, load_library
 ENC_CANONICAL, ENC_MONTGOMERY = 0, 1
 ST_OK, ST_COEFF_RANGE, ST_NORM_BOUND = 0, 1, 2
 E_RANGE = -5
+G_LESS_THAN_Q, G_MOD_Q, G_ADD_MOD, G_L2_ELEM, G_NORM_BOUND_512, G_NORM_BOUND_1024 = range(6)
 
 
 @dataclass(frozen=True)
@@ -101,6 +102,26 @@ class WitnessEngine:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         check(self._lib.frw_ntt_modq(self._ctx, logn, batch, p(poly), encoding, p(wit), p(out), p(st)), "frw_ntt_modq")
         return wit, out, st
+
+    def gadget(self, kind, a, b=None, encoding=ENC_MONTGOMERY):
+        """Stand-alone gadget blocks (frw_gadget): a = python ints; returns (blocks u64[count, BLK, 4], status)."""
+        blk = self._lib.frw_gadget_block_len(kind)
+        if blk < 0:
+            raise ValueError("unknown gadget kind %r" % (kind,))
+        vals = [int(x) for x in a]
+        count = len(vals)
+        if kind == G_MOD_Q:
+            if any(v >> 160 for v in vals):
+                raise ValueError("mod_q input exceeds 160 bits (the ladder never produces more)")
+            arr = np.array([[(v >> (32 * i)) & 0xFFFFFFFF for i in range(5)] for v in vals], dtype=np.uint32)
+        else:
+            arr = np.array(vals, dtype=np.uint64)
+        barr = np.array([int(x) for x in b], dtype=np.uint64) if b is not None else None
+        out = np.zeros((count, blk, 4), dtype=np.uint64)
+        st = np.zeros(count, dtype=np.int32)
+        p = lambda x: x.ctypes.data_as(C.c_void_p) if x is not None else None
+        check(self._lib.frw_gadget(self._ctx, kind, count, p(arr), p(barr), encoding, p(out), p(st)), "frw_gadget")
+        return out, st
 
     # ---- device buffers (torch tensors or raw pointers) ---------------------------------
     @staticmethod

@@ -128,6 +128,34 @@ int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
 int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int encoding,
                  uint64_t *witness, uint16_t *ntt_out, int32_t *status);
 
+/* ---- stand-alone gadget blocks ---------------------------------------------------------------
+ * The reference's gadget functions are also called outside the full circuit (its unit tests do; so can any
+ * other circuit built from them).  One call fills the witness block of `count` independent gadget invocations,
+ * `frw_gadget_block_len(kind)` field elements each, in the order the gadget allocates them:
+ *   FRW_G_LESS_THAN_Q     enforce_less_than_q(a)            range_proofs.rs:42-94     a: uint64_t[count]            27
+ *   FRW_G_MOD_Q           mod_q(a, q) -> [t, b, ltq(b)]     arithmetics.rs:105-149    a: uint32_t[count][5] (LE limbs, a < 2^160)  29
+ *   FRW_G_ADD_MOD         add_mod(a, b, q) -> [t, c, ltq(c)] arithmetics.rs:214-262   a, b: uint64_t[count], a+b < 2^64  29
+ *   FRW_G_L2_ELEM         one l2_norm_var element -> [a0..a13, w0, w1, r, sq]  misc.rs:35-47, range_proofs.rs:289-333
+ *                                                                                     a: uint64_t[count], a <= q     18
+ *   FRW_G_NORM_BOUND_512  enforce_less_than_norm_bound      range_proofs.rs:100-186   a: uint64_t[count]            50
+ *   FRW_G_NORM_BOUND_1024                                   range_proofs.rs:192-272   a: uint64_t[count]            52
+ * As in the reference, bit decompositions take the LOW bits of the value (to_bits_le().take(k)); a value that does
+ * not fit yields the block the reference's cfg(test) build assigns (an unsatisfied system), not an error.
+ * status[i] = FRW_ST_COEFF_RANGE only where the input is outside the documented domain.  b is ignored (may be NULL)
+ * unless kind == FRW_G_ADD_MOD. */
+#define FRW_G_LESS_THAN_Q       0
+#define FRW_G_MOD_Q             1
+#define FRW_G_ADD_MOD           2
+#define FRW_G_L2_ELEM           3
+#define FRW_G_NORM_BOUND_512    4
+#define FRW_G_NORM_BOUND_1024   5
+
+int frw_gadget_block_len(int kind);   /* elements per block, or FRW_E_INVALID_ARG */
+int frw_gadget_dev(frw_ctx *ctx, int kind, size_t count, const void *d_a, const uint64_t *d_b, int encoding,
+                   uint64_t *d_out, int32_t *d_status, void *stream);
+int frw_gadget(frw_ctx *ctx, int kind, size_t count, const void *a, const uint64_t *b, int encoding,
+               uint64_t *out, int32_t *status);
+
 /* ---- utilities ---------------------------------------------------------------------------- */
 /* Per-item digest of a device buffer of `items` x `words_per_item` uint64_t:
  * d_out[i] = sum_j splitmix64(buf[i][j] + j * 0x9E3779B97F4A7C15) mod 2^64.

@@ -187,3 +187,64 @@ def test_full_size_properties(engine, logn):
     assert torch.equal((w0[:, S[7]: S[7] + nbits] * weights).sum(dim=1), sq.sum(dim=1))
     # boolean segments really are 0/1
     assert int(w0[:, S[2]: S[3]].max()) == 1 and int(w0[:, S[2]: S[3]].min()) == 0
+
+
+def test_standalone_gadget_blocks_match_gadget_oracle(engine):
+    """frw_gadget: the witness block of a gadget called on its own == what the restated gadget assigns on the
+    arkworks front-end simulation (oracle/falcon_gadgets.py), including out-of-range inputs (cfg(test) behaviour)."""
+    import falcon_r1cs_amd as frw
+    from oracle import falcon_gadgets as G
+    from oracle.ark_sim import ConstraintSystem, FpVar
+    rng = random.Random(8)
+    q = T.Q
+
+    def sim(fn, *vals):
+        cs = ConstraintSystem()
+        vs = [FpVar.new_witness(cs, v) for v in vals]
+        w0 = cs.num_witness_variables()
+        fn(cs, *vs)
+        return cs.witness_assignment[w0:]
+
+    qv = lambda cs: FpVar.constant(cs, q)
+    cases = {
+        frw.G_LESS_THAN_Q: ([42, 0, 1 << 12, 1 << 13, q - 1, q, q + 1, q * 10000] + [rng.randrange(1 << 15) for _ in range(150)],
+                            lambda cs, a: G.enforce_less_than_q(cs, a)),
+        frw.G_MOD_Q: ([6, 0, q, q + 1, (1 << 160) - 1, sum((1 << k) * q ** (k + 1) for k in range(11)) - 1]
+                      + [rng.randrange(1 << 160) for _ in range(150)] + [rng.randrange(1 << 30) for _ in range(50)],
+                      lambda cs, a: G.mod_q(cs, a, qv(cs))),
+        frw.G_L2_ELEM: ([42, 0, 6143, 6144, 6145, q - 1, q] + [rng.randrange(q) for _ in range(150)],
+                        lambda cs, a: G.l2_norm_var(cs, [a], qv(cs))),
+        frw.G_NORM_BOUND_512: ([42, 0, 1 << 25, 34034725, 34034726, 34034727, 1 << 26, 1 << 27]
+                               + [rng.randrange(1 << 27) for _ in range(150)],
+                               lambda cs, a: G.enforce_less_than_norm_bound(cs, a, 9)),
+        frw.G_NORM_BOUND_1024: ([42, 0, 1 << 26, 70265241, 70265242, 70265243, 1 << 27]
+                                + [rng.randrange(1 << 27) for _ in range(150)],
+                                lambda cs, a: G.enforce_less_than_norm_bound(cs, a, 10)),
+    }
+    for kind, (vals, fn) in cases.items():
+        for enc in (0, 1):
+            blocks, st = engine.gadget(kind, vals, encoding=enc)
+            assert not st.any()
+            for i, v in enumerate(vals):
+                want = G.encode_elements(sim(fn, v), enc == 1)
+                assert blocks[i].tobytes() == want, (kind, enc, v)
+    # add_mod: [t, c, ltq(c)]
+    pairs = [(6, 36), (0, 100), (100, 0), (5, q - 1)] + [(rng.randrange(1 << 30), rng.randrange(1 << 30)) for _ in range(150)] \
+        + [(q - 1, (q - 1) ** 2)]
+    blocks, st = engine.gadget(frw.G_ADD_MOD, [a for a, _ in pairs], [b for _, b in pairs], encoding=1)
+    assert not st.any()
+    for i, (a, b) in enumerate(pairs):
+        want = G.encode_elements(sim(lambda cs, x, y: G.add_mod(cs, x, y, qv(cs)), a, b), True)
+        assert blocks[i].tobytes() == want, (a, b)
+    # ragged counts around the 64-block tile and the 256-block workgroup
+    for count in (1, 63, 64, 65, 255, 257, 1000):
+        vals = [rng.randrange(1 << 160) for _ in range(count)]
+        blocks, st = engine.gadget(frw.G_MOD_Q, vals, encoding=0)
+        for i in (0, count // 2, count - 1):
+            t = sum(int(x) << (64 * k) for k, x in enumerate(blocks[i, 0]))
+            assert t == vals[i] // q and int(blocks[i, 1, 0]) == vals[i] % q
+    # documented domain limits are reported, not silently wrapped
+    _, st = engine.gadget(frw.G_L2_ELEM, [q + 1])
+    assert st.tolist() == [frw.ST_COEFF_RANGE]
+    _, st = engine.gadget(frw.G_ADD_MOD, [(1 << 64) - 1], [5])
+    assert st.tolist() == [frw.ST_COEFF_RANGE]
