@@ -17,6 +17,8 @@ struct frw_ctx {
     int device;
     int num_cu;
     frw::Tables *d_tables;
+    unsigned long long *d_queues;      // QUEUE_SLOTS work-queue heads (one cache line apart), one per launch in flight
+    unsigned next_queue;
 };
 
 namespace {
@@ -68,6 +70,14 @@ void build_tables(frw::Tables &t)
         }
         memcpy(t.ck[k], c, sizeof c);
     }
+}
+
+// Successive launches take successive queue heads, so launches that overlap on different streams never share one.
+unsigned long long *take_queue(frw_ctx *ctx)
+{
+    unsigned long long *q = ctx->d_queues + (size_t)(ctx->next_queue % frw::QUEUE_SLOTS) * 16;
+    ctx->next_queue++;
+    return q;
 }
 
 bool bad_common(const frw_ctx *ctx, int logn, int encoding)
@@ -137,12 +147,16 @@ int frw_ctx_create(int device, frw_ctx **out)
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
     ctx->d_tables = nullptr;
+    ctx->d_queues = nullptr;
+    ctx->next_queue = 0;
     frw::Tables host;
     build_tables(host);
     hipError_t e = hipMalloc((void **)&ctx->d_tables, sizeof(frw::Tables));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tables, &host, sizeof host, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queues, frw::QUEUE_SLOTS * 16 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+        if (ctx->d_queues) (void)hipFree(ctx->d_queues);
         delete ctx;
         return hip_fail(e, "table upload");
     }
@@ -155,6 +169,7 @@ void frw_ctx_destroy(frw_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_queues) (void)hipFree(ctx->d_queues);
     delete ctx;
 }
 
@@ -166,7 +181,7 @@ int frw_witness_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const uint1
     if (batch == 0) return FRW_OK;
     if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, batch, d_sig, d_pk, d_hm,
+    FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, batch, d_sig, d_pk, d_hm,
                                            d_witness, d_instance, d_status, (hipStream_t)stream));
     return FRW_OK;
 }
@@ -178,7 +193,7 @@ int frw_ntt_modq_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_pol
     if (batch == 0) return FRW_OK;
     if (!d_poly || !d_witness || !d_ntt_out || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, ctx->num_cu, logn, encoding, batch, d_poly, d_witness, d_ntt_out,
+    FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, batch, d_poly, d_witness, d_ntt_out,
                                  d_status, (hipStream_t)stream));
     return FRW_OK;
 }
@@ -213,7 +228,7 @@ int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch, const uint16_t 
     for (size_t lo = 0; lo < batch; lo += chunk) {
         const size_t cnt = std::min(chunk, batch - lo);
         for (int k = 0; k < 3; k++) FRW_HIP(hipMemcpy(d_in[k].p, src[k] + lo * n, cnt * n * 2, hipMemcpyHostToDevice));
-        FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, cnt,
+        FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt,
                                                (const uint16_t *)d_in[0].p, (const uint16_t *)d_in[1].p,
                                                (const uint16_t *)d_in[2].p, (uint64_t *)d_wit.p, (uint64_t *)d_inst.p,
                                                (int32_t *)d_st.p, nullptr));
@@ -242,7 +257,7 @@ int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int
     for (size_t lo = 0; lo < batch; lo += chunk) {
         const size_t cnt = std::min(chunk, batch - lo);
         FRW_HIP(hipMemcpy(d_in.p, poly + lo * n, cnt * n * 2, hipMemcpyHostToDevice));
-        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in.p,
+        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in.p,
                                      (uint64_t *)d_wit.p, (uint16_t *)d_out.p, (int32_t *)d_st.p, nullptr));
         FRW_HIP(hipMemcpy(status + lo, d_st.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
         FRW_HIP(hipMemcpy((char *)witness + lo * wbytes, d_wit.p, cnt * wbytes, hipMemcpyDeviceToHost));

@@ -11,6 +11,8 @@ constexpr int WAVE = 64;               // CDNA wavefront
 constexpr int BLOCK = 256;             // one workgroup = 4 wavefronts = one signature
 constexpr int WAVES = BLOCK / WAVE;
 
+constexpr int QUEUE_SLOTS = 64;        // work-queue heads per context, used round-robin by successive launches
+
 constexpr int ST_OK = 0, ST_COEFF_RANGE = 1, ST_NORM_BOUND = 2;    // == FRW_ST_* of include/frw.h
 
 // stand-alone gadget kinds == FRW_G_* of include/frw.h
@@ -23,10 +25,10 @@ struct Tables {
     uint32_t ck[11][5];     // C_k = 2^k q^(k+1), 32-bit limbs (falcon_ntt.rs:31-39)
 };
 
-hipError_t launch_witness_ntt_verify(const Tables *tab, int num_cu, int logn, int enc, size_t batch,
+hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch,
                                      const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st);
-hipError_t launch_ntt_modq(const Tables *tab, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
+hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
                            uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st);
 hipError_t launch_gadget(int kind, int enc, size_t count, const void *a, const uint64_t *b, uint64_t *out,
                          int32_t *status, hipStream_t st);

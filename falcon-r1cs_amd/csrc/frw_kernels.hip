@@ -377,7 +377,8 @@ __device__ __forceinline__ M lane_read(M v, int k)
 // LIMIT = false: the tile is complete (64 blocks).  LIMIT = true: only the first `nchunks` 16-byte chunks exist
 // (last, partial tile of a ragged gadget batch).
 template <int ENC, int BLK, int NVAL, int VFIRST, bool LIMIT = false, typename MASK = uint32_t>
-__device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab, MASK mask, int lane, int nchunks = 0)
+__device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab, MASK mask, int lane, int nchunks = 0,
+                                          const v4u *slab2 = nullptr)
 {
     constexpr uint32_t R[8] = FRW_R32;
     const int half = lane & 1;
@@ -399,7 +400,10 @@ __device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab
         if (NVAL > 0) {
             const int slot = pos - VFIRST;
             const bool isval = (unsigned)slot < (unsigned)NVAL;
-            const v4u lv = slab[((isval ? slot : 0) * 2 + half) * WAVE + k];
+            // slots 0,1 live in the wave's slab; a third slot (S5 only) is parked in `slab2`
+            const v4u *src = (NVAL > 2 && slot == 2) ? slab2 + half * WAVE + k
+                                                     : slab + ((isval ? slot : 0) * 2 + half) * WAVE + k;
+            const v4u lv = *src;
             if (isval) val = lv;
         }
         if (!LIMIT || it * WAVE + lane < nchunks) stream_store(val, &out[it * WAVE + lane]);
@@ -410,18 +414,59 @@ __device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab
 }
 
 // ------------------------------------------------------------------------------------------------
+// work distribution.  A launch is a persistent grid; which workgroup takes which signature is decided at run time
+// from one 64-bit queue head per launch (zeroed by a memset node in front of the launch): a workgroup's first
+// item is its blockIdx, later ones are gridDim.x + atomicAdd(head, 1).  Workgroups that get less HBM bandwidth
+// (placement, neighbours) simply take fewer signatures, and the tail of a launch drains at full chip bandwidth
+// instead of waiting for the slowest static stripe.  Measured (tools/ab_variants.py, one process, interleaved):
+// +1.4...2.5 % at N=1024, -2.4 % at N=512 (smaller items, 3 workgroups/CU), so the queue is used for LOGN=10 only.
+// FRW_DYNAMIC_SCHED=0 / =2 force static / dynamic for both parameter sets in A/B builds.
+// ------------------------------------------------------------------------------------------------
+#ifndef FRW_DYNAMIC_SCHED
+#define FRW_DYNAMIC_SCHED 1
+#endif
+// The ticket for the NEXT item is drawn (by thread 0) when the current item starts, so the atomic's round trip is
+// hidden behind the whole item; `publish` hands it to the other waves at the item's end.
+template <int LOGN>
+constexpr bool use_queue() { return FRW_DYNAMIC_SCHED == 2 || (FRW_DYNAMIC_SCHED == 1 && LOGN == 10); }
+
+template <int LOGN>
+__device__ __forceinline__ unsigned long long draw_ticket(unsigned long long *queue, int tid)
+{
+    if constexpr (use_queue<LOGN>()) return tid == 0 ? (unsigned long long)gridDim.x + atomicAdd(queue, 1ull) : 0ull;
+    else return 0ull;
+}
+template <int LOGN>
+__device__ __forceinline__ size_t next_item(size_t cur, unsigned long long ticket, unsigned long long *lds_slot, int tid)
+{
+    if constexpr (use_queue<LOGN>()) {
+        __syncthreads();                              // all waves are done with the previous item (and with *lds_slot)
+        if (tid == 0) *lds_slot = ticket;
+        __syncthreads();
+        return (size_t)*lds_slot;
+    } else {
+        return cur + gridDim.x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS carve-up of one workgroup
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
 struct Smem {
     static constexpr int N = 1 << LOGN;
-    v4u slab[WAVES][3 * 2 * WAVE];     // per-wave value slab: 3 slots x 2 halves x 64 lanes x 16 B = 6 KB
-    uint32_t lad[5 * N];                 // ladder integers, limb-major
-    uint16_t tw[1024], itw[1024];
+    v4u slab[WAVES][2 * 2 * WAVE];       // per-wave value slab: 2 slots x 2 halves x 64 lanes x 16 B = 4 KB
+    uint32_t lad[5 * N];                 // ladder integers, limb-major; while the small segments are written (no
+                                         // ladder alive) its first 8 KB hold the waves' third value slot (S5)
+    uint16_t tw[1024];
     uint16_t sig[N], v[N];               // coefficient domain
     uint16_t nsig[N], npk[N], nhm[N], nv[N];   // NTT domain, all reduced mod q
     unsigned long long norm;
+    unsigned long long next;              // next signature index taken from the launch's work queue
     int bad;
+#if defined(FRW_LDS_PAD) && FRW_LDS_PAD > 0
+    uint32_t pad[FRW_LDS_PAD / 4];        // occupancy experiments only (tools/ab_variants.py)
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -429,7 +474,7 @@ struct Smem {
 // ------------------------------------------------------------------------------------------------
 template <int LOGN, int ENC>
 __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
-    const Tables *__restrict__ tab, size_t batch,
+    const Tables *__restrict__ tab, unsigned long long *__restrict__ queue, size_t batch,
     const uint16_t *__restrict__ g_sig, const uint16_t *__restrict__ g_pk, const uint16_t *__restrict__ g_hm,
     v4u *__restrict__ g_wit, v4u *__restrict__ g_inst, int32_t *__restrict__ g_status)
 {
@@ -445,9 +490,12 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
     const int wave = tid >> 6;
     v4u *slab = sm.slab[wave];
 
-    for (int j = tid; j < 1024; j += BLOCK) { sm.tw[j] = tab->tw[j]; sm.itw[j] = tab->itw[j]; }
+    v4u *slab2 = (v4u *)sm.lad + wave * 2 * WAVE;
+    for (int j = tid; j < 1024; j += BLOCK) sm.tw[j] = tab->tw[j];
 
-    for (size_t s = blockIdx.x; s < batch; s += gridDim.x) {
+    unsigned long long ticket = 0;
+    for (size_t s = blockIdx.x; s < batch; s = next_item<LOGN>(s, ticket, &sm.next, tid)) {
+        ticket = draw_ticket<LOGN>(queue, tid);
         // ---- 1. load + range check ----------------------------------------------------------
         if (tid == 0) { sm.norm = 0; sm.bad = 0; }
         __syncthreads();
@@ -475,7 +523,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
             sm.nv[j] = (uint16_t)x; sm.v[j] = (uint16_t)x;
         }
         __syncthreads();
-        intt_modq_lds<LOGN>(sm.v, sm.itw, tid);                                // v = hm - sig*pk   :48-49
+        intt_modq_lds<LOGN>(sm.v, tab->itw, tid);                                // v = hm - sig*pk   :48-49
 
         v4u *wit = g_wit + s * W * 2;
         v4u *inst = g_inst + s * I * 2;
@@ -510,8 +558,9 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
                 const uint32_t tq = ab / Q, c = ab - tq * Q;              // :242-243
                 encode_u32<ENC>(prod, e8); slab_put(slab, 0, lane, e8);
                 encode_u32<ENC>(tq, e8);   slab_put(slab, 1, lane, e8);
-                encode_u32<ENC>(c, e8);    slab_put(slab, 2, lane, e8);
-                emit_tile<ENC, 30, 3, 0>(wit + ((size_t)87 * N + (size_t)t * WAVE * 30) * 2, slab, ltq_mask(c) << 3, lane);
+                encode_u32<ENC>(c, e8);    slab_put(slab2, 0, lane, e8);
+                emit_tile<ENC, 30, 3, 0>(wit + ((size_t)87 * N + (size_t)t * WAVE * 30) * 2, slab, ltq_mask(c) << 3, lane,
+                                         0, slab2);
             }
         }
         // S6 l2_norm_var over v || sig: [a0..a13, w0, w1, r, sq]                             :116-120
@@ -577,12 +626,14 @@ struct SmemNtt {
     uint32_t lad[5 * N];
     uint16_t tw[1024];
     uint16_t in[N];
+    unsigned long long next;
     int bad;
 };
 
 template <int LOGN, int ENC>
 __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
-    const Tables *__restrict__ tab, size_t batch, const uint16_t *__restrict__ g_poly,
+    const Tables *__restrict__ tab, unsigned long long *__restrict__ queue, size_t batch,
+    const uint16_t *__restrict__ g_poly,
     v4u *__restrict__ g_wit, uint16_t *__restrict__ g_ntt, int32_t *__restrict__ g_status)
 {
     constexpr int N = 1 << LOGN;
@@ -592,7 +643,9 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
     v4u *slab = sm.slab[wave];
     for (int j = tid; j < 1024; j += BLOCK) sm.tw[j] = tab->tw[j];
 
-    for (size_t s = blockIdx.x; s < batch; s += gridDim.x) {
+    unsigned long long ticket = 0;
+    for (size_t s = blockIdx.x; s < batch; s = next_item<LOGN>(s, ticket, &sm.next, tid)) {
+        ticket = draw_ticket<LOGN>(queue, tid);
         if (tid == 0) sm.bad = 0;
         __syncthreads();
         int bad = 0;
@@ -742,18 +795,20 @@ static int resident_grid(K kernel, size_t batch, int num_cu, int &cache)
     return (int)(batch < cap ? batch : cap);
 }
 
-hipError_t launch_witness_ntt_verify(const Tables *tab, int num_cu, int logn, int enc, size_t batch,
+hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch,
                                      const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
+    hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+    if (qe != hipSuccess) return qe;
     static int occ[4] = {0, 0, 0, 0};
 #define FRW_LAUNCH(LOGN, ENC)                                                                                  \
     do {                                                                                                       \
         const int grid = resident_grid(witness_ntt_verify_kernel<LOGN, ENC>, batch, num_cu,                    \
                                        occ[(LOGN - 9) * 2 + ENC]);                                             \
-        hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, batch, \
-                           sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                                      \
+        hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, \
+                           batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                               \
     } while (0)
     if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);
     else if (logn == 9) FRW_LAUNCH(9, 1);
@@ -763,16 +818,18 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, int num_cu, int logn, in
     return hipGetLastError();
 }
 
-hipError_t launch_ntt_modq(const Tables *tab, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
+hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
                            uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
+    hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+    if (qe != hipSuccess) return qe;
     static int occ[4] = {0, 0, 0, 0};
 #define FRW_LAUNCH(LOGN, ENC)                                                                                  \
     do {                                                                                                       \
         const int grid = resident_grid(ntt_modq_kernel<LOGN, ENC>, batch, num_cu, occ[(LOGN - 9) * 2 + ENC]);  \
-        hipLaunchKernelGGL((ntt_modq_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, batch, poly,     \
-                           (v4u *)wit, ntt_out, status);                                                       \
+        hipLaunchKernelGGL((ntt_modq_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, batch,    \
+                           poly, (v4u *)wit, ntt_out, status);                                                 \
     } while (0)
     if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);
     else if (logn == 9) FRW_LAUNCH(9, 1);
