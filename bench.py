@@ -236,6 +236,21 @@ def main():
     bytes_per_sig = 32 * (L.num_witness + 2 * n) + 3 * 2 * n          # 5,086,848 B for Falcon-1024
     achieved = chunk * bytes_per_sig / (launch_ms * 1e-3) / 1e9
 
+    # ---- calibration (untimed): what a compute-free write stream of the same shape reaches on THIS device now ------
+    wbytes = d_wit.numel() * 8
+    cal = []
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        eng.diag_write_stream_dev(d_wit, wbytes, L.num_witness * 32, stream.cuda_stream)
+        e1.record(stream)
+        eng.witness_ntt_verify_dev(logn, chunk, d_sig[:chunk], d_pk[:chunk], d_hm[:chunk], d_wit, d_inst, d_st[:chunk],
+                                   frw.ENC_MONTGOMERY, stream.cuda_stream)      # keep the device in its loaded state
+        cal.append((e0, e1))
+    torch.cuda.synchronize()
+    cal_ms = sorted(a.elapsed_time(b) for a, b in cal[1:])
+    write_stream_gbs = wbytes / (cal_ms[len(cal_ms) // 2] * 1e-3) / 1e9
+
     result = None
     traffic = measured_traffic(logn, chunk)
     if rank == 0:
@@ -257,7 +272,9 @@ def main():
                          "traffic_source": traffic[1] if traffic else None,
                          "kernel": "witness_ntt_verify_kernel<%d,1>" % logn,
                          "algorithmic_bytes_per_launch": chunk * bytes_per_sig,
-                         "avg_launch_ms": round(launch_ms, 4), "launches_timed": len(full)},
+                         "avg_launch_ms": round(launch_ms, 4), "launches_timed": len(full),
+                         "device_write_stream_GBs": round(write_stream_gbs, 1),
+                         "frac_of_device_write_stream": round(achieved / write_stream_gbs, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             # digests of the first launch's witnesses (recomputed: the buffer holds the last chunk now)

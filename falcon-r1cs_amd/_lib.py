@@ -49,6 +49,7 @@ PROTOTYPES = {
     "frw_gadget": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                              C.c_void_p]),
     "frw_digest_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "frw_diag_write_stream_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "frw_synth_triples": (C.c_int, [C.c_int, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "frw_free": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -317,6 +317,14 @@ int frw_digest_dev(frw_ctx *ctx, const uint64_t *d_buf, size_t words_per_item, s
     return FRW_OK;
 }
 
+int frw_diag_write_stream_dev(frw_ctx *ctx, void *d_buf, size_t bytes, size_t slab_bytes, void *stream)
+{
+    if (!ctx || !d_buf || slab_bytes < 16) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_write_stream(d_buf, bytes, slab_bytes, ctx->num_cu, (hipStream_t)stream));
+    return FRW_OK;
+}
+
 int frw_malloc(frw_ctx *ctx, size_t bytes, void **d_ptr)
 {
     if (!ctx || !d_ptr) return FRW_E_INVALID_ARG;

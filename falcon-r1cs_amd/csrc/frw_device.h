@@ -32,6 +32,7 @@ hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num
                            uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st);
 hipError_t launch_gadget(int kind, int enc, size_t count, const void *a, const uint64_t *b, uint64_t *out,
                          int32_t *status, hipStream_t st);
+hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int num_cu, hipStream_t st);
 hipError_t launch_digest(const uint64_t *buf, size_t words, size_t items, uint64_t *out, hipStream_t st);
 
 }  // namespace frw

@@ -779,6 +779,32 @@ __global__ __launch_bounds__(BLOCK) void digest_kernel(const uint64_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// diagnostic: a compute-free write stream with the witness kernel's store shape (each workgroup fills contiguous
+// slabs, 16 B per lane, 1 KiB per store instruction).  bench.py runs it on the same device, in the same process,
+// next to the timed region, so that `roofline.achieved` can be read against what the device's HBM actually takes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void write_stream_kernel(v4u *__restrict__ out, size_t slab16, size_t nslabs, uint32_t seed)
+{
+    v4u v = mk4(seed, seed ^ threadIdx.x, 3u, 4u);
+    for (size_t s = blockIdx.x; s < nslabs; s += gridDim.x) {
+        v4u *o = out + s * slab16;
+        for (size_t i = threadIdx.x; i < slab16; i += BLOCK) stream_store(v, &o[i]);
+    }
+}
+
+hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int num_cu, hipStream_t st)
+{
+    const size_t slab16 = slab_bytes / 16;
+    if (slab16 == 0) return hipErrorInvalidValue;
+    const size_t nslabs = bytes / (slab16 * 16);
+    if (nslabs == 0) return hipSuccess;
+    size_t grid = (size_t)num_cu * 3;
+    if (grid > nslabs) grid = nslabs;
+    hipLaunchKernelGGL(write_stream_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, st, (v4u *)buf, slab16, nslabs, 7u);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers (called from frw_capi.cpp)
 // ------------------------------------------------------------------------------------------------
 // Persistent grid: as many workgroups as the device keeps resident (LDS-limited: 2-3 per CU), each

@@ -140,6 +140,10 @@ class WitnessEngine:
                                          self._ptr(d_ntt), self._ptr(d_status), C.c_void_p(stream)),
               "frw_ntt_modq_dev")
 
+    def diag_write_stream_dev(self, d_buf, nbytes, slab_bytes, stream=0):
+        check(self._lib.frw_diag_write_stream_dev(self._ctx, self._ptr(d_buf), nbytes, slab_bytes, C.c_void_p(stream)),
+              "frw_diag_write_stream_dev")
+
     def digest_dev(self, d_buf, words_per_item, items, d_out, stream=0):
         check(self._lib.frw_digest_dev(self._ctx, self._ptr(d_buf), words_per_item, items, self._ptr(d_out),
                                        C.c_void_p(stream)), "frw_digest_dev")

@@ -163,6 +163,11 @@ int frw_gadget(frw_ctx *ctx, int kind, size_t count, const void *a, const uint64
 int frw_digest_dev(frw_ctx *ctx, const uint64_t *d_buf, size_t words_per_item, size_t items,
                    uint64_t *d_out, void *stream);
 
+/* Roofline calibration: overwrites d_buf[0, bytes) with a compute-free write stream of the witness kernel's store
+ * shape (workgroup-contiguous slabs of slab_bytes, 16 B per lane).  Timed by bench.py on the same device and
+ * stream as the witness kernel to report the write bandwidth the device's HBM actually sustains. */
+int frw_diag_write_stream_dev(frw_ctx *ctx, void *d_buf, size_t bytes, size_t slab_bytes, void *stream);
+
 /* Synthetic, always-valid inputs (host side; stands where the reference's tests call
  * KeyPair::keygen + sign, falcon_ntt.rs:134-138): sig, v ~ rounded Gaussian(sigma_logn),
  * pk uniform in [0,q), hm := v + sig*pk mod (x^N+1, q); triples whose norm reaches the bound are

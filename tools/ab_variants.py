@@ -35,6 +35,7 @@ def build(name, flags):
     lib.frw_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.frw_witness_ntt_verify_dev.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int] + \
         [C.c_void_p] * 4
+    lib.frw_diag_write_stream_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
     ctx = C.c_void_p()
     assert lib.frw_ctx_create(0, C.byref(ctx)) == 0
     return lib, ctx
@@ -79,6 +80,22 @@ def main():
             e1.record(stream)
             e1.synchronize()
             times[name].append(e0.elapsed_time(e1) / 4)
+    # compute-free write stream over the same buffer, interleaved the same way (first variant's library)
+    lib0, ctx0 = libs[0][2], libs[0][3]
+    wbytes = wit.numel() * 8
+    ceil_t = []
+    for _ in range(a.rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(4):
+            assert lib0.frw_diag_write_stream_dev(ctx0, wit.data_ptr(), wbytes, L.num_witness * 32, stream.cuda_stream) == 0
+        e1.record(stream)
+        e1.synchronize()
+        ceil_t.append(e0.elapsed_time(e1) / 4)
+        for name, _, lib, ctx in libs:           # keep the device in the same thermal/clock state
+            launch(lib, ctx)
+    print("%-12s median %.4f ms  min %.4f ms  -> %.1f GB/s (median)   [compute-free write stream, same buffer]"
+          % ("write-only", statistics.median(ceil_t), min(ceil_t), wbytes / statistics.median(ceil_t) / 1e6))
     for name, flags, _, _ in libs:
         t = times[name]
         print("%-12s median %.4f ms  min %.4f ms  -> %.1f GB/s (median)   [%s]"

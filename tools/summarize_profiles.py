@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def find(d, suffix):
     hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None      # gpurun merges, never deletes: newest wins
 
 
 def pmc_avg(d, counter, kernel_substr):
