@@ -43,6 +43,14 @@ PROTOTYPES = {
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "frw_ntt_modq": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
+    "frw_hash_to_point_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "frw_decode_public_keys_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
+    "frw_decode_signatures_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_prepare_inputs": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_gadget_block_len": (C.c_int, [C.c_int]),
     "frw_gadget_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),

@@ -266,6 +266,83 @@ int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int
     return FRW_OK;
 }
 
+int frw_hash_to_point_dev(frw_ctx *ctx, int logn, size_t batch, const uint8_t *d_nonces, const uint8_t *d_msgs,
+                          const uint64_t *d_msg_off, uint16_t *d_hm, void *stream)
+{
+    if (bad_common(ctx, logn, FRW_ENC_CANONICAL)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!d_nonces || !d_msgs || !d_msg_off || !d_hm) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_hash_to_point(logn, batch, d_nonces, d_msgs, d_msg_off, d_hm, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+int frw_decode_public_keys_dev(frw_ctx *ctx, int logn, size_t batch, const uint8_t *d_pk_bytes, uint16_t *d_pk,
+                               int32_t *d_status, void *stream)
+{
+    if (bad_common(ctx, logn, FRW_ENC_CANONICAL)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!d_pk_bytes || !d_pk || !d_status) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_decode_public_keys(logn, batch, d_pk_bytes, d_pk, d_status, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+int frw_decode_signatures_dev(frw_ctx *ctx, int logn, size_t batch, const uint8_t *d_sig_bytes, size_t sig_len,
+                              uint16_t *d_sig, uint8_t *d_nonce_out, int32_t *d_status, void *stream)
+{
+    if (bad_common(ctx, logn, FRW_ENC_CANONICAL)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!d_sig_bytes || !d_sig || !d_status || sig_len <= 1 + FRW_NONCE_LEN) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_decode_signatures(logn, batch, d_sig_bytes, sig_len, d_sig, d_nonce_out, d_status, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+int frw_prepare_inputs(frw_ctx *ctx, int logn, size_t batch, const uint8_t *pk_bytes, const uint8_t *sig_bytes,
+                       size_t sig_len, const uint8_t *msgs, const uint64_t *msg_off, uint16_t *sig, uint16_t *pk,
+                       uint16_t *hm, int32_t *status)
+{
+    if (bad_common(ctx, logn, FRW_ENC_CANONICAL)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!pk_bytes || !sig_bytes || !msg_off || !sig || !pk || !hm || !status || sig_len <= 1 + FRW_NONCE_LEN) return FRW_E_INVALID_ARG;
+    if (!msgs && msg_off[batch] != msg_off[0]) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << logn, pk_len = FRW_PK_LEN(logn);
+    const size_t msg_bytes = (size_t)(msg_off[batch] - msg_off[0]);
+    DevBuf d_pkb, d_sigb, d_msgs, d_off, d_sig, d_pk, d_hm, d_nonce, d_st1, d_st2;
+    FRW_HIP(d_pkb.alloc(batch * pk_len));
+    FRW_HIP(d_sigb.alloc(batch * sig_len));
+    FRW_HIP(d_msgs.alloc(msg_bytes ? msg_bytes : 1));
+    FRW_HIP(d_off.alloc((batch + 1) * sizeof(uint64_t)));
+    FRW_HIP(d_sig.alloc(batch * n * 2));
+    FRW_HIP(d_pk.alloc(batch * n * 2));
+    FRW_HIP(d_hm.alloc(batch * n * 2));
+    FRW_HIP(d_nonce.alloc(batch * FRW_NONCE_LEN));
+    FRW_HIP(d_st1.alloc(batch * sizeof(int32_t)));
+    FRW_HIP(d_st2.alloc(batch * sizeof(int32_t)));
+    std::vector<uint64_t> off(batch + 1);
+    for (size_t i = 0; i <= batch; i++) off[i] = msg_off[i] - msg_off[0];
+    FRW_HIP(hipMemcpy(d_pkb.p, pk_bytes, batch * pk_len, hipMemcpyHostToDevice));
+    FRW_HIP(hipMemcpy(d_sigb.p, sig_bytes, batch * sig_len, hipMemcpyHostToDevice));
+    if (msg_bytes) FRW_HIP(hipMemcpy(d_msgs.p, msgs + msg_off[0], msg_bytes, hipMemcpyHostToDevice));
+    FRW_HIP(hipMemcpy(d_off.p, off.data(), (batch + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    FRW_HIP(hipMemset(d_nonce.p, 0, batch * FRW_NONCE_LEN));
+    FRW_HIP(frw::launch_decode_public_keys(logn, batch, (const uint8_t *)d_pkb.p, (uint16_t *)d_pk.p, (int32_t *)d_st1.p, nullptr));
+    FRW_HIP(frw::launch_decode_signatures(logn, batch, (const uint8_t *)d_sigb.p, sig_len, (uint16_t *)d_sig.p,
+                                          (uint8_t *)d_nonce.p, (int32_t *)d_st2.p, nullptr));
+    FRW_HIP(frw::launch_hash_to_point(logn, batch, (const uint8_t *)d_nonce.p, (const uint8_t *)d_msgs.p,
+                                      (const uint64_t *)d_off.p, (uint16_t *)d_hm.p, nullptr));
+    std::vector<int32_t> st2(batch);
+    FRW_HIP(hipMemcpy(status, d_st1.p, batch * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FRW_HIP(hipMemcpy(st2.data(), d_st2.p, batch * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < batch; i++) if (st2[i] != FRW_ST_OK) status[i] = st2[i];
+    FRW_HIP(hipMemcpy(sig, d_sig.p, batch * n * 2, hipMemcpyDeviceToHost));
+    FRW_HIP(hipMemcpy(pk, d_pk.p, batch * n * 2, hipMemcpyDeviceToHost));
+    FRW_HIP(hipMemcpy(hm, d_hm.p, batch * n * 2, hipMemcpyDeviceToHost));
+    return FRW_OK;
+}
+
 int frw_gadget_block_len(int kind)
 {
     static const int len[6] = {27, 29, 29, 18, 50, 52};

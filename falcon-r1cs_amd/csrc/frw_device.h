@@ -13,7 +13,7 @@ constexpr int WAVES = BLOCK / WAVE;
 
 constexpr int QUEUE_SLOTS = 64;        // work-queue heads per context, used round-robin by successive launches
 
-constexpr int ST_OK = 0, ST_COEFF_RANGE = 1, ST_NORM_BOUND = 2;    // == FRW_ST_* of include/frw.h
+constexpr int ST_OK = 0, ST_COEFF_RANGE = 1, ST_NORM_BOUND = 2, ST_DECODE = 3;    // == FRW_ST_* of include/frw.h
 
 // stand-alone gadget kinds == FRW_G_* of include/frw.h
 constexpr int G_LESS_THAN_Q = 0, G_MOD_Q = 1, G_ADD_MOD = 2, G_L2_ELEM = 3, G_NORM_512 = 4, G_NORM_1024 = 5;
@@ -32,6 +32,11 @@ hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num
                            uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st);
 hipError_t launch_gadget(int kind, int enc, size_t count, const void *a, const uint64_t *b, uint64_t *out,
                          int32_t *status, hipStream_t st);
+hipError_t launch_hash_to_point(int logn, size_t batch, const uint8_t *nonces, const uint8_t *msgs, const uint64_t *msg_off,
+                                uint16_t *hm, hipStream_t st);
+hipError_t launch_decode_public_keys(int logn, size_t batch, const uint8_t *pk_bytes, uint16_t *pk, int32_t *status, hipStream_t st);
+hipError_t launch_decode_signatures(int logn, size_t batch, const uint8_t *sig_bytes, size_t sig_len, uint16_t *sig,
+                                    uint8_t *nonce_out, int32_t *status, hipStream_t st);
 hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int num_cu, hipStream_t st);
 hipError_t launch_digest(const uint64_t *buf, size_t words, size_t items, uint64_t *out, hipStream_t st);
 

@@ -13,7 +13,10 @@ import numpy as np
 from ._lib import FrwError, LayoutStruct, check, load_library
 
 ENC_CANONICAL, ENC_MONTGOMERY = 0, 1
-ST_OK, ST_COEFF_RANGE, ST_NORM_BOUND = 0, 1, 2
+ST_OK, ST_COEFF_RANGE, ST_NORM_BOUND, ST_DECODE = 0, 1, 2, 3
+NONCE_LEN = 40
+PK_LEN = {9: 897, 10: 1793}
+SIG_LEN = {9: 666, 10: 1280}
 E_RANGE = -5
 G_LESS_THAN_Q, G_MOD_Q, G_ADD_MOD, G_L2_ELEM, G_NORM_BOUND_512, G_NORM_BOUND_1024 = range(6)
 
@@ -102,6 +105,28 @@ class WitnessEngine:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         check(self._lib.frw_ntt_modq(self._ctx, logn, batch, p(poly), encoding, p(wit), p(out), p(st)), "frw_ntt_modq")
         return wit, out, st
+
+    def prepare_inputs(self, logn, pks, msgs, sigs):
+        """(pk bytes, msg bytes, sig bytes) per signature -> (sig, pk, hm) uint16[batch, N] + status, i.e. what the
+        reference derives with falcon-rust at falcon_ntt.rs:27-28,44 (decode + SHAKE256 hash-to-point, on the GPU)."""
+        batch = len(pks)
+        if len(msgs) != batch or len(sigs) != batch:
+            raise ValueError("batch mismatch")
+        sig_len = len(sigs[0]) if batch else SIG_LEN[logn]
+        if any(len(p) != PK_LEN[logn] for p in pks) or any(len(s) != sig_len for s in sigs):
+            raise ValueError("public keys must be %d bytes and signatures of one common length" % PK_LEN[logn])
+        n = 1 << logn
+        pkb = np.frombuffer(b"".join(pks), dtype=np.uint8)
+        sgb = np.frombuffer(b"".join(sigs), dtype=np.uint8)
+        blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+        off = np.zeros(batch + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(m) for m in msgs])
+        out = [np.zeros((batch, n), dtype=np.uint16) for _ in range(3)]
+        st = np.zeros(batch, dtype=np.int32)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        check(self._lib.frw_prepare_inputs(self._ctx, logn, batch, p(pkb), p(sgb), sig_len, p(blob), p(off),
+                                           p(out[0]), p(out[1]), p(out[2]), p(st)), "frw_prepare_inputs")
+        return out[0], out[1], out[2], st
 
     def gadget(self, kind, a, b=None, encoding=ENC_MONTGOMERY):
         """Stand-alone gadget blocks (frw_gadget): a = python ints; returns (blocks u64[count, BLK, 4], status)."""

@@ -63,6 +63,7 @@ extern "C" {
 #define FRW_ST_OK           0
 #define FRW_ST_COEFF_RANGE  1
 #define FRW_ST_NORM_BOUND   2
+#define FRW_ST_DECODE       3   /* input preparation: malformed public key / signature encoding */
 
 #define FRW_NUM_SEGMENTS    8
 
@@ -127,6 +128,32 @@ int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
 
 int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int encoding,
                  uint64_t *witness, uint16_t *ntt_out, int32_t *status);
+
+/* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
+ * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),
+ * hm = Polynomial::from_hash_of_message(msg, sig.nonce()).  Formats are the Falcon specification's:
+ *   public key  FRW_PK_LEN(logn)  = 1 + 14 N / 8 bytes: header 0x00 + logn, N x 14-bit coefficients (big-endian bits)
+ *   signature   sig_len bytes (falcon.rs: 666 / 1280, the padded lengths): header 0x30 + logn, 40-byte nonce,
+ *               compressed s2 (sign bit, 7 low bits, unary high part), zero padding
+ *   hash        SHAKE256(nonce || msg) read as big-endian 16-bit words w, w < 5q accepted as w mod q
+ * Messages are one byte blob plus batch+1 offsets (message i = msgs[msg_off[i] .. msg_off[i+1])).
+ * status[i] = FRW_ST_DECODE for a malformed encoding (that signature must not be fed to the witness call). */
+#define FRW_NONCE_LEN 40
+#define FRW_PK_LEN(logn)  (1 + 14 * (1 << (logn)) / 8)
+#define FRW_SIG_LEN(logn) ((logn) == 9 ? 666 : 1280)
+
+int frw_hash_to_point_dev(frw_ctx *ctx, int logn, size_t batch, const uint8_t *d_nonces /* batch x 40 */,
+                          const uint8_t *d_msgs, const uint64_t *d_msg_off /* batch + 1 */, uint16_t *d_hm, void *stream);
+int frw_decode_public_keys_dev(frw_ctx *ctx, int logn, size_t batch, const uint8_t *d_pk_bytes, uint16_t *d_pk,
+                               int32_t *d_status, void *stream);
+int frw_decode_signatures_dev(frw_ctx *ctx, int logn, size_t batch, const uint8_t *d_sig_bytes, size_t sig_len,
+                              uint16_t *d_sig, uint8_t *d_nonce_out /* batch x 40, may be NULL */, int32_t *d_status,
+                              void *stream);
+/* host buffers: decode + hash for `batch` (pk, msg, sig) triples -> the three coefficient vectors the witness
+ * entry points take.  status[i]: FRW_ST_OK or FRW_ST_DECODE. */
+int frw_prepare_inputs(frw_ctx *ctx, int logn, size_t batch, const uint8_t *pk_bytes, const uint8_t *sig_bytes,
+                       size_t sig_len, const uint8_t *msgs, const uint64_t *msg_off, uint16_t *sig, uint16_t *pk,
+                       uint16_t *hm, int32_t *status);
 
 /* ---- stand-alone gadget blocks ---------------------------------------------------------------
  * The reference's gadget functions are also called outside the full circuit (its unit tests do; so can any

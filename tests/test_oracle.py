@@ -284,3 +284,59 @@ def test_synth_triples_are_valid_statements(logn):
         assert norm < T.SIG_L2_BOUND[logn]
         sigma2 = norm / (2 << logn)
         assert 0.8 * T.SIGMA[logn] ** 2 < sigma2 < 1.2 * T.SIGMA[logn] ** 2
+
+
+# ---------------------------------------------------------------------------------------------
+# input preparation: codec restatement self-consistency + SHAKE256 anchor
+# ---------------------------------------------------------------------------------------------
+def test_codec_roundtrip_and_strictness():
+    from oracle import falcon_codec as K
+    rng = random.Random(12)
+    for logn in (9, 10):
+        n = 1 << logn
+        pk = [rng.randrange(Q) for _ in range(n)]
+        assert K.modq_decode(K.modq_encode(pk, logn), logn) == pk
+        enc = bytearray(K.modq_encode(pk, logn))
+        enc[0] ^= 1
+        assert K.modq_decode(bytes(enc), logn) is None                     # wrong header
+        bad = list(pk)
+        bad[5] = 0x3FFF                                                     # 14-bit value >= q
+        acc = 0
+        for c in bad:
+            acc = (acc << 14) | c
+        assert K.modq_decode(bytes([logn]) + acc.to_bytes(14 * n // 8, "big"), logn) is None
+        s2 = [max(-2047, min(2047, round(rng.gauss(0, T.SIGMA[logn])))) for _ in range(n)]
+        nonce = bytes(rng.randrange(256) for _ in range(40))
+        blob = K.comp_encode(s2, logn, nonce)
+        assert len(blob) == K.SIG_LEN[logn]
+        got = K.comp_decode(blob, logn)
+        assert got is not None and got[0] == nonce and got[1] == [x % Q for x in s2]
+        t = bytearray(blob)
+        t[-1] |= 1
+        assert K.comp_decode(bytes(t), logn) is None                        # non-zero padding
+        assert K.comp_decode(blob[:200], logn) is None                      # truncated
+        t = bytearray(blob)
+        t[0] = 0x50 + logn
+        assert K.comp_decode(bytes(t), logn) is None                        # wrong header
+        # "-0": sign bit set, magnitude 0 -> first body byte 0b1000_0000 followed by the unary terminator
+        t = bytearray(blob)
+        t[41], t[42] = 0x80, t[42] | 0x80
+        assert K.comp_decode(bytes(t), logn) is None
+
+
+def test_hash_to_point_matches_fips202_stream():
+    """hashlib's SHAKE256 is the anchor (FIPS 202 KAT: SHAKE256("") starts 46b9dd2b0ba88d13...)."""
+    import hashlib
+    from oracle import falcon_codec as K
+    assert hashlib.shake_256(b"").hexdigest(8) == "46b9dd2b0ba88d13"
+    nonce, msg = bytes(range(40)), b"testing message"
+    for logn in (9, 10):
+        hm = K.hash_to_point(nonce, msg, logn)
+        assert len(hm) == 1 << logn and max(hm) < Q
+        stream = hashlib.shake_256(nonce + msg).digest(64)
+        first = []
+        for i in range(0, 64, 2):
+            w = (stream[i] << 8) | stream[i + 1]
+            if w < 61445:
+                first.append(w % Q)
+        assert hm[:len(first)] == first
