@@ -142,6 +142,56 @@ def bench_ntt_modq(args, world, rank, dev):
                          "avg_launch_ms": round(ms, 4), "launches_timed": len(ev)}}), flush=True)
 
 
+def bench_prepare(args, world, rank, dev):
+    """Input preparation: decode(pk) + decode(sig) + SHAKE256 hash-to-point for a resident batch of
+    encoded (pk, msg, sig); 64-byte messages.  ALU/latency work, two orders of magnitude below the witness kernel."""
+    logn, batch = args.logn, args.batch
+    n = 1 << logn
+    eng = frw.WitnessEngine(dev.index)
+    rng = np.random.default_rng(SEED + rank)
+    pk_len, sig_len, mlen = frw.PK_LEN[logn], frw.SIG_LEN[logn], 64
+    # random bytes are fine for timing: pk fields are 14 random bits (some >= q -> status 3), signatures decode or not
+    pkb = torch.from_numpy(rng.integers(0, 256, size=(batch, pk_len), dtype=np.uint8)).to(dev)
+    sgb_h = np.zeros((batch, sig_len), dtype=np.uint8)
+    sgb_h[:, 0] = 0x30 + logn
+    sgb_h[:, 1:41] = rng.integers(0, 256, size=(batch, 40), dtype=np.uint8)
+    sgb_h[:, 41:41 + n * 9 // 8] = 0x81          # every coefficient = "+1" then terminator pattern: decodes
+    sgb = torch.from_numpy(sgb_h).to(dev)
+    msgs = torch.from_numpy(rng.integers(0, 256, size=batch * mlen, dtype=np.uint8)).to(dev)
+    off = torch.arange(0, (batch + 1) * mlen, mlen, dtype=torch.int64, device=dev)
+    out = [torch.empty((batch, n), dtype=torch.int16, device=dev) for _ in range(3)]
+    nonce = torch.empty((batch, 40), dtype=torch.uint8, device=dev)
+    st = [torch.empty(batch, dtype=torch.int32, device=dev) for _ in range(2)]
+    stream = torch.cuda.current_stream()
+    lib, ctx = eng._lib, eng._ctx
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+
+    def run():
+        assert lib.frw_decode_public_keys_dev(ctx, logn, batch, P(pkb), P(out[1]), P(st[0]), C.c_void_p(stream.cuda_stream)) == 0
+        assert lib.frw_decode_signatures_dev(ctx, logn, batch, P(sgb), sig_len, P(out[0]), P(nonce), P(st[1]),
+                                             C.c_void_p(stream.cuda_stream)) == 0
+        assert lib.frw_hash_to_point_dev(ctx, logn, batch, P(nonce), P(msgs), P(off), P(out[2]),
+                                         C.c_void_p(stream.cuda_stream)) == 0
+    for _ in range(max(1, args.warmup)):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(args.steps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / args.steps
+    print(json.dumps({"metric": "falcon%d_input_preparation_signatures_per_sec" % n, "value": round(batch * args.steps / elapsed, 1),
+                      "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(ms, 4), "higher_is_better": True, "dtype": "u64 (Keccak lanes)", "data": "synthetic",
+                      "config": {"workload": "decode pk + decode sig + SHAKE256 hash-to-point, %d-byte messages" % mlen,
+                                 "logn": logn, "batch_per_gpu": batch}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,7 +204,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL over xGMI, the default) or gloo (rehearsal of "
                          "the N > 1 code path with several ranks sharing one GPU)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "ntt_modq"],
+    ap.add_argument("--workload", default="verify", choices=["verify", "ntt_modq", "prepare"],
                     help="verify = full verify-with-ntt witness (default, BASELINE configs[2]); ntt_modq = the "
                          "NTT + mod_q witness kernel alone (BASELINE configs[1]: --logn 9 --batch 4096 --chunk 4096)")
     args = ap.parse_args()
@@ -182,6 +232,8 @@ def main():
 
     if args.workload == "ntt_modq":
         return bench_ntt_modq(args, world, rank, dev)
+    if args.workload == "prepare":
+        return bench_prepare(args, world, rank, dev)
     logn, batch, chunk = args.logn, args.batch, min(args.chunk, args.batch)
     L = frw.layout(logn)
     eng = frw.WitnessEngine(dev_index)

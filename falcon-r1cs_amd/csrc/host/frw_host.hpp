@@ -458,6 +458,16 @@ struct NTTPolynomial {
     std::vector<uint16_t> c;
     const std::vector<uint16_t> &coeff() const { return c; }
 };
+// falcon-rust PublicKey / Signature: the encoded bytes (Falcon spec 3.11.3-3.11.4; see include/frw.h)
+struct PublicKey {
+    std::vector<uint8_t> bytes;
+    int logn() const { return bytes.empty() ? -1 : (int)bytes[0]; }
+};
+struct Signature {
+    std::vector<uint8_t> bytes;
+    // Signature::nonce(): the 40 bytes after the header (falcon_ntt.rs:44)
+    std::vector<uint8_t> nonce() const { return std::vector<uint8_t>(bytes.begin() + 1, bytes.begin() + 1 + FRW_NONCE_LEN); }
+};
 
 inline uint32_t powmod_q(uint32_t b, uint32_t e) { uint64_t r = 1, x = b; while (e) { if (e & 1) r = r * x % MODULUS; x = x * x % MODULUS; e >>= 1; } return (uint32_t)r; }
 // falcon-rust NTT_TABLE[i] = 7^bitrev10(i) mod q (script/ntt_param.sage:3-132)
@@ -741,9 +751,21 @@ inline std::vector<FpVar> const_q_power_vars(const ConstraintSystemRef &cs, int 
 // ---------------------------------------------------------------------------------------------------------------
 class FalconNTTVerificationCircuit {
 public:
-    // falcon_ntt.rs:15-17.  The reference takes (pk, msg, sig) and derives three coefficient vectors with
-    // falcon-rust (Polynomial::from(&pk), ::from(&sig), ::from_hash_of_message(msg, nonce), :27-28,:44); decoding and
-    // hash-to-point are the next scope row, so this round the circuit is built from those vectors.
+    // falcon_ntt.rs:15-17: build_circuit(pk, msg, sig).  The three coefficient vectors of :27-28,:44 are derived by
+    // the engine (frw_prepare_inputs: decoders + SHAKE256 hash-to-point on the GPU) when generate_constraints runs.
+    static FalconNTTVerificationCircuit build_circuit(PublicKey pk, std::vector<uint8_t> msg, Signature sig)
+    {
+        const int logn = pk.logn();
+        if (logn != 9 && logn != 10) throw std::invalid_argument("public key header is not a Falcon-512/1024 key");
+        FalconNTTVerificationCircuit c;
+        c.logn_ = logn;
+        c.pk_bytes_ = std::move(pk); c.msg_ = std::move(msg); c.sig_bytes_ = std::move(sig);
+        c.from_bytes_ = true;
+        return c;
+    }
+
+    // The same circuit from the coefficient vectors themselves (a caller that already holds Polynomial::from(&pk),
+    // from_hash_of_message(..) and Polynomial::from(&sig), e.g. a batch prover after one frw_prepare_inputs call).
     static FalconNTTVerificationCircuit build_circuit(Polynomial pk, Polynomial hm, Polynomial sig, int logn)
     {
         const size_t N = (size_t)1 << logn;
@@ -760,6 +782,19 @@ public:
         const int logn = logn_;
         const size_t N = (size_t)1 << logn;
         NTTPolynomial pk_ntt{std::vector<uint16_t>(N, 1)}, hm_ntt{std::vector<uint16_t>(N, 1)};
+        Polynomial pk_ = this->pk_, hm_ = this->hm_, sig_ = this->sig_;
+        if (from_bytes_) {
+            pk_.c.assign(N, 0); hm_.c.assign(N, 0); sig_.c.assign(N, 0);
+            if (!cs->is_in_setup_mode() && !preset_wit_) {       // falcon_ntt.rs:27-28,44 on the engine
+                detail::require_engine(cs, "FalconNTTVerificationCircuit");
+                const uint64_t off[2] = {0, msg_.size()};
+                int32_t st = 0;
+                detail::check(frw_prepare_inputs(cs->engine()->get(), logn, 1, pk_bytes_.bytes.data(), sig_bytes_.bytes.data(),
+                                                 sig_bytes_.bytes.size(), msg_.empty() ? nullptr : msg_.data(), off, sig_.c.data(),
+                                                 pk_.c.data(), hm_.c.data(), &st), "frw_prepare_inputs");
+                if (st != FRW_ST_OK) throw std::domain_error("Invalid input: malformed public key or signature encoding");
+            }
+        }
         if (!cs->is_in_setup_mode()) {
             frw_layout_t L;
             frw_layout(logn, &L);
@@ -817,6 +852,10 @@ public:
 
 private:
     Polynomial pk_, hm_, sig_;
+    PublicKey pk_bytes_;
+    Signature sig_bytes_;
+    std::vector<uint8_t> msg_;
+    bool from_bytes_ = false;
     int logn_ = 10;
     const uint64_t *preset_wit_ = nullptr, *preset_inst_ = nullptr;
 };

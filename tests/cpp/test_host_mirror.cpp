@@ -286,6 +286,68 @@ static void test_ntt_verification_r1cs(const Engine &eng, int logn)
     EXPECT(!cs->is_satisfied());
 }
 
+// test-side encoders (Falcon spec 3.11.2-3.11.4), to feed build_circuit(pk, msg, sig) with bytes
+static std::vector<uint8_t> modq_encode(const std::vector<uint16_t> &c, int logn)
+{
+    std::vector<uint8_t> out{(uint8_t)logn};
+    uint32_t acc = 0; int bits = 0;
+    for (uint16_t x : c) { acc = (acc << 14) | x; bits += 14; while (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); } }
+    return out;
+}
+static std::vector<uint8_t> comp_encode(const std::vector<uint16_t> &c, int logn, uint8_t nonce_byte)
+{
+    std::vector<uint8_t> out{(uint8_t)(0x30 + logn)};
+    out.insert(out.end(), FRW_NONCE_LEN, nonce_byte);
+    uint32_t acc = 0; int bits = 0;
+    auto put = [&](uint32_t v, int n) { acc = (acc << n) | v; bits += n; while (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); } };
+    for (uint16_t x : c) {
+        const bool neg = x >= 6144;
+        const uint32_t m = neg ? MODULUS - x : x;
+        put(neg ? 1 : 0, 1); put(m & 127, 7);
+        for (uint32_t k = 0; k < (m >> 7); k++) put(0, 1);
+        put(1, 1);
+    }
+    if (bits) put(0, 8 - bits);
+    out.resize((size_t)FRW_SIG_LEN(logn), 0);
+    return out;
+}
+
+static void test_build_circuit_from_bytes(const Engine &eng, int logn)
+{   // falcon_ntt.rs:15-17,27-28,44: build_circuit(pk, msg, sig) with encoded inputs; hash-to-point and decoding on the engine.
+    // No Falcon signer exists here, so hm = H(nonce || msg) is unrelated to sig*pk and v is not short: in the permissive
+    // (cfg(test)) build every constraint in front of the norm-bound gadget must hold (the norm does not even fit its
+    // 26/27-bit decomposition, so the first failure is inside that gadget's last 52/54 constraints).
+    std::printf("test_build_circuit_from_bytes logn=%d\n", logn);
+    const size_t N = (size_t)1 << logn;
+    std::vector<uint16_t> sig(N), pk(N), hm(N);
+    EXPECT(frw_synth_triples(logn, 1, 5, 0, sig.data(), pk.data(), hm.data()) == FRW_OK);
+    PublicKey pkb{modq_encode(pk, logn)};
+    Signature sgb{comp_encode(sig, logn, 0x5a)};
+    EXPECT(pkb.bytes.size() == (size_t)FRW_PK_LEN(logn) && sgb.bytes.size() == (size_t)FRW_SIG_LEN(logn));
+    EXPECT(sgb.nonce().size() == FRW_NONCE_LEN && sgb.nonce()[0] == 0x5a);
+    std::string text = "testing message";
+    auto cs = ConstraintSystem::new_ref();
+    cs->attach_engine(&eng, false);
+    FalconNTTVerificationCircuit::build_circuit(pkb, std::vector<uint8_t>(text.begin(), text.end()), sgb).generate_constraints(cs);
+    auto bad = cs->which_is_unsatisfied();
+    EXPECT(bad.has_value() && *bad >= cs->num_constraints() - (logn == 9 ? 52 : 54));
+    // S0 must be the decoded signature
+    for (size_t i = 0; i < N; i++) EXPECT(cs->witness_assignment[i] == Fr::from(sig[i]));
+    // instance = NTT(pk) as decoded
+    auto pk_ntt = ntt_clear(pk, logn);
+    for (size_t i = 0; i < N; i++) EXPECT(cs->instance_assignment[1 + i] == Fr::from(pk_ntt[i]));
+    // malformed signature -> the reference's decode would fail; here a domain error
+    Signature broken = sgb;
+    broken.bytes.back() = 1;
+    bool threw = false;
+    try {
+        auto cs2 = ConstraintSystem::new_ref();
+        cs2->attach_engine(&eng, false);
+        FalconNTTVerificationCircuit::build_circuit(pkb, {}, broken).generate_constraints(cs2);
+    } catch (const std::domain_error &) { threw = true; }
+    EXPECT(threw);
+}
+
 static void test_no_engine_is_assignment_missing()
 {
     std::printf("test_no_engine_is_assignment_missing\n");
@@ -311,6 +373,7 @@ int main(int argc, char **argv)
         test_range_proofs(eng);
         for (int logn : {9, 10}) test_ntt_mul_circuit(eng, logn);
         for (int logn : {9, 10}) test_ntt_verification_r1cs(eng, logn);
+        for (int logn : {9, 10}) test_build_circuit_from_bytes(eng, logn);
     } else {
         std::printf("usage: %s structure | gpu | check <logn> <sig> <pk> <hm> <witness> <instance>\n", argv[0]);
         return 64;
