@@ -27,6 +27,12 @@ class LayoutStruct(C.Structure):
                 ("seg_off", C.c_int32 * 8), ("seg_len", C.c_int32 * 8)]
 
 
+class LayoutDualStruct(C.Structure):
+    _fields_ = [("logn", C.c_int32), ("n", C.c_int32), ("num_witness", C.c_int32),
+                ("num_instance", C.c_int32), ("num_constraints", C.c_int32),
+                ("seg_off", C.c_int32 * 15), ("seg_len", C.c_int32 * 15)]
+
+
 # name -> (restype, argtypes); must list every symbol include/frw.h declares
 PROTOTYPES = {
     "frw_layout": (C.c_int, [C.c_int, C.POINTER(LayoutStruct)]),
@@ -43,6 +49,11 @@ PROTOTYPES = {
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "frw_ntt_modq": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
+    "frw_layout_dual": (C.c_int, [C.c_int, C.POINTER(LayoutDualStruct)]),
+    "frw_witness_dual_ntt_verify_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_witness_dual_ntt_verify": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "frw_hash_to_point_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     "frw_decode_public_keys_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,

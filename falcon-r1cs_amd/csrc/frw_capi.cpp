@@ -206,18 +206,19 @@ struct DevBuf {
 };
 }  // namespace
 
-int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch, const uint16_t *sig, const uint16_t *pk,
-                           const uint16_t *hm, int encoding, uint64_t *witness, uint64_t *instance, int32_t *status,
-                           int strict)
+namespace {
+// host-buffer driver shared by the two circuits: H2D inputs, launch, D2H outputs, chunked
+int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t *sig, const uint16_t *pk,
+                 const uint16_t *hm, int encoding, uint64_t *witness, uint64_t *instance, int32_t *status, int strict)
 {
     if (bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
     if (!sig || !pk || !hm || !witness || !instance || !status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    frw_layout_t L;
-    frw_layout(logn, &L);
-    const size_t n = (size_t)L.n, wbytes = (size_t)L.num_witness * 32, ibytes = (size_t)L.num_instance * 32;
-    const size_t chunk = std::min<size_t>(batch, 512);            // <= 2.6 GB of witness per chunk
+    const size_t n = (size_t)1 << logn;
+    const size_t nb = logn == 9 ? 50 : 52;
+    const size_t wbytes = (dual ? 186 * n + 4 + nb : 153 * n + nb) * 32, ibytes = (2 * n + 1) * 32;
+    const size_t chunk = std::min<size_t>(batch, 512);            // <= 3.2 GB of witness per chunk
     DevBuf d_in[3], d_wit, d_inst, d_st;
     for (auto &b : d_in) FRW_HIP(b.alloc(chunk * n * 2));
     FRW_HIP(d_wit.alloc(chunk * wbytes));
@@ -228,16 +229,69 @@ int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch, const uint16_t 
     for (size_t lo = 0; lo < batch; lo += chunk) {
         const size_t cnt = std::min(chunk, batch - lo);
         for (int k = 0; k < 3; k++) FRW_HIP(hipMemcpy(d_in[k].p, src[k] + lo * n, cnt * n * 2, hipMemcpyHostToDevice));
-        FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt,
-                                               (const uint16_t *)d_in[0].p, (const uint16_t *)d_in[1].p,
-                                               (const uint16_t *)d_in[2].p, (uint64_t *)d_wit.p, (uint64_t *)d_inst.p,
-                                               (int32_t *)d_st.p, nullptr));
+        if (dual)
+            FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt,
+                                                        (const uint16_t *)d_in[0].p, (const uint16_t *)d_in[1].p,
+                                                        (const uint16_t *)d_in[2].p, (uint64_t *)d_wit.p,
+                                                        (uint64_t *)d_inst.p, (int32_t *)d_st.p, nullptr));
+        else
+            FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt,
+                                                   (const uint16_t *)d_in[0].p, (const uint16_t *)d_in[1].p,
+                                                   (const uint16_t *)d_in[2].p, (uint64_t *)d_wit.p, (uint64_t *)d_inst.p,
+                                                   (int32_t *)d_st.p, nullptr));
         FRW_HIP(hipMemcpy(status + lo, d_st.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
         FRW_HIP(hipMemcpy((char *)witness + lo * wbytes, d_wit.p, cnt * wbytes, hipMemcpyDeviceToHost));
         FRW_HIP(hipMemcpy((char *)instance + lo * ibytes, d_inst.p, cnt * ibytes, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < cnt; i++) any_bad |= status[lo + i] != FRW_ST_OK;
     }
     return strict && any_bad ? FRW_E_RANGE : FRW_OK;
+}
+}  // namespace
+
+int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch, const uint16_t *sig, const uint16_t *pk,
+                           const uint16_t *hm, int encoding, uint64_t *witness, uint64_t *instance, int32_t *status,
+                           int strict)
+{
+    return witness_host(ctx, false, logn, batch, sig, pk, hm, encoding, witness, instance, status, strict);
+}
+
+int frw_witness_dual_ntt_verify(frw_ctx *ctx, int logn, size_t batch, const uint16_t *sig, const uint16_t *pk,
+                                const uint16_t *hm, int encoding, uint64_t *witness, uint64_t *instance,
+                                int32_t *status, int strict)
+{
+    return witness_host(ctx, true, logn, batch, sig, pk, hm, encoding, witness, instance, status, strict);
+}
+
+int frw_witness_dual_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_sig, const uint16_t *d_pk,
+                                    const uint16_t *d_hm, int encoding, uint64_t *d_witness, uint64_t *d_instance,
+                                    int32_t *d_status, void *stream)
+{
+    if (bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, batch, d_sig,
+                                                d_pk, d_hm, d_witness, d_instance, d_status, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+int frw_layout_dual(int logn, frw_layout_dual_t *out)
+{
+    if (!out || (logn != 9 && logn != 10)) return FRW_E_INVALID_ARG;
+    const int n = 1 << logn, nb = logn == 9 ? 50 : 52;
+    const int len[FRW_NUM_SEGMENTS_DUAL] = {n, n, n, 2, n, n, n, 2, 29 * n, 29 * n, 29 * n, 29 * n, 60 * n, 4 * n, nb};
+    int off = 0;
+    out->logn = logn;
+    out->n = n;
+    for (int i = 0; i < FRW_NUM_SEGMENTS_DUAL; i++) {
+        out->seg_off[i] = off;
+        out->seg_len[i] = len[i];
+        off += len[i];
+    }
+    out->num_witness = off;
+    out->num_instance = 2 * n + 1;
+    out->num_constraints = 189 * n + 10 + nb;
+    return FRW_OK;
 }
 
 int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int encoding, uint64_t *witness,

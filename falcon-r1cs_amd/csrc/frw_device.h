@@ -28,6 +28,9 @@ struct Tables {
 hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch,
                                      const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st);
+hipError_t launch_witness_dual_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc,
+                                          size_t batch, const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
+                                          uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st);
 hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
                            uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st);
 hipError_t launch_gadget(int kind, int enc, size_t count, const void *a, const uint64_t *b, uint64_t *out,

@@ -617,6 +617,173 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// kernel: the signed-split variant, FalconDualNTTVerificationCircuit::generate_constraints
+// (circuits/falcon_dual_ntt.rs:26-132, gadgets/dual_poly.rs:15-51, gadgets/misc.rs:55-65).  Same building blocks,
+// different layout (units: field elements; W = 186 N + 4 + nb):
+//   0      sig.pos N | N sig.neg N | 2N pos*neg products N | 3N is_zero [is_not_equal, multiplier]       dual_poly.rs:20-29
+//   3N+2   v.pos N | 4N+2 v.neg N | 5N+2 products N | 6N+2 is_zero 2                                     falcon_dual_ntt.rs:73
+//   6N+4   mod_q blocks of ntt_circuit(sig.pos), +29N (sig.neg), +58N (v.pos), +87N (v.neg)             :85-92
+//   122N+4 per i: [sig_ntt.neg*pk_ntt, t, b, ltq(b)] [sig_ntt.pos*pk_ntt, t, b, ltq(b)]  (2 x 30)        :95-116
+//   182N+4 squares of v.pos, v.neg, sig.pos, sig.neg (4N)                                                :121-129
+//   186N+4 norm bound (50 | 52)                                                                          :131
+// A DualPolynomial has pos[i]*neg[i] = 0 for every i, so the products are zeros, is_not_equal = 0, multiplier = 1.
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+struct SmemDual {
+    static constexpr int N = 1 << LOGN;
+    v4u slab[WAVES][2 * 2 * WAVE];
+    uint32_t lad[5 * N];                  // also: third value slot of the pointwise tiles while no ladder is alive
+    uint16_t tw[1024];
+    uint16_t sp[N], sn[N], vp[N], vn[N];          // coefficient domain (signed split, threshold 6144)
+    uint16_t nsp[N], nsn[N], nvp[N], nvn[N], npk[N], nhm[N];   // NTT domain
+    unsigned long long norm;
+    unsigned long long next;
+    int bad;
+};
+
+template <int LOGN, int ENC>
+__global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
+    const Tables *__restrict__ tab, unsigned long long *__restrict__ queue, size_t batch,
+    const uint16_t *__restrict__ g_sig, const uint16_t *__restrict__ g_pk, const uint16_t *__restrict__ g_hm,
+    v4u *__restrict__ g_wit, v4u *__restrict__ g_inst, int32_t *__restrict__ g_status)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int NB = LOGN == 9 ? 50 : 52;
+    constexpr size_t W = 186 * (size_t)N + 4 + NB;
+    constexpr size_t I = 2 * (size_t)N + 1;
+    constexpr int TILES = N / WAVE;
+    constexpr uint32_t HALF_Q = 6144;
+    __shared__ SmemDual<LOGN> sm;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    v4u *slab = sm.slab[wave];
+    v4u *slab2 = (v4u *)sm.lad + wave * 2 * WAVE;
+    for (int j = tid; j < 1024; j += BLOCK) sm.tw[j] = tab->tw[j];
+    constexpr uint32_t R[8] = FRW_R32;
+    const int half = lane & 1;
+    const v4u one = ENC == 0 ? (half ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0))
+                             : (half ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]));
+
+    unsigned long long ticket = 0;
+    for (size_t s = blockIdx.x; s < batch; s = next_item<LOGN>(s, ticket, &sm.next, tid)) {
+        ticket = draw_ticket<LOGN>(queue, tid);
+        if (tid == 0) { sm.norm = 0; sm.bad = 0; }
+        __syncthreads();
+        int bad = 0;
+        for (int j = tid; j < N; j += BLOCK) {
+            const uint32_t a = g_sig[s * N + j], b = g_pk[s * N + j], c = g_hm[s * N + j];
+            bad |= (a >= Q) | (b >= Q) | (c >= Q);
+            const uint16_t p = (uint16_t)(a < HALF_Q ? a : 0), m = (uint16_t)(a < HALF_Q ? 0 : Q - a);   // falcon_dual_ntt.rs:27
+            sm.sp[j] = p; sm.sn[j] = m; sm.nsp[j] = p; sm.nsn[j] = m;
+            sm.npk[j] = (uint16_t)b; sm.nhm[j] = (uint16_t)c;
+        }
+        if (bad) sm.bad = 1;
+        __syncthreads();
+        if (sm.bad) {
+            if (tid == 0) g_status[s] = ST_COEFF_RANGE;
+            continue;
+        }
+        {
+            uint16_t *const polys[4] = {sm.nsp, sm.nsn, sm.npk, sm.nhm};
+            ntt_modq_lds<LOGN, 4>(polys, sm.tw, tid);                              // :45,:53
+        }
+        for (int j = tid; j < N; j += BLOCK) {                                     // v = hm - uh_pos + uh_neg   :48-50
+            const uint32_t sg = sm.nsp[j] + Q - sm.nsn[j];
+            uint32_t x = sm.nhm[j] + Q - mod_q_u32(mod_q_u32(sg) * sm.npk[j]);
+            sm.vp[j] = (uint16_t)(x >= Q ? x - Q : x);
+        }
+        __syncthreads();
+        intt_modq_lds<LOGN>(sm.vp, tab->itw, tid);
+        for (int j = tid; j < N; j += BLOCK) {                                     // DualPolynomial::from(&v)   :51
+            const uint32_t a = sm.vp[j];
+            const uint16_t p = (uint16_t)(a < HALF_Q ? a : 0), m = (uint16_t)(a < HALF_Q ? 0 : Q - a);
+            sm.vp[j] = p; sm.vn[j] = m; sm.nvp[j] = p; sm.nvn[j] = m;
+        }
+        __syncthreads();
+        {
+            uint16_t *const polys[2] = {sm.nvp, sm.nvn};
+            ntt_modq_lds<LOGN, 2>(polys, sm.tw, tid);
+        }
+
+        v4u *wit = g_wit + s * W * 2;
+        v4u *inst = g_inst + s * I * 2;
+        uint32_t e8[8];
+        if (tid < 2) inst[tid] = one;                                              // instance_assignment[0] = 1
+        if (tid < 4) {                                                             // is_zero: [0, 1] twice
+            const v4u z = mk4(0, 0, 0, 0);
+            wit[(size_t)3 * N * 2 + tid] = tid < 2 ? z : one;
+            wit[((size_t)6 * N + 2) * 2 + tid] = tid < 2 ? z : one;
+        }
+        unsigned long long nrm = 0;
+        for (int t = wave; t < TILES; t += WAVES) {
+            const int k = t * WAVE + lane;
+            const size_t to = (size_t)t * WAVE * 2;
+            encode_u32<ENC>(sm.npk[k], e8); slab_put(slab, 0, lane, e8);
+            emit_tile<ENC, 1, 1, 0>(inst + 2 + to, slab, 0u, lane);
+            encode_u32<ENC>(sm.nhm[k], e8); slab_put(slab, 0, lane, e8);
+            emit_tile<ENC, 1, 1, 0>(inst + 2 + (size_t)N * 2 + to, slab, 0u, lane);
+            // dual_poly.rs:20-21 pos, neg; :24-27 products (all zero)
+#pragma unroll 1
+            for (int q4 = 0; q4 < 4; q4++) {                                       // v.pos, v.neg, sig.pos, sig.neg
+                const uint16_t *src = q4 == 0 ? sm.vp : q4 == 1 ? sm.vn : q4 == 2 ? sm.sp : sm.sn;
+                const size_t lin = q4 == 0 ? (size_t)3 * N + 2 : q4 == 1 ? (size_t)4 * N + 2 : q4 == 2 ? (size_t)0 : (size_t)N;
+                const uint32_t val = src[k];
+                encode_u32<ENC>(val, e8); slab_put(slab, 0, lane, e8);
+                emit_tile<ENC, 1, 1, 0>(wit + lin * 2 + to, slab, 0u, lane);
+                // misc.rs:58-62 squares, in the order v.pos, v.neg, sig.pos, sig.neg
+                const uint32_t sq = val * val;
+                nrm += sq;
+                encode_u32<ENC>(sq, e8); slab_put(slab, 0, lane, e8);
+                emit_tile<ENC, 1, 1, 0>(wit + ((size_t)(182 + q4) * N + 4) * 2 + to, slab, 0u, lane);
+            }
+            emit_tile<ENC, 1, 0, 0>(wit + (size_t)2 * N * 2 + to, slab, 0u, lane);
+            emit_tile<ENC, 1, 0, 0>(wit + ((size_t)5 * N + 2) * 2 + to, slab, 0u, lane);
+        }
+        // pointwise (:95-116): 2N blocks of 30, block 2i = left, 2i+1 = right
+        for (int t = wave; t < 2 * TILES; t += WAVES) {
+            const int j = t * WAVE + lane, i = j >> 1;
+            const uint32_t pkv = sm.npk[i];
+            uint32_t prod, a;
+            if (j & 1) { prod = (uint32_t)sm.nsp[i] * pkv; a = sm.nvp[i] + prod; }              // right :109-114
+            else { prod = (uint32_t)sm.nsn[i] * pkv; a = sm.nhm[i] + sm.nvn[i] + prod; }        // left  :100-107
+            const uint32_t tq = a / Q, b = a - tq * Q;
+            encode_u32<ENC>(prod, e8); slab_put(slab, 0, lane, e8);
+            encode_u32<ENC>(tq, e8);   slab_put(slab, 1, lane, e8);
+            encode_u32<ENC>(b, e8);    slab_put(slab2, 0, lane, e8);
+            emit_tile<ENC, 30, 3, 0>(wit + ((size_t)122 * N + 4 + (size_t)t * WAVE * 30) * 2, slab, ltq_mask(b) << 3, lane, 0, slab2);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor((unsigned long long)nrm, off, WAVE);
+        if (lane == 0) atomicAdd(&sm.norm, nrm);
+        __syncthreads();
+        if (wave == 0) {                                                           // :131
+            const unsigned long long norm = sm.norm;
+            const unsigned long long nm = LOGN == 9 ? norm_mask_512(norm) : norm_mask_1024(norm);
+            v4u *o = wit + ((size_t)186 * N + 4) * 2;
+            for (int c = lane; c < NB * 2; c += WAVE) o[c] = (nm >> (c >> 1)) & 1ull ? one : mk4(0, 0, 0, 0);
+            if (lane == 0) g_status[s] = norm >= (LOGN == 9 ? 34034726ull : 70265242ull) ? ST_NORM_BOUND : ST_OK;
+        }
+        // four ladders (:85-92): sig.pos, sig.neg, v.pos, v.neg
+#pragma unroll 1
+        for (int which = 0; which < 4; which++) {
+            const uint16_t *in = which == 0 ? sm.sp : which == 1 ? sm.sn : which == 2 ? sm.vp : sm.vn;
+            ladder_lds<LOGN>(sm.lad, in, sm.tw, &tab->ck[0][0], tid);
+            v4u *seg = wit + ((size_t)(6 + 29 * which) * N + 4) * 2;
+            for (int t = wave; t < TILES; t += WAVES) {
+                const int k = t * WAVE + lane;
+                uint32_t a[5], q5[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) a[i] = sm.lad[i * N + k];
+                const uint32_t b = divmod_q_u160(a, q5);
+                encode_u160<ENC>(q5, e8); slab_put(slab, 0, lane, e8);
+                encode_u32<ENC>(b, e8);   slab_put(slab, 1, lane, e8);
+                emit_tile<ENC, 29, 2, 0>(seg + (size_t)t * WAVE * 29 * 2, slab, ltq_mask(b) << 2, lane);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernel: NTTPolyVar::ntt_circuit alone (poly.rs:104-159): N mod_q blocks + the reduced NTT
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
@@ -835,6 +1002,29 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queu
                                        occ[(LOGN - 9) * 2 + ENC]);                                             \
         hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, \
                            batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                               \
+    } while (0)
+    if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);
+    else if (logn == 9) FRW_LAUNCH(9, 1);
+    else if (enc == 0) FRW_LAUNCH(10, 0);
+    else FRW_LAUNCH(10, 1);
+#undef FRW_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_witness_dual_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc,
+                                          size_t batch, const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
+                                          uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+    if (qe != hipSuccess) return qe;
+    static int occ[4] = {0, 0, 0, 0};
+#define FRW_LAUNCH(LOGN, ENC)                                                                                       \
+    do {                                                                                                            \
+        const int grid = resident_grid(witness_dual_ntt_verify_kernel<LOGN, ENC>, batch, num_cu,                    \
+                                       occ[(LOGN - 9) * 2 + ENC]);                                                  \
+        hipLaunchKernelGGL((witness_dual_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, \
+                           batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                                    \
     } while (0)
     if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);
     else if (logn == 9) FRW_LAUNCH(9, 1);

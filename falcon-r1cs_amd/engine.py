@@ -10,7 +10,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from ._lib import FrwError, LayoutStruct, check, load_library
+from ._lib import FrwError, LayoutDualStruct, LayoutStruct, check, load_library
 
 ENC_CANONICAL, ENC_MONTGOMERY = 0, 1
 ST_OK, ST_COEFF_RANGE, ST_NORM_BOUND, ST_DECODE = 0, 1, 2, 3
@@ -35,6 +35,13 @@ class Layout:
 def layout(logn) -> Layout:
     s = LayoutStruct()
     check(load_library().frw_layout(int(logn), C.byref(s)), "frw_layout")
+    return Layout(s.logn, s.n, s.num_witness, s.num_instance, s.num_constraints, tuple(s.seg_off), tuple(s.seg_len))
+
+
+def layout_dual(logn) -> Layout:
+    """Layout of FalconDualNTTVerificationCircuit's witness (frw_layout_dual; 15 segments)."""
+    s = LayoutDualStruct()
+    check(load_library().frw_layout_dual(int(logn), C.byref(s)), "frw_layout_dual")
     return Layout(s.logn, s.n, s.num_witness, s.num_instance, s.num_constraints, tuple(s.seg_off), tuple(s.seg_len))
 
 
@@ -74,9 +81,13 @@ class WitnessEngine:
     __del__ = close
 
     # ---- host buffers ------------------------------------------------------------------
-    def witness_ntt_verify(self, logn, sig, pk, hm, encoding=ENC_MONTGOMERY, strict=True):
+    def witness_dual_ntt_verify(self, logn, sig, pk, hm, encoding=ENC_MONTGOMERY, strict=True):
+        """FalconDualNTTVerificationCircuit (falcon_dual_ntt.rs:26-132); same conventions as witness_ntt_verify."""
+        return self.witness_ntt_verify(logn, sig, pk, hm, encoding, strict, dual=True)
+
+    def witness_ntt_verify(self, logn, sig, pk, hm, encoding=ENC_MONTGOMERY, strict=True, dual=False):
         """-> (witness u64[batch, W, 4], instance u64[batch, I, 4], status i32[batch])."""
-        L = layout(logn)
+        L = layout_dual(logn) if dual else layout(logn)
         sig, pk, hm = (_u16(a, L.n) for a in (sig, pk, hm))
         batch = sig.shape[0]
         if pk.shape[0] != batch or hm.shape[0] != batch:
@@ -85,8 +96,8 @@ class WitnessEngine:
         inst = np.zeros((batch, L.num_instance, 4), dtype=np.uint64)
         st = np.zeros(batch, dtype=np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        rc = self._lib.frw_witness_ntt_verify(self._ctx, logn, batch, p(sig), p(pk), p(hm), encoding,
-                                              p(wit), p(inst), p(st), 1 if strict else 0)
+        fn = self._lib.frw_witness_dual_ntt_verify if dual else self._lib.frw_witness_ntt_verify
+        rc = fn(self._ctx, logn, batch, p(sig), p(pk), p(hm), encoding, p(wit), p(inst), p(st), 1 if strict else 0)
         if rc == E_RANGE:
             bad = np.nonzero(st)[0]
             raise FrwError(rc, "frw_witness_ntt_verify",
@@ -159,6 +170,13 @@ class WitnessEngine:
                                                    self._ptr(d_hm), encoding, self._ptr(d_wit), self._ptr(d_inst),
                                                    self._ptr(d_status), C.c_void_p(stream)),
               "frw_witness_ntt_verify_dev")
+
+    def witness_dual_ntt_verify_dev(self, logn, batch, d_sig, d_pk, d_hm, d_wit, d_inst, d_status,
+                                    encoding=ENC_MONTGOMERY, stream=0):
+        check(self._lib.frw_witness_dual_ntt_verify_dev(self._ctx, logn, batch, self._ptr(d_sig), self._ptr(d_pk),
+                                                        self._ptr(d_hm), encoding, self._ptr(d_wit), self._ptr(d_inst),
+                                                        self._ptr(d_status), C.c_void_p(stream)),
+              "frw_witness_dual_ntt_verify_dev")
 
     def ntt_modq_dev(self, logn, batch, d_poly, d_wit, d_ntt, d_status, encoding=ENC_MONTGOMERY, stream=0):
         check(self._lib.frw_ntt_modq_dev(self._ctx, logn, batch, self._ptr(d_poly), encoding, self._ptr(d_wit),

@@ -129,6 +129,33 @@ int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
 int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int encoding,
                  uint64_t *witness, uint16_t *ntt_out, int32_t *status);
 
+/* ---- the signed-split variant: FalconDualNTTVerificationCircuit (circuits/falcon_dual_ntt.rs:26-132) -----------
+ * Same statement, signature and v split into non-negative (pos, neg) parts (gadgets/dual_poly.rs:15-31), four
+ * ntt_circuits, two mod_q per NTT coefficient, squares without range checks (gadgets/misc.rs:55-65).
+ * W = 186 N + 4 + {50|52}, I = 2 N + 1, C = 189 N + 10 + {50|52}.  Segment order (allocation order):
+ *   0 sig.pos N | 1 sig.neg N | 2 pos*neg products N | 3 is_zero [is_not_equal, multiplier] 2
+ *   4 v.pos N | 5 v.neg N | 6 products N | 7 is_zero 2
+ *   8..11 mod_q blocks of ntt_circuit(sig.pos), (sig.neg), (v.pos), (v.neg), 29 N each
+ *   12 per coefficient [sig_ntt.neg*pk_ntt, t, b, ltq(b)] [sig_ntt.pos*pk_ntt, t, b, ltq(b)], 60 N
+ *   13 squares of v.pos, v.neg, sig.pos, sig.neg, 4 N | 14 norm bound
+ * The signed lift uses the threshold q/2 = 6144 (falcon-rust's DualPolynomial; un-vendored). */
+#define FRW_NUM_SEGMENTS_DUAL 15
+typedef struct frw_layout_dual {
+    int32_t logn, n, num_witness, num_instance, num_constraints;
+    int32_t seg_off[FRW_NUM_SEGMENTS_DUAL];
+    int32_t seg_len[FRW_NUM_SEGMENTS_DUAL];
+} frw_layout_dual_t;
+
+int frw_layout_dual(int logn, frw_layout_dual_t *out);
+int frw_witness_dual_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch,
+                                    const uint16_t *d_sig, const uint16_t *d_pk, const uint16_t *d_hm,
+                                    int encoding, uint64_t *d_witness, uint64_t *d_instance,
+                                    int32_t *d_status, void *stream);
+int frw_witness_dual_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
+                                const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
+                                int encoding, uint64_t *witness, uint64_t *instance,
+                                int32_t *status, int strict);
+
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),
  * hm = Polynomial::from_hash_of_message(msg, sig.nonce()).  Formats are the Falcon specification's:

@@ -210,6 +210,23 @@ class AllocatedFp:
     def negate(self):
         return AllocatedFp(self.cs, -self.value, self.cs.new_lc([(self.cs.p - 1, self.variable)]))
 
+    def is_neq(self, o):
+        # AllocatedFp::is_neq: Boolean witness is_not_equal (with booleanity) + multiplier witness (no variable of
+        # its own type: a bare cs.new_witness_variable), then
+        #   (self - other) * multiplier = is_not_equal ;  (self - other) * not(is_not_equal) = 0
+        cs = self.cs
+        ne = self.value != o.value
+        is_not_equal = Boolean.new_witness(cs, ne)
+        mult = pow((self.value - o.value) % cs.p, cs.p - 2, cs.p) if ne else 1
+        mvar = cs.new_witness_variable(mult)
+        diff = [(1, self.variable), (cs.p - 1, o.variable)]
+        cs.enforce_constraint(diff, [(1, mvar)], is_not_equal.lc())
+        cs.enforce_constraint(diff, is_not_equal.not_().lc(), [])
+        return is_not_equal
+
+    def is_eq(self, o):
+        return self.is_neq(o).not_()
+
     def conditional_enforce_equal(self, o, should_enforce):
         # (self - other) * should_enforce = 0
         self.cs.enforce_constraint(
@@ -283,6 +300,14 @@ class FpVar:
             return FpVar(const=1 if b.const else 0)
         cs = b.ab.cs
         return FpVar(var=AllocatedFp(cs, 1 if b.value() else 0, cs.new_lc(b.lc())))
+
+    def is_zero(self):
+        # FieldVar::is_zero = self.is_eq(&Self::zero()); FpVar::is_eq with a Constant operand wraps the constant in
+        # an AllocatedFp (new_constant) and calls c.is_eq(v): the constant is `self` of AllocatedFp::is_neq
+        if self.var is None:
+            return Boolean.constant(self.const == 0)
+        c = AllocatedFp.new_constant(self.var.cs, 0)
+        return c.is_eq(self.var)
 
     def enforce_equal(self, o):
         # EqGadget::enforce_equal -> conditional_enforce_equal(other, &Boolean::TRUE)

@@ -360,6 +360,82 @@ class FalconNTTVerificationCircuit:
 
 
 # ---------------------------------------------------------------------------------------
+# gadgets/dual_poly.rs + circuits/falcon_dual_ntt.rs  
+# ---------------------------------------------------------------------------------------
+MODULUS_OVER_TWO = 6144     # falcon-rust: threshold of the signed lift; unpinned (falcon-rust is not under /root/reference)
+
+
+def dual_from_poly(poly):
+    """falcon-rust DualPolynomial::from(&Polynomial): c < q/2 -> (c, 0) else (0, q - c); pos - neg = poly mod q."""
+    pos = [c if c < MODULUS_OVER_TWO else 0 for c in poly]
+    neg = [0 if c < MODULUS_OVER_TWO else MODULUS - c for c in poly]
+    return pos, neg
+
+
+def l2_norm_var_without_range_check(inputs):
+    """misc.rs:55-65 -- sum of squares, one product witness per element."""
+    res = None
+    for e in inputs:
+        sq = e * e
+        res = sq if res is None else res + sq
+    return res
+
+
+def dual_poly_alloc_vars(cs, pos, neg, mode):
+    """dual_poly.rs:15-31 -- pos, neg, then sum(pos[i]*neg[i]) == 0 via is_zero (N products + 2 witnesses)."""
+    p = alloc_vars(cs, pos, mode)
+    n = alloc_vars(cs, neg, mode)
+    acc = p[0] * n[0]
+    for a, b in zip(p[1:], n[1:]):
+        acc = acc + a * b
+    acc.is_zero().enforce_equal_const(True)
+    return p, n
+
+
+class FalconDualNTTVerificationCircuit:
+    """falcon_dual_ntt.rs:8-17, built from the coefficient vectors falcon-rust derives (:27-28,:43)."""
+
+    def __init__(self, sig, pk, hm, logn):
+        n = 1 << logn
+        assert len(sig) == len(pk) == len(hm) == n
+        self.sig, self.pk, self.hm, self.logn = list(sig), list(pk), list(hm), logn
+
+    def generate_constraints(self, cs: ConstraintSystem, strict=False):
+        """falcon_dual_ntt.rs:26-132."""
+        logn = self.logn
+        n = 1 << logn
+        sig_pos, sig_neg = dual_from_poly(self.sig)                # :27  (DualPolynomial from the signed signature)
+        consts = const_q_power_vars(cs, logn)                      # :31-39
+        param_vars = ntt_param_var(cs, logn)                       # :40
+        hm_ntt = ntt_clear(self.hm, logn)                          # :45
+        uh_pos = poly_mul_clear(sig_pos, self.pk)                  # :48
+        uh_neg = poly_mul_clear(sig_neg, self.pk)                  # :49
+        v = [(h - a + b) % MODULUS for h, a, b in zip(self.hm, uh_pos, uh_neg)]   # :50
+        v_pos, v_neg = dual_from_poly(v)                           # :51
+        pk_ntt = ntt_clear(self.pk, logn)                          # :53
+        sp, sn = dual_poly_alloc_vars(cs, sig_pos, sig_neg, "Witness")             # :60-61
+        pk_ntt_vars = alloc_vars(cs, pk_ntt, "Input")              # :65
+        hm_ntt_vars = alloc_vars(cs, hm_ntt, "Input")              # :69
+        vp, vn = dual_poly_alloc_vars(cs, v_pos, v_neg, "Witness") # :73
+        sp_ntt = ntt_circuit(cs, sp, consts, param_vars, logn, strict)             # :85-90 (pos then neg, dual_poly.rs:47-48)
+        sn_ntt = ntt_circuit(cs, sn, consts, param_vars, logn, strict)
+        vp_ntt = ntt_circuit(cs, vp, consts, param_vars, logn, strict)             # :91-92
+        vn_ntt = ntt_circuit(cs, vn, consts, param_vars, logn, strict)
+        for i in range(n):                                         # :95-116
+            left = mod_q(cs, hm_ntt_vars[i] + vn_ntt[i] + sn_ntt[i] * pk_ntt_vars[i], consts[0], strict)
+            right = mod_q(cs, vp_ntt[i] + sp_ntt[i] * pk_ntt_vars[i], consts[0], strict)
+            left.enforce_equal(right)
+        l2 = l2_norm_var_without_range_check(vp + vn + sp + sn)    # :121-129
+        enforce_less_than_norm_bound(cs, l2, logn, strict)         # :131
+
+
+def run_reference_flow_dual(sig, pk, hm, logn, strict=False):
+    cs = ConstraintSystem()
+    FalconDualNTTVerificationCircuit(sig, pk, hm, logn).generate_constraints(cs, strict)
+    return cs
+
+
+# ---------------------------------------------------------------------------------------
 # Encodings of the assignment vectors
 # ---------------------------------------------------------------------------------------
 R_MONT = (1 << 256) % P_BLS12_381_FR  # ark-ff Fp256 Montgomery radix

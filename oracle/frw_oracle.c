@@ -408,6 +408,99 @@ int frw_oracle_witness_ntt_verify(int logn, size_t batch, const uint16_t *sig, c
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * circuits/falcon_dual_ntt.rs:26-132: the signed-split variant.
+ * Layout (allocation order), N = 1 << logn, nb = 50 | 52, W = 186 N + 4 + nb:
+ *   sig.pos N | sig.neg N | pos*neg products N | is_zero [is_not_equal, multiplier] 2      dual_poly.rs:20-29
+ *   v.pos N | v.neg N | products N | is_zero 2                                            falcon_dual_ntt.rs:73
+ *   mod_q blocks of ntt_circuit(sig.pos), (sig.neg), (v.pos), (v.neg): 4 x 29 N           :85-92, dual_poly.rs:47-48
+ *   per i: [sig_ntt.neg*pk_ntt, mod_q block (29)] [sig_ntt.pos*pk_ntt, mod_q block (29)]   :95-116    60 N
+ *   squares of v.pos, v.neg, sig.pos, sig.neg   4 N                                        :121-129, misc.rs:55-65
+ *   norm bound nb                                                                          :131
+ * ------------------------------------------------------------------------------------------- */
+static fr_t *emit_dual_alloc(fr_t *w, const enc_t *e, const uint32_t *pos, const uint32_t *neg, int n)
+{
+    uint64_t acc = 0;
+    for (int i = 0; i < n; i++) fr_encode_small(w++, pos[i], e->encoding);
+    for (int i = 0; i < n; i++) fr_encode_small(w++, neg[i], e->encoding);
+    for (int i = 0; i < n; i++) { uint64_t pr = (uint64_t)pos[i] * neg[i]; acc += pr; fr_encode_small(w++, pr, e->encoding); }
+    /* AllocatedFp::is_neq: is_not_equal = (acc != 0); multiplier = acc^-1 if so, else 1.  A DualPolynomial has
+     * pos[i]*neg[i] = 0 for every i, so acc = 0 on this path. */
+    put_bit(w++, e, acc != 0);
+    *w++ = e->one;
+    return w;
+}
+
+static fr_t *emit_mod_q_small(fr_t *w, const enc_t *e, uint64_t a)
+{
+    u192 v = {{a, 0, 0}};
+    uint32_t b;
+    return emit_mod_q(w, e, &v, &b);
+}
+
+static int witness_dual_one(int logn, const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
+                            int encoding, fr_t *wit, fr_t *inst, u192 *scratch)
+{
+    int n = 1 << logn;
+    uint32_t sp[1024], sn[1024], vp[1024], vn[1024], pkn[1024], hmn[1024], s[1024], v[1024];
+    uint32_t b_sp[1024], b_sn[1024], b_vp[1024], b_vn[1024];
+    enc_t e; e.encoding = encoding;
+    memset(&e.zero, 0, sizeof e.zero);
+    fr_encode_small(&e.one, 1, encoding);
+    for (int i = 0; i < n; i++) {
+        if (sig[i] >= Q || pk[i] >= Q || hm[i] >= Q) return 1;
+        s[i] = sig[i]; pkn[i] = pk[i]; hmn[i] = hm[i];
+        sp[i] = sig[i] < 6144 ? sig[i] : 0;                        /* DualPolynomial: signed split */
+        sn[i] = sig[i] < 6144 ? 0 : Q - sig[i];
+    }
+    ntt_modq(hmn, logn); ntt_modq(pkn, logn); ntt_modq(s, logn);
+    for (int i = 0; i < n; i++) v[i] = (hmn[i] + Q - s[i] * pkn[i] % Q) % Q;      /* v = hm - uh_pos + uh_neg  :48-50 */
+    intt_modq(v, logn);
+    for (int i = 0; i < n; i++) { vp[i] = v[i] < 6144 ? v[i] : 0; vn[i] = v[i] < 6144 ? 0 : Q - v[i]; }   /* :51 */
+
+    inst[0] = e.one;
+    for (int i = 0; i < n; i++) fr_encode_small(&inst[1 + i], pkn[i], encoding);
+    for (int i = 0; i < n; i++) fr_encode_small(&inst[1 + n + i], hmn[i], encoding);
+
+    fr_t *w = wit;
+    w = emit_dual_alloc(w, &e, sp, sn, n);                                       /* :60-61 */
+    w = emit_dual_alloc(w, &e, vp, vn, n);                                       /* :73 */
+    w = emit_ntt_circuit(w, &e, sp, logn, b_sp, scratch);                        /* :85-90 */
+    w = emit_ntt_circuit(w, &e, sn, logn, b_sn, scratch);
+    w = emit_ntt_circuit(w, &e, vp, logn, b_vp, scratch);                        /* :91-92 */
+    w = emit_ntt_circuit(w, &e, vn, logn, b_vn, scratch);
+    for (int i = 0; i < n; i++) {                                                /* :95-116 */
+        uint64_t prl = (uint64_t)b_sn[i] * pkn[i];
+        fr_encode_small(w++, prl, encoding);
+        w = emit_mod_q_small(w, &e, hmn[i] + b_vn[i] + prl);
+        uint64_t prr = (uint64_t)b_sp[i] * pkn[i];
+        fr_encode_small(w++, prr, encoding);
+        w = emit_mod_q_small(w, &e, b_vp[i] + prr);
+    }
+    uint64_t norm = 0;                                                           /* :121-129 */
+    const uint32_t *parts[4] = {vp, vn, sp, sn};
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < n; i++) { uint64_t sq = (uint64_t)parts[k][i] * parts[k][i]; norm += sq; fr_encode_small(w++, sq, encoding); }
+    w = logn == 9 ? emit_norm_512(w, &e, norm) : emit_norm_1024(w, &e, norm);    /* :131 */
+    return norm >= SIG_L2_BOUND[logn - 9] ? 2 : 0;
+}
+
+int frw_oracle_dual_num_witness(int logn) { return 186 * (1 << logn) + 4 + (logn == 9 ? 50 : 52); }
+
+int frw_oracle_witness_dual_ntt_verify(int logn, size_t batch, const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
+                                       int encoding, uint64_t *witness, uint64_t *instance, int32_t *status)
+{
+    if ((logn != 9 && logn != 10) || (encoding != 0 && encoding != 1)) return -1;
+    pthread_once(&tables_once, init_tables);
+    size_t n = (size_t)1 << logn, W = (size_t)frw_oracle_dual_num_witness(logn), I = 2 * n + 1;
+    u192 *scratch = (u192 *)malloc(sizeof(u192) * n);
+    for (size_t i = 0; i < batch; i++)
+        status[i] = witness_dual_one(logn, sig + i * n, pk + i * n, hm + i * n, encoding, (fr_t *)witness + i * W,
+                                     (fr_t *)instance + i * I, scratch);
+    free(scratch);
+    return 0;
+}
+
 /* gadgets/poly.rs:104-159 alone (the reference's "ntt conversion" row, examples/constraint_counts.rs:74-113):
  * witness: batch x 29N x 4 u64 (the N mod_q blocks); ntt_out: batch x N (the b values == NTTPolynomial::from) */
 int frw_oracle_ntt_modq(int logn, size_t batch, const uint16_t *poly, int encoding, uint64_t *witness, uint16_t *ntt_out)

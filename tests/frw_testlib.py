@@ -31,6 +31,8 @@ class Oracle:
             [C.c_void_p] * 3 + [C.c_int]
         lib.frw_oracle_ntt_modq.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.frw_oracle_ntt_clear.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        lib.frw_oracle_witness_dual_ntt_verify.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int] + \
+            [C.c_void_p] * 3
         lib.frw_oracle_digest.argtypes = [C.c_void_p, C.c_size_t]
         lib.frw_oracle_digest.restype = C.c_uint64
         self.lib = lib
@@ -51,6 +53,18 @@ class Oracle:
         rc = self.lib.frw_oracle_witness_ntt_verify(logn, batch, p(sig), p(pk), p(hm), encoding, p(wit), p(inst),
                                                     p(st), threads)
         assert rc == 0
+        return wit, inst, st
+
+    def witness_dual_ntt_verify(self, logn, sig, pk, hm, encoding=1):
+        n = 1 << logn
+        sig, pk, hm = (np.ascontiguousarray(a, dtype=np.uint16).reshape(-1, n) for a in (sig, pk, hm))
+        batch = sig.shape[0]
+        wit = np.zeros((batch, self.lib.frw_oracle_dual_num_witness(logn), 4), dtype=np.uint64)
+        inst = np.zeros((batch, 2 * n + 1, 4), dtype=np.uint64)
+        st = np.zeros(batch, dtype=np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert self.lib.frw_oracle_witness_dual_ntt_verify(logn, batch, p(sig), p(pk), p(hm), encoding, p(wit), p(inst),
+                                                           p(st)) == 0
         return wit, inst, st
 
     def ntt_modq(self, logn, poly, encoding=1):

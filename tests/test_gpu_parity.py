@@ -297,3 +297,26 @@ def test_input_preparation_matches_codec_oracle(engine, oracle, logn):
     wit, inst, stw = engine.witness_ntt_verify(logn, sig2, pk2, hm2, 1, strict=False)
     owit, oinst, ost = oracle.witness_ntt_verify(logn, sig2, pk2, hm2, 1)
     assert stw.tolist() == ost.tolist() and np.array_equal(wit, owit) and np.array_equal(inst, oinst)
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+@pytest.mark.parametrize("enc", [0, 1])
+def test_dual_witness_matches_oracle(engine, oracle, logn, enc):
+    """falcon_dual_ntt.rs:26-132 end to end."""
+    import falcon_r1cs_amd as frw
+    sig, pk, hm = frw.synth_triples(logn, 5, seed=777 + logn)
+    wit, inst, st = engine.witness_dual_ntt_verify(logn, sig, pk, hm, enc, strict=True)
+    owit, oinst, ost = oracle.witness_dual_ntt_verify(logn, sig, pk, hm, enc)
+    assert st.tolist() == ost.tolist() == [0] * 5
+    assert np.array_equal(inst, oinst), _first_diff(inst, oinst)
+    assert np.array_equal(wit, owit), _first_diff(wit, owit)
+    # status paths: norm above the bound (permissive), coefficient out of range
+    rng = random.Random(3)
+    bs, bp, bh, bv = T.random_triple(logn, rng, scale=1.6)
+    bad = sig[0].copy()
+    bad[0] = T.Q
+    S, P, H = np.stack([bs, bad]), np.stack([bp, pk[0]]), np.stack([bh, hm[0]])
+    wit, inst, st = engine.witness_dual_ntt_verify(logn, S, P, H, enc, strict=False)
+    owit, oinst, ost = oracle.witness_dual_ntt_verify(logn, S, P, H, enc)
+    assert st.tolist() == ost.tolist() == [frw.ST_NORM_BOUND, frw.ST_COEFF_RANGE]
+    assert np.array_equal(wit[0], owit[0]) and np.array_equal(inst[0], oinst[0])

@@ -340,3 +340,31 @@ def test_hash_to_point_matches_fips202_stream():
             if w < 61445:
                 first.append(w % Q)
         assert hm[:len(first)] == first
+
+
+# ---------------------------------------------------------------------------------------------
+# the signed-split variant: falcon_dual_ntt.rs / dual_poly.rs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("logn", [9, 10])
+def test_dual_circuit_oracles_agree_and_are_satisfied(oracle, logn):
+    import falcon_r1cs_amd as frw
+    rng = random.Random(91 + logn)
+    sig, pk, hm, _ = T.random_triple(logn, rng)
+    cs = G.run_reference_flow_dual(sig.tolist(), pk.tolist(), hm.tolist(), logn, strict=True)
+    assert cs.is_satisfied()                                            # falcon_dual_ntt.rs:168
+    L = frw.layout_dual(logn)
+    assert (cs.num_instance_variables(), cs.num_witness_variables(), cs.num_constraints()) == \
+        (L.num_instance, L.num_witness, L.num_constraints)
+    n = 1 << logn
+    assert L.num_witness == 186 * n + 4 + (50 if logn == 9 else 52)
+    for enc in (0, 1):
+        wit, inst, st = oracle.witness_dual_ntt_verify(logn, sig, pk, hm, enc)
+        assert st[0] == 0
+        assert wit.tobytes() == G.encode_elements(cs.witness_assignment, enc == 1)
+        assert inst.tobytes() == G.encode_elements(cs.instance_assignment, enc == 1)
+    # a tampered "pos" part (both pos and neg non-zero at one index) must break the pos*neg = 0 check
+    cs2 = ConstraintSystem()
+    pos, neg = G.dual_from_poly(sig.tolist())
+    pos[3], neg[3] = 5, 7
+    G.dual_poly_alloc_vars(cs2, pos, neg, "Witness")
+    assert not cs2.is_satisfied()
