@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="signatures per GPU per step")
     ap.add_argument("--chunk", type=int, default=4096, help="signatures per kernel launch (HBM witness buffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--circuit", default="ntt", choices=["ntt", "dual"],
+                    help="ntt = FalconNTTVerificationCircuit (default, the BASELINE metric); dual = the signed-split "
+                         "FalconDualNTTVerificationCircuit (SURVEY 8-f row 2; not the headline metric)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL over xGMI, the default) or gloo (rehearsal of "
                          "the N > 1 code path with several ranks sharing one GPU)")
@@ -235,8 +238,10 @@ def main():
     if args.workload == "prepare":
         return bench_prepare(args, world, rank, dev)
     logn, batch, chunk = args.logn, args.batch, min(args.chunk, args.batch)
-    L = frw.layout(logn)
+    dual = args.circuit == "dual"
+    L = frw.layout_dual(logn) if dual else frw.layout(logn)
     eng = frw.WitnessEngine(dev_index)
+    launch = eng.witness_dual_ntt_verify_dev if dual else eng.witness_ntt_verify_dev
     threads = max(1, min(os.cpu_count() or 1, 16) // world)
 
     # ---- inputs resident in HBM -------------------------------------------------------------
@@ -257,8 +262,8 @@ def main():
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            eng.witness_ntt_verify_dev(logn, cnt, d_sig[a:a + cnt], d_pk[a:a + cnt], d_hm[a:a + cnt], d_wit, d_inst,
-                                       d_st[a:a + cnt], frw.ENC_MONTGOMERY, stream.cuda_stream)
+            launch(logn, cnt, d_sig[a:a + cnt], d_pk[a:a + cnt], d_hm[a:a + cnt], d_wit, d_inst,
+                   d_st[a:a + cnt], frw.ENC_MONTGOMERY, stream.cuda_stream)
             if events is not None:
                 e1.record(stream)
                 events.append((e0, e1, cnt))
@@ -296,24 +301,24 @@ def main():
         e0.record(stream)
         eng.diag_write_stream_dev(d_wit, wbytes, L.num_witness * 32, stream.cuda_stream)
         e1.record(stream)
-        eng.witness_ntt_verify_dev(logn, chunk, d_sig[:chunk], d_pk[:chunk], d_hm[:chunk], d_wit, d_inst, d_st[:chunk],
-                                   frw.ENC_MONTGOMERY, stream.cuda_stream)      # keep the device in its loaded state
+        launch(logn, chunk, d_sig[:chunk], d_pk[:chunk], d_hm[:chunk], d_wit, d_inst, d_st[:chunk],
+               frw.ENC_MONTGOMERY, stream.cuda_stream)      # keep the device in its loaded state
         cal.append((e0, e1))
     torch.cuda.synchronize()
     cal_ms = sorted(a.elapsed_time(b) for a, b in cal[1:])
     write_stream_gbs = wbytes / (cal_ms[len(cal_ms) // 2] * 1e-3) / 1e9
 
     result = None
-    traffic = measured_traffic(logn, chunk)
+    traffic = None if dual else measured_traffic(logn, chunk)
     if rank == 0:
         value = world * batch * args.steps / elapsed
         result = {
-            "metric": "falcon%d_verify_with_ntt_r1cs_witnesses_per_sec" % n, "value": round(value, 1),
+            "metric": "falcon%d_verify_with_%sntt_r1cs_witnesses_per_sec" % (n, "dual_" if dual else ""), "value": round(value, 1),
             "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "falcon-%d full verify-with-ntt witness (NTT ladder + mod_q + pointwise + l2-norm), "
-                                   "batch=%d signatures per GPU per step" % (n, batch),
+            "config": {"workload": "falcon-%d full verify-with-%sntt witness (NTT ladder + mod_q + pointwise + l2-norm), "
+                                   "batch=%d signatures per GPU per step" % (n, "dual-" if dual else "", batch),
                        "logn": logn, "batch_per_gpu": batch, "chunk": chunk, "launches_per_step": nchunks,
                        "encoding": "bls12-381-fr montgomery (arkworks witness_assignment bytes)",
                        "seed": hex(SEED), "sharding": "by signature index, no data-path collective",
@@ -322,13 +327,13 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "witness_ntt_verify_kernel<%d,1>" % logn,
+                         "kernel": "witness_%sntt_verify_kernel<%d,1>" % ("dual_" if dual else "", logn),
                          "algorithmic_bytes_per_launch": chunk * bytes_per_sig,
                          "avg_launch_ms": round(launch_ms, 4), "launches_timed": len(full),
                          "device_write_stream_GBs": round(write_stream_gbs, 1),
                          "frac_of_device_write_stream": round(achieved / write_stream_gbs, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dual:
             # digests of the first launch's witnesses (recomputed: the buffer holds the last chunk now)
             k = min(512, chunk)
             dig = torch.zeros(k, dtype=torch.int64, device=dev)

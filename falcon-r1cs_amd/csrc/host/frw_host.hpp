@@ -288,6 +288,7 @@ public:
         cs->enforce_constraint({{Fr::one(), x}, {-Fr::one(), y}}, {{Fr::one(), VarOne()}}, {});
     }
 
+    Boolean is_zero() const;       // FieldVar::is_zero = is_eq(&zero): AllocatedFp::is_neq, 2 witnesses / 3 constraints
     static FpVar from_boolean(const Boolean &b);
     static FpVar conditionally_select(const Boolean &cond, const FpVar &t, const FpVar &f);
 
@@ -430,6 +431,20 @@ inline FpVar FpVar::from_boolean(const Boolean &b)
 {
     if (b.kind() == Boolean::Constant) return constant(b.value() ? Fr::one() : Fr::zero());
     return var(b.cs(), b.value() ? Fr::one() : Fr::zero(), b.cs()->new_lc(b.lc()));
+}
+
+// AllocatedFp::is_neq(c, v) with c = new_constant(0): is_not_equal (Boolean witness, with booleanity) and the
+// multiplier (bare witness variable), then (c - v) * multiplier = is_not_equal and (c - v) * !is_not_equal = 0.
+inline Boolean FpVar::is_zero() const
+{
+    if (is_constant()) return Boolean::constant(value_.is_zero());
+    Variable zero = cs_->new_lc({{Fr::zero(), VarOne()}});
+    Boolean is_not_equal = Boolean::new_witness_from_engine(cs_, "is_zero is_not_equal");
+    Variable mult = cs_->new_witness_variable(cs_->pop_feed("is_zero multiplier"));
+    LinearCombination diff{{Fr::one(), zero}, {-Fr::one(), variable_}};
+    cs_->enforce_constraint(diff, {{Fr::one(), mult}}, is_not_equal.lc());
+    cs_->enforce_constraint(diff, is_not_equal.not_().lc(), {});
+    return is_not_equal.not_();
 }
 
 inline FpVar FpVar::conditionally_select(const Boolean &cond, const FpVar &t, const FpVar &f)
@@ -856,6 +871,119 @@ private:
     Signature sig_bytes_;
     std::vector<uint8_t> msg_;
     bool from_bytes_ = false;
+    int logn_ = 10;
+    const uint64_t *preset_wit_ = nullptr, *preset_inst_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// gadgets/dual_poly.rs, gadgets/misc.rs:55-65, circuits/falcon_dual_ntt.rs  (the signed-split variant)
+// ---------------------------------------------------------------------------------------------------------------
+struct DualPolynomial { Polynomial pos, neg; };
+
+// misc.rs:55-65
+inline FpVar l2_norm_var_without_range_check(const std::vector<FpVar> &input)
+{
+    std::optional<FpVar> res;
+    for (const FpVar &e : input) { FpVar sq = e * e; res = res ? *res + sq : sq; }
+    return *res;
+}
+
+struct DualPolyVar {
+    PolyVar pos, neg;
+    // dual_poly.rs:15-31
+    static DualPolyVar alloc_vars(const ConstraintSystemRef &cs, const DualPolynomial &dual_poly, AllocationMode mode)
+    {
+        DualPolyVar r;
+        r.pos = PolyVar::alloc_vars(cs, dual_poly.pos, mode);
+        r.neg = PolyVar::alloc_vars(cs, dual_poly.neg, mode);
+        FpVar acc = r.pos.coeff()[0] * r.neg.coeff()[0];
+        for (size_t i = 1; i < r.pos.coeff().size(); i++) acc = acc + r.pos.coeff()[i] * r.neg.coeff()[i];
+        acc.is_zero().enforce_equal(Boolean::TRUE_());
+        return r;
+    }
+};
+
+struct DualNTTPolyVar {
+    NTTPolyVar pos, neg;
+    // dual_poly.rs:41-51
+    static DualNTTPolyVar ntt_circuit(const ConstraintSystemRef &cs, const DualPolyVar &input, const std::vector<FpVar> &const_vars,
+                                      const std::vector<FpVar> &param, int logn)
+    {
+        DualNTTPolyVar r;
+        r.pos = NTTPolyVar::ntt_circuit(cs, input.pos, const_vars, param, logn);
+        r.neg = NTTPolyVar::ntt_circuit(cs, input.neg, const_vars, param, logn);
+        return r;
+    }
+};
+
+class FalconDualNTTVerificationCircuit {
+public:
+    // falcon_dual_ntt.rs:15-17, from the coefficient vectors falcon-rust derives (:27-28,:43)
+    static FalconDualNTTVerificationCircuit build_circuit(Polynomial pk, Polynomial hm, Polynomial sig, int logn)
+    {
+        const size_t N = (size_t)1 << logn;
+        if (pk.c.size() != N || hm.c.size() != N || sig.c.size() != N) throw std::invalid_argument("input length is not N");
+        FalconDualNTTVerificationCircuit c;
+        c.pk_ = std::move(pk); c.hm_ = std::move(hm); c.sig_ = std::move(sig); c.logn_ = logn;
+        return c;
+    }
+    void use_engine_output(const uint64_t *witness_slice, const uint64_t *instance_slice) { preset_wit_ = witness_slice; preset_inst_ = instance_slice; }
+
+    // falcon_dual_ntt.rs:26-132
+    void generate_constraints(const ConstraintSystemRef &cs) const
+    {
+        const int logn = logn_;
+        const size_t N = (size_t)1 << logn;
+        NTTPolynomial pk_ntt{std::vector<uint16_t>(N, 1)}, hm_ntt{std::vector<uint16_t>(N, 1)};
+        if (!cs->is_in_setup_mode()) {
+            frw_layout_dual_t L;
+            frw_layout_dual(logn, &L);
+            std::vector<uint64_t> wit_buf, inst_buf;
+            const uint64_t *wit = preset_wit_, *inst = preset_inst_;
+            if (!wit) {
+                detail::require_engine(cs, "FalconDualNTTVerificationCircuit");
+                wit_buf.resize((size_t)L.num_witness * 4);
+                inst_buf.resize((size_t)L.num_instance * 4);
+                int32_t st = 0;
+                int rc = frw_witness_dual_ntt_verify(cs->engine()->get(), logn, 1, sig_.c.data(), pk_.c.data(), hm_.c.data(),
+                                                     FRW_ENC_MONTGOMERY, wit_buf.data(), inst_buf.data(), &st, cs->strict() ? 1 : 0);
+                if (rc == FRW_E_RANGE) throw std::domain_error("Invalid input: range check failed (status " + std::to_string(st) + ")");
+                detail::check(rc, "frw_witness_dual_ntt_verify");
+                if (st == FRW_ST_COEFF_RANGE) throw std::domain_error("Invalid input: coefficient >= MODULUS");
+                wit = wit_buf.data();
+                inst = inst_buf.data();
+            }
+            cs->push_feed(wit, (size_t)L.num_witness);
+            for (size_t i = 0; i < N; i++) {
+                uint64_t c[4];
+                Fr::from_montgomery(&inst[4 * (1 + i)]).to_canonical(c); pk_ntt.c[i] = (uint16_t)c[0];
+                Fr::from_montgomery(&inst[4 * (1 + N + i)]).to_canonical(c); hm_ntt.c[i] = (uint16_t)c[0];
+            }
+        }
+        const DualPolynomial zero{Polynomial{std::vector<uint16_t>(N, 0)}, Polynomial{std::vector<uint16_t>(N, 0)}};   // values come from the engine
+        std::vector<FpVar> consts = const_q_power_vars(cs, logn);                                   // :31-39
+        std::vector<FpVar> param_vars = ntt_param_var(cs, logn);                                   // :40
+        DualPolyVar sig_poly_vars = DualPolyVar::alloc_vars(cs, zero, AllocationMode::Witness);    // :60-61
+        NTTPolyVar pk_ntt_vars = NTTPolyVar::alloc_vars(cs, pk_ntt, AllocationMode::Input);        // :65
+        NTTPolyVar hm_ntt_vars = NTTPolyVar::alloc_vars(cs, hm_ntt, AllocationMode::Input);        // :69
+        DualPolyVar v_vars = DualPolyVar::alloc_vars(cs, zero, AllocationMode::Witness);           // :73
+        DualNTTPolyVar sig_ntt_vars = DualNTTPolyVar::ntt_circuit(cs, sig_poly_vars, consts, param_vars, logn);   // :85-90
+        DualNTTPolyVar v_ntt_vars = DualNTTPolyVar::ntt_circuit(cs, v_vars, consts, param_vars, logn);            // :91-92
+        for (size_t i = 0; i < N; i++) {                                                           // :95-116
+            FpVar left = mod_q(cs, hm_ntt_vars.coeff()[i] + v_ntt_vars.neg.coeff()[i] + sig_ntt_vars.neg.coeff()[i] * pk_ntt_vars.coeff()[i], consts[0]);
+            FpVar right = mod_q(cs, v_ntt_vars.pos.coeff()[i] + sig_ntt_vars.pos.coeff()[i] * pk_ntt_vars.coeff()[i], consts[0]);
+            left.enforce_equal(right);
+        }
+        std::vector<FpVar> all = v_vars.pos.coeff();                                               // :121-129
+        for (const auto *part : {&v_vars.neg, &sig_poly_vars.pos, &sig_poly_vars.neg}) all.insert(all.end(), part->coeff().begin(), part->coeff().end());
+        FpVar l2 = l2_norm_var_without_range_check(all);
+        enforce_less_than_norm_bound(cs, l2, logn);                                                // :131
+        if (!cs->is_in_setup_mode() && cs->feed_remaining())
+            throw SynthesisError(SynthesisError::Engine, "engine produced more values than the circuit allocates");
+    }
+
+private:
+    Polynomial pk_, hm_, sig_;
     int logn_ = 10;
     const uint64_t *preset_wit_ = nullptr, *preset_inst_ = nullptr;
 };

@@ -73,6 +73,16 @@ static void count_table(int logn)
         EXPECT(cs->num_instance_variables() == (size_t)L.num_instance);
         EXPECT(cs->num_witness_variables() == (size_t)L.num_witness);
         EXPECT(cs->num_constraints() == (size_t)L.num_constraints);
+        {   // count_verify_with_dual_ntt_constraints, constraint_counts.rs:115-138 (numbers not in the README)
+            auto csd = ConstraintSystem::new_ref();
+            csd->set_setup_mode(true);
+            FalconDualNTTVerificationCircuit::build_circuit(z, z, z, logn).generate_constraints(csd);
+            std::printf("|verify with dual ntt|\t%8zu |\t%8zu |\t%8zu |\n", csd->num_instance_variables(), csd->num_witness_variables(), csd->num_constraints());
+            frw_layout_dual_t D;
+            frw_layout_dual(logn, &D);
+            EXPECT(csd->num_instance_variables() == (size_t)D.num_instance && csd->num_witness_variables() == (size_t)D.num_witness &&
+                   csd->num_constraints() == (size_t)D.num_constraints);
+        }
         const size_t want[2][3] = {{1025, 78386, 81460}, {2049, 156724, 162870}};     // README.md:55, :44
         EXPECT(cs->num_instance_variables() == want[logn - 9][0] && cs->num_witness_variables() == want[logn - 9][1] &&
                cs->num_constraints() == want[logn - 9][2]);
@@ -90,16 +100,22 @@ static std::vector<T> read_file(const char *path)
     return out;
 }
 
-static int check_external(int logn, char **files)
+static int check_external(int logn, char **files, bool dual)
 {
     Polynomial sig{read_file<uint16_t>(files[0])}, pk{read_file<uint16_t>(files[1])}, hm{read_file<uint16_t>(files[2])};
     auto wit = read_file<uint64_t>(files[3]);
     auto inst = read_file<uint64_t>(files[4]);
     auto cs = ConstraintSystem::new_ref();
     cs->attach_engine(nullptr, /*strict=*/false);
-    auto circuit = FalconNTTVerificationCircuit::build_circuit(pk, hm, sig, logn);
-    circuit.use_engine_output(wit.data(), inst.data());
-    circuit.generate_constraints(cs);
+    if (dual) {
+        auto circuit = FalconDualNTTVerificationCircuit::build_circuit(pk, hm, sig, logn);
+        circuit.use_engine_output(wit.data(), inst.data());
+        circuit.generate_constraints(cs);
+    } else {
+        auto circuit = FalconNTTVerificationCircuit::build_circuit(pk, hm, sig, logn);
+        circuit.use_engine_output(wit.data(), inst.data());
+        circuit.generate_constraints(cs);
+    }
     auto bad = cs->which_is_unsatisfied();
     std::printf("constraints %zu witnesses %zu instances %zu -> %s", cs->num_constraints(), cs->num_witness_variables(),
                 cs->num_instance_variables(), bad ? "UNSATISFIED" : "satisfied");
@@ -348,6 +364,23 @@ static void test_build_circuit_from_bytes(const Engine &eng, int logn)
     EXPECT(threw);
 }
 
+static void test_dual_ntt_verification_r1cs(const Engine &eng, int logn)
+{   // falcon_dual_ntt.rs:142-169
+    std::printf("test_dual_ntt_verification_r1cs logn=%d\n", logn);
+    const size_t N = (size_t)1 << logn;
+    Polynomial sig{std::vector<uint16_t>(N)}, pk{std::vector<uint16_t>(N)}, hm{std::vector<uint16_t>(N)};
+    EXPECT(frw_synth_triples(logn, 1, 78, 0, sig.c.data(), pk.c.data(), hm.c.data()) == FRW_OK);
+    auto cs = ConstraintSystem::new_ref();
+    cs->attach_engine(&eng);
+    FalconDualNTTVerificationCircuit::build_circuit(pk, hm, sig, logn).generate_constraints(cs);
+    std::printf("  number of variables %zu %zu and constraints %zu\n", cs->num_instance_variables(), cs->num_witness_variables(), cs->num_constraints());
+    auto bad = cs->which_is_unsatisfied();
+    if (bad) std::printf("  unsatisfied at %zu\n", *bad);
+    EXPECT(!bad);
+    cs->witness_assignment[5] = cs->witness_assignment[5] + Fr::one();       // sig.pos[5] tampered
+    EXPECT(!cs->is_satisfied());
+}
+
 static void test_no_engine_is_assignment_missing()
 {
     std::printf("test_no_engine_is_assignment_missing\n");
@@ -364,8 +397,8 @@ int main(int argc, char **argv)
     if (mode == "structure") {
         for (int logn : {10, 9}) { std::printf("Falcon-%d\n", 1 << logn); count_table(logn); }
         test_no_engine_is_assignment_missing();
-    } else if (mode == "check" && argc == 8) {
-        return check_external(std::atoi(argv[2]), argv + 3);
+    } else if ((mode == "check" || mode == "check-dual") && argc == 8) {
+        return check_external(std::atoi(argv[2]), argv + 3, mode == "check-dual");
     } else if (mode == "gpu") {
         Engine eng(0);
         test_mod_q(eng);
@@ -374,6 +407,7 @@ int main(int argc, char **argv)
         for (int logn : {9, 10}) test_ntt_mul_circuit(eng, logn);
         for (int logn : {9, 10}) test_ntt_verification_r1cs(eng, logn);
         for (int logn : {9, 10}) test_build_circuit_from_bytes(eng, logn);
+        for (int logn : {9, 10}) test_dual_ntt_verification_r1cs(eng, logn);
     } else {
         std::printf("usage: %s structure | gpu | check <logn> <sig> <pk> <hm> <witness> <instance>\n", argv[0]);
         return 64;

@@ -67,6 +67,33 @@ def test_oracle_witness_satisfies_cpp_constraint_system(mirror_bin, oracle, tmp_
     assert out.returncode == 2
 
 
+@pytest.mark.parametrize("logn", [9, 10])
+def test_oracle_dual_witness_satisfies_cpp_constraint_system(mirror_bin, oracle, tmp_path, logn):
+    """FalconDualNTTVerificationCircuit (falcon_dual_ntt.rs): C++ emitter vs the oracle's closed-form witness."""
+    rng = random.Random(41 + logn)
+    sig, pk, hm, _ = T.random_triple(logn, rng)
+    wit, inst, st = oracle.witness_dual_ntt_verify(logn, sig, pk, hm, 1)
+    assert st[0] == 0
+    files = {}
+    for name, arr in (("sig", sig), ("pk", pk), ("hm", hm), ("wit", wit), ("inst", inst)):
+        files[name] = str(tmp_path / (name + ".bin"))
+        arr.tofile(files[name])
+    cmd = [mirror_bin, "check-dual", str(logn)] + [files[k] for k in ("sig", "pk", "hm", "wit", "inst")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "UNSATISFIED" not in out.stdout, out.stdout + out.stderr
+    n = 1 << logn
+    bad = wit.copy()
+    bad[0, 3 * n + 1, 0] ^= np.uint64(1)            # the is_zero multiplier of the signature's DualPolyVar
+    bad.tofile(files["wit"])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode in (0, 2)                # multiplier is unconstrained when acc == 0: (0 - acc) * m = 0 holds
+    bad = wit.copy()
+    bad[0, 2 * n + 7, 0] = np.uint64(5)             # a pos*neg product that is not the product
+    bad.tofile(files["wit"])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2
+
+
 @pytest.mark.gpu
 def test_reference_unit_tests_on_the_engine(mirror_bin):
     """test_mod_q, test_add_mod, test_range_proof_*, test_ntt_mul_circuit, test_ntt_verification_r1cs -- values from HIP."""
