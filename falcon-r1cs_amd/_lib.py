@@ -54,6 +54,7 @@ PROTOTYPES = {
                                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_witness_dual_ntt_verify": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "frw_r1cs_export": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_void_p]),
     "frw_hash_to_point_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     "frw_decode_public_keys_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -24,7 +24,9 @@
 // What IS evaluated on the host: linear combinations (needed by is_satisfied and to hand a stand-alone gadget its
 // input value), exactly the `value` bookkeeping ark-r1cs-std's AllocatedFp carries.
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <optional>
@@ -136,6 +138,45 @@ inline Variable VarOne() { return {VarKind::One, 0}; }
 using LinearCombination = std::vector<std::pair<Fr, Variable>>;
 enum class AllocationMode { Constant, Input, Witness };
 
+// ark_relations::r1cs::ConstraintMatrices: A, B, C with every symbolic LC inlined (what a prover ingests after
+// cs.finalize() / cs.to_matrices(), examples/pok_sig.rs:30-32).  Column j < num_instance_variables is instance
+// variable j (column 0 = the constant one); column num_instance_variables + k is witness k.  Rows are sorted by
+// column, duplicate columns summed, zero coefficients dropped.
+struct ConstraintMatrices {
+    using Row = std::vector<std::pair<Fr, uint32_t>>;
+    size_t num_instance_variables = 0, num_witness_variables = 0, num_constraints = 0;
+    std::vector<Row> a, b, c;
+    size_t non_zero(const std::vector<Row> &m) const { size_t n = 0; for (const auto &r : m) n += r.size(); return n; }
+    // (A z) o (B z) == C z for z = instance || witness
+    bool is_satisfied(const std::vector<Fr> &instance, const std::vector<Fr> &witness) const
+    {
+        auto dot = [&](const Row &r) { Fr acc = Fr::zero(); for (const auto &t : r) acc = acc + t.first * (t.second < instance.size() ? instance[t.second] : witness[t.second - instance.size()]); return acc; };
+        for (size_t i = 0; i < num_constraints; i++) if (dot(a[i]) * dot(b[i]) != dot(c[i])) return false;
+        return true;
+    }
+    // Binary file: "FRWR1CS1", u64 {num_instance, num_witness, num_constraints, nnz_a, nnz_b, nnz_c}, then per matrix
+    // CSR: u64 row_ptr[C+1], u32 col[nnz], u64 value[nnz][4] (canonical little-endian limbs).
+    bool write(const char *path) const
+    {
+        FILE *f = std::fopen(path, "wb");
+        if (!f) return false;
+        const uint64_t hdr[6] = {num_instance_variables, num_witness_variables, num_constraints, non_zero(a), non_zero(b), non_zero(c)};
+        bool ok = std::fwrite("FRWR1CS1", 1, 8, f) == 8 && std::fwrite(hdr, 8, 6, f) == 6;
+        for (const auto *m : {&a, &b, &c}) {
+            std::vector<uint64_t> ptr{0};
+            std::vector<uint32_t> col;
+            std::vector<uint64_t> val;
+            for (const Row &r : *m) {
+                for (const auto &t : r) { uint64_t cl[4]; t.first.to_canonical(cl); col.push_back(t.second); val.insert(val.end(), cl, cl + 4); }
+                ptr.push_back(col.size());
+            }
+            ok = ok && std::fwrite(ptr.data(), 8, ptr.size(), f) == ptr.size() && std::fwrite(col.data(), 4, col.size(), f) == col.size() &&
+                 std::fwrite(val.data(), 8, val.size(), f) == val.size();
+        }
+        return std::fclose(f) == 0 && ok;
+    }
+};
+
 class ConstraintSystem;
 using ConstraintSystemRef = std::shared_ptr<ConstraintSystem>;
 
@@ -191,6 +232,47 @@ public:
         return std::nullopt;
     }
     bool is_satisfied() { return !which_is_unsatisfied().has_value(); }
+
+    // ConstraintSystem::to_matrices() after inline_all_lcs(): structure only, valid in setup mode too
+    ConstraintMatrices to_matrices() const
+    {
+        using Row = ConstraintMatrices::Row;
+        const uint32_t ni = (uint32_t)instance_assignment.size();
+        auto normalise = [](Row &r) {
+            std::sort(r.begin(), r.end(), [](const auto &x, const auto &y) { return x.second < y.second; });
+            Row out;
+            for (const auto &t : r) {
+                if (!out.empty() && out.back().second == t.second) out.back().first = out.back().first + t.first;
+                else out.push_back(t);
+            }
+            out.erase(std::remove_if(out.begin(), out.end(), [](const auto &t) { return t.first.is_zero(); }), out.end());
+            r.swap(out);
+        };
+        std::vector<Row> inl(lcs_.size());                     // expansion of every symbolic LC, in creation order
+        auto expand = [&](const LinearCombination &lc) {
+            Row r;
+            for (const auto &t : lc) {
+                switch (t.second.kind) {
+                case VarKind::Zero: break;
+                case VarKind::One: r.push_back({t.first, 0u}); break;
+                case VarKind::Instance: r.push_back({t.first, t.second.index}); break;
+                case VarKind::Witness: r.push_back({t.first, ni + t.second.index}); break;
+                case VarKind::SymbolicLc:
+                    for (const auto &u : inl[t.second.index]) r.push_back({t.first * u.first, u.second});
+                    break;
+                }
+            }
+            normalise(r);
+            return r;
+        };
+        for (size_t i = 0; i < lcs_.size(); i++) inl[i] = expand(lcs_[i]);
+        ConstraintMatrices m;
+        m.num_instance_variables = instance_assignment.size();
+        m.num_witness_variables = witness_assignment.size();
+        m.num_constraints = a_.size();
+        for (size_t i = 0; i < a_.size(); i++) { m.a.push_back(expand(a_[i])); m.b.push_back(expand(b_[i])); m.c.push_back(expand(c_[i])); }
+        return m;
+    }
 
     const std::vector<LinearCombination> &a() const { return a_; }
     const std::vector<LinearCombination> &b() const { return b_; }

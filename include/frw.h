@@ -156,6 +156,16 @@ int frw_witness_dual_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
                                 int encoding, uint64_t *witness, uint64_t *instance,
                                 int32_t *status, int strict);
 
+/* ---- R1CS matrix export (structure only; host, no GPU) --------------------------------------------------------
+ * What a prover ingests after the hot path (examples/pok_sig.rs:30-32: Groth16 setup/prove call cs.to_matrices()):
+ * A, B, C of the chosen circuit with every symbolic linear combination inlined.  Column j < I is instance variable
+ * j (column 0 = the constant one), column I + k is witness k -- the same order as the witness/instance buffers
+ * above.  File: "FRWR1CS1", u64 {I, W, C, nnz_A, nnz_B, nnz_C}, then per matrix CSR: u64 row_ptr[C+1],
+ * u32 col[nnz], u64 value[nnz][4] (canonical little-endian).  counts (optional) receives the six header words. */
+#define FRW_CIRCUIT_NTT       0   /* FalconNTTVerificationCircuit      circuits/falcon_ntt.rs      */
+#define FRW_CIRCUIT_DUAL_NTT  1   /* FalconDualNTTVerificationCircuit  circuits/falcon_dual_ntt.rs */
+int frw_r1cs_export(int circuit, int logn, const char *path, uint64_t *counts);
+
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),
  * hm = Polynomial::from_hash_of_message(msg, sig.nonce()).  Formats are the Falcon specification's:

@@ -148,6 +148,31 @@ class ConstraintSystem:
     def is_satisfied(self):
         return self.which_is_unsatisfied() is None
 
+    def to_matrices(self):
+        """ConstraintSystem::to_matrices() after inline_all_lcs(): three lists of rows, each row a sorted list of
+        (column, coeff) with column j < num_instance = instance j (0 = the constant one), else witness j - num_instance;
+        duplicates summed, zero coefficients dropped."""
+        p = self.p
+        ni = len(self.instance_assignment)
+        inl = []
+
+        def expand(lc):
+            acc = {}
+            for coeff, (kind, idx) in lc:
+                if kind == "Z":
+                    continue
+                if kind == "L":
+                    for col, c in inl[idx]:
+                        acc[col] = (acc.get(col, 0) + coeff * c) % p
+                else:
+                    col = 0 if kind == "O" else (idx if kind == "I" else ni + idx)
+                    acc[col] = (acc.get(col, 0) + coeff) % p
+            return sorted((col, c) for col, c in acc.items() if c)
+
+        for lc in self.lcs:
+            inl.append(expand(lc))
+        return ([expand(r) for r in self.a], [expand(r) for r in self.b], [expand(r) for r in self.c])
+
 
 # ---------------------------------------------------------------------------------------
 # ark-r1cs-std::fields::fp::{AllocatedFp, FpVar}
