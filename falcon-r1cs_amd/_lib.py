@@ -71,6 +71,8 @@ PROTOTYPES = {
     "frw_digest_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "frw_diag_write_stream_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "frw_synth_triples": (C.c_int, [C.c_int, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "frw_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "frw_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "frw_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "frw_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -207,7 +207,21 @@ struct DevBuf {
 }  // namespace
 
 namespace {
-// host-buffer driver shared by the two circuits: H2D inputs, launch, D2H outputs, chunked
+struct Stream {
+    hipStream_t s = nullptr;
+    ~Stream() { if (s) (void)hipStreamDestroy(s); }
+    hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+};
+struct Event {
+    hipEvent_t e = nullptr;
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+    hipError_t create() { return hipEventCreateWithFlags(&e, hipEventDisableTiming); }
+};
+
+// Host-buffer driver shared by the two circuits.  Two device buffer sets and two streams: while the copy stream
+// drains chunk k (5 MB per signature over PCIe), the compute stream already fills chunk k+1.  With caller buffers
+// from frw_host_alloc (pinned) every copy is a true asynchronous DMA; with pageable memory the runtime stages the
+// copies itself and the overlap degrades gracefully, the results are the same.
 int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t *sig, const uint16_t *pk,
                  const uint16_t *hm, int encoding, uint64_t *witness, uint64_t *instance, int32_t *status, int strict)
 {
@@ -218,32 +232,50 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
     const size_t n = (size_t)1 << logn;
     const size_t nb = logn == 9 ? 50 : 52;
     const size_t wbytes = (dual ? 186 * n + 4 + nb : 153 * n + nb) * 32, ibytes = (2 * n + 1) * 32;
-    const size_t chunk = std::min<size_t>(batch, 512);            // <= 3.2 GB of witness per chunk
-    DevBuf d_in[3], d_wit, d_inst, d_st;
-    for (auto &b : d_in) FRW_HIP(b.alloc(chunk * n * 2));
-    FRW_HIP(d_wit.alloc(chunk * wbytes));
-    FRW_HIP(d_inst.alloc(chunk * ibytes));
-    FRW_HIP(d_st.alloc(chunk * sizeof(int32_t)));
+    const size_t chunk = std::min<size_t>(batch, 256);            // 2 x (<= 1.6 GB) of device witness
+    DevBuf d_in[2][3], d_wit[2], d_inst[2], d_st[2];
+    Stream compute, copy;
+    Event done[2], drained[2];
+    FRW_HIP(compute.create());
+    FRW_HIP(copy.create());
+    const int nbuf = batch > chunk ? 2 : 1;
+    for (int b = 0; b < nbuf; b++) {
+        for (auto &x : d_in[b]) FRW_HIP(x.alloc(chunk * n * 2));
+        FRW_HIP(d_wit[b].alloc(chunk * wbytes));
+        FRW_HIP(d_inst[b].alloc(chunk * ibytes));
+        FRW_HIP(d_st[b].alloc(chunk * sizeof(int32_t)));
+        FRW_HIP(done[b].create());
+        FRW_HIP(drained[b].create());
+    }
     const uint16_t *src[3] = {sig, pk, hm};
-    bool any_bad = false;
-    for (size_t lo = 0; lo < batch; lo += chunk) {
+    size_t k = 0;
+    for (size_t lo = 0; lo < batch; lo += chunk, k++) {
         const size_t cnt = std::min(chunk, batch - lo);
-        for (int k = 0; k < 3; k++) FRW_HIP(hipMemcpy(d_in[k].p, src[k] + lo * n, cnt * n * 2, hipMemcpyHostToDevice));
+        const int b = (int)(k & 1);
+        if (k >= 2) FRW_HIP(hipStreamWaitEvent(compute.s, drained[b].e, 0));      // buffer b has been copied out
+        for (int j = 0; j < 3; j++)
+            FRW_HIP(hipMemcpyAsync(d_in[b][j].p, src[j] + lo * n, cnt * n * 2, hipMemcpyHostToDevice, compute.s));
         if (dual)
             FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt,
-                                                        (const uint16_t *)d_in[0].p, (const uint16_t *)d_in[1].p,
-                                                        (const uint16_t *)d_in[2].p, (uint64_t *)d_wit.p,
-                                                        (uint64_t *)d_inst.p, (int32_t *)d_st.p, nullptr));
+                                                        (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
+                                                        (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
+                                                        (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
         else
             FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt,
-                                                   (const uint16_t *)d_in[0].p, (const uint16_t *)d_in[1].p,
-                                                   (const uint16_t *)d_in[2].p, (uint64_t *)d_wit.p, (uint64_t *)d_inst.p,
-                                                   (int32_t *)d_st.p, nullptr));
-        FRW_HIP(hipMemcpy(status + lo, d_st.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
-        FRW_HIP(hipMemcpy((char *)witness + lo * wbytes, d_wit.p, cnt * wbytes, hipMemcpyDeviceToHost));
-        FRW_HIP(hipMemcpy((char *)instance + lo * ibytes, d_inst.p, cnt * ibytes, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < cnt; i++) any_bad |= status[lo + i] != FRW_ST_OK;
+                                                   (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
+                                                   (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
+                                                   (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
+        FRW_HIP(hipEventRecord(done[b].e, compute.s));
+        FRW_HIP(hipStreamWaitEvent(copy.s, done[b].e, 0));
+        FRW_HIP(hipMemcpyAsync(status + lo, d_st[b].p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, copy.s));
+        FRW_HIP(hipMemcpyAsync((char *)witness + lo * wbytes, d_wit[b].p, cnt * wbytes, hipMemcpyDeviceToHost, copy.s));
+        FRW_HIP(hipMemcpyAsync((char *)instance + lo * ibytes, d_inst[b].p, cnt * ibytes, hipMemcpyDeviceToHost, copy.s));
+        FRW_HIP(hipEventRecord(drained[b].e, copy.s));
     }
+    FRW_HIP(hipStreamSynchronize(compute.s));
+    FRW_HIP(hipStreamSynchronize(copy.s));
+    bool any_bad = false;
+    for (size_t i = 0; i < batch; i++) any_bad |= status[i] != FRW_ST_OK;
     return strict && any_bad ? FRW_E_RANGE : FRW_OK;
 }
 }  // namespace
@@ -453,6 +485,22 @@ int frw_diag_write_stream_dev(frw_ctx *ctx, void *d_buf, size_t bytes, size_t sl
     if (!ctx || !d_buf || slab_bytes < 16) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
     FRW_HIP(frw::launch_write_stream(d_buf, bytes, slab_bytes, ctx->num_cu, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+int frw_host_alloc(frw_ctx *ctx, size_t bytes, void **ptr)
+{
+    if (!ctx || !ptr) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return FRW_OK;
+}
+
+int frw_host_free(frw_ctx *ctx, void *ptr)
+{
+    if (!ctx) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(hipHostFree(ptr));
     return FRW_OK;
 }
 

@@ -6,6 +6,7 @@ hand over (sig, pk, hm) coefficient vectors, receive ``witness_assignment`` / ``
 of every signature in arkworks order.  torch is used only to own device memory and streams.
 """
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -80,21 +81,40 @@ class WitnessEngine:
 
     __del__ = close
 
+    def pinned_empty(self, shape, dtype):
+        """numpy array over page-locked host memory (frw_host_alloc); freed when the array is collected."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        ptr = C.c_void_p()
+        check(self._lib.frw_host_alloc(self._ctx, nbytes, C.byref(ptr)), "frw_host_alloc")
+        buf = (C.c_char * max(nbytes, 1)).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        lib, ctx, addr = self._lib, self._ctx, ptr.value
+        weakref.finalize(buf, lambda: lib.frw_host_free(ctx, C.c_void_p(addr)))
+        return arr
+
     # ---- host buffers ------------------------------------------------------------------
     def witness_dual_ntt_verify(self, logn, sig, pk, hm, encoding=ENC_MONTGOMERY, strict=True):
         """FalconDualNTTVerificationCircuit (falcon_dual_ntt.rs:26-132); same conventions as witness_ntt_verify."""
         return self.witness_ntt_verify(logn, sig, pk, hm, encoding, strict, dual=True)
 
-    def witness_ntt_verify(self, logn, sig, pk, hm, encoding=ENC_MONTGOMERY, strict=True, dual=False):
-        """-> (witness u64[batch, W, 4], instance u64[batch, I, 4], status i32[batch])."""
+    def witness_ntt_verify(self, logn, sig, pk, hm, encoding=ENC_MONTGOMERY, strict=True, dual=False, pinned=False):
+        """-> (witness u64[batch, W, 4], instance u64[batch, I, 4], status i32[batch]).
+        pinned=True puts the outputs in page-locked memory so that the D2H copies overlap with the kernels."""
         L = layout_dual(logn) if dual else layout(logn)
         sig, pk, hm = (_u16(a, L.n) for a in (sig, pk, hm))
         batch = sig.shape[0]
         if pk.shape[0] != batch or hm.shape[0] != batch:
             raise ValueError("batch mismatch")
-        wit = np.zeros((batch, L.num_witness, 4), dtype=np.uint64)
-        inst = np.zeros((batch, L.num_instance, 4), dtype=np.uint64)
-        st = np.zeros(batch, dtype=np.int32)
+        if pinned:
+            wit = self.pinned_empty((batch, L.num_witness, 4), np.uint64)
+            inst = self.pinned_empty((batch, L.num_instance, 4), np.uint64)
+            st = self.pinned_empty((batch,), np.int32)
+            st[:] = 0
+        else:
+            wit = np.zeros((batch, L.num_witness, 4), dtype=np.uint64)
+            inst = np.zeros((batch, L.num_instance, 4), dtype=np.uint64)
+            st = np.zeros(batch, dtype=np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         fn = self._lib.frw_witness_dual_ntt_verify if dual else self._lib.frw_witness_ntt_verify
         rc = fn(self._ctx, logn, batch, p(sig), p(pk), p(hm), encoding, p(wit), p(inst), p(st), 1 if strict else 0)

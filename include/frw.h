@@ -239,6 +239,11 @@ int frw_diag_write_stream_dev(frw_ctx *ctx, void *d_buf, size_t bytes, size_t sl
 int frw_synth_triples(int logn, size_t batch, uint64_t seed, uint64_t first_index,
                       uint16_t *sig, uint16_t *pk, uint16_t *hm);
 
+/* Page-locked host memory.  Output buffers of the host-buffer entry points allocated here are filled by
+ * asynchronous DMA that overlaps with the kernels of the next chunk (pageable buffers work too, slower). */
+int frw_host_alloc(frw_ctx *ctx, size_t bytes, void **ptr);
+int frw_host_free(frw_ctx *ctx, void *ptr);
+
 /* thin wrappers so that a host without a HIP binding can own device memory */
 int frw_malloc(frw_ctx *ctx, size_t bytes, void **d_ptr);
 int frw_free(frw_ctx *ctx, void *d_ptr);
