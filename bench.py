@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="signatures per GPU per step")
     ap.add_argument("--chunk", type=int, default=4096, help="signatures per kernel launch (HBM witness buffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true",
+                    help="N > 1 only: skip the secondary, bounded 'generate + RCCL all-gather of the witness chunks' leg")
+    ap.add_argument("--allgather-chunk", type=int, default=512, help="signatures per rank per all-gather")
     ap.add_argument("--circuit", default="ntt", choices=["ntt", "dual"],
                     help="ntt = FalconNTTVerificationCircuit (default, the BASELINE metric); dual = the signed-split "
                          "FalconDualNTTVerificationCircuit (SURVEY 8-f row 2; not the headline metric)")
@@ -308,6 +311,45 @@ def main():
     cal_ms = sorted(a.elapsed_time(b) for a, b in cal[1:])
     write_stream_gbs = wbytes / (cal_ms[len(cal_ms) // 2] * 1e-3) / 1e9
 
+    # ---- secondary leg (N > 1, untimed w.r.t. `value`): generate + all-gather of the witness chunks --------------
+    # BASELINE north_star / configs[3] describe an RCCL all-gather of the per-signature witness vectors.  It is not on
+    # the default data path (no consumer needs every witness on every GPU, and xGMI ingest caps it
+    # near 2.4e5 signatures/s per node), but it is measured here, bounded, so the number exists next to `value`.
+    gather_info = None
+    if world > 1 and not args.no_allgather:
+        try:
+            gc = min(args.allgather_chunk, chunk)
+            iters = 6
+            loc = [d_wit[:gc], d_wit[gc:2 * gc]] if chunk >= 2 * gc else [d_wit[:gc], torch.empty_like(d_wit[:gc])]
+            gdev = dev if args.backend == "nccl" else dev
+            gathered = torch.empty((world,) + tuple(loc[0].shape), dtype=torch.int64, device=gdev)
+            works = [None, None]
+            torch.cuda.synchronize()
+            sharding.barrier()
+            tg = time.perf_counter()
+            for it in range(iters):
+                b = it & 1
+                if works[b] is not None:
+                    works[b].wait()                       # the gather that read loc[b] two iterations ago is done
+                a = (it * gc) % max(gc, batch - gc + 1)
+                launch(logn, gc, d_sig[a:a + gc], d_pk[a:a + gc], d_hm[a:a + gc], loc[b], d_inst, d_st[a:a + gc],
+                       frw.ENC_MONTGOMERY, stream.cuda_stream)
+                works[b] = sharding.all_gather_chunks(loc[b], gathered, async_op=(args.backend == "nccl"))
+            for w_ in works:
+                if w_ is not None:
+                    w_.wait()
+            torch.cuda.synchronize()
+            sharding.barrier()
+            tg = sharding.max_over_ranks(time.perf_counter() - tg, cdev)
+            gather_info = {"signatures_per_s_node": round(world * gc * iters / tg, 1), "chunk_per_rank": gc,
+                           "iterations": iters, "seconds": round(tg, 4),
+                           "ingest_GBs_per_gpu": round((world - 1) * gc * L.num_witness * 32 * iters / tg / 1e9, 1),
+                           "collective": "all_gather_into_tensor (RCCL)" if args.backend == "nccl" else "gloo rehearsal",
+                           "overlap": "kernel of chunk k+1 runs while chunk k is gathered (double buffer)"}
+            del gathered
+        except Exception as ex:      # the primary metric must not depend on this leg
+            gather_info = {"error": repr(ex)[:300]}
+
     result = None
     traffic = None if dual else measured_traffic(logn, chunk)
     if rank == 0:
@@ -333,6 +375,8 @@ def main():
                          "device_write_stream_GBs": round(write_stream_gbs, 1),
                          "frac_of_device_write_stream": round(achieved / write_stream_gbs, 4)},
         }
+        if gather_info is not None:
+            result["allgather"] = gather_info
         if world == 1 and not args.no_cpu_baseline and not dual:
             # digests of the first launch's witnesses (recomputed: the buffer holds the last chunk now)
             k = min(512, chunk)

@@ -54,3 +54,21 @@ def gather_per_signature(local, total, rank, world):
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded)
     return torch.cat([o[:n] for o, n in zip(out, sizes)])
+
+
+def all_gather_chunks(local, gathered, async_op=False):
+    """All-gather one witness chunk (same shape on every rank) into ``gathered`` ([world, *local.shape]).
+
+    ``nccl`` (= RCCL): one ``all_gather_into_tensor`` straight between HBM buffers over xGMI; every rank ingests
+    world-1 shards over its point-to-point links, so the time is ~ local_bytes * (world-1) / per-GPU ingest bandwidth.
+    ``gloo`` (CPU rehearsal of the code path): staged through host memory.  Returns the work handle when async."""
+    if not is_dist():
+        gathered[0].copy_(local)
+        return None
+    if dist.get_backend() == "nccl":
+        return dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), async_op=async_op)
+    host = [torch.empty(local.shape, dtype=local.dtype) for _ in range(dist.get_world_size())]
+    dist.all_gather(host, local.cpu())
+    for r, h in enumerate(host):
+        gathered[r].copy_(h)
+    return None

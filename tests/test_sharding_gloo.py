@@ -33,11 +33,15 @@ def _worker(rank, world, port, total, q):
     sharding.barrier()
     g_status = sharding.gather_per_signature(status, total, rank, world)
     g_digest = sharding.gather_per_signature(digest, total, rank, world)
+    local = torch.full((4, 3), rank + 10, dtype=torch.int64)
+    gathered = torch.empty((world, 4, 3), dtype=torch.int64)
+    sharding.all_gather_chunks(local, gathered)
+    chunks_ok = all(bool((gathered[r] == r + 10).all()) for r in range(world))
     slow = sharding.max_over_ranks(1.0 + rank, dev)
     n = sharding.sum_over_ranks(hi - lo, dev)
     ok = (g_status.tolist() == [i % 3 for i in range(total)]
           and g_digest.tolist() == [i * 2654435761 for i in range(total)]
-          and slow == float(world) and n == total)
+          and slow == float(world) and n == total and chunks_ok)
     q.put((rank, ok))
     dist.destroy_process_group()
 
