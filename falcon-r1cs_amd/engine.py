@@ -125,6 +125,26 @@ class WitnessEngine:
         check(rc, "frw_witness_ntt_verify")
         return wit, inst, st
 
+    def aggregate(self, items, encoding=ENC_MONTGOMERY, strict=True):
+        """Aggregate driver (the reference's falcon-aggregate-sig is an empty stub, so the behaviour
+        is defined here): a mixed batch of Falcon-512 / Falcon-1024 statements, each ``(logn, sig, pk, hm)``, is
+        grouped by parameter set, each group goes through one batched engine call, and the results come back in
+        input order as ``[(witness u64[W,4], instance u64[I,4], status)]``."""
+        groups = {9: [], 10: []}
+        for idx, (logn, sig, pk, hm) in enumerate(items):
+            if logn not in groups:
+                raise ValueError("logn must be 9 or 10")
+            groups[logn].append((idx, sig, pk, hm))
+        out = [None] * len(items)
+        for logn, members in groups.items():
+            if not members:
+                continue
+            sig, pk, hm = (np.stack([np.asarray(m[k], dtype=np.uint16) for m in members]) for k in (1, 2, 3))
+            wit, inst, st = self.witness_ntt_verify(logn, sig, pk, hm, encoding, strict)
+            for j, m in enumerate(members):
+                out[m[0]] = (wit[j], inst[j], int(st[j]))
+        return out
+
     def ntt_modq(self, logn, poly, encoding=ENC_MONTGOMERY):
         """NTTPolyVar::ntt_circuit alone -> (witness u64[batch, 29N, 4], ntt u16[batch, N], status)."""
         n = 1 << logn

@@ -320,3 +320,19 @@ def test_dual_witness_matches_oracle(engine, oracle, logn, enc):
     owit, oinst, ost = oracle.witness_dual_ntt_verify(logn, S, P, H, enc)
     assert st.tolist() == ost.tolist() == [frw.ST_NORM_BOUND, frw.ST_COEFF_RANGE]
     assert np.array_equal(wit[0], owit[0]) and np.array_equal(inst[0], oinst[0])
+
+
+def test_aggregate_mixed_batch(engine, oracle):
+    """BASELINE configs[4] shape: a mixed Falcon-512 / Falcon-1024 batch; every member == its oracle witness."""
+    import falcon_r1cs_amd as frw
+    rng = random.Random(6)
+    items = []
+    for i in range(11):
+        logn = rng.choice([9, 10])
+        s, p, h = frw.synth_triples(logn, 1, seed=900 + i)
+        items.append((logn, s[0], p[0], h[0]))
+    res = engine.aggregate(items)
+    assert len(res) == len(items)
+    for (logn, s, p, h), (wit, inst, st) in zip(items, res):
+        ow, oi, ost = oracle.witness_ntt_verify(logn, s, p, h, 1)
+        assert st == 0 and np.array_equal(wit, ow[0]) and np.array_equal(inst, oi[0])

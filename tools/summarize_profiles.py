@@ -36,10 +36,11 @@ def main():
     tag, trace, pmc_w, pmc_f = sys.argv[1:5]
     chunk = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
     logn = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+    kname = sys.argv[7] if len(sys.argv) > 7 else "witness_ntt_verify_kernel"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(find(trace, "_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
-    kern = "witness_ntt_verify_kernel<%d, 1>" % logn
+    kern = "%s<%d, 1>" % (kname, logn)
     w, nw, _ = pmc_avg(pmc_w, "WRITE_SIZE", kern)
     f, nf, _ = pmc_avg(pmc_f, "FETCH_SIZE", kern)
     stats = [r for r in csv.DictReader(open(find(trace, "_kernel_stats.csv"))) if kern in r["Name"]][0]
