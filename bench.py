@@ -43,7 +43,8 @@ def measured_traffic(logn, chunk):
             j = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if j.get("logn") == logn and j.get("signatures_per_launch") == chunk:
+        if (j.get("logn") == logn and j.get("signatures_per_launch") == chunk
+                and str(j.get("kernel", "")).startswith("witness_ntt_verify_kernel")):
             best = (j["hbm_bytes_per_launch"], os.path.basename(path))
     return best
 

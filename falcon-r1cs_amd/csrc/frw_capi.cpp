@@ -8,6 +8,7 @@
 #include <string.h>
 #include <algorithm>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/frw.h"
@@ -17,8 +18,11 @@ struct frw_ctx {
     int device;
     int num_cu;
     frw::Tables *d_tables;
-    unsigned long long *d_queues;      // QUEUE_SLOTS work-queue heads (one cache line apart), one per launch in flight
-    unsigned next_queue;
+    // Work-queue heads, one per stream the context has launched on: launches of one stream are ordered (memset node,
+    // then kernel), launches of different streams never share a head, however many are in flight.
+    std::vector<unsigned long long *> queue_blocks;                 // device allocations of QUEUE_SLOTS heads each
+    std::unordered_map<hipStream_t, unsigned long long *> queue_of;
+    hipStream_t host_compute, host_copy;                            // streams of the host-buffer entry points
 };
 
 namespace {
@@ -72,11 +76,19 @@ void build_tables(frw::Tables &t)
     }
 }
 
-// Successive launches take successive queue heads, so launches that overlap on different streams never share one.
-unsigned long long *take_queue(frw_ctx *ctx)
+// The work-queue head of `stream` (allocated on first use; one 128-byte line each).  nullptr on allocation failure.
+unsigned long long *queue_for(frw_ctx *ctx, hipStream_t stream)
 {
-    unsigned long long *q = ctx->d_queues + (size_t)(ctx->next_queue % frw::QUEUE_SLOTS) * 16;
-    ctx->next_queue++;
+    auto it = ctx->queue_of.find(stream);
+    if (it != ctx->queue_of.end()) return it->second;
+    const size_t used = ctx->queue_of.size();
+    if (used % frw::QUEUE_SLOTS == 0) {
+        unsigned long long *blk = nullptr;
+        if (hipMalloc((void **)&blk, frw::QUEUE_SLOTS * 16 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        ctx->queue_blocks.push_back(blk);
+    }
+    unsigned long long *q = ctx->queue_blocks.back() + (used % frw::QUEUE_SLOTS) * 16;
+    ctx->queue_of.emplace(stream, q);
     return q;
 }
 
@@ -147,16 +159,17 @@ int frw_ctx_create(int device, frw_ctx **out)
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
     ctx->d_tables = nullptr;
-    ctx->d_queues = nullptr;
-    ctx->next_queue = 0;
+    ctx->host_compute = ctx->host_copy = nullptr;
     frw::Tables host;
     build_tables(host);
     hipError_t e = hipMalloc((void **)&ctx->d_tables, sizeof(frw::Tables));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tables, &host, sizeof host, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queues, frw::QUEUE_SLOTS * 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->host_compute, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->host_copy, hipStreamNonBlocking);
     if (e != hipSuccess) {
         if (ctx->d_tables) (void)hipFree(ctx->d_tables);
-        if (ctx->d_queues) (void)hipFree(ctx->d_queues);
+        if (ctx->host_compute) (void)hipStreamDestroy(ctx->host_compute);
+        if (ctx->host_copy) (void)hipStreamDestroy(ctx->host_copy);
         delete ctx;
         return hip_fail(e, "table upload");
     }
@@ -169,7 +182,9 @@ void frw_ctx_destroy(frw_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
-    if (ctx->d_queues) (void)hipFree(ctx->d_queues);
+    for (unsigned long long *blk : ctx->queue_blocks) (void)hipFree(blk);
+    if (ctx->host_compute) (void)hipStreamDestroy(ctx->host_compute);
+    if (ctx->host_copy) (void)hipStreamDestroy(ctx->host_copy);
     delete ctx;
 }
 
@@ -181,7 +196,7 @@ int frw_witness_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const uint1
     if (batch == 0) return FRW_OK;
     if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, batch, d_sig, d_pk, d_hm,
+    FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, queue_for(ctx, (hipStream_t)stream), ctx->num_cu, logn, encoding, batch, d_sig, d_pk, d_hm,
                                            d_witness, d_instance, d_status, (hipStream_t)stream));
     return FRW_OK;
 }
@@ -193,7 +208,7 @@ int frw_ntt_modq_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_pol
     if (batch == 0) return FRW_OK;
     if (!d_poly || !d_witness || !d_ntt_out || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, batch, d_poly, d_witness, d_ntt_out,
+    FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, queue_for(ctx, (hipStream_t)stream), ctx->num_cu, logn, encoding, batch, d_poly, d_witness, d_ntt_out,
                                  d_status, (hipStream_t)stream));
     return FRW_OK;
 }
@@ -207,11 +222,6 @@ struct DevBuf {
 }  // namespace
 
 namespace {
-struct Stream {
-    hipStream_t s = nullptr;
-    ~Stream() { if (s) (void)hipStreamDestroy(s); }
-    hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
-};
 struct Event {
     hipEvent_t e = nullptr;
     ~Event() { if (e) (void)hipEventDestroy(e); }
@@ -234,10 +244,8 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
     const size_t wbytes = (dual ? 186 * n + 4 + nb : 153 * n + nb) * 32, ibytes = (2 * n + 1) * 32;
     const size_t chunk = std::min<size_t>(batch, 256);            // 2 x (<= 1.6 GB) of device witness
     DevBuf d_in[2][3], d_wit[2], d_inst[2], d_st[2];
-    Stream compute, copy;
+    struct { hipStream_t s; } compute{ctx->host_compute}, copy{ctx->host_copy};
     Event done[2], drained[2];
-    FRW_HIP(compute.create());
-    FRW_HIP(copy.create());
     const int nbuf = batch > chunk ? 2 : 1;
     for (int b = 0; b < nbuf; b++) {
         for (auto &x : d_in[b]) FRW_HIP(x.alloc(chunk * n * 2));
@@ -256,12 +264,12 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
         for (int j = 0; j < 3; j++)
             FRW_HIP(hipMemcpyAsync(d_in[b][j].p, src[j] + lo * n, cnt * n * 2, hipMemcpyHostToDevice, compute.s));
         if (dual)
-            FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt,
+            FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, queue_for(ctx, compute.s), ctx->num_cu, logn, encoding, cnt,
                                                         (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
                                                         (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
                                                         (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
         else
-            FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt,
+            FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, queue_for(ctx, compute.s), ctx->num_cu, logn, encoding, cnt,
                                                    (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
                                                    (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
                                                    (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
@@ -302,7 +310,7 @@ int frw_witness_dual_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const 
     if (batch == 0) return FRW_OK;
     if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, batch, d_sig,
+    FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, queue_for(ctx, (hipStream_t)stream), ctx->num_cu, logn, encoding, batch, d_sig,
                                                 d_pk, d_hm, d_witness, d_instance, d_status, (hipStream_t)stream));
     return FRW_OK;
 }
@@ -343,7 +351,7 @@ int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int
     for (size_t lo = 0; lo < batch; lo += chunk) {
         const size_t cnt = std::min(chunk, batch - lo);
         FRW_HIP(hipMemcpy(d_in.p, poly + lo * n, cnt * n * 2, hipMemcpyHostToDevice));
-        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, take_queue(ctx), ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in.p,
+        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, queue_for(ctx, nullptr), ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in.p,
                                      (uint64_t *)d_wit.p, (uint16_t *)d_out.p, (int32_t *)d_st.p, nullptr));
         FRW_HIP(hipMemcpy(status + lo, d_st.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
         FRW_HIP(hipMemcpy((char *)witness + lo * wbytes, d_wit.p, cnt * wbytes, hipMemcpyDeviceToHost));

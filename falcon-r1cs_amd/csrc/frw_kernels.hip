@@ -993,6 +993,7 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queu
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
+    if (!queue) return hipErrorOutOfMemory;
     hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
     if (qe != hipSuccess) return qe;
     static int occ[4] = {0, 0, 0, 0};
@@ -1016,6 +1017,7 @@ hipError_t launch_witness_dual_ntt_verify(const Tables *tab, unsigned long long 
                                           uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
+    if (!queue) return hipErrorOutOfMemory;
     hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
     if (qe != hipSuccess) return qe;
     static int occ[4] = {0, 0, 0, 0};
@@ -1038,6 +1040,7 @@ hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num
                            uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
+    if (!queue) return hipErrorOutOfMemory;
     hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
     if (qe != hipSuccess) return qe;
     static int occ[4] = {0, 0, 0, 0};
