@@ -326,6 +326,16 @@ class FpVar:
         cs = b.ab.cs
         return FpVar(var=AllocatedFp(cs, 1 if b.value() else 0, cs.new_lc(b.lc())))
 
+    def is_eq(self, o):
+        # EqGadget::is_eq for FpVar: constants fold; a Constant operand is wrapped (new_constant) and becomes `self`
+        if self.var is None and o.var is None:
+            return Boolean.constant(self.const == o.const)
+        if self.var is None:
+            return AllocatedFp.new_constant(o.var.cs, self.const).is_eq(o.var)
+        if o.var is None:
+            return AllocatedFp.new_constant(self.var.cs, o.const).is_eq(self.var)
+        return self.var.is_eq(o.var)
+
     def is_zero(self):
         # FieldVar::is_zero = self.is_eq(&Self::zero()); FpVar::is_eq with a Constant operand wraps the constant in
         # an AllocatedFp (new_constant) and calls c.is_eq(v): the constant is `self` of AllocatedFp::is_neq

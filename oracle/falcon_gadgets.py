@@ -360,6 +360,64 @@ class FalconNTTVerificationCircuit:
 
 
 # ---------------------------------------------------------------------------------------
+# gadgets/arithmetics.rs:34-100 + circuits/falcon_schoolbook.rs -- NOT on the product's path (SURVEY section 2 rows 3, 8:
+# out of scope).  Restated only because README.md:45,56 publishes this circuit's counts: reproducing them by execution
+# pins more of the arkworks front-end simulation (Var*Var products, FpVar::is_eq = AllocatedFp::is_neq with its two
+# witnesses, Boolean::or on Not operands) than the NTT circuit alone exercises.
+# ---------------------------------------------------------------------------------------
+def inner_product_mod(cs, a, b, modulus_var, strict=False):
+    """arithmetics.rs:34-100 -- witnesses [t, c] first, then the N products, then enforce_less_than_q(c)."""
+    if len(a) != len(b) or not a:
+        raise ValueError("Invalid input length")
+    ab_int = sum(x.value() * y.value() for x, y in zip(a, b)) % cs.p
+    t_int, c_int = divmod(ab_int, MODULUS)
+    t_var = FpVar.new_witness(cs, t_int)
+    c_var = FpVar.new_witness(cs, c_int)
+    ab_var = a[0] * b[0]
+    for x, y in zip(a[1:], b[1:]):
+        ab_var = ab_var + x * y
+    left = ab_var - t_var * modulus_var
+    left.enforce_equal(c_var)
+    enforce_less_than_q(cs, c_var, strict)
+    return c_var
+
+
+class FalconSchoolBookVerificationCircuit:
+    """falcon_schoolbook.rs:26-131, from the coefficient vectors (sig, pk, hm)."""
+
+    def __init__(self, sig, pk, hm, logn):
+        self.sig, self.pk, self.hm, self.logn = list(sig), list(pk), list(hm), logn
+
+    def generate_constraints(self, cs: ConstraintSystem, strict=False):
+        logn = self.logn
+        n = 1 << logn
+        const_q_var = FpVar.constant(cs, MODULUS)                                   # :30
+        uh = poly_mul_clear(self.sig, self.pk)                                      # :38
+        v = poly_sub_clear(self.hm, uh)                                             # :39
+        sig_poly_vars = [FpVar.new_witness(cs, e) for e in self.sig]                # :45-59
+        pk_poly_vars, neg_pk_poly_vars = [], []
+        for e in self.pk:                                                           # :66-75
+            tmp = FpVar.new_input(cs, e)
+            neg_pk_poly_vars.append(const_q_var - tmp)
+            pk_poly_vars.append(tmp)
+        hm_vars = [FpVar.new_input(cs, e) for e in self.hm]                         # :78-83
+        v_pos_vars = []
+        for e in v:                                                                 # :86-93
+            tmp = FpVar.new_witness(cs, e)
+            enforce_less_than_q(cs, tmp, strict)
+            v_pos_vars.append(tmp)
+        buf = (neg_pk_poly_vars + pk_poly_vars)[::-1]                               # :103-104
+        for i in range(n):                                                          # :106-125
+            current_col = inner_product_mod(cs, sig_poly_vars, buf[n - 1 - i:2 * n - 1 - i], const_q_var, strict)
+            rhs = hm_vars[i] + const_q_var - current_col
+            first = rhs.is_eq(v_pos_vars[i])
+            second = rhs.is_eq(v_pos_vars[i] + const_q_var)
+            first.or_(second).enforce_equal_const(True)
+        l2 = l2_norm_var(cs, v_pos_vars + sig_poly_vars, const_q_var)               # :130-134
+        enforce_less_than_norm_bound(cs, l2, logn, strict)                          # :135
+
+
+# ---------------------------------------------------------------------------------------
 # gadgets/dual_poly.rs + circuits/falcon_dual_ntt.rs  (SURVEY 8-f row 2)
 # ---------------------------------------------------------------------------------------
 MODULUS_OVER_TWO = 6144     # falcon-rust: threshold of the signed lift; unpinned (falcon-rust is not under /root/reference)

@@ -368,3 +368,19 @@ def test_dual_circuit_oracles_agree_and_are_satisfied(oracle, logn):
     pos[3], neg[3] = 5, 7
     G.dual_poly_alloc_vars(cs2, pos, neg, "Witness")
     assert not cs2.is_satisfied()
+
+
+# ---------------------------------------------------------------------------------------------
+# one more published pin of the arkworks front-end simulation: the schoolbook circuit's counts (README.md:45,56)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("logn,want", [(9, (1025, 312882, 315956)), (10, (2049, 1150004, 1156150))])
+def test_schoolbook_counts_match_reference_readme(logn, want):
+    """falcon_schoolbook.rs is not on the product's path; its counts exercise Var*Var products, FpVar::is_eq
+    (AllocatedFp::is_neq: 2 witnesses / 3 constraints -- the rule the dual circuit's is_zero relies on) and
+    Boolean::or on Not operands, all reproduced by execution and satisfied."""
+    rng = random.Random(50 + logn)
+    sig, pk, hm, _ = T.random_triple(logn, rng)
+    cs = ConstraintSystem()
+    G.FalconSchoolBookVerificationCircuit(sig.tolist(), pk.tolist(), hm.tolist(), logn).generate_constraints(cs, strict=True)
+    assert (cs.num_instance_variables(), cs.num_witness_variables(), cs.num_constraints()) == want
+    assert cs.is_satisfied()
