@@ -196,8 +196,8 @@ def bench_prepare(args, world, rank, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logn", type=int, default=10, choices=[9, 10])
     ap.add_argument("--batch", type=int, default=65536, help="signatures per GPU per step")
     ap.add_argument("--chunk", type=int, default=4096, help="signatures per kernel launch (HBM witness buffer)")

@@ -336,3 +336,43 @@ def test_aggregate_mixed_batch(engine, oracle):
     for (logn, s, p, h), (wit, inst, st) in zip(items, res):
         ow, oi, ost = oracle.witness_ntt_verify(logn, s, p, h, 1)
         assert st == 0 and np.array_equal(wit, ow[0]) and np.array_equal(inst, oi[0])
+
+
+def test_full_launch_sample_digests_and_concurrent_streams(engine, oracle):
+    """One full-size launch (4096 Falcon-1024 signatures, work-queue scheduling under load): every 64th witness is
+    compared with the oracle by digest; and two launches running concurrently on two streams of one context (each
+    stream has its own queue head) produce the same digests as when run alone."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    logn, batch = 10, 4096
+    L = frw.layout(logn)
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=31337)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    dig = torch.zeros(batch, dtype=torch.int64, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    engine.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, s0)
+    engine.digest_dev(wit, L.num_witness * 4, batch, dig, s0)
+    torch.cuda.synchronize()
+    assert int((st != 0).sum()) == 0
+    got = dig.cpu().numpy().view(np.uint64)
+    idx = list(range(0, batch, 64)) + [batch - 1]
+    owit, _, _ = oracle.witness_ntt_verify(logn, sig[idx], pk[idx], hm[idx], 1, threads=8)
+    assert [int(got[i]) for i in idx] == [oracle.digest(owit[j]) for j in range(len(idx))]
+    # two halves concurrently on two side streams
+    half = batch // 2
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    wit.zero_()
+    dig2 = torch.zeros(batch, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    engine.witness_ntt_verify_dev(logn, half, d[0][:half], d[1][:half], d[2][:half], wit[:half], inst[:half], st[:half], 1,
+                                  sa.cuda_stream)
+    engine.witness_ntt_verify_dev(logn, half, d[0][half:], d[1][half:], d[2][half:], wit[half:], inst[half:], st[half:], 1,
+                                  sb.cuda_stream)
+    torch.cuda.synchronize()
+    engine.digest_dev(wit, L.num_witness * 4, batch, dig2, s0)
+    torch.cuda.synchronize()
+    assert torch.equal(dig, dig2)
