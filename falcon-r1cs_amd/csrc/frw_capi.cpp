@@ -76,7 +76,8 @@ void build_tables(frw::Tables &t)
     }
 }
 
-// The work-queue head of `stream` (allocated on first use; one 128-byte line each).  nullptr on allocation failure.
+// The work-queue head of `stream` (one 128-byte line each, carved from blocks of QUEUE_SLOTS; the first block is
+// allocated with the context, so the first QUEUE_SLOTS distinct streams never allocate).  nullptr on allocation failure.
 unsigned long long *queue_for(frw_ctx *ctx, hipStream_t stream)
 {
     auto it = ctx->queue_of.find(stream);
@@ -172,6 +173,13 @@ int frw_ctx_create(int device, frw_ctx **out)
         if (ctx->host_copy) (void)hipStreamDestroy(ctx->host_copy);
         delete ctx;
         return hip_fail(e, "table upload");
+    }
+    // everything a launch needs is set up now, so the _dev entry points are stream-capture safe: residency of the
+    // persistent kernels, and queue heads for the default stream and the two host-path streams
+    frw::init_launch_config();
+    if (!queue_for(ctx, nullptr) || !queue_for(ctx, ctx->host_compute)) {
+        frw_ctx_destroy(ctx);
+        return FRW_E_OUT_OF_MEMORY;
     }
     *out = ctx;
     return FRW_OK;

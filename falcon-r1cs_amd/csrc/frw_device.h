@@ -25,6 +25,7 @@ struct Tables {
     uint32_t ck[11][5];     // C_k = 2^k q^(k+1), 32-bit limbs (falcon_ntt.rs:31-39)
 };
 
+void init_launch_config();
 hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch,
                                      const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st);

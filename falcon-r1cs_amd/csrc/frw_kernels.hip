@@ -976,6 +976,8 @@ hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int n
 // ------------------------------------------------------------------------------------------------
 // Persistent grid: as many workgroups as the device keeps resident (LDS-limited: 2-3 per CU), each
 // striding over the batch.  Residency is asked from the runtime once per kernel instantiation.
+static int g_occ_verify[4], g_occ_dual[4], g_occ_ntt[4];       // resident workgroups per CU, [(LOGN-9)*2 + ENC]
+
 template <typename K>
 static int resident_grid(K kernel, size_t batch, int num_cu, int &cache)
 {
@@ -988,6 +990,22 @@ static int resident_grid(K kernel, size_t batch, int num_cu, int &cache)
     return (int)(batch < cap ? batch : cap);
 }
 
+// Called once per context: asks the runtime for the residency of every persistent kernel, so that no launch ever
+// has to (a launch may be inside a stream capture, where such queries are not allowed).
+void init_launch_config()
+{
+    int dummy = 0;
+#define FRW_Q(K, CACHE, LOGN, ENC) dummy += resident_grid(K<LOGN, ENC>, 1, 1, CACHE[(LOGN - 9) * 2 + ENC])
+    FRW_Q(witness_ntt_verify_kernel, g_occ_verify, 9, 0); FRW_Q(witness_ntt_verify_kernel, g_occ_verify, 9, 1);
+    FRW_Q(witness_ntt_verify_kernel, g_occ_verify, 10, 0); FRW_Q(witness_ntt_verify_kernel, g_occ_verify, 10, 1);
+    FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 0); FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 1);
+    FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 10, 0); FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 10, 1);
+    FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 1);
+    FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 1);
+#undef FRW_Q
+    (void)dummy;
+}
+
 hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch,
                                      const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st)
@@ -996,11 +1014,10 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queu
     if (!queue) return hipErrorOutOfMemory;
     hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
     if (qe != hipSuccess) return qe;
-    static int occ[4] = {0, 0, 0, 0};
 #define FRW_LAUNCH(LOGN, ENC)                                                                                  \
     do {                                                                                                       \
         const int grid = resident_grid(witness_ntt_verify_kernel<LOGN, ENC>, batch, num_cu,                    \
-                                       occ[(LOGN - 9) * 2 + ENC]);                                             \
+                                       g_occ_verify[(LOGN - 9) * 2 + ENC]);                                             \
         hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, \
                            batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                               \
     } while (0)
@@ -1020,11 +1037,10 @@ hipError_t launch_witness_dual_ntt_verify(const Tables *tab, unsigned long long 
     if (!queue) return hipErrorOutOfMemory;
     hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
     if (qe != hipSuccess) return qe;
-    static int occ[4] = {0, 0, 0, 0};
 #define FRW_LAUNCH(LOGN, ENC)                                                                                       \
     do {                                                                                                            \
         const int grid = resident_grid(witness_dual_ntt_verify_kernel<LOGN, ENC>, batch, num_cu,                    \
-                                       occ[(LOGN - 9) * 2 + ENC]);                                                  \
+                                       g_occ_dual[(LOGN - 9) * 2 + ENC]);                                                  \
         hipLaunchKernelGGL((witness_dual_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, \
                            batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                                    \
     } while (0)
@@ -1043,10 +1059,9 @@ hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num
     if (!queue) return hipErrorOutOfMemory;
     hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
     if (qe != hipSuccess) return qe;
-    static int occ[4] = {0, 0, 0, 0};
 #define FRW_LAUNCH(LOGN, ENC)                                                                                  \
     do {                                                                                                       \
-        const int grid = resident_grid(ntt_modq_kernel<LOGN, ENC>, batch, num_cu, occ[(LOGN - 9) * 2 + ENC]);  \
+        const int grid = resident_grid(ntt_modq_kernel<LOGN, ENC>, batch, num_cu, g_occ_ntt[(LOGN - 9) * 2 + ENC]);  \
         hipLaunchKernelGGL((ntt_modq_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, batch,    \
                            poly, (v4u *)wit, ntt_out, status);                                                 \
     } while (0)

@@ -376,3 +376,34 @@ def test_full_launch_sample_digests_and_concurrent_streams(engine, oracle):
     engine.digest_dev(wit, L.num_witness * 4, batch, dig2, s0)
     torch.cuda.synchronize()
     assert torch.equal(dig, dig2)
+
+
+def test_device_entry_point_is_graph_capturable(engine, oracle):
+    """The _dev entry point is a memset node + a kernel node: captured into a hipGraph and replayed on fresh inputs."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    logn, batch = 9, 96
+    L = frw.layout(logn)
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=555)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.zeros((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.zeros((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    dig = torch.zeros(batch, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        engine.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, side.cuda_stream)
+    # new inputs in the same buffers, then replay
+    sig2, pk2, hm2 = frw.synth_triples(logn, batch, seed=556)
+    for t, a in zip(d, (sig2, pk2, hm2)):
+        t.copy_(torch.from_numpy(a.view(np.int16)))
+    graph.replay()
+    torch.cuda.synchronize()
+    engine.digest_dev(wit, L.num_witness * 4, batch, dig, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int((st != 0).sum()) == 0
+    owit, _, _ = oracle.witness_ntt_verify(logn, sig2, pk2, hm2, 1, threads=8)
+    assert [int(x) for x in dig.cpu().numpy().view(np.uint64)] == [oracle.digest(owit[i]) for i in range(batch)]
