@@ -354,7 +354,10 @@ __device__ __forceinline__ void ladder_lds(uint32_t *lad, const uint16_t *in, co
 #endif
 __device__ __forceinline__ void stream_store(v4u val, v4u *p)
 {
-#if FRW_NT_STORE
+#if defined(FRW_NO_STORE)
+    // timing-only build (tools/ab_variants.py): everything but the store, value and address kept alive
+    asm volatile("" ::"v"(val), "v"(p));
+#elif FRW_NT_STORE
     __builtin_nontemporal_store(val, p);
 #else
     *p = val;
@@ -374,6 +377,10 @@ __device__ __forceinline__ M lane_read(M v, int k)
     else return (M)__shfl((unsigned long long)v, k, WAVE);
 }
 
+// Measured alternatives (tools/ab_variants.py, stores disabled = pure instruction time per 4,096 signatures): this
+// form (one ds_bpermute for the mask, ~26 instructions per store) 1.14 ms; wave-uniform block tracking with three
+// v_readlane per window and a mask-blended unconditional slab read, ~57 instructions per store, 1.79 ms -- the
+// LDS round trips of this form are hidden by the other waves, extra VALU instructions are not.
 // LIMIT = false: the tile is complete (64 blocks).  LIMIT = true: only the first `nchunks` 16-byte chunks exist
 // (last, partial tile of a ragged gadget batch).
 template <int ENC, int BLK, int NVAL, int VFIRST, bool LIMIT = false, typename MASK = uint32_t>
