@@ -75,13 +75,13 @@ def cpu_baseline(logn, sig, pk, hm, gpu_digests, threads):
     oracle = frw_testlib.load_oracle()
     sub = 256                               # 1.3 GB of host witness at a time
     # single thread: the analogue of the reference's one-threaded generate_constraints
-    n1 = 1024
+    n1 = min(len(sig), 4096)
     t0 = time.perf_counter()
     for lo in range(0, n1, sub):
         oracle.witness_ntt_verify(logn, sig[lo:lo + sub], pk[lo:lo + sub], hm[lo:lo + sub], 1, threads=1)
     one = n1 / (time.perf_counter() - t0)
     # all cores, and digest parity with the GPU on the same signatures
-    nall = min(len(sig), 4096)
+    nall = min(len(sig), 32768)
     checked, t_all = 0, 0.0
     for lo in range(0, nall, sub):
         t0 = time.perf_counter()

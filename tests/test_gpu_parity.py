@@ -407,3 +407,26 @@ def test_device_entry_point_is_graph_capturable(engine, oracle):
     assert int((st != 0).sum()) == 0
     owit, _, _ = oracle.witness_ntt_verify(logn, sig2, pk2, hm2, 1, threads=8)
     assert [int(x) for x in dig.cpu().numpy().view(np.uint64)] == [oracle.digest(owit[i]) for i in range(batch)]
+
+
+def test_empty_batches_and_bad_arguments(engine):
+    """Empty input is a no-op (FRW_OK), malformed arguments are rejected before anything is launched."""
+    import ctypes as C
+    import falcon_r1cs_amd as frw
+    lib, ctx = engine._lib, engine._ctx
+    for logn in (9, 10):
+        n = 1 << logn
+        empty = np.zeros((0, n), dtype=np.uint16)
+        wit, inst, st = engine.witness_ntt_verify(logn, empty, empty, empty)
+        assert wit.shape[0] == inst.shape[0] == st.shape[0] == 0
+        w, o, s_ = engine.ntt_modq(logn, empty)
+        assert w.shape[0] == 0
+    assert lib.frw_witness_ntt_verify_dev(ctx, 10, 0, None, None, None, 1, None, None, None, None) == 0
+    assert lib.frw_witness_ntt_verify_dev(ctx, 10, 4, None, None, None, 1, None, None, None, None) == -1
+    assert lib.frw_witness_ntt_verify_dev(ctx, 11, 4, None, None, None, 1, None, None, None, None) == -1
+    assert lib.frw_witness_ntt_verify_dev(ctx, 10, 4, None, None, None, 2, None, None, None, None) == -1
+    assert lib.frw_gadget(ctx, 99, 1, None, None, 1, None, None) == -1
+    blocks, st = engine.gadget(frw.G_MOD_Q, [])
+    assert blocks.shape[0] == 0
+    with pytest.raises(ValueError):
+        engine.gadget(frw.G_MOD_Q, [1 << 161])
