@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="signatures per GPU per step")
     ap.add_argument("--chunk", type=int, default=4096, help="signatures per kernel launch (HBM witness buffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-r1cs-check", action="store_true",
+                    help="N = 1 only: skip the untimed on-device check that every witness of one full launch satisfies the "
+                         "independently emitted constraint system (builds the matrices on the host, ~6 s)")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1 only: skip the secondary, bounded 'generate + RCCL all-gather of the witness chunks' leg")
     ap.add_argument("--allgather-chunk", type=int, default=512, help="signatures per rank per all-gather")
@@ -378,6 +381,23 @@ def main():
         }
         if gather_info is not None:
             result["allgather"] = gather_info
+        if world == 1 and not args.no_r1cs_check:
+            # untimed: the reference's assert!(cs.is_satisfied()) for every signature of one launch, on the device,
+            # against matrices emitted from the gadget definitions by the host mirror (not the kernels' closed form)
+            launch(logn, chunk, d_sig[:chunk], d_pk[:chunk], d_hm[:chunk], d_wit, d_inst, d_st[:chunk],
+                   frw.ENC_MONTGOMERY, stream.cuda_stream)
+            h = eng.r1cs_load(1 if dual else 0, logn)
+            bad = torch.zeros(chunk, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            eng.r1cs_check_dev(h, chunk, d_wit, d_inst, bad, stream.cuda_stream)
+            torch.cuda.synchronize()
+            tc = time.perf_counter() - tc
+            eng.r1cs_free(h)
+            n_unsat = int((bad != 0).sum().item())
+            assert n_unsat == 0, "%d witnesses violate the constraint system" % n_unsat
+            result["r1cs_check"] = {"witnesses_checked": chunk, "unsatisfied": n_unsat, "constraints_each": L.num_constraints,
+                                    "seconds": round(tc, 3)}
         if world == 1 and not args.no_cpu_baseline and not dual:
             # digests of the first launch's witnesses (recomputed: the buffer holds the last chunk now)
             k = min(512, chunk)

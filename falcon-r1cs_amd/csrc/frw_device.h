@@ -41,6 +41,19 @@ hipError_t launch_hash_to_point(int logn, size_t batch, const uint8_t *nonces, c
 hipError_t launch_decode_public_keys(int logn, size_t batch, const uint8_t *pk_bytes, uint16_t *pk, int32_t *status, hipStream_t st);
 hipError_t launch_decode_signatures(int logn, size_t batch, const uint8_t *sig_bytes, size_t sig_len, uint16_t *sig,
                                     uint8_t *nonce_out, int32_t *status, hipStream_t st);
+// R1CS matrices resident on the device (frw_r1cs_load): CSR, coefficients in Montgomery form (8 x u32)
+struct R1csMatrixDev {
+    const uint64_t *row_ptr;    // num_constraints + 1
+    const uint32_t *col;        // nnz; < num_instance: instance variable (0 = the constant one), else witness
+    const uint32_t *val;        // nnz x 8
+};
+struct R1csDev {
+    uint32_t num_instance, num_witness, num_constraints;
+    R1csMatrixDev a, b, c;
+    const uint32_t *order;      // constraint rows by decreasing length
+};
+hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
+                             uint32_t *num_unsatisfied, hipStream_t st);
 hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int num_cu, hipStream_t st);
 hipError_t launch_digest(const uint64_t *buf, size_t words, size_t items, uint64_t *out, hipStream_t st);
 

@@ -2,24 +2,120 @@
 // (examples/pok_sig.rs:30-32 hands the circuit to Groth16, which calls cs.finalize() / to_matrices()).
 // Structure only: runs the host mirror (host/frw_host.hpp) in setup mode -- no values, no GPU -- inlines every
 // symbolic linear combination and writes A, B, C in a small CSR file a prover can ingest without arkworks.
+#include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <exception>
+#include <numeric>
+#include <vector>
 
 #include "../../include/frw.h"
+#include "frw_device.h"
 #include "host/frw_host.hpp"
+
+namespace {
+frw::host::ConstraintMatrices build_matrices(int circuit, int logn)
+{
+    using namespace frw::host;
+    const size_t N = (size_t)1 << logn;
+    auto cs = ConstraintSystem::new_ref();
+    cs->set_setup_mode(true);
+    Polynomial z{std::vector<uint16_t>(N, 0)};
+    if (circuit == FRW_CIRCUIT_NTT) FalconNTTVerificationCircuit::build_circuit(z, z, z, logn).generate_constraints(cs);
+    else FalconDualNTTVerificationCircuit::build_circuit(z, z, z, logn).generate_constraints(cs);
+    return cs->to_matrices();
+}
+}  // namespace
+
+// Device-resident matrices for frw_r1cs_check_dev
+struct frw_r1cs {
+    int device;
+    frw::R1csDev dev;
+    std::vector<void *> allocs;
+};
+
+extern "C" void frw_r1cs_free(frw_r1cs *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    for (void *p : r->allocs) (void)hipFree(p);
+    delete r;
+}
+
+extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
+{
+    if (!out || (logn != 9 && logn != 10) || (circuit != FRW_CIRCUIT_NTT && circuit != FRW_CIRCUIT_DUAL_NTT)) return FRW_E_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FRW_E_HIP;
+    frw_r1cs *r = nullptr;
+    try {
+        const frw::host::ConstraintMatrices m = build_matrices(circuit, logn);
+        r = new frw_r1cs;
+        r->device = device;
+        r->dev.num_instance = (uint32_t)m.num_instance_variables;
+        r->dev.num_witness = (uint32_t)m.num_witness_variables;
+        r->dev.num_constraints = (uint32_t)m.num_constraints;
+        auto upload = [&](const void *src, size_t bytes) -> void * {
+            void *d = nullptr;
+            if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) throw std::runtime_error("hipMalloc");
+            r->allocs.push_back(d);
+            if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy");
+            return d;
+        };
+        auto put = [&](const std::vector<frw::host::ConstraintMatrices::Row> &rows, frw::R1csMatrixDev &dst) {
+            std::vector<uint64_t> ptr{0};
+            std::vector<uint32_t> col, val;
+            for (const auto &row : rows) {
+                for (const auto &t : row) {
+                    col.push_back(t.second);
+                    for (int k = 0; k < 4; k++) { val.push_back((uint32_t)t.first.l[k]); val.push_back((uint32_t)(t.first.l[k] >> 32)); }   // Montgomery limbs
+                }
+                ptr.push_back(col.size());
+            }
+            dst.row_ptr = (const uint64_t *)upload(ptr.data(), ptr.size() * 8);
+            dst.col = (const uint32_t *)upload(col.data(), col.size() * 4);
+            dst.val = (const uint32_t *)upload(val.data(), val.size() * 4);
+        };
+        put(m.a, r->dev.a);
+        put(m.b, r->dev.b);
+        put(m.c, r->dev.c);
+        std::vector<uint32_t> order(m.num_constraints);
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            return m.a[x].size() + m.b[x].size() + m.c[x].size() > m.a[y].size() + m.b[y].size() + m.c[y].size();
+        });
+        r->dev.order = (const uint32_t *)upload(order.data(), order.size() * 4);
+        *out = r;
+        return FRW_OK;
+    } catch (const std::exception &) {
+        frw_r1cs_free(r);
+        return FRW_E_OUT_OF_MEMORY;
+    }
+}
+
+extern "C" int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                                  uint32_t *d_num_unsatisfied, void *stream)
+{
+    if (!r || (batch && (!d_witness || !d_instance || !d_num_unsatisfied))) return FRW_E_INVALID_ARG;
+    if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
+    for (size_t lo = 0; lo < batch; lo += 32768) {
+        const size_t cnt = std::min<size_t>(32768, batch - lo);
+        if (frw::launch_r1cs_check(r->dev, cnt, d_witness + lo * (size_t)r->dev.num_witness * 4,
+                                   d_instance + lo * (size_t)r->dev.num_instance * 4, d_num_unsatisfied + lo,
+                                   (hipStream_t)stream) != hipSuccess)
+            return FRW_E_HIP;
+    }
+    return FRW_OK;
+}
 
 extern "C" int frw_r1cs_export(int circuit, int logn, const char *path, uint64_t *counts /* 6 x u64, may be NULL */)
 {
     using namespace frw::host;
     if ((logn != 9 && logn != 10) || !path || (circuit != FRW_CIRCUIT_NTT && circuit != FRW_CIRCUIT_DUAL_NTT)) return FRW_E_INVALID_ARG;
     try {
-        const size_t N = (size_t)1 << logn;
-        auto cs = ConstraintSystem::new_ref();
-        cs->set_setup_mode(true);
-        Polynomial z{std::vector<uint16_t>(N, 0)};
-        if (circuit == FRW_CIRCUIT_NTT) FalconNTTVerificationCircuit::build_circuit(z, z, z, logn).generate_constraints(cs);
-        else FalconDualNTTVerificationCircuit::build_circuit(z, z, z, logn).generate_constraints(cs);
-        ConstraintMatrices m = cs->to_matrices();
+        ConstraintMatrices m = build_matrices(circuit, logn);
         if (counts) {
             counts[0] = m.num_instance_variables; counts[1] = m.num_witness_variables; counts[2] = m.num_constraints;
             counts[3] = m.non_zero(m.a); counts[4] = m.non_zero(m.b); counts[5] = m.non_zero(m.c);

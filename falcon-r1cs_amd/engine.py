@@ -227,6 +227,19 @@ class WitnessEngine:
         check(self._lib.frw_diag_write_stream_dev(self._ctx, self._ptr(d_buf), nbytes, slab_bytes, C.c_void_p(stream)),
               "frw_diag_write_stream_dev")
 
+    def r1cs_load(self, circuit, logn):
+        """Device-resident A/B/C of circuit 0 (NTT) / 1 (dual NTT) for r1cs_check_dev; free with r1cs_free."""
+        h = C.c_void_p()
+        check(self._lib.frw_r1cs_load(self.device, circuit, logn, C.byref(h)), "frw_r1cs_load")
+        return h
+
+    def r1cs_free(self, handle):
+        self._lib.frw_r1cs_free(handle)
+
+    def r1cs_check_dev(self, handle, batch, d_wit, d_inst, d_num_unsatisfied, stream=0):
+        check(self._lib.frw_r1cs_check_dev(handle, batch, self._ptr(d_wit), self._ptr(d_inst),
+                                           self._ptr(d_num_unsatisfied), C.c_void_p(stream)), "frw_r1cs_check_dev")
+
     def digest_dev(self, d_buf, words_per_item, items, d_out, stream=0):
         check(self._lib.frw_digest_dev(self._ctx, self._ptr(d_buf), words_per_item, items, self._ptr(d_out),
                                        C.c_void_p(stream)), "frw_digest_dev")

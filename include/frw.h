@@ -166,6 +166,17 @@ int frw_witness_dual_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
 #define FRW_CIRCUIT_DUAL_NTT  1   /* FalconDualNTTVerificationCircuit  circuits/falcon_dual_ntt.rs */
 int frw_r1cs_export(int circuit, int logn, const char *path, uint64_t *counts);
 
+/* Batch satisfaction check on the device: the reference's `assert!(cs.is_satisfied())` (falcon_ntt.rs:159) for every
+ * signature of an HBM-resident batch, against the matrices above (emitted from the gadget definitions, independently
+ * of the witness kernels' closed form).  frw_r1cs_load builds them on the host (seconds) and uploads them once;
+ * d_witness / d_instance are the buffers of the witness entry points with encoding FRW_ENC_MONTGOMERY;
+ * d_num_unsatisfied[i] = number of constraint rows signature i violates (0 = satisfied). */
+typedef struct frw_r1cs frw_r1cs;
+int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out);
+void frw_r1cs_free(frw_r1cs *r);
+int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                       uint32_t *d_num_unsatisfied, void *stream);
+
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),
  * hm = Polynomial::from_hash_of_message(msg, sig.nonce()).  Formats are the Falcon specification's:

@@ -430,3 +430,45 @@ def test_empty_batches_and_bad_arguments(engine):
     assert blocks.shape[0] == 0
     with pytest.raises(ValueError):
         engine.gadget(frw.G_MOD_Q, [1 << 161])
+
+
+@pytest.mark.parametrize("circuit,logn,batch", [(0, 9, 512), (0, 10, 4096), (1, 10, 256)])
+def test_whole_launch_satisfies_independent_r1cs_on_device(engine, circuit, logn, batch):
+    """falcon_ntt.rs:159 / falcon_dual_ntt.rs:168 `assert!(cs.is_satisfied())` for EVERY signature of a launch, on the
+    device, against matrices emitted by the C++ host mirror from the gadget definitions (not from the kernels' closed
+    form).  Then targeted corruptions must be caught, and only in the signatures that were touched."""
+    import time
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    L = frw.layout_dual(logn) if circuit else frw.layout(logn)
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=4242 + circuit)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    bad = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    launch = engine.witness_dual_ntt_verify_dev if circuit else engine.witness_ntt_verify_dev
+    launch(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, s0)
+    h = engine.r1cs_load(circuit, logn)
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        engine.r1cs_check_dev(h, batch, wit, inst, bad, s0)
+        torch.cuda.synchronize()
+        print("r1cs check of %d witnesses: %.3f s" % (batch, time.perf_counter() - t0))
+        assert int((st != 0).sum()) == 0
+        assert int(bad.abs().sum()) == 0
+        # corruptions: a boolean in S2/first segment area, a quotient t, a public input
+        n = L.n
+        targets = {3: (2 * n + 40, 0), 7: (L.seg_off[8 if circuit else 3], 0), batch - 1: (5, 1)}
+        for s_, (elem, limb) in targets.items():
+            wit[s_, elem, limb] += 1
+        inst[11, 4, 0] += 1
+        engine.r1cs_check_dev(h, batch, wit, inst, bad, s0)
+        torch.cuda.synchronize()
+        flagged = set(torch.nonzero(bad).flatten().tolist())
+        assert flagged == set(targets) | {11}
+    finally:
+        engine.r1cs_free(h)
