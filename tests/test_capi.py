@@ -80,3 +80,15 @@ def test_synth_rejects_bad_arguments():
     p = buf.ctypes.data_as(C.c_void_p)
     assert lib.frw_synth_triples(8, 1, 0, 0, p, p, p) == -1
     assert lib.frw_synth_triples(9, 1, 0, 0, None, p, p) == -1
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/frw.h compiles with gcc -std=c99 -pedantic and the library links from C."""
+    import subprocess
+    exe = str(tmp_path / "hdr")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-o", exe,
+                           os.path.join(ROOT, "tests", "c", "test_header_c99.c"),
+                           "-L" + os.path.join(ROOT, "falcon-r1cs_amd"), "-lfrw",
+                           "-Wl,-rpath," + os.path.join(ROOT, "falcon-r1cs_amd")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
