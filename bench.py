@@ -7,7 +7,7 @@
 A step = one pass of the hot path (falcon-r1cs/src/circuits/falcon_ntt.rs:26-123 of the reference) over one batch
 of synthetic signatures per GPU: BASELINE.json configs[2], "Falcon-1024 batch=65536 sigs, full verify-with-ntt
 witness".  65,536 witnesses are 329 GB, more than one GPU's 288 GB, so a step streams the batch through one reused
-HBM witness buffer in chunks (default 4,096 signatures = 20.5 GB per launch); inputs are resident in HBM before the
+HBM witness buffer in chunks (default 16,384 signatures = 82 GB per launch); inputs are resident in HBM before the
 timed region and outputs stay in HBM (the boundary a GPU prover or a peer would consume them from).
 Multi-GPU: signatures shard by index, every rank processes its own 65,536 (weak scaling), no data-path collective.
 
@@ -200,7 +200,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logn", type=int, default=10, choices=[9, 10])
     ap.add_argument("--batch", type=int, default=65536, help="signatures per GPU per step")
-    ap.add_argument("--chunk", type=int, default=4096, help="signatures per kernel launch (HBM witness buffer)")
+    ap.add_argument("--chunk", type=int, default=16384,
+                    help="signatures per kernel launch = size of the reused HBM witness buffer (16,384 Falcon-1024 "
+                         "witnesses = 82 GB of the 288 GB; larger launches measured faster: tools/time_chunk_sizes.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-r1cs-check", action="store_true",
                     help="N = 1 only: skip the untimed on-device check that every witness of one full launch satisfies the "
@@ -300,20 +302,20 @@ def main():
     bytes_per_sig = 32 * (L.num_witness + 2 * n) + 3 * 2 * n          # 5,086,848 B for Falcon-1024
     achieved = chunk * bytes_per_sig / (launch_ms * 1e-3) / 1e9
 
-    # ---- calibration (untimed): what a compute-free write stream of the same shape reaches on THIS device now ------
+    # ---- calibration (untimed): what a compute-free write stream of the same shape SUSTAINS on this device now -----
+    # Same regime as the timed region: one step's worth of launches back to back, second of two rounds (a single
+    # launch squeezed between witness kernels reads 5-10 % high: the device boosts after every change of load).
     wbytes = d_wit.numel() * 8
-    cal = []
-    for _ in range(6):
+    cal_ms = 0.0
+    for _ in range(2):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        eng.diag_write_stream_dev(d_wit, wbytes, L.num_witness * 32, stream.cuda_stream)
+        for _ in range(nchunks):
+            eng.diag_write_stream_dev(d_wit, wbytes, L.num_witness * 32, stream.cuda_stream)
         e1.record(stream)
-        launch(logn, chunk, d_sig[:chunk], d_pk[:chunk], d_hm[:chunk], d_wit, d_inst, d_st[:chunk],
-               frw.ENC_MONTGOMERY, stream.cuda_stream)      # keep the device in its loaded state
-        cal.append((e0, e1))
-    torch.cuda.synchronize()
-    cal_ms = sorted(a.elapsed_time(b) for a, b in cal[1:])
-    write_stream_gbs = wbytes / (cal_ms[len(cal_ms) // 2] * 1e-3) / 1e9
+        torch.cuda.synchronize()
+        cal_ms = e0.elapsed_time(e1) / nchunks
+    write_stream_gbs = wbytes / (cal_ms * 1e-3) / 1e9
 
     # ---- secondary leg (N > 1, untimed w.r.t. `value`): generate + all-gather of the witness chunks --------------
     # BASELINE north_star / configs[3] describe an RCCL all-gather of the per-signature witness vectors.  It is not on
@@ -384,19 +386,20 @@ def main():
         if world == 1 and not args.no_r1cs_check:
             # untimed: the reference's assert!(cs.is_satisfied()) for every signature of one launch, on the device,
             # against matrices emitted from the gadget definitions by the host mirror (not the kernels' closed form)
-            launch(logn, chunk, d_sig[:chunk], d_pk[:chunk], d_hm[:chunk], d_wit, d_inst, d_st[:chunk],
+            nchk = min(chunk, 4096)
+            launch(logn, nchk, d_sig[:nchk], d_pk[:nchk], d_hm[:nchk], d_wit, d_inst, d_st[:nchk],
                    frw.ENC_MONTGOMERY, stream.cuda_stream)
             h = eng.r1cs_load(1 if dual else 0, logn)
-            bad = torch.zeros(chunk, dtype=torch.int32, device=dev)
+            bad = torch.zeros(nchk, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
             tc = time.perf_counter()
-            eng.r1cs_check_dev(h, chunk, d_wit, d_inst, bad, stream.cuda_stream)
+            eng.r1cs_check_dev(h, nchk, d_wit, d_inst, bad, stream.cuda_stream)
             torch.cuda.synchronize()
             tc = time.perf_counter() - tc
             eng.r1cs_free(h)
             n_unsat = int((bad != 0).sum().item())
             assert n_unsat == 0, "%d witnesses violate the constraint system" % n_unsat
-            result["r1cs_check"] = {"witnesses_checked": chunk, "unsatisfied": n_unsat, "constraints_each": L.num_constraints,
+            result["r1cs_check"] = {"witnesses_checked": nchk, "unsatisfied": n_unsat, "constraints_each": L.num_constraints,
                                     "seconds": round(tc, 3)}
         if world == 1 and not args.no_cpu_baseline and not dual:
             # digests of the first launch's witnesses (recomputed: the buffer holds the last chunk now)

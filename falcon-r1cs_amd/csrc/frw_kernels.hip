@@ -994,7 +994,20 @@ static int resident_grid(K kernel, size_t batch, int num_cu, int &cache)
         cache = per_cu;
     }
     const size_t cap = (size_t)cache * (size_t)num_cu;
-    return (int)(batch < cap ? batch : cap);
+    if (batch <= cap) return (int)batch;
+#ifndef FRW_BALANCED_GRID
+#define FRW_BALANCED_GRID 1
+#endif
+#if FRW_BALANCED_GRID
+    // Every workgroup streams one 2.5-5 MB signature at a time, so a batch that is not a multiple of the grid ends in a
+    // tail where most CUs idle.  For short launches (< 8 rounds) a grid between 5/8 and 8/8 of the resident capacity that
+    // divides the batch wins (4,096 signatures: 512 x 8 rounds beats 768 x 5.33 by 1.1 %); for long ones the tail is
+    // amortised and the third workgroup per CU is worth more (16,384 signatures: 768 beats 512 by 1.1 %).
+    if (batch < 8 * cap)
+        for (size_t g = cap; g * 8 >= cap * 5; g--)
+            if (batch % g == 0) return (int)g;
+#endif
+    return (int)cap;
 }
 
 // Called once per context: asks the runtime for the residency of every persistent kernel, so that no launch ever
