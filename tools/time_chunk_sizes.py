@@ -16,18 +16,18 @@ eng = frw.WitnessEngine(0)
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
 L = frw.layout(logn)
-cap = 16384
+cap = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 sig, pk, hm = frw.synth_triples(logn, cap, seed=1)
 d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
 wit = torch.empty((cap, L.num_witness, 4), dtype=torch.int64, device=dev)
 inst = torch.empty((cap, L.num_instance, 4), dtype=torch.int64, device=dev)
 st = torch.empty(cap, dtype=torch.int32, device=dev)
-sizes = [1024, 2048, 3072, 4096, 4608, 6144, 8192, 12288, 16384]
+sizes = [b for b in (1024, 2048, 3072, 4096, 4608, 6144, 8192, 12288, 16384, 24576, 32768, 49152) if b <= cap]
 res = {b: [] for b in sizes}
 bytes_per = 32 * (L.num_witness + 2 * L.n) + 6 * L.n
 for rnd in range(6):
     for b in sizes:
-        reps = max(1, 16384 // b)
+        reps = max(1, cap // b)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(reps):
