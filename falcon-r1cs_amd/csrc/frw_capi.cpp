@@ -514,8 +514,8 @@ int frw_host_alloc(frw_ctx *ctx, size_t bytes, void **ptr)
 
 int frw_host_free(frw_ctx *ctx, void *ptr)
 {
-    if (!ctx) return FRW_E_INVALID_ARG;
-    FRW_HIP(hipSetDevice(ctx->device));
+    // ctx may be NULL (page-locked memory does not belong to a device; a buffer may outlive the context it came from)
+    if (ctx) FRW_HIP(hipSetDevice(ctx->device));
     FRW_HIP(hipHostFree(ptr));
     return FRW_OK;
 }

@@ -89,8 +89,8 @@ class WitnessEngine:
         check(self._lib.frw_host_alloc(self._ctx, nbytes, C.byref(ptr)), "frw_host_alloc")
         buf = (C.c_char * max(nbytes, 1)).from_address(ptr.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-        lib, ctx, addr = self._lib, self._ctx, ptr.value
-        weakref.finalize(buf, lambda: lib.frw_host_free(ctx, C.c_void_p(addr)))
+        lib, addr = self._lib, ptr.value
+        weakref.finalize(buf, lambda: lib.frw_host_free(None, C.c_void_p(addr)))     # may outlive this engine
         return arr
 
     # ---- host buffers ------------------------------------------------------------------

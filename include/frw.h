@@ -253,7 +253,7 @@ int frw_synth_triples(int logn, size_t batch, uint64_t seed, uint64_t first_inde
 /* Page-locked host memory.  Output buffers of the host-buffer entry points allocated here are filled by
  * asynchronous DMA that overlaps with the kernels of the next chunk (pageable buffers work too, slower). */
 int frw_host_alloc(frw_ctx *ctx, size_t bytes, void **ptr);
-int frw_host_free(frw_ctx *ctx, void *ptr);
+int frw_host_free(frw_ctx *ctx /* may be NULL */, void *ptr);
 
 /* thin wrappers so that a host without a HIP binding can own device memory */
 int frw_malloc(frw_ctx *ctx, size_t bytes, void **d_ptr);
