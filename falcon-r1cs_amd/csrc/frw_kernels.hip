@@ -396,11 +396,20 @@ __device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab
     // make sure the slab writes of all lanes have landed (same wave: a wait on LDS ops is enough)
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
+#ifndef FRW_INCREMENTAL_INDEX
+#define FRW_INCREMENTAL_INDEX 1
+#endif
+    // (k, pos) of this lane's element: element e = 32*it + lane/2 belongs to block k = e / BLK at position e % BLK.
+    // Carried from one iteration to the next (e grows by 32) instead of divided out every time.
+    int k = (lane >> 1) / BLK, pos = (lane >> 1) - k * BLK;
+    constexpr int STEP_K = 32 / BLK, STEP_POS = 32 - STEP_K * BLK;
 #pragma unroll 2
     for (int it = 0; it < 2 * BLK; it++) {
+#if !FRW_INCREMENTAL_INDEX
         const int e = it * 32 + (lane >> 1);          // element index inside the tile
-        const int k = e / BLK;                        // owning block == owning lane
-        const int pos = e - k * BLK;
+        k = e / BLK;                                  // owning block == owning lane
+        pos = e - k * BLK;
+#endif
         const MASK mk = lane_read(mask, k);
         const uint32_t bit = (uint32_t)(mk >> pos) & 1u;
         v4u val = bit ? one : mk4(0, 0, 0, 0);
@@ -414,6 +423,12 @@ __device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab
             if (isval) val = lv;
         }
         if (!LIMIT || it * WAVE + lane < nchunks) stream_store(val, &out[it * WAVE + lane]);
+#if FRW_INCREMENTAL_INDEX
+        pos += STEP_POS;
+        k += STEP_K;
+        if (pos >= BLK) { pos -= BLK; k += 1; }
+        if (LIMIT) k &= WAVE - 1;                     // last iteration of a partial tile: keep the lane index legal
+#endif
     }
     // the slab is rewritten by the next tile: all lanes must have finished reading it
     __builtin_amdgcn_s_waitcnt(0xc07f);
