@@ -472,3 +472,43 @@ def test_whole_launch_satisfies_independent_r1cs_on_device(engine, circuit, logn
         assert flagged == set(targets) | {11}
     finally:
         engine.r1cs_free(h)
+
+
+def test_config5_shape_mixed_1024_signatures(engine, oracle):
+    """BASELINE configs[4] shape: 1,024 signatures, Falcon-512 and Falcon-1024 mixed (parameter set drawn from the
+    seed), grouped by logn into two device launches; every witness must satisfy its circuit's constraint system
+    (checked on the device) and a sample must equal the oracle's witness by digest."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    rng = random.Random(2025)
+    logns = [rng.choice([9, 10]) for _ in range(1024)]
+    s0 = torch.cuda.current_stream().cuda_stream
+    for logn in (9, 10):
+        idx = [i for i, l in enumerate(logns) if l == logn]
+        batch = len(idx)
+        assert batch > 400
+        L = frw.layout(logn)
+        sig = np.empty((batch, L.n), dtype=np.uint16); pk = np.empty_like(sig); hm = np.empty_like(sig)
+        for j, i in enumerate(idx):                                  # stream = global signature index
+            s, p, h = frw.synth_triples(logn, 1, seed=77, first_index=i)
+            sig[j], pk[j], hm[j] = s[0], p[0], h[0]
+        d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+        wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+        inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+        st = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        bad = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        dig = torch.zeros(batch, dtype=torch.int64, device=dev)
+        engine.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, s0)
+        engine.digest_dev(wit, L.num_witness * 4, batch, dig, s0)
+        h = engine.r1cs_load(0, logn)
+        try:
+            engine.r1cs_check_dev(h, batch, wit, inst, bad, s0)
+            torch.cuda.synchronize()
+        finally:
+            engine.r1cs_free(h)
+        assert int((st != 0).sum()) == 0 and int(bad.abs().sum()) == 0
+        sample = list(range(0, batch, 37))
+        owit, _, _ = oracle.witness_ntt_verify(logn, sig[sample], pk[sample], hm[sample], 1, threads=8)
+        got = dig.cpu().numpy().view(np.uint64)
+        assert [int(got[j]) for j in sample] == [oracle.digest(owit[k]) for k in range(len(sample))]
