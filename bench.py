@@ -230,9 +230,9 @@ def main():
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("no HIP device visible: this benchmark has no CPU path")
-    if args.backend == "nccl" and local_rank >= ndev:
-        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
-    dev_index = local_rank % ndev                       # gloo rehearsal: ranks may share a GPU
+    # One rank per GPU.  If the launcher narrows visibility to one device per rank, that device is index 0; the gloo
+    # rehearsal deliberately lets ranks share a GPU.
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
