@@ -130,7 +130,7 @@ def bench_ntt_modq(args, world, rank, dev):
     bytes_per = 32 * 29 * n + 2 * n                               # 476,160 / 952,320 B per polynomial
     achieved = batch * bytes_per / (ms * 1e-3) / 1e9
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "falcon%d_ntt_modq_witness_polys_per_sec" % n, "value": round(world * batch * args.steps / elapsed, 1),
             "unit": "polynomials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -140,7 +140,7 @@ def bench_ntt_modq(args, world, rank, dev):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "ntt_modq_kernel<%d,1>" % logn, "algorithmic_bytes_per_launch": batch * bytes_per,
-                         "avg_launch_ms": round(ms, 4), "launches_timed": len(ev)}}), flush=True)
+                         "avg_launch_ms": round(ms, 4), "launches_timed": len(ev)}})
 
 
 def bench_prepare(args, world, rank, dev):
@@ -186,14 +186,35 @@ def bench_prepare(args, world, rank, dev):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ms = e0.elapsed_time(e1) / args.steps
-    print(json.dumps({"metric": "falcon%d_input_preparation_signatures_per_sec" % n, "value": round(batch * args.steps / elapsed, 1),
+    emit({"metric": "falcon%d_input_preparation_signatures_per_sec" % n, "value": round(batch * args.steps / elapsed, 1),
                       "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": round(ms, 4), "higher_is_better": True, "dtype": "u64 (Keccak lanes)", "data": "synthetic",
                       "config": {"workload": "decode pk + decode sig + SHAKE256 hash-to-point, %d-byte messages" % mlen,
-                                 "logn": logn, "batch_per_gpu": batch}}), flush=True)
+                                 "logn": logn, "batch_per_gpu": batch}})
+
+
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner at
+    communicator creation), so everything that goes to fd 1 during the run is sent to stderr and only emit() writes to
+    the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
 def main():
+    quiet_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -210,6 +231,9 @@ def main():
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1 only: skip the secondary, bounded 'generate + RCCL all-gather of the witness chunks' leg")
     ap.add_argument("--allgather-chunk", type=int, default=512, help="signatures per rank per all-gather")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="initialise the process group and run the N > 1 legs even with one rank (rehearses the RCCL "
+                         "calls on a single GPU)")
     ap.add_argument("--circuit", default="ntt", choices=["ntt", "dual"],
                     help="ntt = FalconNTTVerificationCircuit (default, the BASELINE metric); dual = the signed-split "
                          "FalconDualNTTVerificationCircuit (SURVEY 8-f row 2; not the headline metric)")
@@ -235,8 +259,12 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    use_pg = world > 1 or args.force_pg
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -322,7 +350,7 @@ def main():
     # the default data path (no consumer needs every witness on every GPU, and xGMI ingest caps it
     # near 2.4e5 signatures/s per node), but it is measured here, bounded, so the number exists next to `value`.
     gather_info = None
-    if world > 1 and not args.no_allgather:
+    if use_pg and not args.no_allgather:
         try:
             gc = min(args.allgather_chunk, chunk)
             iters = 6
@@ -411,8 +439,8 @@ def main():
             torch.cuda.synchronize()
             gpu_digests = [int(x) & (2 ** 64 - 1) for x in dig.cpu().numpy()]
             result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, gpu_digests, threads)
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        emit(result)
+    if use_pg:
         dist.destroy_process_group()
 
 
