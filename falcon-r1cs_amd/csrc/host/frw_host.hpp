@@ -1070,4 +1070,71 @@ private:
     const uint64_t *preset_wit_ = nullptr, *preset_inst_ = nullptr;
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Aggregate statement.  The reference's falcon-aggregate-sig crate is an empty stub
+// (falcon-aggregate-sig/src/main.rs:1-3), so the behaviour is defined here in the only way the reference's own
+// circuits allow: ONE constraint system on which FalconNTTVerificationCircuit::generate_constraints runs once per
+// statement, in order.  Its witness_assignment is then the concatenation of the per-signature witness vectors and its
+// instance_assignment is [1, (pk_ntt, hm_ntt) of statement 0, of statement 1, ...] -- exactly the batch buffers of
+// frw_witness_ntt_verify, so the whole aggregate witness costs one engine call per parameter set, whatever the count.
+// ---------------------------------------------------------------------------------------------------------------
+class FalconAggregateVerificationCircuit {
+public:
+    struct Statement { Polynomial pk, hm, sig; int logn; };
+
+    static FalconAggregateVerificationCircuit build_circuit(std::vector<Statement> statements)
+    {
+        FalconAggregateVerificationCircuit c;
+        c.st_ = std::move(statements);
+        return c;
+    }
+
+    void generate_constraints(const ConstraintSystemRef &cs) const
+    {
+        // one batched engine call per parameter set (Falcon-512 and Falcon-1024 may be mixed)
+        std::vector<uint64_t> wit[2], inst[2];
+        std::vector<size_t> slot(st_.size());
+        if (!cs->is_in_setup_mode()) {
+            detail::require_engine(cs, "FalconAggregateVerificationCircuit");
+            for (int logn = 9; logn <= 10; logn++) {
+                const size_t N = (size_t)1 << logn;
+                std::vector<uint16_t> sig, pk, hm;
+                size_t count = 0;
+                for (size_t i = 0; i < st_.size(); i++)
+                    if (st_[i].logn == logn) {
+                        sig.insert(sig.end(), st_[i].sig.c.begin(), st_[i].sig.c.end());
+                        pk.insert(pk.end(), st_[i].pk.c.begin(), st_[i].pk.c.end());
+                        hm.insert(hm.end(), st_[i].hm.c.begin(), st_[i].hm.c.end());
+                        slot[i] = count++;
+                    }
+                if (!count) continue;
+                if (sig.size() != count * N || pk.size() != count * N || hm.size() != count * N) throw std::invalid_argument("input length is not N");
+                frw_layout_t L;
+                frw_layout(logn, &L);
+                wit[logn - 9].resize(count * (size_t)L.num_witness * 4);
+                inst[logn - 9].resize(count * (size_t)L.num_instance * 4);
+                std::vector<int32_t> status(count);
+                int rc = frw_witness_ntt_verify(cs->engine()->get(), logn, count, sig.data(), pk.data(), hm.data(), FRW_ENC_MONTGOMERY,
+                                                wit[logn - 9].data(), inst[logn - 9].data(), status.data(), cs->strict() ? 1 : 0);
+                if (rc == FRW_E_RANGE) throw std::domain_error("Invalid input: a statement failed its range checks");
+                detail::check(rc, "frw_witness_ntt_verify");
+            }
+        }
+        for (size_t i = 0; i < st_.size(); i++) {
+            const Statement &s = st_[i];
+            FalconNTTVerificationCircuit one = FalconNTTVerificationCircuit::build_circuit(s.pk, s.hm, s.sig, s.logn);
+            if (!cs->is_in_setup_mode()) {
+                frw_layout_t L;
+                frw_layout(s.logn, &L);
+                one.use_engine_output(wit[s.logn - 9].data() + slot[i] * (size_t)L.num_witness * 4,
+                                      inst[s.logn - 9].data() + slot[i] * (size_t)L.num_instance * 4);
+            }
+            one.generate_constraints(cs);
+        }
+    }
+
+private:
+    std::vector<Statement> st_;
+};
+
 }  // namespace frw::host

@@ -381,6 +381,36 @@ static void test_dual_ntt_verification_r1cs(const Engine &eng, int logn)
     EXPECT(!cs->is_satisfied());
 }
 
+static void test_aggregate_circuit(const Engine &eng)
+{   // SURVEY 8-f row 4 / BASELINE configs[4] shape: mixed Falcon-512 / Falcon-1024 statements on ONE constraint system
+    std::printf("test_aggregate_circuit\n");
+    const int logns[5] = {10, 9, 9, 10, 9};
+    std::vector<FalconAggregateVerificationCircuit::Statement> st;
+    size_t want_w = 0, want_c = 0, want_i = 1;
+    for (int k = 0; k < 5; k++) {
+        const size_t N = (size_t)1 << logns[k];
+        FalconAggregateVerificationCircuit::Statement s{Polynomial{std::vector<uint16_t>(N)}, Polynomial{std::vector<uint16_t>(N)},
+                                                        Polynomial{std::vector<uint16_t>(N)}, logns[k]};
+        EXPECT(frw_synth_triples(logns[k], 1, 99, (uint64_t)k, s.sig.c.data(), s.pk.c.data(), s.hm.c.data()) == FRW_OK);
+        st.push_back(std::move(s));
+        frw_layout_t L;
+        frw_layout(logns[k], &L);
+        want_w += (size_t)L.num_witness; want_c += (size_t)L.num_constraints; want_i += (size_t)L.num_instance - 1;
+    }
+    auto cs = ConstraintSystem::new_ref();
+    cs->attach_engine(&eng);
+    FalconAggregateVerificationCircuit::build_circuit(st).generate_constraints(cs);
+    std::printf("  number of variables %zu %zu and constraints %zu\n", cs->num_instance_variables(), cs->num_witness_variables(), cs->num_constraints());
+    EXPECT(cs->num_witness_variables() == want_w && cs->num_constraints() == want_c && cs->num_instance_variables() == want_i);
+    EXPECT(cs->is_satisfied());
+    // the aggregate witness is the concatenation of the per-statement witnesses: the third statement's first element is its sig[0]
+    frw_layout_t L10, L9;
+    frw_layout(10, &L10); frw_layout(9, &L9);
+    EXPECT(cs->witness_assignment[(size_t)L10.num_witness + (size_t)L9.num_witness] == Fr::from(st[2].sig.c[0]));
+    cs->witness_assignment[(size_t)L10.num_witness + 17] = cs->witness_assignment[(size_t)L10.num_witness + 17] + Fr::one();
+    EXPECT(!cs->is_satisfied());
+}
+
 static void test_no_engine_is_assignment_missing()
 {
     std::printf("test_no_engine_is_assignment_missing\n");
@@ -408,6 +438,7 @@ int main(int argc, char **argv)
         for (int logn : {9, 10}) test_ntt_verification_r1cs(eng, logn);
         for (int logn : {9, 10}) test_build_circuit_from_bytes(eng, logn);
         for (int logn : {9, 10}) test_dual_ntt_verification_r1cs(eng, logn);
+        test_aggregate_circuit(eng);
     } else {
         std::printf("usage: %s structure | gpu | check <logn> <sig> <pk> <hm> <witness> <instance>\n", argv[0]);
         return 64;
