@@ -53,7 +53,7 @@ struct R1csDev {
     const uint32_t *order;      // constraint rows by decreasing length
 };
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
-                             uint32_t *num_unsatisfied, hipStream_t st);
+                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st);
 hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int num_cu, hipStream_t st);
 hipError_t launch_digest(const uint64_t *buf, size_t words, size_t items, uint64_t *out, hipStream_t st);
 

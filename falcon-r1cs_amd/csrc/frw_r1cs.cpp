@@ -95,8 +95,8 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
     }
 }
 
-extern "C" int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
-                                  uint32_t *d_num_unsatisfied, void *stream)
+extern "C" int frw_r1cs_eval_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                                 uint32_t *d_num_unsatisfied, uint64_t *d_abc, void *stream)
 {
     if (!r || (batch && (!d_witness || !d_instance || !d_num_unsatisfied))) return FRW_E_INVALID_ARG;
     if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
@@ -104,10 +104,17 @@ extern "C" int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_
         const size_t cnt = std::min<size_t>(32768, batch - lo);
         if (frw::launch_r1cs_check(r->dev, cnt, d_witness + lo * (size_t)r->dev.num_witness * 4,
                                    d_instance + lo * (size_t)r->dev.num_instance * 4, d_num_unsatisfied + lo,
+                                   d_abc ? d_abc + lo * (size_t)3 * r->dev.num_constraints * 4 : nullptr,
                                    (hipStream_t)stream) != hipSuccess)
             return FRW_E_HIP;
     }
     return FRW_OK;
+}
+
+extern "C" int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                                  uint32_t *d_num_unsatisfied, void *stream)
+{
+    return frw_r1cs_eval_dev(r, batch, d_witness, d_instance, d_num_unsatisfied, nullptr, stream);
 }
 
 extern "C" int frw_r1cs_export(int circuit, int logn, const char *path, uint64_t *counts /* 6 x u64, may be NULL */)

@@ -112,9 +112,18 @@ __device__ __forceinline__ Fr8 row_dot(const R1csMatrixDev &m, uint32_t row, con
     return acc;
 }
 
+__device__ __forceinline__ void fr_store(uint32_t *p, const Fr8 &v)
+{
+    *(uint4 *)p = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    *(uint4 *)(p + 4) = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// abc != nullptr: also write Az, Bz, Cz (Montgomery form) as [batch][3][num_constraints][8 x u32] -- the inputs of a
+// prover's QAP witness map (what ark-groth16 computes on the CPU right after generate_constraints).
 __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
                                                            const uint32_t *__restrict__ instance,
-                                                           unsigned int *__restrict__ num_unsatisfied)
+                                                           unsigned int *__restrict__ num_unsatisfied,
+                                                           uint32_t *__restrict__ abc)
 {
     const size_t sig = blockIdx.y;
     if (sig >= batch) return;
@@ -126,6 +135,12 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
         const Fr8 az = row_dot(r.a, row, wit, inst, r.num_instance);
         const Fr8 bz = row_dot(r.b, row, wit, inst, r.num_instance);
         const Fr8 cz = row_dot(r.c, row, wit, inst, r.num_instance);
+        if (abc) {
+            uint32_t *o = abc + sig * (size_t)3 * r.num_constraints * 8;
+            fr_store(o + (size_t)row * 8, az);
+            fr_store(o + ((size_t)r.num_constraints + row) * 8, bz);
+            fr_store(o + ((size_t)2 * r.num_constraints + row) * 8, cz);
+        }
         const Fr8 ab = fr_mul(az, bz);              // (Az R)(Bz R)/R = Az Bz R
         bool eq = true;
 #pragma unroll
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
 }
 
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
-                             uint32_t *num_unsatisfied, hipStream_t st)
+                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
     if (batch > 65535) return hipErrorInvalidValue;
@@ -147,7 +162,7 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
     // enough workgroups per signature that the dense ladder rows (first in `order`) spread over many waves
     const unsigned gx = (r.num_constraints + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(r1cs_check_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
-                       (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied);
+                       (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied, (uint32_t *)abc);
     return hipGetLastError();
 }
 

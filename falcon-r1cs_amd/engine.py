@@ -240,6 +240,12 @@ class WitnessEngine:
         check(self._lib.frw_r1cs_check_dev(handle, batch, self._ptr(d_wit), self._ptr(d_inst),
                                            self._ptr(d_num_unsatisfied), C.c_void_p(stream)), "frw_r1cs_check_dev")
 
+    def r1cs_eval_dev(self, handle, batch, d_wit, d_inst, d_num_unsatisfied, d_abc, stream=0):
+        """r1cs_check_dev + A z, B z, C z into d_abc (int64[batch, 3, C, 4], Montgomery)."""
+        check(self._lib.frw_r1cs_eval_dev(handle, batch, self._ptr(d_wit), self._ptr(d_inst),
+                                          self._ptr(d_num_unsatisfied), self._ptr(d_abc), C.c_void_p(stream)),
+              "frw_r1cs_eval_dev")
+
     def digest_dev(self, d_buf, words_per_item, items, d_out, stream=0):
         check(self._lib.frw_digest_dev(self._ctx, self._ptr(d_buf), words_per_item, items, self._ptr(d_out),
                                        C.c_void_p(stream)), "frw_digest_dev")

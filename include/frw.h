@@ -176,6 +176,11 @@ int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out);
 void frw_r1cs_free(frw_r1cs *r);
 int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
                        uint32_t *d_num_unsatisfied, void *stream);
+/* Same pass, additionally writing the three matrix-vector products a prover's QAP witness map starts from (what
+ * ark-groth16 computes on the CPU right after generate_constraints, examples/pok_sig.rs:32):
+ * d_abc = uint64_t[batch][3][C][4] = A z, B z, C z per signature, Montgomery form, rows in constraint order. */
+int frw_r1cs_eval_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                      uint32_t *d_num_unsatisfied, uint64_t *d_abc, void *stream);
 
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),

@@ -512,3 +512,41 @@ def test_config5_shape_mixed_1024_signatures(engine, oracle):
         owit, _, _ = oracle.witness_ntt_verify(logn, sig[sample], pk[sample], hm[sample], 1, threads=8)
         got = dig.cpu().numpy().view(np.uint64)
         assert [int(got[j]) for j in sample] == [oracle.digest(owit[k]) for k in range(len(sample))]
+
+
+def test_r1cs_matrix_vector_products_match_oracle(engine, oracle, tmp_path):
+    """frw_r1cs_eval_dev: A z, B z, C z per signature on the device == the oracle's matrices (independent inlining in
+    oracle/ark_sim.py) applied to the oracle's witness with Python integers."""
+    import torch
+    import falcon_r1cs_amd as frw
+    from oracle import falcon_gadgets as G
+    dev = torch.device("cuda:0")
+    logn, batch = 9, 3
+    L = frw.layout(logn)
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=8080)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.empty(batch, dtype=torch.int32, device=dev)
+    bad = torch.empty(batch, dtype=torch.int32, device=dev)
+    abc = torch.zeros((batch, 3, L.num_constraints, 4), dtype=torch.int64, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    engine.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, s0)
+    h = engine.r1cs_load(0, logn)
+    try:
+        engine.r1cs_eval_dev(h, batch, wit, inst, bad, abc, s0)
+        torch.cuda.synchronize()
+    finally:
+        engine.r1cs_free(h)
+    assert int(bad.abs().sum()) == 0
+    P = G.P_BLS12_381_FR
+    rinv = pow(G.R_MONT, -1, P)
+    k = 1                                                         # check the middle signature completely
+    cs = G.run_reference_flow(sig[k].tolist(), pk[k].tolist(), hm[k].tolist(), logn, strict=True)
+    z = cs.instance_assignment + cs.witness_assignment
+    got = abc[k].cpu().numpy().view(np.uint64)
+    to_int = lambda limbs: (int(limbs[0]) | int(limbs[1]) << 64 | int(limbs[2]) << 128 | int(limbs[3]) << 192) * rinv % P
+    for m, rows in enumerate(cs.to_matrices()):
+        for i in list(range(0, len(rows), 997)) + [29 * 512 * 0 + 27 * 512 + 29 * 5, len(rows) - 1]:   # sample incl. a dense ladder row
+            want = sum(c * z[col] for col, c in rows[i]) % P
+            assert to_int(got[m, i]) == want, (m, i)
