@@ -8,6 +8,9 @@ simulation of the arkworks front end).  They pin the closed-form C oracle and th
 * witness_*.json  -- one seeded (sig, pk, hm) triple each: the inputs (hex, u16 LE), SHA-256 of the witness and
                      instance assignment bytes in both encodings, the counts, and a few sampled elements
                      (the first mod_q quotients `t`, 132-/146-bit integers, as decimal strings).
+* dual_*.json     -- the same for FalconDualNTTVerificationCircuit (falcon_dual_ntt.rs).
+* prepare.json    -- input preparation: (nonce, msg) -> hash_to_point digests, encoded key / signature -> coefficient
+                     digests (oracle/falcon_codec.py; SHAKE256 from hashlib).
 * ntt_table.json  -- SHA-256 of falcon-rust's NTT_TABLE as the oracle regenerates it (7^bitrev10(i) mod q).
                      When /root/reference is present the script ALSO parses script/ntt_param.sage:3-132
                      (Falcon's GMb table, the reference's own data) and checks forward[i]/4091 mod q against the
@@ -76,7 +79,52 @@ def witness_fixture(logn, seed):
     }
 
 
+def dual_fixture(logn, seed):
+    """FalconDualNTTVerificationCircuit (falcon_dual_ntt.rs) on a seeded triple."""
+    rng = random.Random(seed)
+    sig, pk, hm, v = T.random_triple(logn, rng)
+    cs = G.run_reference_flow_dual(sig.tolist(), pk.tolist(), hm.tolist(), logn, strict=True)
+    assert cs.is_satisfied()
+    return {
+        "circuit": "dual", "logn": logn, "seed": seed,
+        "sig": sig.tobytes().hex(), "pk": pk.tobytes().hex(), "hm": hm.tobytes().hex(),
+        "num_instance": cs.num_instance_variables(), "num_witness": cs.num_witness_variables(),
+        "num_constraints": cs.num_constraints(),
+        "witness_sha256": {"canonical": sha(G.encode_elements(cs.witness_assignment, False)),
+                           "montgomery": sha(G.encode_elements(cs.witness_assignment, True))},
+        "instance_sha256": {"canonical": sha(G.encode_elements(cs.instance_assignment, False)),
+                            "montgomery": sha(G.encode_elements(cs.instance_assignment, True))},
+    }
+
+
+def prepare_fixture():
+    """Input preparation (oracle/falcon_codec.py): fixed (nonce, msg) pairs -> hash_to_point; encoded key/signature."""
+    from oracle import falcon_codec as K
+    rng = random.Random(77)
+    cases = []
+    for logn in (9, 10):
+        n = 1 << logn
+        for mlen in (0, 15, 96, 97, 300):
+            nonce = bytes(rng.randrange(256) for _ in range(40))
+            msg = bytes(rng.randrange(256) for _ in range(mlen))
+            hm = K.hash_to_point(nonce, msg, logn)
+            cases.append({"logn": logn, "nonce": nonce.hex(), "msg": msg.hex(), "hm_first8": hm[:8],
+                          "hm_sha256": sha(np.array(hm, dtype=np.uint16).tobytes())})
+        pk = [rng.randrange(G.MODULUS) for _ in range(n)]
+        s2 = [max(-2047, min(2047, round(rng.gauss(0, T.SIGMA[logn])))) for _ in range(n)]
+        nonce = bytes(rng.randrange(256) for _ in range(40))
+        cases.append({"logn": logn, "pk_bytes": K.modq_encode(pk, logn).hex(), "sig_bytes": K.comp_encode(s2, logn, nonce).hex(),
+                      "pk_sha256": sha(np.array(pk, dtype=np.uint16).tobytes()),
+                      "sig_sha256": sha(np.array([x % G.MODULUS for x in s2], dtype=np.uint16).tobytes())})
+    return {"description": "SHAKE256 hash-to-point and Falcon codecs (Falcon spec; hashlib SHAKE256)", "cases": cases}
+
+
 def main():
+    json.dump(prepare_fixture(), open(os.path.join(HERE, "prepare.json"), "w"), indent=1)
+    for logn, seed in [(9, 301), (10, 302)]:
+        fx = dual_fixture(logn, seed)
+        json.dump(fx, open(os.path.join(HERE, "dual_logn%d_seed%d.json" % (logn, seed)), "w"), indent=1)
+        print("wrote dual", logn, seed, fx["witness_sha256"]["montgomery"][:16])
     json.dump(ntt_table_fixture(), open(os.path.join(HERE, "ntt_table.json"), "w"), indent=1)
     for logn, seed in [(9, 101), (9, 102), (10, 201)]:
         fx = witness_fixture(logn, seed)

@@ -550,3 +550,35 @@ def test_r1cs_matrix_vector_products_match_oracle(engine, oracle, tmp_path):
         for i in list(range(0, len(rows), 997)) + [29 * 512 * 0 + 27 * 512 + 29 * 5, len(rows) - 1]:   # sample incl. a dense ladder row
             want = sum(c * z[col] for col, c in rows[i]) % P
             assert to_int(got[m, i]) == want, (m, i)
+
+
+def test_hip_matches_dual_and_prepare_golden(engine):
+    """Committed fixtures of the widened rows: dual-NTT witness digests (tests/golden/dual_*.json) and input
+    preparation digests (tests/golden/prepare.json)."""
+    import glob
+    import hashlib
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for path in sorted(glob.glob(os.path.join(gold, "dual_*.json"))):
+        fx = json.load(open(path))
+        sig, pk, hm = (np.frombuffer(bytes.fromhex(fx[k]), dtype=np.uint16) for k in ("sig", "pk", "hm"))
+        for enc, name in ((0, "canonical"), (1, "montgomery")):
+            wit, inst, st = engine.witness_dual_ntt_verify(fx["logn"], sig, pk, hm, enc, strict=True)
+            assert hashlib.sha256(wit.tobytes()).hexdigest() == fx["witness_sha256"][name]
+            assert hashlib.sha256(inst.tobytes()).hexdigest() == fx["instance_sha256"][name]
+    fx = json.load(open(os.path.join(gold, "prepare.json")))
+    import falcon_r1cs_amd as frw
+    for logn in (9, 10):
+        hashes = [c for c in fx["cases"] if c["logn"] == logn and "nonce" in c]
+        codec = [c for c in fx["cases"] if c["logn"] == logn and "pk_bytes" in c][0]
+        pkb, sgb = bytes.fromhex(codec["pk_bytes"]), bytes.fromhex(codec["sig_bytes"])
+        # the hash cases reuse the one encoded key/signature but need their own nonce: re-stamp the signature's nonce
+        sigs = [sgb[:1] + bytes.fromhex(c["nonce"]) + sgb[41:] for c in hashes]
+        s, p, h, st = engine.prepare_inputs(logn, [pkb] * len(hashes), [bytes.fromhex(c["msg"]) for c in hashes], sigs)
+        assert not st.any()
+        for i, c in enumerate(hashes):
+            assert h[i, :8].tolist() == c["hm_first8"]
+            assert hashlib.sha256(h[i].tobytes()).hexdigest() == c["hm_sha256"]
+        assert hashlib.sha256(p[0].tobytes()).hexdigest() == codec["pk_sha256"]
+        assert hashlib.sha256(s[0].tobytes()).hexdigest() == codec["sig_sha256"]

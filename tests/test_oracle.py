@@ -384,3 +384,14 @@ def test_schoolbook_counts_match_reference_readme(logn, want):
     G.FalconSchoolBookVerificationCircuit(sig.tolist(), pk.tolist(), hm.tolist(), logn).generate_constraints(cs, strict=True)
     assert (cs.num_instance_variables(), cs.num_witness_variables(), cs.num_constraints()) == want
     assert cs.is_satisfied()
+
+
+def test_c_oracle_matches_dual_golden(oracle):
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "dual_*.json"))):
+        fx = json.load(open(path))
+        sig, pk, hm = (np.frombuffer(bytes.fromhex(fx[k]), dtype=np.uint16) for k in ("sig", "pk", "hm"))
+        for enc, name in ((0, "canonical"), (1, "montgomery")):
+            wit, inst, st = oracle.witness_dual_ntt_verify(fx["logn"], sig, pk, hm, enc)
+            assert st[0] == 0 and wit.shape[1] == fx["num_witness"]
+            assert hashlib.sha256(wit.tobytes()).hexdigest() == fx["witness_sha256"][name]
+            assert hashlib.sha256(inst.tobytes()).hexdigest() == fx["instance_sha256"][name]
