@@ -500,7 +500,11 @@ struct Smem {
 // ------------------------------------------------------------------------------------------------
 // kernel: full verify-with-ntt witness (falcon_ntt.rs:26-123)
 // ------------------------------------------------------------------------------------------------
-template <int LOGN, int ENC>
+// SPLIT = false: one work item = one signature (the throughput form).  SPLIT = true (small batches, chosen by the
+// launcher when five items per signature still fit the resident grid, batch <= 153): one signature = five items of
+// ~30 N elements each -- {instance, S0, S1, S2}, {S5}, {S6, S7, status}, {S3}, {S4} -- taken by different workgroups,
+// each recomputing the part of the clear arithmetic it needs (a single Falcon-1024 witness: 167 us -> ~60 us).
+template <int LOGN, int ENC, bool SPLIT>
 __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
     const Tables *__restrict__ tab, unsigned long long *__restrict__ queue, size_t batch,
     const uint16_t *__restrict__ g_sig, const uint16_t *__restrict__ g_pk, const uint16_t *__restrict__ g_hm,
@@ -521,9 +525,13 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
     v4u *slab2 = (v4u *)sm.lad + wave * 2 * WAVE;
     for (int j = tid; j < 1024; j += BLOCK) sm.tw[j] = tab->tw[j];
 
+    constexpr int PARTS = SPLIT ? 5 : 1;
     unsigned long long ticket = 0;
-    for (size_t s = blockIdx.x; s < batch; s = next_item<LOGN>(s, ticket, &sm.next, tid)) {
+    for (size_t item = blockIdx.x; item < batch * PARTS; item = next_item<LOGN>(item, ticket, &sm.next, tid)) {
         ticket = draw_ticket<LOGN>(queue, tid);
+        const size_t s = SPLIT ? item / PARTS : item;
+        const int part = SPLIT ? (int)(item % PARTS) : -1;
+        auto does = [&](int p) { return !SPLIT || part == p; };             // workgroup-uniform
         // ---- 1. load + range check ----------------------------------------------------------
         if (tid == 0) { sm.norm = 0; sm.bad = 0; }
         __syncthreads();
@@ -536,22 +544,24 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         if (bad) sm.bad = 1;
         __syncthreads();
         if (sm.bad) {                                    // uniform across the workgroup
-            if (tid == 0) g_status[s] = ST_COEFF_RANGE;
+            if (tid == 0 && does(2)) g_status[s] = ST_COEFF_RANGE;
             __syncthreads();
             continue;
         }
-        // ---- 2. clear arithmetic -------------------------------------------------------------
-        {
-            uint16_t *const polys[3] = {sm.nsig, sm.npk, sm.nhm};
-            ntt_modq_lds<LOGN, 3>(polys, sm.tw, tid);                          // falcon_ntt.rs:45,51
+        // ---- 2. clear arithmetic (only what this item's segments need) ---------------------------
+        if (does(0) || does(1) || does(2) || does(4)) {
+            {
+                uint16_t *const polys[3] = {sm.nsig, sm.npk, sm.nhm};
+                ntt_modq_lds<LOGN, 3>(polys, sm.tw, tid);                      // falcon_ntt.rs:45,51
+            }
+            for (int j = tid; j < N; j += BLOCK) {
+                uint32_t x = sm.nhm[j] + Q - mod_q_u32((uint32_t)sm.nsig[j] * sm.npk[j]);
+                x = x >= Q ? x - Q : x;
+                sm.nv[j] = (uint16_t)x; sm.v[j] = (uint16_t)x;
+            }
+            __syncthreads();
+            if (does(0) || does(2) || does(4)) intt_modq_lds<LOGN>(sm.v, tab->itw, tid);   // v = hm - sig*pk   :48-49
         }
-        for (int j = tid; j < N; j += BLOCK) {
-            uint32_t x = sm.nhm[j] + Q - mod_q_u32((uint32_t)sm.nsig[j] * sm.npk[j]);
-            x = x >= Q ? x - Q : x;
-            sm.nv[j] = (uint16_t)x; sm.v[j] = (uint16_t)x;
-        }
-        __syncthreads();
-        intt_modq_lds<LOGN>(sm.v, tab->itw, tid);                                // v = hm - sig*pk   :48-49
 
         v4u *wit = g_wit + s * W * 2;
         v4u *inst = g_inst + s * I * 2;
@@ -559,14 +569,16 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         // ---- 3. small segments ---------------------------------------------------------------
         uint32_t e8[8];
         // instance_assignment[0] = 1; then pk_ntt, hm_ntt                                   :63,:67
-        if (tid < 2) {
+        if (tid < 2 && does(0)) {
             constexpr uint32_t R[8] = FRW_R32;
             v4u one = ENC == 0 ? (tid ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0))
                                  : (tid ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]));
             inst[tid] = one;
         }
+        if (does(0) || does(1))
         for (int t = wave; t < TILES; t += WAVES) {
             const int k = t * WAVE + lane;
+            if (does(0)) {
             encode_u32<ENC>(sm.npk[k], e8); slab_put(slab, 0, lane, e8);
             emit_tile<ENC, 1, 1, 0>(inst + 2 + (size_t)t * WAVE * 2, slab, 0, lane);
             encode_u32<ENC>(sm.nhm[k], e8); slab_put(slab, 0, lane, e8);
@@ -579,8 +591,9 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
             emit_tile<ENC, 1, 1, 0>(wit + (size_t)(N + t * WAVE) * 2, slab, 0, lane);
             // S2 enforce_less_than_q(v[k])                                                  :73-77
             emit_tile<ENC, 27, 0, 0>(wit + ((size_t)2 * N + (size_t)t * WAVE * 27) * 2, slab, ltq_mask(vk), lane);
+            }
             // S5 pointwise: [prod, t, c, ltq(c)]                                            :94-111
-            {
+            if (does(1)) {
                 const uint32_t prod = (uint32_t)sm.nsig[k] * sm.npk[k];
                 const uint32_t ab = sm.nv[k] + prod;                      // arithmetics.rs:238
                 const uint32_t tq = ab / Q, c = ab - tq * Q;              // :242-243
@@ -593,6 +606,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         }
         // S6 l2_norm_var over v || sig: [a0..a13, w0, w1, r, sq]                             :116-120
         unsigned long long nrm = 0;
+        if (does(2))
         for (int t = wave; t < 2 * TILES; t += WAVES) {
             const int k = t * WAVE + lane;
             const uint32_t a = k < N ? sm.v[k] : sm.sig[k - N];
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         if (lane == 0) atomicAdd(&sm.norm, nrm);
         __syncthreads();
         // S7 enforce_less_than_norm_bound                                                   :122
-        if (wave == 0) {
+        if (wave == 0 && does(2)) {
             const unsigned long long norm = sm.norm;
             const unsigned long long nm = LOGN == 9 ? norm_mask_512(norm) : norm_mask_1024(norm);
             constexpr uint32_t R[8] = FRW_R32;
@@ -627,6 +641,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         // ---- 4./5. ladders: S3 = mod_q blocks of NTT(sig), S4 = of NTT(v)                   :88-91
 #pragma unroll 1
         for (int which = 0; which < 2; which++) {
+            if (!does(3 + which)) continue;
             ladder_lds<LOGN>(sm.lad, which ? sm.v : sm.sig, sm.tw, &tab->ck[0][0], tid);
             v4u *seg = wit + (size_t)(which ? 58 : 29) * N * 2;
             for (int t = wave; t < TILES; t += WAVES) {
@@ -1037,8 +1052,9 @@ void init_launch_config()
 {
     int dummy = 0;
 #define FRW_Q(K, CACHE, LOGN, ENC) dummy += resident_grid(K<LOGN, ENC>, 1, 1, CACHE[(LOGN - 9) * 2 + ENC])
-    FRW_Q(witness_ntt_verify_kernel, g_occ_verify, 9, 0); FRW_Q(witness_ntt_verify_kernel, g_occ_verify, 9, 1);
-    FRW_Q(witness_ntt_verify_kernel, g_occ_verify, 10, 0); FRW_Q(witness_ntt_verify_kernel, g_occ_verify, 10, 1);
+#define FRW_QV(LOGN, ENC) dummy += resident_grid(witness_ntt_verify_kernel<LOGN, ENC, false>, 1, 1, g_occ_verify[(LOGN - 9) * 2 + ENC])
+    FRW_QV(9, 0); FRW_QV(9, 1); FRW_QV(10, 0); FRW_QV(10, 1);
+#undef FRW_QV
     FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 0); FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 1);
     FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 10, 0); FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 10, 1);
     FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 1);
@@ -1055,12 +1071,21 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queu
     if (!queue) return hipErrorOutOfMemory;
     hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
     if (qe != hipSuccess) return qe;
-#define FRW_LAUNCH(LOGN, ENC)                                                                                  \
-    do {                                                                                                       \
-        const int grid = resident_grid(witness_ntt_verify_kernel<LOGN, ENC>, batch, num_cu,                    \
-                                       g_occ_verify[(LOGN - 9) * 2 + ENC]);                                             \
-        hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, \
-                           batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                               \
+#define FRW_LAUNCH(LOGN, ENC)                                                                                        \
+    do {                                                                                                             \
+        int &occ = g_occ_verify[(LOGN - 9) * 2 + ENC];                                                               \
+        const size_t cap = (size_t)(occ > 0 ? occ : 2) * (size_t)num_cu;                                             \
+        if (batch * 5 <= cap) { /* small batch: five items per signature, all resident at once (measured: 1 sig    \
+                                   167 -> 56 us, 64 sigs 172 -> 95 us; at 256 signatures the split already loses) */ \
+            const size_t items = batch * 5;                                                                          \
+            const int grid = (int)(items < cap ? items : cap);                                                       \
+            hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC, true>), dim3(grid), dim3(BLOCK), 0, st, tab,    \
+                               queue, batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                          \
+        } else {                                                                                                     \
+            const int grid = resident_grid(witness_ntt_verify_kernel<LOGN, ENC, false>, batch, num_cu, occ);         \
+            hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC, false>), dim3(grid), dim3(BLOCK), 0, st, tab,   \
+                               queue, batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                          \
+        }                                                                                                            \
     } while (0)
     if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);
     else if (logn == 9) FRW_LAUNCH(9, 1);
