@@ -40,12 +40,12 @@ def main():
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(find(trace, "_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
-    kern = "%s<%d, 1>" % (kname, logn)
+    kern = "%s<%d, 1" % (kname, logn)          # prefix: the hot kernel carries a third template argument (SPLIT)
     w, nw, _ = pmc_avg(pmc_w, "WRITE_SIZE", kern)
     f, nf, _ = pmc_avg(pmc_f, "FETCH_SIZE", kern)
     stats = [r for r in csv.DictReader(open(find(trace, "_kernel_stats.csv"))) if kern in r["Name"]][0]
     summary = {
-        "kernel": kern, "logn": logn, "signatures_per_launch": chunk,
+        "kernel": kern + ("" if kern.endswith(">") else ", ...>"), "logn": logn, "signatures_per_launch": chunk,
         "avg_launch_ns": float(stats["AverageNs"]), "calls": int(stats["Calls"]),
         "WRITE_SIZE_KiB_avg": w, "WRITE_SIZE_launches": nw, "FETCH_SIZE_KiB_avg_raw": f, "FETCH_SIZE_launches": nf,
         "write_bytes_per_launch": w * 1024, "read_bytes_per_launch": f * 1024 * 2,
