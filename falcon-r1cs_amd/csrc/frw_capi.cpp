@@ -7,8 +7,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <new>
-#include <unordered_map>
 #include <vector>
 
 #include "../../include/frw.h"
@@ -18,10 +18,18 @@ struct frw_ctx {
     int device;
     int num_cu;
     frw::Tables *d_tables;
-    // Work-queue heads, one per stream the context has launched on: launches of one stream are ordered (memset node,
-    // then kernel), launches of different streams never share a head, however many are in flight.
-    std::vector<unsigned long long *> queue_blocks;                 // device allocations of QUEUE_SLOTS heads each
-    std::unordered_map<hipStream_t, unsigned long long *> queue_of;
+    // Work-queue heads (one 128-byte line each), all allocated with the context -- a launch never allocates.
+    // Slots [0, QUEUE_SLOTS): one per stream the context launches on, recycled least-recently-used; every launch first
+    // makes its stream wait for the event of the slot's previous launch, so a slot that changes hands (eviction, or a
+    // destroyed stream whose handle value comes back) is never reset while its last kernel is still draining.
+    // Slots [QUEUE_SLOTS, QUEUE_SLOTS + CAPTURE_SLOTS): one per launch recorded into a stream capture, never reused
+    // (a captured launch may be replayed on any stream at any time); exhausted -> FRW_E_OUT_OF_MEMORY.
+    unsigned long long *queue_heads;
+    struct StreamSlot { hipStream_t stream; hipEvent_t last; unsigned long long used; bool live; };
+    StreamSlot slots[frw::QUEUE_SLOTS];
+    unsigned long long use_clock;
+    int capture_used;
+    std::mutex queue_mu;
     hipStream_t host_compute, host_copy;                            // streams of the host-buffer entry points
 };
 
@@ -76,21 +84,38 @@ void build_tables(frw::Tables &t)
     }
 }
 
-// The work-queue head of `stream` (one 128-byte line each, carved from blocks of QUEUE_SLOTS; the first block is
-// allocated with the context, so the first QUEUE_SLOTS distinct streams never allocate).  nullptr on allocation failure.
-unsigned long long *queue_for(frw_ctx *ctx, hipStream_t stream)
+// The work-queue head for one launch on `stream`; *slot_out >= 0 names the stream slot whose event queue_launched
+// must record after the launch.  nullptr when the capture pool is exhausted.
+unsigned long long *queue_for(frw_ctx *ctx, hipStream_t stream, int *slot_out)
 {
-    auto it = ctx->queue_of.find(stream);
-    if (it != ctx->queue_of.end()) return it->second;
-    const size_t used = ctx->queue_of.size();
-    if (used % frw::QUEUE_SLOTS == 0) {
-        unsigned long long *blk = nullptr;
-        if (hipMalloc((void **)&blk, frw::QUEUE_SLOTS * 16 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
-        ctx->queue_blocks.push_back(blk);
+    std::lock_guard<std::mutex> lock(ctx->queue_mu);
+    *slot_out = -1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        if (ctx->capture_used >= frw::CAPTURE_SLOTS) return nullptr;
+        return ctx->queue_heads + (size_t)(frw::QUEUE_SLOTS + ctx->capture_used++) * 16;
     }
-    unsigned long long *q = ctx->queue_blocks.back() + (used % frw::QUEUE_SLOTS) * 16;
-    ctx->queue_of.emplace(stream, q);
-    return q;
+    int pick = -1;
+    for (int i = 0; i < frw::QUEUE_SLOTS; i++)
+        if (ctx->slots[i].live && ctx->slots[i].stream == stream) { pick = i; break; }
+    if (pick < 0) {
+        for (int i = 0; i < frw::QUEUE_SLOTS; i++) {
+            if (!ctx->slots[i].live) { pick = i; break; }
+            if (pick < 0 || ctx->slots[i].used < ctx->slots[pick].used) pick = i;      // least recently used
+        }
+        ctx->slots[pick].stream = stream;
+    }
+    frw_ctx::StreamSlot &sl = ctx->slots[pick];
+    if (sl.live) (void)hipStreamWaitEvent(stream, sl.last, 0);    // no-op for the stream that recorded it
+    sl.live = true;
+    sl.used = ++ctx->use_clock;
+    *slot_out = pick;
+    return ctx->queue_heads + (size_t)pick * 16;
+}
+
+void queue_launched(frw_ctx *ctx, hipStream_t stream, int slot)
+{
+    if (slot >= 0) (void)hipEventRecord(ctx->slots[slot].last, stream);
 }
 
 bool bad_common(const frw_ctx *ctx, int logn, int encoding)
@@ -160,6 +185,10 @@ int frw_ctx_create(int device, frw_ctx **out)
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
     ctx->d_tables = nullptr;
+    ctx->queue_heads = nullptr;
+    ctx->use_clock = 0;
+    ctx->capture_used = 0;
+    for (auto &sl : ctx->slots) sl = {nullptr, nullptr, 0, false};
     ctx->host_compute = ctx->host_copy = nullptr;
     frw::Tables host;
     build_tables(host);
@@ -167,20 +196,18 @@ int frw_ctx_create(int device, frw_ctx **out)
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tables, &host, sizeof host, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->host_compute, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->host_copy, hipStreamNonBlocking);
+    const size_t heads = (size_t)(frw::QUEUE_SLOTS + frw::CAPTURE_SLOTS) * 16 * sizeof(unsigned long long);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->queue_heads, heads);
+    if (e == hipSuccess) e = hipMemset(ctx->queue_heads, 0, heads);
+    for (auto &sl : ctx->slots)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.last, hipEventDisableTiming);
     if (e != hipSuccess) {
-        if (ctx->d_tables) (void)hipFree(ctx->d_tables);
-        if (ctx->host_compute) (void)hipStreamDestroy(ctx->host_compute);
-        if (ctx->host_copy) (void)hipStreamDestroy(ctx->host_copy);
-        delete ctx;
-        return hip_fail(e, "table upload");
-    }
-    // everything a launch needs is set up now, so the _dev entry points are stream-capture safe: residency of the
-    // persistent kernels, and queue heads for the default stream and the two host-path streams
-    frw::init_launch_config();
-    if (!queue_for(ctx, nullptr) || !queue_for(ctx, ctx->host_compute)) {
         frw_ctx_destroy(ctx);
-        return FRW_E_OUT_OF_MEMORY;
+        return hip_fail(e, "context setup");
     }
+    // everything a launch needs is set up now (residency of the persistent kernels, every queue head), so the _dev
+    // entry points never allocate or query and are stream-capture safe
+    frw::init_launch_config();
     *out = ctx;
     return FRW_OK;
 }
@@ -190,7 +217,9 @@ void frw_ctx_destroy(frw_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
-    for (unsigned long long *blk : ctx->queue_blocks) (void)hipFree(blk);
+    if (ctx->queue_heads) (void)hipFree(ctx->queue_heads);
+    for (auto &sl : ctx->slots)
+        if (sl.last) (void)hipEventDestroy(sl.last);
     if (ctx->host_compute) (void)hipStreamDestroy(ctx->host_compute);
     if (ctx->host_copy) (void)hipStreamDestroy(ctx->host_copy);
     delete ctx;
@@ -204,8 +233,12 @@ int frw_witness_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const uint1
     if (batch == 0) return FRW_OK;
     if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, queue_for(ctx, (hipStream_t)stream), ctx->num_cu, logn, encoding, batch, d_sig, d_pk, d_hm,
+    int slot;
+    unsigned long long *q = queue_for(ctx, (hipStream_t)stream, &slot);
+    if (!q) return FRW_E_OUT_OF_MEMORY;
+    FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, q, ctx->num_cu, logn, encoding, batch, d_sig, d_pk, d_hm,
                                            d_witness, d_instance, d_status, (hipStream_t)stream));
+    queue_launched(ctx, (hipStream_t)stream, slot);
     return FRW_OK;
 }
 
@@ -216,8 +249,12 @@ int frw_ntt_modq_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_pol
     if (batch == 0) return FRW_OK;
     if (!d_poly || !d_witness || !d_ntt_out || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, queue_for(ctx, (hipStream_t)stream), ctx->num_cu, logn, encoding, batch, d_poly, d_witness, d_ntt_out,
+    int slot;
+    unsigned long long *q = queue_for(ctx, (hipStream_t)stream, &slot);
+    if (!q) return FRW_E_OUT_OF_MEMORY;
+    FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, q, ctx->num_cu, logn, encoding, batch, d_poly, d_witness, d_ntt_out,
                                  d_status, (hipStream_t)stream));
+    queue_launched(ctx, (hipStream_t)stream, slot);
     return FRW_OK;
 }
 
@@ -271,16 +308,20 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
         if (k >= 2) FRW_HIP(hipStreamWaitEvent(compute.s, drained[b].e, 0));      // buffer b has been copied out
         for (int j = 0; j < 3; j++)
             FRW_HIP(hipMemcpyAsync(d_in[b][j].p, src[j] + lo * n, cnt * n * 2, hipMemcpyHostToDevice, compute.s));
+        int slot;
+        unsigned long long *q = queue_for(ctx, compute.s, &slot);
+        if (!q) return FRW_E_OUT_OF_MEMORY;
         if (dual)
-            FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, queue_for(ctx, compute.s), ctx->num_cu, logn, encoding, cnt,
+            FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, q, ctx->num_cu, logn, encoding, cnt,
                                                         (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
                                                         (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
                                                         (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
         else
-            FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, queue_for(ctx, compute.s), ctx->num_cu, logn, encoding, cnt,
+            FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, q, ctx->num_cu, logn, encoding, cnt,
                                                    (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
                                                    (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
                                                    (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
+        queue_launched(ctx, compute.s, slot);
         FRW_HIP(hipEventRecord(done[b].e, compute.s));
         FRW_HIP(hipStreamWaitEvent(copy.s, done[b].e, 0));
         FRW_HIP(hipMemcpyAsync(status + lo, d_st[b].p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, copy.s));
@@ -318,8 +359,12 @@ int frw_witness_dual_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const 
     if (batch == 0) return FRW_OK;
     if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, queue_for(ctx, (hipStream_t)stream), ctx->num_cu, logn, encoding, batch, d_sig,
+    int slot;
+    unsigned long long *q = queue_for(ctx, (hipStream_t)stream, &slot);
+    if (!q) return FRW_E_OUT_OF_MEMORY;
+    FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, q, ctx->num_cu, logn, encoding, batch, d_sig,
                                                 d_pk, d_hm, d_witness, d_instance, d_status, (hipStream_t)stream));
+    queue_launched(ctx, (hipStream_t)stream, slot);
     return FRW_OK;
 }
 
@@ -349,22 +394,42 @@ int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int
     if (batch == 0) return FRW_OK;
     if (!poly || !witness || !ntt_out || !status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
+    // same two-buffer, two-stream pipeline as witness_host: the D2H of chunk k overlaps the kernel of chunk k+1
     const size_t n = (size_t)1 << logn, wbytes = 29 * n * 32;
     const size_t chunk = std::min<size_t>(batch, 2048);
-    DevBuf d_in, d_wit, d_out, d_st;
-    FRW_HIP(d_in.alloc(chunk * n * 2));
-    FRW_HIP(d_wit.alloc(chunk * wbytes));
-    FRW_HIP(d_out.alloc(chunk * n * 2));
-    FRW_HIP(d_st.alloc(chunk * sizeof(int32_t)));
-    for (size_t lo = 0; lo < batch; lo += chunk) {
-        const size_t cnt = std::min(chunk, batch - lo);
-        FRW_HIP(hipMemcpy(d_in.p, poly + lo * n, cnt * n * 2, hipMemcpyHostToDevice));
-        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, queue_for(ctx, nullptr), ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in.p,
-                                     (uint64_t *)d_wit.p, (uint16_t *)d_out.p, (int32_t *)d_st.p, nullptr));
-        FRW_HIP(hipMemcpy(status + lo, d_st.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
-        FRW_HIP(hipMemcpy((char *)witness + lo * wbytes, d_wit.p, cnt * wbytes, hipMemcpyDeviceToHost));
-        FRW_HIP(hipMemcpy(ntt_out + lo * n, d_out.p, cnt * n * 2, hipMemcpyDeviceToHost));
+    DevBuf d_in[2], d_wit[2], d_out[2], d_st[2];
+    Event done[2], drained[2];
+    hipStream_t compute = ctx->host_compute, copy = ctx->host_copy;
+    const int nbuf = batch > chunk ? 2 : 1;
+    for (int b = 0; b < nbuf; b++) {
+        FRW_HIP(d_in[b].alloc(chunk * n * 2));
+        FRW_HIP(d_wit[b].alloc(chunk * wbytes));
+        FRW_HIP(d_out[b].alloc(chunk * n * 2));
+        FRW_HIP(d_st[b].alloc(chunk * sizeof(int32_t)));
+        FRW_HIP(done[b].create());
+        FRW_HIP(drained[b].create());
     }
+    size_t k = 0;
+    for (size_t lo = 0; lo < batch; lo += chunk, k++) {
+        const size_t cnt = std::min(chunk, batch - lo);
+        const int b = (int)(k & 1);
+        if (k >= 2) FRW_HIP(hipStreamWaitEvent(compute, drained[b].e, 0));
+        FRW_HIP(hipMemcpyAsync(d_in[b].p, poly + lo * n, cnt * n * 2, hipMemcpyHostToDevice, compute));
+        int slot;
+        unsigned long long *q = queue_for(ctx, compute, &slot);
+        if (!q) return FRW_E_OUT_OF_MEMORY;
+        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, q, ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in[b].p,
+                                     (uint64_t *)d_wit[b].p, (uint16_t *)d_out[b].p, (int32_t *)d_st[b].p, compute));
+        queue_launched(ctx, compute, slot);
+        FRW_HIP(hipEventRecord(done[b].e, compute));
+        FRW_HIP(hipStreamWaitEvent(copy, done[b].e, 0));
+        FRW_HIP(hipMemcpyAsync(status + lo, d_st[b].p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, copy));
+        FRW_HIP(hipMemcpyAsync((char *)witness + lo * wbytes, d_wit[b].p, cnt * wbytes, hipMemcpyDeviceToHost, copy));
+        FRW_HIP(hipMemcpyAsync(ntt_out + lo * n, d_out[b].p, cnt * n * 2, hipMemcpyDeviceToHost, copy));
+        FRW_HIP(hipEventRecord(drained[b].e, copy));
+    }
+    FRW_HIP(hipStreamSynchronize(compute));
+    FRW_HIP(hipStreamSynchronize(copy));
     return FRW_OK;
 }
 
@@ -409,6 +474,8 @@ int frw_prepare_inputs(frw_ctx *ctx, int logn, size_t batch, const uint8_t *pk_b
     if (batch == 0) return FRW_OK;
     if (!pk_bytes || !sig_bytes || !msg_off || !sig || !pk || !hm || !status || sig_len <= 1 + FRW_NONCE_LEN) return FRW_E_INVALID_ARG;
     if (!msgs && msg_off[batch] != msg_off[0]) return FRW_E_INVALID_ARG;
+    for (size_t i = 0; i < batch; i++)
+        if (msg_off[i + 1] < msg_off[i]) return FRW_E_INVALID_ARG;        // offsets must be non-decreasing
     FRW_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << logn, pk_len = FRW_PK_LEN(logn);
     const size_t msg_bytes = (size_t)(msg_off[batch] - msg_off[0]);

@@ -11,7 +11,8 @@ constexpr int WAVE = 64;               // CDNA wavefront
 constexpr int BLOCK = 256;             // one workgroup = 4 wavefronts = one signature
 constexpr int WAVES = BLOCK / WAVE;
 
-constexpr int QUEUE_SLOTS = 64;        // work-queue heads per context, used round-robin by successive launches
+constexpr int QUEUE_SLOTS = 64;        // work-queue heads per context for ordinary launches: one per stream, recycled LRU
+constexpr int CAPTURE_SLOTS = 448;     // heads for launches recorded into stream captures (one each, never reused)
 
 constexpr int ST_OK = 0, ST_COEFF_RANGE = 1, ST_NORM_BOUND = 2, ST_DECODE = 3;    // == FRW_ST_* of include/frw.h
 

@@ -30,6 +30,7 @@
 // store instruction, so each global_store_dwordx4 writes 1 KiB of contiguous HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "frw_device.h"
 
 namespace frw {
@@ -347,30 +348,217 @@ __device__ __forceinline__ void ladder_lds(uint32_t *lad, const uint16_t *in, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// tile writer.  A tile is 64 consecutive gadget blocks of BLK field elements; block k belongs to
-// lane k.  Element `pos` of a block is either one of the block's NVAL non-boolean values (parked
-// in the wave's LDS slab, 32 B each, as [slot][half][lane] v4u) or a boolean taken from bit
-// `pos` of lane k's mask.  VFIRST = position of the first value (values are contiguous).
-// The wave emits the tile's 64*BLK*32 bytes in address order, 1 KiB per store instruction.
+// tile writer.  A tile is 64 consecutive gadget blocks of BLK field elements; block k belongs to lane k.
+// Element `pos` of a block is either one of the block's NVAL non-boolean values (encoded by lane k and
+// parked in the wave's LDS slab as 16-byte halves) or a boolean taken from bit `pos` of lane k's mask.
+// The wave emits the tile's 64*BLK*32 bytes in address order, 16 B per lane = 1 KiB per store instruction.
+//
+// Round-2 form (3 vector instructions per store; round 1 needed ~26):
+//  * the tile's booleans are first packed into a bit stream in block order, 32 bits per lane (lane i holds
+//    stream bits [32 i, 32 i + 32): three ds_bpermute + shifts, once per tile).  Store `it` covers elements
+//    32 it .. 32 it + 31, i.e. exactly dword `it` of the stream: v_readlane -> SGPR, s_bitreplicate_b64_b32
+//    doubles every bit (two lanes per element) and the result IS the lane mask of a v_cndmask.
+//  * every lane then reads its 16 bytes from LDS: value lanes from the slab, boolean lanes from constants woven into
+//    the slab (zero in slot 0, this half of one in slot 1: `bit ? + slot stride : + 0`).  Which address a lane reads depends only
+//    on (store index mod period, lane) -- the pattern of value positions repeats every lcm(64, 2 BLK) chunks -- so it
+//    comes from a small per-workgroup table (ds_read_u16, immediate offset) and one v_add3 adds the wave's slab base.
+//  * the store is a buffer_store_dwordx4 with the signature's buffer resource, the lane's 16-byte offset in a VGPR and
+//    the running tile offset in an SGPR: no vector address arithmetic at all.
 // ------------------------------------------------------------------------------------------------
-// Output store.  Measured on MI355X (tools/hbm_write_ceiling.hip, 20 GB pure write stream): plain stores
-// 5.67 TB/s, non-temporal 5.39 TB/s; FRW_NT_STORE selects the flavour for A/B runs (tools/ab_variants.py).
-#ifndef FRW_NT_STORE
-#define FRW_NT_STORE 0
+#define FRW_LDS __attribute__((address_space(3)))
+
+// LDS geometry of the value slabs.  A (slot, wave, half) row holds the 64 lanes' 16-byte halves in four groups of 16,
+// each group followed by a 16-byte constant: slab_addr(k) = (k / 16) * SLAB_GRP + (k % 16) * 16.  The constants of
+// slot 0 are zero, those of slot 1 are this half of the field element one, so a boolean lane reads
+// row(slot 0) + 256 + (bit ? SLAB_SLOT : 0) -- and because the constants repeat with the group stride, adding the
+// per-period block advance (a multiple of 16 blocks = SLAB_GRP bytes) to EVERY lane's address moves value lanes to the
+// next blocks and boolean lanes to another copy of the same constant.  All rows of one slot are contiguous, so what a
+// wave reads is at a wave-independent offset from B_w = slab + wave * SLAB_WBLK.  Slots 0 and 1 are the slab proper;
+// slot 2 (S5 only) aliases the first SLAB_SLOT bytes of what follows the slab in LDS (the ladder array, idle while
+// the small segments are written).
+constexpr int SLAB_GRP = 16 * 16 + 16;             // 272
+constexpr int SLAB_HALF = 4 * SLAB_GRP;            // 1,088
+constexpr int SLAB_WBLK = 2 * SLAB_HALF;           // 2,176
+constexpr int SLAB_SLOT = WAVES * SLAB_WBLK;       // 8,704
+constexpr int SLAB_BYTES = 2 * SLAB_SLOT;          // 17,408
+__device__ __forceinline__ constexpr int slab_addr(int k) { return (k >> 4) * SLAB_GRP + (k & 15) * 16; }
+
+// Period structure of a tile shape: the (block, position) pattern of chunk 64 j + lane repeats after P stores, during
+// which the block index advances by KSTEP.
+template <int BLK> struct TileShape;
+template <> struct TileShape<29> { static constexpr int P = 29, NPER = 2, KSTEP = 32, NVAL = 2, VFIRST = 0, ROW0 = 0; };   // mod_q block
+template <> struct TileShape<30> { static constexpr int P = 15, NPER = 4, KSTEP = 16, NVAL = 3, VFIRST = 0, ROW0 = 29; };  // pointwise block
+template <> struct TileShape<18> { static constexpr int P = 9, NPER = 4, KSTEP = 16, NVAL = 2, VFIRST = 16, ROW0 = 44; };  // l2 block
+constexpr int VTAB_ROWS = 53;
+static_assert(TileShape<29>::P * TileShape<29>::NPER == 58 && TileShape<30>::P * TileShape<30>::NPER == 60 &&
+              TileShape<18>::P * TileShape<18>::NPER == 36, "a tile is 2 BLK stores");
+
+// vtab[row][lane] = LDS byte offset (relative to B_w) of the 16 bytes lane `lane` stores in store `row - ROW0` of a
+// period when the element's boolean is 0.  Filled once per workgroup (the kernels are persistent).
+__device__ __forceinline__ void init_vtab(uint16_t *vtab, int rows, int tid)
+{
+    for (int idx = tid; idx < rows * WAVE; idx += BLOCK) {
+        const int row = idx >> 6, lane = idx & 63;
+        int blk, nval, vfirst, j;
+        if (row < TileShape<30>::ROW0) { blk = 29; nval = 2; vfirst = 0; j = row; }
+        else if (row < TileShape<18>::ROW0) { blk = 30; nval = 3; vfirst = 0; j = row - TileShape<30>::ROW0; }
+        else { blk = 18; nval = 2; vfirst = 16; j = row - TileShape<18>::ROW0; }
+        const int c = j * WAVE + lane, e = c >> 1, h = c & 1;
+        const int k = e / blk, slot = e - k * blk - vfirst;
+        vtab[idx] = (uint16_t)((unsigned)slot < (unsigned)nval ? slot * SLAB_SLOT + h * SLAB_HALF + slab_addr(k)
+                                                               : h * SLAB_HALF + 256);
+    }
+}
+
+// the wave's constants: 16 lanes write the four group constants of (slot 0 | 1, half 0 | 1): zero | this half of one
+template <int ENC>
+__device__ __forceinline__ void init_slab_const(uint32_t slab_w, int lane)
+{
+    constexpr uint32_t R[8] = FRW_R32;
+    if (lane < 16) {
+        const int slot = lane >> 3, h = (lane >> 2) & 1, g = lane & 3;
+        v4u c = mk4(0, 0, 0, 0);
+        if (slot == 1) {
+            if (ENC == 0) c = h ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0);
+            else c = h ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]);
+        }
+        *(FRW_LDS v4u *)(uintptr_t)(slab_w + slot * SLAB_SLOT + h * SLAB_HALF + g * SLAB_GRP + 256) = c;
+    }
+}
+
+// what a wave needs to emit tiles
+struct WaveCtx {
+    uint32_t slab;       // LDS byte address of B_w
+    uint32_t vtab;       // LDS byte address of vtab[0][lane]
+    int lane;
+};
+
+__device__ __forceinline__ void slab_put(uint32_t slab_w, int slot, int lane, const uint32_t (&e)[8])
+{
+    const uint32_t a = slab_w + slot * SLAB_SLOT + slab_addr(lane);
+    *(FRW_LDS v4u *)(uintptr_t)a = mk4(e[0], e[1], e[2], e[3]);
+    *(FRW_LDS v4u *)(uintptr_t)(a + SLAB_HALF) = mk4(e[4], e[5], e[6], e[7]);
+}
+
+// Output store.  Round 1 measured plain stores ahead of non-temporal ones (+2.8 % N=1024, +5 % N=512); FRW_STORE_AUX
+// sets the cache-policy bits of the buffer store for A/B builds (tools/ab_variants.py), FRW_NO_STORE compiles the
+// stores out (instruction time only).
+#ifndef FRW_STORE_AUX
+#define FRW_STORE_AUX 0
 #endif
-__device__ __forceinline__ void stream_store(v4u val, v4u *p)
+__device__ __forceinline__ void tile_store(v4u val, __amdgpu_buffer_rsrc_t rsrc, int voff, uint32_t soff)
 {
 #if defined(FRW_NO_STORE)
-    // timing-only build (tools/ab_variants.py): everything but the store, value and address kept alive
-    asm volatile("" ::"v"(val), "v"(p));
-#elif FRW_NT_STORE
-    __builtin_nontemporal_store(val, p);
+    asm volatile("" ::"v"(val), "v"(voff), "s"(soff));
 #else
-    *p = val;
+    __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, voff, (int)soff, FRW_STORE_AUX);
+    // Measured on MI355X (round 2, tools/dev/diag_verify.py): a VALU write to the data registers in the instruction
+    // right after a 128-bit buffer store corrupts some lanes of the stored data, also when `soffset` is an SGPR -- the
+    // case the compiler's hazard recogniser exempts (it pads only the immediate-soffset form).  The asm reads `val`, so
+    // the registers stay allocated up to the two wait states it provides; tests/test_isa_hazards.py checks the
+    // generated code.
+    asm volatile("s_nop 1" ::"v"(val));
 #endif
 }
 
-__device__ __forceinline__ void slab_put(v4u *slab, int slot, int lane, const uint32_t (&e)[8])
+// buffer resource over [base, base + bytes): raw buffer, no swizzle, 32-bit data format (word 3 = 0x00020000 on gfx9-family)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ unsigned long long bit_double(uint32_t s)
+{
+    unsigned long long m;
+    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(m) : "s"(s));
+    return m;
+}
+
+__device__ __forceinline__ void lds_fence()
+{
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same wave, a wait on its LDS operations is enough
+    __builtin_amdgcn_wave_barrier();
+}
+
+// lane i <- bits [32 i, 32 i + 32) of the concatenation of the 64 lanes' BLK-bit masks (upper mask bits must be 0)
+template <int BLK>
+__device__ __forceinline__ uint32_t pack_bits(uint32_t mask, int lane)
+{
+    static_assert(BLK >= 16 && BLK <= 30, "a 32-bit window covers at most three blocks");
+    const int k0 = (lane * 32) / BLK, o = lane * 32 - k0 * BLK;
+    const uint32_t m0 = (uint32_t)__shfl((int)mask, k0 & 63, WAVE);
+    const uint32_t m1 = (uint32_t)__shfl((int)mask, (k0 + 1) & 63, WAVE);
+    const uint32_t m2 = (uint32_t)__shfl((int)mask, (k0 + 2) & 63, WAVE);
+    uint32_t d = (m0 >> o) | (m1 << (BLK - o));
+    if (2 * BLK - o < 32) d |= m2 << (2 * BLK - o);
+    return d;
+}
+
+// a tile of 64 one-element blocks (S0, S1, the instance vector): lane k's element is in slot 0
+__device__ __forceinline__ void emit_values(__amdgpu_buffer_rsrc_t rsrc, uint32_t soff, const WaveCtx &w)
+{
+    lds_fence();
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const v4u val = *(const FRW_LDS v4u *)(uintptr_t)(w.slab + (w.lane & 1) * SLAB_HALF + slab_addr((w.lane >> 1) + 32 * it));
+        tile_store(val, rsrc, w.lane * 16, soff + it * 1024);
+    }
+    lds_fence();                           // the slab is rewritten by the next tile
+}
+
+// a tile of 64 all-zero elements (the dual circuit's pos*neg products)
+__device__ __forceinline__ void emit_zeros(__amdgpu_buffer_rsrc_t rsrc, uint32_t soff, const WaveCtx &w)
+{
+    tile_store(mk4(0, 0, 0, 0), rsrc, w.lane * 16, soff);
+    tile_store(mk4(0, 0, 0, 0), rsrc, w.lane * 16, soff + 1024);
+}
+
+// a tile of 64 blocks of BLK elements; booleans in `mask` (bit pos = element pos, zeros at value positions)
+template <int BLK>
+__device__ __forceinline__ void emit_tile(__amdgpu_buffer_rsrc_t rsrc, uint32_t soff, uint32_t mask, const WaveCtx &w)
+{
+    lds_fence();                           // the slab writes of all lanes have landed
+    const uint32_t bits = pack_bits<BLK>(mask, w.lane);
+    const int voff = w.lane * 16;
+    if constexpr (BLK == 27) {             // enforce_less_than_q on its own: booleans only
+        const uint32_t a0 = w.slab + (w.lane & 1) * SLAB_HALF + 256, a1 = a0 + SLAB_SLOT;
+#pragma unroll 1
+        for (int g = 0; g < 6; g++) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const int it = g * 9 + j;
+                const bool b = __builtin_amdgcn_inverse_ballot_w64(bit_double(__builtin_amdgcn_readlane(bits, it)));
+                const v4u val = *(const FRW_LDS v4u *)(uintptr_t)(b ? a1 : a0);
+                tile_store(val, rsrc, voff, soff + it * 1024);
+            }
+        }
+    } else {
+        using S = TileShape<BLK>;
+        const uint32_t trow = w.vtab + S::ROW0 * WAVE * 2;
+        uint32_t base = w.slab;
+#pragma unroll 1
+        for (int per = 0; per < S::NPER; per++) {
+#pragma unroll
+            for (int j = 0; j < S::P; j++) {
+                const int it = per * S::P + j;
+                const bool b = __builtin_amdgcn_inverse_ballot_w64(bit_double(__builtin_amdgcn_readlane(bits, it)));
+                const uint32_t a = *(const FRW_LDS uint16_t *)(uintptr_t)(trow + j * WAVE * 2);
+                const v4u val = *(const FRW_LDS v4u *)(uintptr_t)(a + (b ? (uint32_t)SLAB_SLOT : 0u) + base);
+                tile_store(val, rsrc, voff, soff + it * 1024);
+                if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);     // bound the scheduler's hoisting (registers)
+            }
+            base += (S::KSTEP / 16) * SLAB_GRP;
+        }
+    }
+    lds_fence();                           // the slab is rewritten by the next tile: all lanes have finished reading it
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic tile writer of the stand-alone gadget kernel (ragged counts, 64-bit masks; not a throughput path): lane l of
+// iteration `it` produces chunk 64 it + l, fetching block k's mask with one ds_bpermute and value halves from a
+// [slot][half][lane] slab.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gslab_put(v4u *slab, int slot, int lane, const uint32_t (&e)[8])
 {
     slab[(slot * 2 + 0) * WAVE + lane] = mk4(e[0], e[1], e[2], e[3]);
     slab[(slot * 2 + 1) * WAVE + lane] = mk4(e[4], e[5], e[6], e[7]);
@@ -383,62 +571,30 @@ __device__ __forceinline__ M lane_read(M v, int k)
     else return (M)__shfl((unsigned long long)v, k, WAVE);
 }
 
-// Measured alternatives (tools/ab_variants.py, stores disabled = pure instruction time per 4,096 signatures): this
-// form (one ds_bpermute for the mask, ~26 instructions per store) 1.14 ms; wave-uniform block tracking with three
-// v_readlane per window and a mask-blended unconditional slab read, ~57 instructions per store, 1.79 ms -- the
-// LDS round trips of this form are hidden by the other waves, extra VALU instructions are not.
-// LIMIT = false: the tile is complete (64 blocks).  LIMIT = true: only the first `nchunks` 16-byte chunks exist
-// (last, partial tile of a ragged gadget batch).
-template <int ENC, int BLK, int NVAL, int VFIRST, bool LIMIT = false, typename MASK = uint32_t>
-__device__ __forceinline__ void emit_tile(v4u *__restrict__ out, const v4u *slab, MASK mask, int lane, int nchunks = 0,
-                                          const v4u *slab2 = nullptr)
+template <int ENC, int BLK, int NVAL, int VFIRST, typename MASK>
+__device__ __forceinline__ void emit_tile_generic(v4u *__restrict__ out, const v4u *slab, MASK mask, int lane, int nchunks)
 {
     constexpr uint32_t R[8] = FRW_R32;
     const int half = lane & 1;
-    // this lane's half of the field element "1"
     v4u one;
     if (ENC == 0) one = half ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0);
     else one = half ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]);
-    // make sure the slab writes of all lanes have landed (same wave: a wait on LDS ops is enough)
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-#ifndef FRW_INCREMENTAL_INDEX
-#define FRW_INCREMENTAL_INDEX 1
-#endif
-    // (k, pos) of this lane's element: element e = 32*it + lane/2 belongs to block k = e / BLK at position e % BLK.
-    // Carried from one iteration to the next (e grows by 32) instead of divided out every time.
-    int k = (lane >> 1) / BLK, pos = (lane >> 1) - k * BLK;
-    constexpr int STEP_K = 32 / BLK, STEP_POS = 32 - STEP_K * BLK;
-#pragma unroll 2
+    lds_fence();
     for (int it = 0; it < 2 * BLK; it++) {
-#if !FRW_INCREMENTAL_INDEX
         const int e = it * 32 + (lane >> 1);          // element index inside the tile
-        k = e / BLK;                                  // owning block == owning lane
-        pos = e - k * BLK;
-#endif
+        const int k = (e / BLK) & (WAVE - 1);         // owning block == owning lane
+        const int pos = e - (e / BLK) * BLK;
         const MASK mk = lane_read(mask, k);
-        const uint32_t bit = (uint32_t)(mk >> pos) & 1u;
-        v4u val = bit ? one : mk4(0, 0, 0, 0);
+        v4u val = (uint32_t)(mk >> pos) & 1u ? one : mk4(0, 0, 0, 0);
         if (NVAL > 0) {
             const int slot = pos - VFIRST;
             const bool isval = (unsigned)slot < (unsigned)NVAL;
-            // slots 0,1 live in the wave's slab; a third slot (S5 only) is parked in `slab2`
-            const v4u *src = (NVAL > 2 && slot == 2) ? slab2 + half * WAVE + k
-                                                     : slab + ((isval ? slot : 0) * 2 + half) * WAVE + k;
-            const v4u lv = *src;
+            const v4u lv = slab[((isval ? slot : 0) * 2 + half) * WAVE + k];
             if (isval) val = lv;
         }
-        if (!LIMIT || it * WAVE + lane < nchunks) stream_store(val, &out[it * WAVE + lane]);
-#if FRW_INCREMENTAL_INDEX
-        pos += STEP_POS;
-        k += STEP_K;
-        if (pos >= BLK) { pos -= BLK; k += 1; }
-        if (LIMIT) k &= WAVE - 1;                     // last iteration of a partial tile: keep the lane index legal
-#endif
+        if (it * WAVE + lane < nchunks) out[it * WAVE + lane] = val;
     }
-    // the slab is rewritten by the next tile: all lanes must have finished reading it
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+    lds_fence();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -478,24 +634,45 @@ __device__ __forceinline__ size_t next_item(size_t cur, unsigned long long ticke
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS carve-up of one workgroup
+// LDS carve-up of one workgroup.  The NTT-domain arrays are dead once the small segments are written and the ladder
+// array is dead until then, so they share memory: behind the third value slot (first SLAB_SLOT bytes of `lad`) as many
+// of them as fit live inside `lad`.  Falcon-1024: 50.3 KB -> 3 workgroups per CU; Falcon-512: 40.1 KB -> 4.
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-struct Smem {
+struct alignas(16) Smem {
     static constexpr int N = 1 << LOGN;
-    v4u slab[WAVES][2 * 2 * WAVE];       // per-wave value slab: 2 slots x 2 halves x 64 lanes x 16 B = 4 KB
-    uint32_t lad[5 * N];                 // ladder integers, limb-major; while the small segments are written (no
-                                         // ladder alive) its first 8 KB hold the waves' third value slot (S5)
-    uint16_t tw[1024];
+    static constexpr int IN_LAD = (5 * N * 4 - SLAB_SLOT) / (2 * N) < 4 ? (5 * N * 4 - SLAB_SLOT) / (2 * N) : 4;   // 4 | 1
+    unsigned char slab[SLAB_BYTES];      // value slots 0, 1 of the four waves + their constant areas
+    uint32_t lad[5 * N];                 // ladder integers, limb-major; before the ladders: slot 2, then NTT-domain arrays
+    uint16_t tw[N];
     uint16_t sig[N], v[N];               // coefficient domain
-    uint16_t nsig[N], npk[N], nhm[N], nv[N];   // NTT domain, all reduced mod q
+    uint16_t ntt_rest[(4 - IN_LAD) * N + 8];     // the NTT-domain arrays that do not fit inside `lad`
+    uint16_t vtab[VTAB_ROWS * WAVE];
     unsigned long long norm;
     unsigned long long next;              // next signature index taken from the launch's work queue
     int bad;
 #if defined(FRW_LDS_PAD) && FRW_LDS_PAD > 0
     uint32_t pad[FRW_LDS_PAD / 4];        // occupancy experiments only (tools/ab_variants.py)
 #endif
+    // NTT-domain array i of {nsig, npk, nhm, nv}, all reduced mod q; nv first so that it is the one inside `lad` at N = 512
+    __device__ __forceinline__ uint16_t *ntt_arr(int i)
+    {
+        uint16_t *in_lad = (uint16_t *)((unsigned char *)lad + SLAB_SLOT);
+        return i < IN_LAD ? in_lad + i * N : ntt_rest + (i - IN_LAD) * N;
+    }
 };
+
+__device__ __forceinline__ size_t uniform_index(size_t x)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return (size_t)lo | ((size_t)hi << 32);
+}
+
+// a rejected signature (coefficient >= q: the reference panics, range_proofs.rs:57-60) leaves zeros, not stale memory
+__device__ __forceinline__ void zero_fill(v4u *p, size_t chunks, int tid)
+{
+    for (size_t i = tid; i < chunks; i += BLOCK) p[i] = mk4(0, 0, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------------
 // kernel: full verify-with-ntt witness (falcon_ntt.rs:26-123)
@@ -515,23 +692,32 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
     constexpr size_t W = 153 * (size_t)N + NB;
     constexpr size_t I = 2 * (size_t)N + 1;
     constexpr int TILES = N / WAVE;
+    constexpr uint32_t TILE1 = WAVE * 32;            // bytes of a tile of one-element blocks
     __shared__ Smem<LOGN> sm;
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
-    const int wave = tid >> 6;
-    v4u *slab = sm.slab[wave];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t *const s_nv = sm.ntt_arr(0), *const s_nsig = sm.ntt_arr(1), *const s_npk = sm.ntt_arr(2), *const s_nhm = sm.ntt_arr(3);
+    WaveCtx wc;
+    wc.slab = (uint32_t)(uintptr_t)(FRW_LDS void *)sm.slab + wave * SLAB_WBLK;
+    wc.vtab = (uint32_t)(uintptr_t)(FRW_LDS void *)sm.vtab + lane * 2;
+    wc.lane = lane;
 
-    v4u *slab2 = (v4u *)sm.lad + wave * 2 * WAVE;
-    for (int j = tid; j < 1024; j += BLOCK) sm.tw[j] = tab->tw[j];
+    for (int j = tid; j < N; j += BLOCK) sm.tw[j] = tab->tw[j];
+    init_vtab(sm.vtab, VTAB_ROWS, tid);
+    init_slab_const<ENC>(wc.slab, lane);
 
     constexpr int PARTS = SPLIT ? 5 : 1;
     unsigned long long ticket = 0;
-    for (size_t item = blockIdx.x; item < batch * PARTS; item = next_item<LOGN>(item, ticket, &sm.next, tid)) {
+    for (size_t item_v = blockIdx.x; item_v < batch * PARTS; item_v = next_item<LOGN>(item_v, ticket, &sm.next, tid)) {
         ticket = draw_ticket<LOGN>(queue, tid);
+        const size_t item = uniform_index(item_v);
         const size_t s = SPLIT ? item / PARTS : item;
         const int part = SPLIT ? (int)(item % PARTS) : -1;
         auto does = [&](int p) { return !SPLIT || part == p; };             // workgroup-uniform
+        v4u *wit = g_wit + s * W * 2;
+        v4u *inst = g_inst + s * I * 2;
         // ---- 1. load + range check ----------------------------------------------------------
         if (tid == 0) { sm.norm = 0; sm.bad = 0; }
         __syncthreads();
@@ -539,32 +725,33 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         for (int j = tid; j < N; j += BLOCK) {
             uint32_t a = g_sig[s * N + j], b = g_pk[s * N + j], c = g_hm[s * N + j];
             bad |= (a >= Q) | (b >= Q) | (c >= Q);
-            sm.sig[j] = (uint16_t)a; sm.nsig[j] = (uint16_t)a; sm.npk[j] = (uint16_t)b; sm.nhm[j] = (uint16_t)c;
+            sm.sig[j] = (uint16_t)a; s_nsig[j] = (uint16_t)a; s_npk[j] = (uint16_t)b; s_nhm[j] = (uint16_t)c;
         }
         if (bad) sm.bad = 1;
         __syncthreads();
         if (sm.bad) {                                    // uniform across the workgroup
             if (tid == 0 && does(2)) g_status[s] = ST_COEFF_RANGE;
+            if (does(0)) { zero_fill(wit, W * 2, tid); zero_fill(inst, I * 2, tid); }
             __syncthreads();
             continue;
         }
         // ---- 2. clear arithmetic (only what this item's segments need) ---------------------------
         if (does(0) || does(1) || does(2) || does(4)) {
             {
-                uint16_t *const polys[3] = {sm.nsig, sm.npk, sm.nhm};
+                uint16_t *const polys[3] = {s_nsig, s_npk, s_nhm};
                 ntt_modq_lds<LOGN, 3>(polys, sm.tw, tid);                      // falcon_ntt.rs:45,51
             }
             for (int j = tid; j < N; j += BLOCK) {
-                uint32_t x = sm.nhm[j] + Q - mod_q_u32((uint32_t)sm.nsig[j] * sm.npk[j]);
+                uint32_t x = s_nhm[j] + Q - mod_q_u32((uint32_t)s_nsig[j] * s_npk[j]);
                 x = x >= Q ? x - Q : x;
-                sm.nv[j] = (uint16_t)x; sm.v[j] = (uint16_t)x;
+                s_nv[j] = (uint16_t)x; sm.v[j] = (uint16_t)x;
             }
             __syncthreads();
             if (does(0) || does(2) || does(4)) intt_modq_lds<LOGN>(sm.v, tab->itw, tid);   // v = hm - sig*pk   :48-49
         }
 
-        v4u *wit = g_wit + s * W * 2;
-        v4u *inst = g_inst + s * I * 2;
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(wit, (uint32_t)(W * 32));
+        const __amdgpu_buffer_rsrc_t ri = make_rsrc(inst, (uint32_t)(I * 32));
 
         // ---- 3. small segments ---------------------------------------------------------------
         uint32_t e8[8];
@@ -579,29 +766,28 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         for (int t = wave; t < TILES; t += WAVES) {
             const int k = t * WAVE + lane;
             if (does(0)) {
-            encode_u32<ENC>(sm.npk[k], e8); slab_put(slab, 0, lane, e8);
-            emit_tile<ENC, 1, 1, 0>(inst + 2 + (size_t)t * WAVE * 2, slab, 0, lane);
-            encode_u32<ENC>(sm.nhm[k], e8); slab_put(slab, 0, lane, e8);
-            emit_tile<ENC, 1, 1, 0>(inst + 2 + (size_t)(N + t * WAVE) * 2, slab, 0, lane);
+            encode_u32<ENC>(s_npk[k], e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(ri, 32 + t * TILE1, wc);
+            encode_u32<ENC>(s_nhm[k], e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(ri, 32 + (N / WAVE + t) * TILE1, wc);
             // S0 sig, S1 v                                                                  :58-59,:71
-            encode_u32<ENC>(sm.sig[k], e8); slab_put(slab, 0, lane, e8);
-            emit_tile<ENC, 1, 1, 0>(wit + (size_t)(t * WAVE) * 2, slab, 0, lane);
+            encode_u32<ENC>(sm.sig[k], e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(rw, t * TILE1, wc);
             const uint32_t vk = sm.v[k];
-            encode_u32<ENC>(vk, e8); slab_put(slab, 0, lane, e8);
-            emit_tile<ENC, 1, 1, 0>(wit + (size_t)(N + t * WAVE) * 2, slab, 0, lane);
+            encode_u32<ENC>(vk, e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(rw, (N / WAVE + t) * TILE1, wc);
             // S2 enforce_less_than_q(v[k])                                                  :73-77
-            emit_tile<ENC, 27, 0, 0>(wit + ((size_t)2 * N + (size_t)t * WAVE * 27) * 2, slab, ltq_mask(vk), lane);
+            emit_tile<27>(rw, (2 * N + t * WAVE * 27) * 32, ltq_mask(vk), wc);
             }
             // S5 pointwise: [prod, t, c, ltq(c)]                                            :94-111
             if (does(1)) {
-                const uint32_t prod = (uint32_t)sm.nsig[k] * sm.npk[k];
-                const uint32_t ab = sm.nv[k] + prod;                      // arithmetics.rs:238
+                const uint32_t prod = (uint32_t)s_nsig[k] * s_npk[k];
+                const uint32_t ab = s_nv[k] + prod;                       // arithmetics.rs:238
                 const uint32_t tq = ab / Q, c = ab - tq * Q;              // :242-243
-                encode_u32<ENC>(prod, e8); slab_put(slab, 0, lane, e8);
-                encode_u32<ENC>(tq, e8);   slab_put(slab, 1, lane, e8);
-                encode_u32<ENC>(c, e8);    slab_put(slab2, 0, lane, e8);
-                emit_tile<ENC, 30, 3, 0>(wit + ((size_t)87 * N + (size_t)t * WAVE * 30) * 2, slab, ltq_mask(c) << 3, lane,
-                                         0, slab2);
+                encode_u32<ENC>(prod, e8); slab_put(wc.slab, 0, lane, e8);
+                encode_u32<ENC>(tq, e8);   slab_put(wc.slab, 1, lane, e8);
+                encode_u32<ENC>(c, e8);    slab_put(wc.slab, 2, lane, e8);
+                emit_tile<30>(rw, (87 * N + t * WAVE * 30) * 32, ltq_mask(c) << 3, wc);
             }
         }
         // S6 l2_norm_var over v || sig: [a0..a13, w0, w1, r, sq]                             :116-120
@@ -614,9 +800,9 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
             const uint32_t r = (m >> 15) & 1u ? a : Q - a;                // misc.rs:35-46
             const uint32_t sq = r * r;
             nrm += sq;
-            encode_u32<ENC>(r, e8);  slab_put(slab, 0, lane, e8);
-            encode_u32<ENC>(sq, e8); slab_put(slab, 1, lane, e8);
-            emit_tile<ENC, 18, 2, 16>(wit + ((size_t)117 * N + (size_t)t * WAVE * 18) * 2, slab, m, lane);
+            encode_u32<ENC>(r, e8);  slab_put(wc.slab, 0, lane, e8);
+            encode_u32<ENC>(sq, e8); slab_put(wc.slab, 1, lane, e8);
+            emit_tile<18>(rw, (117 * N + t * WAVE * 18) * 32, m, wc);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor((unsigned long long)nrm, off, WAVE);
@@ -643,16 +829,16 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         for (int which = 0; which < 2; which++) {
             if (!does(3 + which)) continue;
             ladder_lds<LOGN>(sm.lad, which ? sm.v : sm.sig, sm.tw, &tab->ck[0][0], tid);
-            v4u *seg = wit + (size_t)(which ? 58 : 29) * N * 2;
+            const uint32_t seg = (uint32_t)(which ? 58 : 29) * N * 32;
             for (int t = wave; t < TILES; t += WAVES) {
                 const int k = t * WAVE + lane;
                 uint32_t a[5], q5[5];
 #pragma unroll
                 for (int i = 0; i < 5; i++) a[i] = sm.lad[i * N + k];
                 const uint32_t b = divmod_q_u160(a, q5);                  // arithmetics.rs:127-134
-                encode_u160<ENC>(q5, e8); slab_put(slab, 0, lane, e8);    // t_var :137
-                encode_u32<ENC>(b, e8);   slab_put(slab, 1, lane, e8);    // b_var :138
-                emit_tile<ENC, 29, 2, 0>(seg + (size_t)t * WAVE * 29 * 2, slab, ltq_mask(b) << 2, lane);
+                encode_u160<ENC>(q5, e8); slab_put(wc.slab, 0, lane, e8);    // t_var :137
+                encode_u32<ENC>(b, e8);   slab_put(wc.slab, 1, lane, e8);    // b_var :138
+                emit_tile<29>(rw, seg + t * WAVE * 29 * 32, ltq_mask(b) << 2, wc);
             }
             __syncthreads();
         }
@@ -672,13 +858,14 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
 // A DualPolynomial has pos[i]*neg[i] = 0 for every i, so the products are zeros, is_not_equal = 0, multiplier = 1.
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-struct SmemDual {
+struct alignas(16) SmemDual {
     static constexpr int N = 1 << LOGN;
-    v4u slab[WAVES][2 * 2 * WAVE];
+    unsigned char slab[SLAB_BYTES];
     uint32_t lad[5 * N];                  // also: third value slot of the pointwise tiles while no ladder is alive
-    uint16_t tw[1024];
+    uint16_t tw[N];
     uint16_t sp[N], sn[N], vp[N], vn[N];          // coefficient domain (signed split, threshold 6144)
     uint16_t nsp[N], nsn[N], nvp[N], nvn[N], npk[N], nhm[N];   // NTT domain
+    uint16_t vtab[TileShape<18>::ROW0 * WAVE];   // shapes 29 and 30 only
     unsigned long long norm;
     unsigned long long next;
     int bad;
@@ -695,20 +882,29 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
     constexpr size_t W = 186 * (size_t)N + 4 + NB;
     constexpr size_t I = 2 * (size_t)N + 1;
     constexpr int TILES = N / WAVE;
+    constexpr uint32_t TILE1 = WAVE * 32;
     constexpr uint32_t HALF_Q = 6144;
     __shared__ SmemDual<LOGN> sm;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
-    v4u *slab = sm.slab[wave];
-    v4u *slab2 = (v4u *)sm.lad + wave * 2 * WAVE;
-    for (int j = tid; j < 1024; j += BLOCK) sm.tw[j] = tab->tw[j];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WaveCtx wc;
+    wc.slab = (uint32_t)(uintptr_t)(FRW_LDS void *)sm.slab + wave * SLAB_WBLK;
+    wc.vtab = (uint32_t)(uintptr_t)(FRW_LDS void *)sm.vtab + lane * 2;
+    wc.lane = lane;
+    for (int j = tid; j < N; j += BLOCK) sm.tw[j] = tab->tw[j];
+    init_vtab(sm.vtab, TileShape<18>::ROW0, tid);
+    init_slab_const<ENC>(wc.slab, lane);
     constexpr uint32_t R[8] = FRW_R32;
     const int half = lane & 1;
     const v4u one = ENC == 0 ? (half ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0))
                              : (half ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]));
 
     unsigned long long ticket = 0;
-    for (size_t s = blockIdx.x; s < batch; s = next_item<LOGN>(s, ticket, &sm.next, tid)) {
+    for (size_t s_v = blockIdx.x; s_v < batch; s_v = next_item<LOGN>(s_v, ticket, &sm.next, tid)) {
         ticket = draw_ticket<LOGN>(queue, tid);
+        const size_t s = uniform_index(s_v);
+        v4u *wit = g_wit + s * W * 2;
+        v4u *inst = g_inst + s * I * 2;
         if (tid == 0) { sm.norm = 0; sm.bad = 0; }
         __syncthreads();
         int bad = 0;
@@ -723,6 +919,9 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
         __syncthreads();
         if (sm.bad) {
             if (tid == 0) g_status[s] = ST_COEFF_RANGE;
+            zero_fill(wit, W * 2, tid);
+            zero_fill(inst, I * 2, tid);
+            __syncthreads();                  // every wave has read sm.bad before thread 0 clears it for the next item
             continue;
         }
         {
@@ -747,8 +946,8 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
             ntt_modq_lds<LOGN, 2>(polys, sm.tw, tid);
         }
 
-        v4u *wit = g_wit + s * W * 2;
-        v4u *inst = g_inst + s * I * 2;
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(wit, (uint32_t)(W * 32));
+        const __amdgpu_buffer_rsrc_t ri = make_rsrc(inst, (uint32_t)(I * 32));
         uint32_t e8[8];
         if (tid < 2) inst[tid] = one;                                              // instance_assignment[0] = 1
         if (tid < 4) {                                                             // is_zero: [0, 1] twice
@@ -759,27 +958,27 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
         unsigned long long nrm = 0;
         for (int t = wave; t < TILES; t += WAVES) {
             const int k = t * WAVE + lane;
-            const size_t to = (size_t)t * WAVE * 2;
-            encode_u32<ENC>(sm.npk[k], e8); slab_put(slab, 0, lane, e8);
-            emit_tile<ENC, 1, 1, 0>(inst + 2 + to, slab, 0u, lane);
-            encode_u32<ENC>(sm.nhm[k], e8); slab_put(slab, 0, lane, e8);
-            emit_tile<ENC, 1, 1, 0>(inst + 2 + (size_t)N * 2 + to, slab, 0u, lane);
+            const uint32_t to = t * TILE1;
+            encode_u32<ENC>(sm.npk[k], e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(ri, 32 + to, wc);
+            encode_u32<ENC>(sm.nhm[k], e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(ri, 32 + N * 32 + to, wc);
             // dual_poly.rs:20-21 pos, neg; :24-27 products (all zero)
 #pragma unroll 1
             for (int q4 = 0; q4 < 4; q4++) {                                       // v.pos, v.neg, sig.pos, sig.neg
                 const uint16_t *src = q4 == 0 ? sm.vp : q4 == 1 ? sm.vn : q4 == 2 ? sm.sp : sm.sn;
-                const size_t lin = q4 == 0 ? (size_t)3 * N + 2 : q4 == 1 ? (size_t)4 * N + 2 : q4 == 2 ? (size_t)0 : (size_t)N;
+                const uint32_t lin = q4 == 0 ? 3 * N + 2 : q4 == 1 ? 4 * N + 2 : q4 == 2 ? 0 : N;
                 const uint32_t val = src[k];
-                encode_u32<ENC>(val, e8); slab_put(slab, 0, lane, e8);
-                emit_tile<ENC, 1, 1, 0>(wit + lin * 2 + to, slab, 0u, lane);
+                encode_u32<ENC>(val, e8); slab_put(wc.slab, 0, lane, e8);
+                emit_values(rw, lin * 32 + to, wc);
                 // misc.rs:58-62 squares, in the order v.pos, v.neg, sig.pos, sig.neg
                 const uint32_t sq = val * val;
                 nrm += sq;
-                encode_u32<ENC>(sq, e8); slab_put(slab, 0, lane, e8);
-                emit_tile<ENC, 1, 1, 0>(wit + ((size_t)(182 + q4) * N + 4) * 2 + to, slab, 0u, lane);
+                encode_u32<ENC>(sq, e8); slab_put(wc.slab, 0, lane, e8);
+                emit_values(rw, ((182 + q4) * N + 4) * 32 + to, wc);
             }
-            emit_tile<ENC, 1, 0, 0>(wit + (size_t)2 * N * 2 + to, slab, 0u, lane);
-            emit_tile<ENC, 1, 0, 0>(wit + ((size_t)5 * N + 2) * 2 + to, slab, 0u, lane);
+            emit_zeros(rw, 2 * N * 32 + to, wc);
+            emit_zeros(rw, (5 * N + 2) * 32 + to, wc);
         }
         // pointwise (:95-116): 2N blocks of 30, block 2i = left, 2i+1 = right
         for (int t = wave; t < 2 * TILES; t += WAVES) {
@@ -789,10 +988,10 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
             if (j & 1) { prod = (uint32_t)sm.nsp[i] * pkv; a = sm.nvp[i] + prod; }              // right :109-114
             else { prod = (uint32_t)sm.nsn[i] * pkv; a = sm.nhm[i] + sm.nvn[i] + prod; }        // left  :100-107
             const uint32_t tq = a / Q, b = a - tq * Q;
-            encode_u32<ENC>(prod, e8); slab_put(slab, 0, lane, e8);
-            encode_u32<ENC>(tq, e8);   slab_put(slab, 1, lane, e8);
-            encode_u32<ENC>(b, e8);    slab_put(slab2, 0, lane, e8);
-            emit_tile<ENC, 30, 3, 0>(wit + ((size_t)122 * N + 4 + (size_t)t * WAVE * 30) * 2, slab, ltq_mask(b) << 3, lane, 0, slab2);
+            encode_u32<ENC>(prod, e8); slab_put(wc.slab, 0, lane, e8);
+            encode_u32<ENC>(tq, e8);   slab_put(wc.slab, 1, lane, e8);
+            encode_u32<ENC>(b, e8);    slab_put(wc.slab, 2, lane, e8);
+            emit_tile<30>(rw, (122 * N + 4 + t * WAVE * 30) * 32, ltq_mask(b) << 3, wc);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor((unsigned long long)nrm, off, WAVE);
@@ -810,16 +1009,16 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
         for (int which = 0; which < 4; which++) {
             const uint16_t *in = which == 0 ? sm.sp : which == 1 ? sm.sn : which == 2 ? sm.vp : sm.vn;
             ladder_lds<LOGN>(sm.lad, in, sm.tw, &tab->ck[0][0], tid);
-            v4u *seg = wit + ((size_t)(6 + 29 * which) * N + 4) * 2;
+            const uint32_t seg = ((6 + 29 * which) * N + 4) * 32;
             for (int t = wave; t < TILES; t += WAVES) {
                 const int k = t * WAVE + lane;
                 uint32_t a[5], q5[5];
 #pragma unroll
                 for (int i = 0; i < 5; i++) a[i] = sm.lad[i * N + k];
                 const uint32_t b = divmod_q_u160(a, q5);
-                encode_u160<ENC>(q5, e8); slab_put(slab, 0, lane, e8);
-                encode_u32<ENC>(b, e8);   slab_put(slab, 1, lane, e8);
-                emit_tile<ENC, 29, 2, 0>(seg + (size_t)t * WAVE * 29 * 2, slab, ltq_mask(b) << 2, lane);
+                encode_u160<ENC>(q5, e8); slab_put(wc.slab, 0, lane, e8);
+                encode_u32<ENC>(b, e8);   slab_put(wc.slab, 1, lane, e8);
+                emit_tile<29>(rw, seg + t * WAVE * 29 * 32, ltq_mask(b) << 2, wc);
             }
             __syncthreads();
         }
@@ -830,12 +1029,13 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
 // kernel: NTTPolyVar::ntt_circuit alone (poly.rs:104-159): N mod_q blocks + the reduced NTT
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-struct SmemNtt {
+struct alignas(16) SmemNtt {
     static constexpr int N = 1 << LOGN;
-    v4u slab[WAVES][2 * 2 * WAVE];
+    unsigned char slab[SLAB_BYTES];
     uint32_t lad[5 * N];
-    uint16_t tw[1024];
+    uint16_t tw[N];
     uint16_t in[N];
+    uint16_t vtab[TileShape<30>::ROW0 * WAVE];    // shape 29 only
     unsigned long long next;
     int bad;
 };
@@ -848,14 +1048,22 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
 {
     constexpr int N = 1 << LOGN;
     constexpr int TILES = N / WAVE;
+    constexpr size_t WN = (size_t)29 * N;
     __shared__ SmemNtt<LOGN> sm;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
-    v4u *slab = sm.slab[wave];
-    for (int j = tid; j < 1024; j += BLOCK) sm.tw[j] = tab->tw[j];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WaveCtx wc;
+    wc.slab = (uint32_t)(uintptr_t)(FRW_LDS void *)sm.slab + wave * SLAB_WBLK;
+    wc.vtab = (uint32_t)(uintptr_t)(FRW_LDS void *)sm.vtab + lane * 2;
+    wc.lane = lane;
+    for (int j = tid; j < N; j += BLOCK) sm.tw[j] = tab->tw[j];
+    init_vtab(sm.vtab, TileShape<30>::ROW0, tid);
+    init_slab_const<ENC>(wc.slab, lane);
 
     unsigned long long ticket = 0;
-    for (size_t s = blockIdx.x; s < batch; s = next_item<LOGN>(s, ticket, &sm.next, tid)) {
+    for (size_t s_v = blockIdx.x; s_v < batch; s_v = next_item<LOGN>(s_v, ticket, &sm.next, tid)) {
         ticket = draw_ticket<LOGN>(queue, tid);
+        const size_t s = uniform_index(s_v);
         if (tid == 0) sm.bad = 0;
         __syncthreads();
         int bad = 0;
@@ -867,9 +1075,14 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
         if (bad) sm.bad = 1;
         __syncthreads();
         if (tid == 0) g_status[s] = sm.bad ? ST_COEFF_RANGE : ST_OK;
-        if (sm.bad) { __syncthreads(); continue; }
+        if (sm.bad) {
+            zero_fill(g_wit + s * WN * 2, WN * 2, tid);
+            for (int j = tid; j < N; j += BLOCK) g_ntt[s * N + j] = 0;
+            __syncthreads();
+            continue;
+        }
         ladder_lds<LOGN>(sm.lad, sm.in, sm.tw, &tab->ck[0][0], tid);
-        v4u *seg = g_wit + s * (size_t)29 * N * 2;
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(g_wit + s * WN * 2, (uint32_t)(WN * 32));
         for (int t = wave; t < TILES; t += WAVES) {
             const int k = t * WAVE + lane;
             uint32_t a[5], q5[5], e8[8];
@@ -877,9 +1090,9 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
             for (int i = 0; i < 5; i++) a[i] = sm.lad[i * N + k];
             const uint32_t b = divmod_q_u160(a, q5);
             g_ntt[s * N + k] = (uint16_t)b;
-            encode_u160<ENC>(q5, e8); slab_put(slab, 0, lane, e8);
-            encode_u32<ENC>(b, e8);   slab_put(slab, 1, lane, e8);
-            emit_tile<ENC, 29, 2, 0>(seg + (size_t)t * WAVE * 29 * 2, slab, ltq_mask(b) << 2, lane);
+            encode_u160<ENC>(q5, e8); slab_put(wc.slab, 0, lane, e8);
+            encode_u32<ENC>(b, e8);   slab_put(wc.slab, 1, lane, e8);
+            emit_tile<29>(rw, t * WAVE * 29 * 32, ltq_mask(b) << 2, wc);
         }
         __syncthreads();
     }
@@ -928,8 +1141,8 @@ __global__ __launch_bounds__(BLOCK) void gadget_kernel(size_t count, const void 
 #pragma unroll
             for (int i = 0; i < 5; i++) a[i] = live ? ((const uint32_t *)in_a)[item * 5 + i] : 0;
             const uint32_t b = divmod_q_u160(a, q5);
-            encode_u160<ENC>(q5, e8); slab_put(slab, 0, lane, e8);
-            encode_u32<ENC>(b, e8);   slab_put(slab, 1, lane, e8);
+            encode_u160<ENC>(q5, e8); gslab_put(slab, 0, lane, e8);
+            encode_u32<ENC>(b, e8);   gslab_put(slab, 1, lane, e8);
             mask = ltq_mask(b) << 2;
         } else if (KIND == G_ADD_MOD) {
             const uint64_t a = live ? ((const uint64_t *)in_a)[item] : 0, b = live ? in_b[item] : 0;
@@ -938,8 +1151,8 @@ __global__ __launch_bounds__(BLOCK) void gadget_kernel(size_t count, const void 
             const uint64_t tq = ab / Q;
             const uint32_t c = (uint32_t)(ab - tq * Q);               // :242-243
             const uint32_t t5[5] = {(uint32_t)tq, (uint32_t)(tq >> 32), 0, 0, 0};
-            encode_u160<ENC>(t5, e8); slab_put(slab, 0, lane, e8);
-            encode_u32<ENC>(c, e8);   slab_put(slab, 1, lane, e8);
+            encode_u160<ENC>(t5, e8); gslab_put(slab, 0, lane, e8);
+            encode_u32<ENC>(c, e8);   gslab_put(slab, 1, lane, e8);
             mask = ltq_mask(c) << 2;
         } else if (KIND == G_L2_ELEM) {
             const uint64_t a = live ? ((const uint64_t *)in_a)[item] : 0;
@@ -947,10 +1160,10 @@ __global__ __launch_bounds__(BLOCK) void gadget_kernel(size_t count, const void 
             const uint32_t e = (uint32_t)a;
             mask = lt6144_mask(e & 0x3fffu);
             const uint32_t r = (mask >> 15) & 1u ? e : Q - e;
-            encode_u32<ENC>(r, e8); slab_put(slab, 0, lane, e8);
+            encode_u32<ENC>(r, e8); gslab_put(slab, 0, lane, e8);
             const uint64_t sq = (uint64_t)r * r;
             const uint32_t s5[5] = {(uint32_t)sq, (uint32_t)(sq >> 32), 0, 0, 0};
-            encode_u160<ENC>(s5, e8); slab_put(slab, 1, lane, e8);
+            encode_u160<ENC>(s5, e8); gslab_put(slab, 1, lane, e8);
         } else {
             const uint64_t a = live ? ((const uint64_t *)in_a)[item] : 0;
             mask = KIND == G_NORM_512 ? norm_mask_512(a) : norm_mask_1024(a);
@@ -958,7 +1171,7 @@ __global__ __launch_bounds__(BLOCK) void gadget_kernel(size_t count, const void 
         if (live && status) status[item] = st;
         const size_t remaining = count - t * WAVE;
         const int nchunks = (int)(remaining >= WAVE ? WAVE : remaining) * S::BLK * 2;
-        emit_tile<ENC, S::BLK, S::NVAL, S::VFIRST, true, mask_t>(out + t * WAVE * S::BLK * 2, slab, mask, lane, nchunks);
+        emit_tile_generic<ENC, S::BLK, S::NVAL, S::VFIRST, mask_t>(out + t * WAVE * S::BLK * 2, slab, mask, lane, nchunks);
     }
 }
 
@@ -998,7 +1211,13 @@ __global__ __launch_bounds__(BLOCK) void write_stream_kernel(v4u *__restrict__ o
     v4u v = mk4(seed, seed ^ threadIdx.x, 3u, 4u);
     for (size_t s = blockIdx.x; s < nslabs; s += gridDim.x) {
         v4u *o = out + s * slab16;
-        for (size_t i = threadIdx.x; i < slab16; i += BLOCK) stream_store(v, &o[i]);
+        for (size_t i = threadIdx.x; i < slab16; i += BLOCK) {
+#if defined(FRW_NO_STORE)
+            asm volatile("" ::"v"(v), "v"(&o[i]));
+#else
+            o[i] = v;
+#endif
+        }
     }
 }
 
@@ -1019,17 +1238,22 @@ hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int n
 // ------------------------------------------------------------------------------------------------
 // Persistent grid: as many workgroups as the device keeps resident (LDS-limited: 2-3 per CU), each
 // striding over the batch.  Residency is asked from the runtime once per kernel instantiation.
+// Filled exactly once per process (std::call_once in init_launch_config, which every context creation calls before
+// any launch), read-only afterwards: contexts on several devices / threads share it safely.
 static int g_occ_verify[4], g_occ_dual[4], g_occ_ntt[4];       // resident workgroups per CU, [(LOGN-9)*2 + ENC]
+static std::once_flag g_occ_once;
 
 template <typename K>
-static int resident_grid(K kernel, size_t batch, int num_cu, int &cache)
+static void query_residency(K kernel, int &cache)
 {
-    if (cache == 0) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        cache = per_cu;
-    }
-    const size_t cap = (size_t)cache * (size_t)num_cu;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    cache = per_cu;
+}
+
+static int resident_grid(size_t batch, int num_cu, int per_cu)
+{
+    const size_t cap = (size_t)(per_cu > 0 ? per_cu : 2) * (size_t)num_cu;
     if (batch <= cap) return (int)batch;
 #ifndef FRW_BALANCED_GRID
 #define FRW_BALANCED_GRID 1
@@ -1050,17 +1274,17 @@ static int resident_grid(K kernel, size_t batch, int num_cu, int &cache)
 // has to (a launch may be inside a stream capture, where such queries are not allowed).
 void init_launch_config()
 {
-    int dummy = 0;
-#define FRW_Q(K, CACHE, LOGN, ENC) dummy += resident_grid(K<LOGN, ENC>, 1, 1, CACHE[(LOGN - 9) * 2 + ENC])
-#define FRW_QV(LOGN, ENC) dummy += resident_grid(witness_ntt_verify_kernel<LOGN, ENC, false>, 1, 1, g_occ_verify[(LOGN - 9) * 2 + ENC])
-    FRW_QV(9, 0); FRW_QV(9, 1); FRW_QV(10, 0); FRW_QV(10, 1);
+    std::call_once(g_occ_once, [] {
+#define FRW_Q(K, CACHE, LOGN, ENC) query_residency(K<LOGN, ENC>, CACHE[(LOGN - 9) * 2 + ENC])
+#define FRW_QV(LOGN, ENC) query_residency(witness_ntt_verify_kernel<LOGN, ENC, false>, g_occ_verify[(LOGN - 9) * 2 + ENC])
+        FRW_QV(9, 0); FRW_QV(9, 1); FRW_QV(10, 0); FRW_QV(10, 1);
 #undef FRW_QV
-    FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 0); FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 1);
-    FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 10, 0); FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 10, 1);
-    FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 1);
-    FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 1);
+        FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 0); FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 1);
+        FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 10, 0); FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 10, 1);
+        FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 1);
+        FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 1);
 #undef FRW_Q
-    (void)dummy;
+    });
 }
 
 hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch,
@@ -1073,7 +1297,7 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queu
     if (qe != hipSuccess) return qe;
 #define FRW_LAUNCH(LOGN, ENC)                                                                                        \
     do {                                                                                                             \
-        int &occ = g_occ_verify[(LOGN - 9) * 2 + ENC];                                                               \
+        const int occ = g_occ_verify[(LOGN - 9) * 2 + ENC];                                                          \
         const size_t cap = (size_t)(occ > 0 ? occ : 2) * (size_t)num_cu;                                             \
         if (batch * 5 <= cap) { /* small batch: five items per signature, all resident at once (measured: 1 sig    \
                                    167 -> 56 us, 64 sigs 172 -> 95 us; at 256 signatures the split already loses) */ \
@@ -1082,7 +1306,7 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queu
             hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC, true>), dim3(grid), dim3(BLOCK), 0, st, tab,    \
                                queue, batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                          \
         } else {                                                                                                     \
-            const int grid = resident_grid(witness_ntt_verify_kernel<LOGN, ENC, false>, batch, num_cu, occ);         \
+            const int grid = resident_grid(batch, num_cu, occ);                                                      \
             hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC, false>), dim3(grid), dim3(BLOCK), 0, st, tab,   \
                                queue, batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                          \
         }                                                                                                            \
@@ -1105,8 +1329,7 @@ hipError_t launch_witness_dual_ntt_verify(const Tables *tab, unsigned long long 
     if (qe != hipSuccess) return qe;
 #define FRW_LAUNCH(LOGN, ENC)                                                                                       \
     do {                                                                                                            \
-        const int grid = resident_grid(witness_dual_ntt_verify_kernel<LOGN, ENC>, batch, num_cu,                    \
-                                       g_occ_dual[(LOGN - 9) * 2 + ENC]);                                                  \
+        const int grid = resident_grid(batch, num_cu, g_occ_dual[(LOGN - 9) * 2 + ENC]);                            \
         hipLaunchKernelGGL((witness_dual_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, \
                            batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                                    \
     } while (0)
@@ -1127,7 +1350,7 @@ hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num
     if (qe != hipSuccess) return qe;
 #define FRW_LAUNCH(LOGN, ENC)                                                                                  \
     do {                                                                                                       \
-        const int grid = resident_grid(ntt_modq_kernel<LOGN, ENC>, batch, num_cu, g_occ_ntt[(LOGN - 9) * 2 + ENC]);  \
+        const int grid = resident_grid(batch, num_cu, g_occ_ntt[(LOGN - 9) * 2 + ENC]);                        \
         hipLaunchKernelGGL((ntt_modq_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, batch,    \
                            poly, (v4u *)wit, ntt_out, status);                                                 \
     } while (0)

@@ -68,7 +68,10 @@ __global__ __launch_bounds__(BLOCK) void hash_to_point_kernel(int logn, size_t b
     const int n = 1 << logn;
     const uint8_t *nonce = nonces + s * NONCE_LEN;
     const uint8_t *msg = msgs + msg_off[s];
-    const size_t total = NONCE_LEN + (size_t)(msg_off[s + 1] - msg_off[s]);
+    // the host entry point rejects decreasing offsets; a device-side caller that breaks the precondition of
+    // include/frw.h gets an empty message here rather than a 2^64-byte absorb loop
+    const uint64_t o0 = msg_off[s], o1 = msg_off[s + 1];
+    const size_t total = NONCE_LEN + (size_t)(o1 >= o0 ? o1 - o0 : 0);
     uint64_t st[25];
 #pragma unroll
     for (int i = 0; i < 25; i++) st[i] = 0;

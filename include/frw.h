@@ -29,8 +29,8 @@
  *   - witness:  uint64_t[batch][W][4] in arkworks allocation order (layout: frw_layout()).
  *     instance: uint64_t[batch][I][4], I = 2N+1: [1, pk_ntt[0..N), hm_ntt[0..N)]
  *     (falcon_ntt.rs:63,67; public-input order as in examples/pok_sig.rs:38-45).
- *   - status:   int32_t[batch]: FRW_ST_OK, FRW_ST_COEFF_RANGE (an input coefficient >= q; nothing is
- *     written for that signature), FRW_ST_NORM_BOUND (l2 norm >= SIG_L2_BOUND; the witness IS written,
+ *   - status:   int32_t[batch]: FRW_ST_OK, FRW_ST_COEFF_RANGE (an input coefficient >= q; that signature's
+ *     witness and instance slots are zero-filled), FRW_ST_NORM_BOUND (l2 norm >= SIG_L2_BOUND; the witness IS written,
  *     with the truncated bit decomposition the reference assigns when its `#[cfg(not(test))]`
  *     panic is compiled out (range_proofs.rs:112-117,203-208), so the system is unsatisfied).
  *   - every function returns FRW_OK (0) or a negative FRW_E_* code; frw_strerror() names it.
@@ -189,7 +189,9 @@ int frw_r1cs_eval_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness
  *   signature   sig_len bytes (falcon.rs: 666 / 1280, the padded lengths): header 0x30 + logn, 40-byte nonce,
  *               compressed s2 (sign bit, 7 low bits, unary high part), zero padding
  *   hash        SHAKE256(nonce || msg) read as big-endian 16-bit words w, w < 5q accepted as w mod q
- * Messages are one byte blob plus batch+1 offsets (message i = msgs[msg_off[i] .. msg_off[i+1])).
+ * Messages are one byte blob plus batch+1 NON-DECREASING offsets (message i = msgs[msg_off[i] .. msg_off[i+1]));
+ * frw_prepare_inputs returns FRW_E_INVALID_ARG for decreasing offsets, the _dev variant reads such a message as empty
+ * and trusts the caller that msg_off[batch] does not exceed the blob.
  * status[i] = FRW_ST_DECODE for a malformed encoding (that signature must not be fed to the witness call). */
 #define FRW_NONCE_LEN 40
 #define FRW_PK_LEN(logn)  (1 + 14 * (1 << (logn)) / 8)

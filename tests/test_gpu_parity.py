@@ -582,3 +582,126 @@ def test_hip_matches_dual_and_prepare_golden(engine):
             assert hashlib.sha256(h[i].tobytes()).hexdigest() == c["hm_sha256"]
         assert hashlib.sha256(p[0].tobytes()).hexdigest() == codec["pk_sha256"]
         assert hashlib.sha256(s[0].tobytes()).hexdigest() == codec["sig_sha256"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: the launch shapes bench.py times, and the rejection path under load
+# ---------------------------------------------------------------------------------------------------------------------
+def _launch_and_digest(engine, logn, sig, pk, hm, dual=False, enc=1):
+    """One device launch over the whole batch; returns (wit, inst, status, digests as python ints)."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    L = frw.layout_dual(logn) if dual else frw.layout(logn)
+    batch = sig.shape[0]
+    d = [torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    wit.fill_(0x5A5A5A5A5A5A5A5A)                      # stale memory must never survive a launch
+    st = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    dig = torch.zeros(batch, dtype=torch.int64, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    launch = engine.witness_dual_ntt_verify_dev if dual else engine.witness_ntt_verify_dev
+    launch(logn, batch, d[0], d[1], d[2], wit, inst, st, enc, s0)
+    engine.digest_dev(wit, L.num_witness * 4, batch, dig, s0)
+    torch.cuda.synchronize()
+    return wit, inst, st, [int(x) for x in dig.cpu().numpy().view(np.uint64)]
+
+
+def _r1cs_all_satisfied(engine, circuit, logn, wit, inst):
+    import torch
+    batch = wit.shape[0]
+    bad = torch.full((batch,), -1, dtype=torch.int32, device=wit.device)
+    h = engine.r1cs_load(circuit, logn)
+    try:
+        engine.r1cs_check_dev(h, batch, wit, inst, bad, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        engine.r1cs_free(h)
+    return int((bad != 0).sum().item())
+
+
+@pytest.mark.parametrize("logn,batch", [(10, 16384), (9, 8192)])
+def test_benchmark_launch_shape_is_checked(engine, oracle, logn, batch):
+    """The launch shape bench.py times (BASELINE configs[2]: 16,384 Falcon-1024 signatures per launch = persistent grid at
+    its residency cap, ~21 rounds, work-queue tail; and the Falcon-512 counterpart, 8,192 per launch, static striding):
+    every witness of the launch satisfies the independently emitted constraint system on the device
+    (falcon_ntt.rs:159), a strided sample of 256 + the last one equals the oracle's witness by digest, all statuses OK."""
+    import falcon_r1cs_amd as frw
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=0xBE7C4 + logn)
+    wit, inst, st, dig = _launch_and_digest(engine, logn, sig, pk, hm)
+    assert int((st != 0).sum()) == 0
+    assert len(set(dig)) == batch
+    assert _r1cs_all_satisfied(engine, 0, logn, wit, inst) == 0
+    idx = list(range(0, batch, batch // 256)) + [batch - 1]
+    for lo in range(0, len(idx), 64):
+        part = idx[lo:lo + 64]
+        owit, oinst, _ = oracle.witness_ntt_verify(logn, sig[part], pk[part], hm[part], 1, threads=8)
+        assert [dig[i] for i in part] == [oracle.digest(owit[j]) for j in range(len(part))]
+        got_inst = inst[part].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got_inst, oinst)
+
+
+def test_config2_full_size_ntt_modq_all_digests(engine, oracle):
+    """BASELINE configs[1] at its stated size: 4,096 Falcon-512 polynomials through frw_ntt_modq_dev in ONE launch,
+    EVERY witness block compared with the oracle by digest and every reduced NTT output compared exactly."""
+    import torch
+    dev = torch.device("cuda:0")
+    logn, batch = 9, 4096
+    n = 1 << logn
+    rng = np.random.default_rng(20262)
+    poly = rng.integers(0, T.Q, size=(batch, n), dtype=np.uint16)
+    d_poly = torch.from_numpy(poly.view(np.int16)).to(dev)
+    wit = torch.empty((batch, 29 * n, 4), dtype=torch.int64, device=dev)
+    out = torch.empty((batch, n), dtype=torch.int16, device=dev)
+    st = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    dig = torch.zeros(batch, dtype=torch.int64, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    engine.ntt_modq_dev(logn, batch, d_poly, wit, out, st, 1, s0)
+    engine.digest_dev(wit, 29 * n * 4, batch, dig, s0)
+    torch.cuda.synchronize()
+    assert int((st != 0).sum()) == 0
+    got = [int(x) for x in dig.cpu().numpy().view(np.uint64)]
+    got_out = out.cpu().numpy().view(np.uint16)
+    for lo in range(0, batch, 512):
+        owit, oout = oracle.ntt_modq(logn, poly[lo:lo + 512], 1)
+        assert np.array_equal(got_out[lo:lo + 512], oout)
+        assert got[lo:lo + 512] == [oracle.digest(owit[i]) for i in range(owit.shape[0])]
+
+
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("logn", [9, 10])
+def test_rejected_signatures_scattered_through_a_large_batch(engine, oracle, logn, dual):
+    """range_proofs.rs:57-60 under load: ~30 % of a batch much larger than the persistent grid carries a coefficient >= q
+    at a random place in sig, pk or hm, so every workgroup meets rejected items followed by good ones (static striding
+    at Falcon-512, the work queue at Falcon-1024).  Statuses equal the oracle's, every accepted witness and instance is
+    digest-equal to the oracle's, every rejected slot is zero-filled."""
+    import falcon_r1cs_amd as frw
+    batch = 2400 if not (dual and logn == 10) else 1536
+    n = 1 << logn
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=0xBAD + logn + 7 * dual)
+    rng = np.random.default_rng(1000 + logn + dual)
+    bad = rng.random(batch) < 0.3
+    bad[:3] = [True, False, True]
+    bad[-2:] = [True, False]
+    for i in np.nonzero(bad)[0]:
+        arr = (sig, pk, hm)[rng.integers(3)]
+        arr[i, rng.integers(n)] = rng.choice([T.Q, T.Q + 1, 0x3FFF, 0xFFFF])
+    wit, inst, st, dig = _launch_and_digest(engine, logn, sig, pk, hm, dual=dual)
+    st = st.cpu().numpy()
+    assert np.array_equal(st != 0, bad) and set(st[bad].tolist()) == {frw.ST_COEFF_RANGE}
+    L = frw.layout_dual(logn) if dual else frw.layout(logn)
+    zero_digest = oracle.digest(np.zeros((L.num_witness, 4), dtype=np.uint64))
+    fn = oracle.witness_dual_ntt_verify if dual else oracle.witness_ntt_verify
+    step = 128
+    for lo in range(0, batch, step):
+        sl = slice(lo, lo + step)
+        if dual:
+            owit, oinst, ost = fn(logn, sig[sl], pk[sl], hm[sl], 1)
+        else:
+            owit, oinst, ost = fn(logn, sig[sl], pk[sl], hm[sl], 1, threads=8)
+        assert np.array_equal(ost, st[sl])
+        want = [oracle.digest(owit[j]) for j in range(owit.shape[0])]
+        assert dig[lo:lo + step] == want
+        assert all(want[j] == zero_digest for j in np.nonzero(bad[sl])[0])
+        assert np.array_equal(inst[sl].cpu().numpy().view(np.uint64), oinst)
