@@ -6,16 +6,21 @@
 
 A step = one pass of the hot path (falcon-r1cs/src/circuits/falcon_ntt.rs:26-123 of the reference) over one batch
 of synthetic signatures per GPU: BASELINE.json configs[2], "Falcon-1024 batch=65536 sigs, full verify-with-ntt
-witness".  65,536 witnesses are 329 GB, more than one GPU's 288 GB, so a step streams the batch through one reused
-HBM witness buffer in chunks (default 16,384 signatures = 82 GB per launch); inputs are resident in HBM before the
-timed region and outputs stay in HBM (the boundary a GPU prover or a peer would consume them from).
-Multi-GPU: signatures shard by index, every rank processes its own 65,536 (weak scaling), no data-path collective.
+witness" (N = 8: configs[3], 1 M signatures over the node = 131,072 per GPU).  65,536 witnesses are 329 GB, more than
+one GPU's 288 GB, so a step streams the batch through one reused HBM witness buffer in launches of `--chunk`
+signatures; inputs are resident in HBM before the timed region and outputs stay in HBM (the boundary a GPU prover or a
+peer would consume them from).  Multi-GPU: signatures shard by index, every rank processes its own batch (weak scaling),
+no data-path collective inside `value`; the north-star's all-gather of the witness vectors is measured as a second,
+separately reported curve (compact encoding over RCCL, expanded on every receiver).
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream; `cpu_baseline`
-times the oracle (oracle/frw_oracle.c, a restatement -- the Rust reference cannot run here) on this host's cores
-over a bounded sample of the same inputs and checks the GPU's witnesses against it by digest.
+Prints ONE JSON line (rank 0).  What is checked is what was timed: after the timed region the witnesses the LAST timed
+launch left in HBM are digested, checked against the independently emitted constraint system on the device
+(falcon_ntt.rs:159 `assert!(cs.is_satisfied())`), and a strided sample of them is compared with the oracle.
+`roofline` is measured live with HIP events on the launch stream; `cpu_baseline` times the oracle (oracle/frw_oracle.c, a
+restatement -- the Rust reference cannot run here) on this host's cores over a bounded sample of the same inputs.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,25 +37,32 @@ sys.path.insert(0, ROOT)
 import falcon_r1cs_amd as frw  # noqa: E402
 from falcon_r1cs_amd import sharding  # noqa: E402
 
-def measured_traffic(logn, chunk):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/*_hbm_traffic.json, written by
-    tools/summarize_profiles.py from separate --pmc WRITE_SIZE / FETCH_SIZE passes of this same command);
-    None when no summary matches this configuration."""
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+SEED = 0x46414C434F4E31        # recorded in the output
+KERNEL_SRC = os.path.join(ROOT, "falcon-r1cs_amd", "csrc", "frw_kernels.hip")
+
+
+def kernel_source_sha():
+    return hashlib.sha256(open(KERNEL_SRC, "rb").read()).hexdigest()[:16]
+
+
+def measured_traffic(logn, chunk, kernel_prefix="witness_ntt_verify_kernel"):
+    """HBM bytes per launch from a committed rocprofv3 PMC summary (profiles/*_hbm_traffic.json, written by
+    tools/summarize_profiles.py from separate --pmc WRITE_SIZE / FETCH_SIZE passes of this same command).  Only a
+    summary taken from the kernel source that is being run counts: each records the sha-256 of frw_kernels.hip it was
+    profiled with, and a mismatch (the kernel changed since) yields None rather than a stale figure."""
     import glob
+    sha = kernel_source_sha()
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
         try:
             j = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if (j.get("logn") == logn and j.get("signatures_per_launch") == chunk
-                and str(j.get("kernel", "")).startswith("witness_ntt_verify_kernel")):
+        if (j.get("logn") == logn and j.get("signatures_per_launch") == chunk and j.get("kernel_source_sha256_16") == sha
+                and str(j.get("kernel", "")).startswith(kernel_prefix)):
             best = (j["hbm_bytes_per_launch"], os.path.basename(path))
     return best
-
-
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-SEED = 0x46414C434F4E31        # recorded in the output
 
 
 def synth(logn, count, first_index, threads):
@@ -68,79 +80,130 @@ def synth(logn, count, first_index, threads):
     return out
 
 
-def cpu_baseline(logn, sig, pk, hm, gpu_digests, threads):
-    """Oracle ("port") on the host cores over a bounded sample; also the parity check of the GPU run."""
+def load_oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import frw_testlib                      # the ONLY place bench.py touches oracle/: as the timed CPU baseline + checker
-    oracle = frw_testlib.load_oracle()
+    return frw_testlib.load_oracle()
+
+
+def cpu_baseline(logn, sig, pk, hm, sample_idx, gpu_digest_of, budget_s=9.0):
+    """Oracle ("port") on the host cores over a bounded sample of the signatures of the last timed launch; also the
+    parity check of that launch: the first >= 256 sampled witnesses are compared with the GPU's by digest.
+    Output buffers are allocated and touched once, outside the timed calls."""
+    oracle = load_oracle()
+    L = frw.layout(logn)
+    nproc = os.cpu_count() or 1
     sub = 256                               # 1.3 GB of host witness at a time
-    # single thread: the analogue of the reference's one-threaded generate_constraints
-    n1 = min(len(sig), 4096)
-    t0 = time.perf_counter()
+    out = (np.zeros((sub, L.num_witness, 4), dtype=np.uint64), np.zeros((sub, L.num_instance, 4), dtype=np.uint64),
+           np.zeros(sub, dtype=np.int32))
+    for a in out:
+        a.fill(1)                            # first touch happens here
+    # single thread: the analogue of the reference's one-threaded generate_constraints (Cargo.toml:32 `parallel = []`)
+    n1 = min(len(sample_idx), 2048)
+    t1 = 0.0
     for lo in range(0, n1, sub):
-        oracle.witness_ntt_verify(logn, sig[lo:lo + sub], pk[lo:lo + sub], hm[lo:lo + sub], 1, threads=1)
-    one = n1 / (time.perf_counter() - t0)
-    # all cores, and digest parity with the GPU on the same signatures
-    nall = min(len(sig), 32768)
-    checked, t_all = 0, 0.0
-    for lo in range(0, nall, sub):
+        idx = sample_idx[lo:lo + sub]
         t0 = time.perf_counter()
-        wit, _, st = oracle.witness_ntt_verify(logn, sig[lo:lo + sub], pk[lo:lo + sub], hm[lo:lo + sub], 1,
-                                               threads=threads)
+        oracle.witness_ntt_verify(logn, sig[idx], pk[idx], hm[idx], 1, threads=1, out=out)
+        t1 += time.perf_counter() - t0
+    # all cores, time-bounded; digest parity with the GPU on the same signatures
+    checked, t_all, nall = 0, 0.0, 0
+    for lo in range(0, len(sample_idx), sub):
+        idx = sample_idx[lo:lo + sub]
+        t0 = time.perf_counter()
+        wit, _, st = oracle.witness_ntt_verify(logn, sig[idx], pk[idx], hm[idx], 1, threads=nproc, out=out)
         t_all += time.perf_counter() - t0
-        if lo < 512:                        # digest a few hundred on the host (python loop over ctypes calls)
-            for i in range(len(wit)):
-                assert oracle.digest(wit[i]) == gpu_digests[lo + i], "GPU witness %d differs from the oracle" % (lo + i)
+        nall += len(idx)
+        if checked < 256:                   # digest a few hundred on the host (python loop over ctypes calls)
+            for j, i in enumerate(idx):
+                assert st[j] == 0
+                assert oracle.digest(wit[j]) == gpu_digest_of(i), "GPU witness %d differs from the oracle" % i
                 checked += 1
-    return {"value": round(nall / t_all, 1), "unit": "signatures/s", "cores": threads, "kind": "port",
-            "sample": "%d Falcon-1024 signatures of the same synthetic batch, %d threads (oracle/frw_oracle.c, "
-                      "a C restatement; the Rust reference cannot be built here)" % (nall, threads),
-            "single_thread": round(one, 1), "single_thread_sample": n1,
-            "gpu_witnesses_checked_by_digest": checked}
+        if t_all > budget_s:
+            break
+    return {"value": round(nall / t_all, 1), "unit": "signatures/s", "cores": nproc, "kind": "port",
+            "sample": "%d Falcon-%d signatures, a strided sample of the last timed launch, %d threads on %d host cores "
+                      "(oracle/frw_oracle.c, a C restatement; the Rust reference cannot be built here); output buffers "
+                      "pre-touched and reused" % (nall, 1 << logn, nproc, nproc),
+            "nproc": nproc, "threads": nproc, "single_thread": round(n1 / t1, 1), "single_thread_sample": n1,
+            "gpu_witnesses_checked_by_digest": checked, "checked_witnesses_are_from": "the last timed launch"}
 
 
-def bench_ntt_modq(args, world, rank, dev):
-    """NTTPolyVar::ntt_circuit alone (poly.rs:104-159): uniform random polynomials -> N mod_q witness blocks."""
-    logn, batch = args.logn, args.batch
+def time_ntt_modq(eng, dev, logn, batch, launches, warm):
+    """NTTPolyVar::ntt_circuit alone (poly.rs:104-159): `launches` back-to-back launches between two HIP events."""
     n = 1 << logn
-    eng = frw.WitnessEngine(dev.index)
-    rng = np.random.default_rng(SEED + rank)
+    rng = np.random.default_rng(SEED & 0xFFFFFFFF)
     poly = torch.from_numpy(rng.integers(0, 12289, size=(batch, n), dtype=np.uint16).view(np.int16)).to(dev)
     wit = torch.empty((batch, 29 * n, 4), dtype=torch.int64, device=dev)
     out = torch.empty((batch, n), dtype=torch.int16, device=dev)
     st = torch.empty(batch, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
     run = lambda: eng.ntt_modq_dev(logn, batch, poly, wit, out, st, frw.ENC_MONTGOMERY, stream.cuda_stream)
-    for _ in range(max(1, args.warmup)):
+    for _ in range(warm):
         run()
     torch.cuda.synchronize()
-    sharding.barrier()
-    ev = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
+    e0.record(stream)
+    for _ in range(launches):
         run()
-        e1.record(stream)
-        ev.append((e0, e1))
+    e1.record(stream)
     torch.cuda.synchronize()
-    sharding.barrier()
-    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev if args.backend == "nccl" else torch.device("cpu"))
-    ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    wall = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / launches
+    assert int((st != 0).sum().item()) == 0
     bytes_per = 32 * 29 * n + 2 * n                               # SURVEY 8(d): 476,160 / 952,320 B per polynomial
     achieved = batch * bytes_per / (ms * 1e-3) / 1e9
+    return {"kernel": "ntt_modq_kernel<%d,1>" % logn, "workload": "falcon-%d NTT + mod_q witness kernel, batch=%d" % (n, batch),
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4), "launches_timed": launches,
+            "algorithmic_bytes_per_launch": batch * bytes_per, "polynomials_per_s": round(batch * launches / wall, 1)}
+
+
+def time_verify(eng, dev, logn, batch, launches, warm, threads):
+    """Full verify-with-ntt witness at another parameter set / launch size: `launches` launches between two HIP events."""
+    L = frw.layout(logn)
+    sig, pk, hm = synth(logn, batch, 1 << 40, threads)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.empty(batch, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    run = lambda: eng.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, frw.ENC_MONTGOMERY, stream.cuda_stream)
+    for _ in range(warm):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(launches):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    assert int((st != 0).sum().item()) == 0
+    bytes_per = 32 * (L.num_witness + 2 * L.n) + 3 * 2 * L.n
+    achieved = batch * bytes_per / (ms * 1e-3) / 1e9
+    return {"kernel": "witness_ntt_verify_kernel<%d,1>" % logn,
+            "workload": "falcon-%d full verify-with-ntt witness, %d signatures per launch" % (L.n, batch),
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4), "launches_timed": launches,
+            "algorithmic_bytes_per_launch": batch * bytes_per, "signatures_per_s": round(batch / (ms * 1e-3), 1),
+            "launch_shape": eng.launch_shape(logn, batch)}
+
+
+def bench_ntt_modq(args, world, rank, dev):
+    """--workload ntt_modq: BASELINE configs[1] as the primary line."""
+    eng = frw.WitnessEngine(dev.index)
+    sharding.barrier()
+    r = time_ntt_modq(eng, dev, args.logn, args.batch, args.steps, max(1, args.warmup))
+    n = 1 << args.logn
     if rank == 0:
-        emit({
-            "metric": "falcon%d_ntt_modq_witness_polys_per_sec" % n, "value": round(world * batch * args.steps / elapsed, 1),
-            "unit": "polynomials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "falcon-%d NTT + mod_q witness kernel, batch=%d polynomials" % (n, batch), "logn": logn,
-                       "batch_per_gpu": batch},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "ntt_modq_kernel<%d,1>" % logn, "algorithmic_bytes_per_launch": batch * bytes_per,
-                         "avg_launch_ms": round(ms, 4), "launches_timed": len(ev)}})
+        emit({"metric": "falcon%d_ntt_modq_witness_polys_per_sec" % n, "value": r["polynomials_per_s"] * world,
+              "unit": "polynomials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": r["avg_launch_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "u32", "data": "synthetic",
+              "config": {"workload": r["workload"], "logn": args.logn, "batch_per_gpu": args.batch},
+              "roofline": dict(r, traffic=None)})
 
 
 def bench_prepare(args, world, rank, dev):
@@ -187,10 +250,10 @@ def bench_prepare(args, world, rank, dev):
     elapsed = time.perf_counter() - t0
     ms = e0.elapsed_time(e1) / args.steps
     emit({"metric": "falcon%d_input_preparation_signatures_per_sec" % n, "value": round(batch * args.steps / elapsed, 1),
-                      "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                      "ms_per_step": round(ms, 4), "higher_is_better": True, "dtype": "u64 (Keccak lanes)", "data": "synthetic",
-                      "config": {"workload": "decode pk + decode sig + SHAKE256 hash-to-point, %d-byte messages" % mlen,
-                                 "logn": logn, "batch_per_gpu": batch}})
+          "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+          "ms_per_step": round(ms, 4), "higher_is_better": True, "dtype": "u64 (Keccak lanes)", "data": "synthetic",
+          "config": {"workload": "decode pk + decode sig + SHAKE256 hash-to-point, %d-byte messages" % mlen,
+                     "logn": logn, "batch_per_gpu": batch}})
 
 
 _REAL_STDOUT = None
@@ -213,6 +276,105 @@ def emit(obj):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
+def gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d_wit, d_st, stream):
+    """Second curve (north_star / BASELINE configs[3]): generate + all-gather of the per-signature witness vectors for a
+    FULL step, every chunk.  MI355X-first form: each rank generates its chunk in FRW_ENC_COMPACT (0.51 MB per signature
+    instead of 5.08 MB), one all_gather_into_tensor (RCCL over xGMI) moves the compact chunks, and every receiver
+    expands all `world` shards locally into the arkworks layout (frw_expand_dev) -- so every GPU ends up holding every
+    witness of the chunk, byte-identical to the direct output.  Double-buffered: the expansion of chunk k-1 and the
+    generation of chunk k+1 run while chunk k is on the fabric.  The expansion writes world x 5 MB per signature on
+    every GPU, so this curve is bounded by HBM write bandwidth at ~1/world of `value` per GPU -- not by xGMI."""
+    CL = frw.compact_layout(logn)
+    d_sig, d_pk, d_hm = d_in
+    gc = max(1, min(args.allgather_chunk or (chunk // world), chunk // world))
+    nk = batch // gc
+    loc = [torch.empty((gc, CL.bytes_per_signature), dtype=torch.uint8, device=dev) for _ in range(2)]
+    gathered = [torch.empty((world, gc, CL.bytes_per_signature), dtype=torch.uint8, device=dev) for _ in range(2)]
+    exp_wit = d_wit[:world * gc]
+    exp_inst = torch.empty((world * gc, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.empty(gc, dtype=torch.int32, device=dev)
+    nccl = args.backend == "nccl"
+
+    def run(k_count):
+        works = [None, None]
+        for k in range(k_count):
+            b = k & 1
+            a = k * gc
+            eng.witness_ntt_verify_compact_dev(logn, gc, d_sig[a:a + gc], d_pk[a:a + gc], d_hm[a:a + gc], loc[b], st,
+                                               stream.cuda_stream)
+            works[b] = sharding.all_gather_chunks(loc[b], gathered[b], async_op=nccl)
+            if k >= 1:
+                if works[1 - b] is not None:
+                    works[1 - b].wait()
+                eng.expand_dev(logn, world * gc, gathered[1 - b], exp_wit, exp_inst, stream.cuda_stream)
+        b = (k_count - 1) & 1
+        if works[b] is not None:
+            works[b].wait()
+        eng.expand_dev(logn, world * gc, gathered[b], exp_wit, exp_inst, stream.cuda_stream)
+
+    run(min(2, nk))                                       # warm-up: communicator, kernels
+    torch.cuda.synchronize()
+    sharding.barrier()
+    t0 = time.perf_counter()
+    run(nk)
+    torch.cuda.synchronize()
+    sharding.barrier()
+    t = sharding.max_over_ranks(time.perf_counter() - t0, cdev)
+    # parity of what was gathered: the expanded buffer now holds the LAST chunk of every rank; its digests must be
+    # identical on every rank and, for this rank's own shard, equal to a direct FRW_ENC_MONTGOMERY launch
+    dig = torch.zeros(world * gc, dtype=torch.int64, device=dev)
+    eng.digest_dev(exp_wit, L.num_witness * 4, world * gc, dig, stream.cuda_stream)
+    torch.cuda.synchronize()
+    a = (nk - 1) * gc
+    own_wit = torch.empty((gc, L.num_witness, 4), dtype=torch.int64, device=dev)
+    own_dig = torch.zeros(gc, dtype=torch.int64, device=dev)
+    eng.witness_ntt_verify_dev(logn, gc, d_sig[a:a + gc], d_pk[a:a + gc], d_hm[a:a + gc], own_wit, exp_inst[:gc], st,
+                               frw.ENC_MONTGOMERY, stream.cuda_stream)
+    eng.digest_dev(own_wit, L.num_witness * 4, gc, own_dig, stream.cuda_stream)
+    torch.cuda.synchronize()
+    own_ok = bool(torch.equal(own_dig, dig[rank * gc:(rank + 1) * gc]))
+    all_dig = sharding.gather_per_signature(dig.to(cdev), world * world * gc, rank, world) if world > 1 else dig.to(cdev)
+    same = all(bool(torch.equal(all_dig[r * world * gc:(r + 1) * world * gc], all_dig[:world * gc])) for r in range(world))
+    del own_wit
+    return {"signatures_per_s_node": round(world * nk * gc / t, 1), "seconds": round(t, 4),
+            "signatures_per_rank": nk * gc, "chunk_per_rank": gc, "chunks": nk,
+            "wire_format": "FRW_ENC_COMPACT, %d bytes per signature (arkworks layout: %d)"
+                           % (CL.bytes_per_signature, 32 * (L.num_witness + L.num_instance)),
+            "fabric_ingest_GBs_per_gpu": round((world - 1) * nk * gc * CL.bytes_per_signature / t / 1e9, 1),
+            "expanded_bytes_written_GBs_per_gpu": round(world * nk * gc * 32 * (L.num_witness + L.num_instance) / t / 1e9, 1),
+            "collective": "all_gather_into_tensor (RCCL)" if nccl else "gloo rehearsal (staged through the host)",
+            "overlap": "expand(k-1) and generate(k+1) run while chunk k is gathered (double buffer)",
+            "expanded_own_shard_equals_direct_output": own_ok, "expanded_digests_identical_on_all_ranks": same}
+
+
+def arkworks_gather_probe(args, eng, dev, cdev, world, rank, logn, L, d_in, d_wit, d_inst, d_st, stream, chunk):
+    """Bounded probe of the naive form (32-byte elements over the wire), for the xGMI ceiling it runs into."""
+    d_sig, d_pk, d_hm = d_in
+    gc, iters = min(512, chunk // 2), 6
+    loc = [d_wit[:gc], d_wit[gc:2 * gc]]
+    gathered = torch.empty((world,) + tuple(loc[0].shape), dtype=torch.int64, device=dev)
+    works = [None, None]
+    torch.cuda.synchronize()
+    sharding.barrier()
+    tg = time.perf_counter()
+    for it in range(iters):
+        b = it & 1
+        if works[b] is not None:
+            works[b].wait()
+        a = (it * gc) % max(1, d_sig.shape[0] - gc + 1)
+        eng.witness_ntt_verify_dev(logn, gc, d_sig[a:a + gc], d_pk[a:a + gc], d_hm[a:a + gc], loc[b], d_inst, d_st[a:a + gc],
+                                   frw.ENC_MONTGOMERY, stream.cuda_stream)
+        works[b] = sharding.all_gather_chunks(loc[b], gathered, async_op=(args.backend == "nccl"))
+    for w_ in works:
+        if w_ is not None:
+            w_.wait()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    tg = sharding.max_over_ranks(time.perf_counter() - tg, cdev)
+    return {"signatures_per_s_node": round(world * gc * iters / tg, 1), "chunk_per_rank": gc, "iterations": iters,
+            "fabric_ingest_GBs_per_gpu": round((world - 1) * gc * L.num_witness * 32 * iters / tg / 1e9, 1)}
+
+
 def main():
     quiet_stdout()
     ap = argparse.ArgumentParser()
@@ -220,17 +382,22 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logn", type=int, default=10, choices=[9, 10])
-    ap.add_argument("--batch", type=int, default=65536, help="signatures per GPU per step")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="signatures per GPU per step (default: 65,536 = BASELINE configs[2]; with --gpus 8: 131,072 = "
+                         "configs[3], 1 M signatures over the node)")
     ap.add_argument("--chunk", type=int, default=16384,
                     help="signatures per kernel launch = size of the reused HBM witness buffer (16,384 Falcon-1024 "
-                         "witnesses = 82 GB of the 288 GB; larger launches measured faster: tools/time_chunk_sizes.py)")
+                         "witnesses = 82 GB of the 288 GB; tools/time_chunk_sizes.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-r1cs-check", action="store_true",
-                    help="N = 1 only: skip the untimed on-device check that every witness of one full launch satisfies the "
+                    help="skip the untimed on-device check that every witness of the last timed launch satisfies the "
                          "independently emitted constraint system (builds the matrices on the host, ~6 s)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1 only: skip the untimed secondary rooflines (NTT + mod_q kernel at BASELINE configs[1], "
+                         "Falcon-512 full verify)")
     ap.add_argument("--no-allgather", action="store_true",
-                    help="N > 1 only: skip the secondary, bounded 'generate + RCCL all-gather of the witness chunks' leg")
-    ap.add_argument("--allgather-chunk", type=int, default=512, help="signatures per rank per all-gather")
+                    help="N > 1 only: skip the second curve, 'generate + RCCL all-gather of the witness vectors'")
+    ap.add_argument("--allgather-chunk", type=int, default=0, help="signatures per rank per all-gather (default chunk/world)")
     ap.add_argument("--force-pg", action="store_true",
                     help="initialise the process group and run the N > 1 legs even with one rank (rehearses the RCCL "
                          "calls on a single GPU)")
@@ -242,7 +409,10 @@ def main():
                          "the N > 1 code path with several ranks sharing one GPU)")
     ap.add_argument("--workload", default="verify", choices=["verify", "ntt_modq", "prepare"],
                     help="verify = full verify-with-ntt witness (default, BASELINE configs[2]); ntt_modq = the "
-                         "NTT + mod_q witness kernel alone (BASELINE configs[1]: --logn 9 --batch 4096 --chunk 4096)")
+                         "NTT + mod_q witness kernel alone (BASELINE configs[1]: --logn 9 --batch 4096)")
+    ap.add_argument("--dump-digests", default="",
+                    help="after the run, write this rank's per-signature (global index, status, witness digest) of one "
+                         "extra, untimed pass to PATH.rank<r>.npy (multi-rank consistency tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -271,15 +441,21 @@ def main():
             dist.init_process_group("gloo")
 
     if args.workload == "ntt_modq":
+        if not args.batch:
+            args.batch = 4096
         return bench_ntt_modq(args, world, rank, dev)
     if args.workload == "prepare":
+        if not args.batch:
+            args.batch = 65536
         return bench_prepare(args, world, rank, dev)
-    logn, batch, chunk = args.logn, args.batch, min(args.chunk, args.batch)
+    logn = args.logn
+    batch = args.batch or (131072 if world == 8 else 65536)
+    chunk = min(args.chunk, batch)
     dual = args.circuit == "dual"
     L = frw.layout_dual(logn) if dual else frw.layout(logn)
     eng = frw.WitnessEngine(dev_index)
     launch = eng.witness_dual_ntt_verify_dev if dual else eng.witness_ntt_verify_dev
-    threads = max(1, min(os.cpu_count() or 1, 16) // world)
+    threads = max(1, (os.cpu_count() or 1) // world)
 
     # ---- inputs resident in HBM -------------------------------------------------------------
     lo, hi = sharding.shard_range(batch * world, rank, world)      # this rank's global signature indices
@@ -323,8 +499,39 @@ def main():
     # ---- control-plane exchange (untimed): global status vector ---------------------------------
     status = sharding.gather_per_signature(d_st.to(cdev), batch * world, rank, world)
     n_bad = int((status != 0).sum().item())
+    assert n_bad == 0, "%d of the synthetic signatures failed their range checks: the throughput would not be that of " \
+                       "valid witnesses" % n_bad
 
-    # ---- roofline of the dominant (only) kernel, from HIP events on the launch stream ------------------
+    # ---- what the LAST timed launch left in HBM: digest all of it, check all of it (untimed) -------------------------
+    last_a = (nchunks - 1) * chunk                       # rank-local index of the first signature in the buffer
+    last_cnt = batch - last_a
+    d_dig = torch.zeros(last_cnt, dtype=torch.int64, device=dev)
+    eng.digest_dev(d_wit, L.num_witness * 4, last_cnt, d_dig, stream.cuda_stream)
+    torch.cuda.synchronize()
+    last_dig = d_dig.cpu().numpy().view(np.uint64)
+    shape = eng.launch_shape(logn, last_cnt) if not dual else {}
+    checked = {"signatures": last_cnt, "is_the_last_timed_launch": True, "distinct_digests": int(len(np.unique(last_dig)))}
+    if shape:
+        checked.update(grid=shape["grid"], resident_workgroups_per_cu=shape["resident_per_cu"],
+                       rounds=round(last_cnt / max(1, shape["grid"]), 2), split=shape["split"])
+    r1cs = None
+    if not args.no_r1cs_check:
+        # the reference's assert!(cs.is_satisfied()) (falcon_ntt.rs:159) for every signature of that launch, on the
+        # device, in place, against matrices emitted from the gadget definitions by the host mirror (not the closed form)
+        h = eng.r1cs_load(1 if dual else 0, logn)
+        badrows = torch.zeros(last_cnt, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        eng.r1cs_check_dev(h, last_cnt, d_wit, d_inst, badrows, stream.cuda_stream)
+        torch.cuda.synchronize()
+        tc = time.perf_counter() - tc
+        eng.r1cs_free(h)
+        n_unsat = sharding.sum_over_ranks(int((badrows != 0).sum().item()), cdev)
+        assert n_unsat == 0, "%d witnesses of the last timed launch violate the constraint system" % n_unsat
+        r1cs = {"witnesses_checked": last_cnt * world, "per_rank": last_cnt, "unsatisfied": n_unsat,
+                "constraints_each": L.num_constraints, "seconds": round(tc, 3), "buffer": "as left by the last timed launch"}
+
+    # ---- roofline of the dominant kernel, from HIP events on the launch stream ------------------
     full = [(e0.elapsed_time(e1), cnt) for e0, e1, cnt in events if cnt == chunk]
     launch_ms = sum(t for t, _ in full) / max(1, len(full))
     bytes_per_sig = 32 * (L.num_witness + 2 * n) + 3 * 2 * n          # 5,086,848 B for Falcon-1024
@@ -333,6 +540,7 @@ def main():
     # ---- calibration (untimed): what a compute-free write stream of the same shape SUSTAINS on this device now -----
     # Same regime as the timed region: one step's worth of launches back to back, second of two rounds (a single
     # launch squeezed between witness kernels reads 5-10 % high: the device boosts after every change of load).
+    # Runs after the checks above: it overwrites the witness buffer.
     wbytes = d_wit.numel() * 8
     cal_ms = 0.0
     for _ in range(2):
@@ -345,100 +553,79 @@ def main():
         cal_ms = e0.elapsed_time(e1) / nchunks
     write_stream_gbs = wbytes / (cal_ms * 1e-3) / 1e9
 
-    # ---- secondary leg (N > 1, untimed w.r.t. `value`): generate + all-gather of the witness chunks --------------
-    # BASELINE north_star / configs[3] describe an RCCL all-gather of the per-signature witness vectors.  It is not on
-    # the default data path (no consumer needs every witness on every GPU, and xGMI ingest caps it
-    # near 2.4e5 signatures/s per node), but it is measured here, bounded, so the number exists next to `value`.
+    # ---- second curve (N > 1): generate + all-gather of the witness vectors, full step ------------------------------
     gather_info = None
-    if use_pg and not args.no_allgather:
+    if use_pg and not args.no_allgather and not dual:
         try:
-            gc = min(args.allgather_chunk, chunk)
-            iters = 6
-            loc = [d_wit[:gc], d_wit[gc:2 * gc]] if chunk >= 2 * gc else [d_wit[:gc], torch.empty_like(d_wit[:gc])]
-            gdev = dev if args.backend == "nccl" else dev
-            gathered = torch.empty((world,) + tuple(loc[0].shape), dtype=torch.int64, device=gdev)
-            works = [None, None]
-            torch.cuda.synchronize()
-            sharding.barrier()
-            tg = time.perf_counter()
-            for it in range(iters):
-                b = it & 1
-                if works[b] is not None:
-                    works[b].wait()                       # the gather that read loc[b] two iterations ago is done
-                a = (it * gc) % max(gc, batch - gc + 1)
-                launch(logn, gc, d_sig[a:a + gc], d_pk[a:a + gc], d_hm[a:a + gc], loc[b], d_inst, d_st[a:a + gc],
-                       frw.ENC_MONTGOMERY, stream.cuda_stream)
-                works[b] = sharding.all_gather_chunks(loc[b], gathered, async_op=(args.backend == "nccl"))
-            for w_ in works:
-                if w_ is not None:
-                    w_.wait()
-            torch.cuda.synchronize()
-            sharding.barrier()
-            tg = sharding.max_over_ranks(time.perf_counter() - tg, cdev)
-            gather_info = {"signatures_per_s_node": round(world * gc * iters / tg, 1), "chunk_per_rank": gc,
-                           "iterations": iters, "seconds": round(tg, 4),
-                           "ingest_GBs_per_gpu": round((world - 1) * gc * L.num_witness * 32 * iters / tg / 1e9, 1),
-                           "collective": "all_gather_into_tensor (RCCL)" if args.backend == "nccl" else "gloo rehearsal",
-                           "overlap": "kernel of chunk k+1 runs while chunk k is gathered (double buffer)"}
-            del gathered
+            gather_info = gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit, d_st,
+                                     stream)
+            gather_info["naive_32_byte_elements_probe"] = arkworks_gather_probe(
+                args, eng, dev, cdev, world, rank, logn, L, (d_sig, d_pk, d_hm), d_wit, d_inst, d_st, stream, chunk)
         except Exception as ex:      # the primary metric must not depend on this leg
-            gather_info = {"error": repr(ex)[:300]}
+            gather_info = dict(gather_info or {}, error=repr(ex)[:300])
+    ranks_seen = dist.get_world_size() if use_pg else 1
+    devs = sharding.gather_per_signature(torch.tensor([dev_index], dtype=torch.int64, device=cdev), world, rank, world)
+
+    if args.dump_digests:
+        # one extra, untimed pass with every launch digested: per-signature (global index, status, digest) of this rank
+        dd = torch.zeros(batch, dtype=torch.int64, device=dev)
+        for c in range(nchunks):
+            a = c * chunk
+            cnt = min(chunk, batch - a)
+            launch(logn, cnt, d_sig[a:a + cnt], d_pk[a:a + cnt], d_hm[a:a + cnt], d_wit, d_inst, d_st[a:a + cnt],
+                   frw.ENC_MONTGOMERY, stream.cuda_stream)
+            eng.digest_dev(d_wit, L.num_witness * 4, cnt, dd[a:a + cnt], stream.cuda_stream)
+        torch.cuda.synchronize()
+        np.save("%s.rank%d.npy" % (args.dump_digests, rank),
+                np.stack([np.arange(lo, hi, dtype=np.uint64), d_st.cpu().numpy().astype(np.uint64),
+                          dd.cpu().numpy().view(np.uint64)]))
 
     result = None
     traffic = None if dual else measured_traffic(logn, chunk)
     if rank == 0:
         value = world * batch * args.steps / elapsed
+        cfg_name = "BASELINE configs[3]: %d signatures sharded over %d GPUs" % (batch * world, world) if world == 8 \
+            else "BASELINE configs[2]"
         result = {
             "metric": "falcon%d_verify_with_%sntt_r1cs_witnesses_per_sec" % (n, "dual_" if dual else ""), "value": round(value, 1),
             "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "falcon-%d full verify-with-%sntt witness (NTT ladder + mod_q + pointwise + l2-norm), "
-                                   "batch=%d signatures per GPU per step" % (n, "dual-" if dual else "", batch),
-                       "logn": logn, "batch_per_gpu": batch, "chunk": chunk, "launches_per_step": nchunks,
+                                   "batch=%d signatures per GPU per step (%s)" % (n, "dual-" if dual else "", batch, cfg_name),
+                       "logn": logn, "batch_per_gpu": batch, "signatures_per_step_all_gpus": batch * world,
+                       "chunk": chunk, "launches_per_step": nchunks,
                        "encoding": "bls12-381-fr montgomery (arkworks witness_assignment bytes)",
                        "seed": hex(SEED), "sharding": "by signature index, no data-path collective",
-                       "signatures_failing_range_checks": n_bad},
+                       "signatures_failing_range_checks": n_bad,
+                       "ranks_seen": ranks_seen, "device_index_per_rank": [int(x) for x in devs.tolist()],
+                       "backend": (args.backend if use_pg else None)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic[0] if traffic else None,
-                         "traffic_source": traffic[1] if traffic else None,
+                         "traffic_from_committed_profile": traffic[1] if traffic else None,
                          "kernel": "witness_%sntt_verify_kernel<%d,1>" % ("dual_" if dual else "", logn),
+                         "kernel_source_sha256_16": kernel_source_sha(),
                          "algorithmic_bytes_per_launch": chunk * bytes_per_sig,
                          "avg_launch_ms": round(launch_ms, 4), "launches_timed": len(full),
                          "device_write_stream_GBs": round(write_stream_gbs, 1),
                          "frac_of_device_write_stream": round(achieved / write_stream_gbs, 4)},
+            "launch_shape_checked": checked,
         }
+        if r1cs is not None:
+            result["r1cs_check"] = r1cs
         if gather_info is not None:
-            result["allgather"] = gather_info
-        if world == 1 and not args.no_r1cs_check:
-            # untimed: the reference's assert!(cs.is_satisfied()) for every signature of one launch, on the device,
-            # against matrices emitted from the gadget definitions by the host mirror (not the kernels' closed form)
-            nchk = min(chunk, 4096)
-            launch(logn, nchk, d_sig[:nchk], d_pk[:nchk], d_hm[:nchk], d_wit, d_inst, d_st[:nchk],
-                   frw.ENC_MONTGOMERY, stream.cuda_stream)
-            h = eng.r1cs_load(1 if dual else 0, logn)
-            bad = torch.zeros(nchk, dtype=torch.int32, device=dev)
-            torch.cuda.synchronize()
-            tc = time.perf_counter()
-            eng.r1cs_check_dev(h, nchk, d_wit, d_inst, bad, stream.cuda_stream)
-            torch.cuda.synchronize()
-            tc = time.perf_counter() - tc
-            eng.r1cs_free(h)
-            n_unsat = int((bad != 0).sum().item())
-            assert n_unsat == 0, "%d witnesses violate the constraint system" % n_unsat
-            result["r1cs_check"] = {"witnesses_checked": nchk, "unsatisfied": n_unsat, "constraints_each": L.num_constraints,
-                                    "seconds": round(tc, 3)}
+            result["scaling_curves"] = {"generate_only_signatures_per_s": round(value, 1),
+                                        "generate_plus_allgather": gather_info}
+        if world == 1 and not args.no_secondary and not dual:
+            # untimed w.r.t. `value`: the other two rooflines BASELINE / north_star name, measured in this process
+            result["secondary"] = {
+                "ntt_modq_falcon512_batch4096": time_ntt_modq(eng, dev, 9, 4096, 200, 20),
+                "verify_falcon512_8192_per_launch": time_verify(eng, dev, 9, 8192, 12, 3, threads)}
         if world == 1 and not args.no_cpu_baseline and not dual:
-            # digests of the first launch's witnesses (recomputed: the buffer holds the last chunk now)
-            k = min(512, chunk)
-            dig = torch.zeros(k, dtype=torch.int64, device=dev)
-            eng.witness_ntt_verify_dev(logn, k, d_sig[:k], d_pk[:k], d_hm[:k], d_wit, d_inst, d_st[:k],
-                                       frw.ENC_MONTGOMERY, stream.cuda_stream)
-            eng.digest_dev(d_wit, L.num_witness * 4, k, dig, stream.cuda_stream)
-            torch.cuda.synchronize()
-            gpu_digests = [int(x) & (2 ** 64 - 1) for x in dig.cpu().numpy()]
-            result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, gpu_digests, threads)
+            stride = max(1, last_cnt // 4096)
+            sample = np.arange(0, last_cnt, stride)[:4096] + last_a
+            result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, sample, lambda i: int(last_dig[i - last_a]))
         emit(result)
     if use_pg:
         dist.destroy_process_group()

@@ -33,6 +33,13 @@ class LayoutDualStruct(C.Structure):
                 ("seg_off", C.c_int32 * 15), ("seg_len", C.c_int32 * 15)]
 
 
+class CompactLayoutStruct(C.Structure):
+    _fields_ = [("logn", C.c_int32), ("n", C.c_int32), ("bytes_per_signature", C.c_uint64),
+                ("values_off", C.c_uint64), ("num_values", C.c_uint64), ("bits_off", C.c_uint64),
+                ("num_bit_words", C.c_uint64), ("bit_seg_off", C.c_uint64 * 6), ("instance_off", C.c_uint64),
+                ("num_instance_values", C.c_uint64)]
+
+
 # name -> (restype, argtypes); must list every symbol include/frw.h declares
 PROTOTYPES = {
     "frw_layout": (C.c_int, [C.c_int, C.POINTER(LayoutStruct)]),
@@ -49,6 +56,11 @@ PROTOTYPES = {
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "frw_ntt_modq": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
+    "frw_compact_layout": (C.c_int, [C.c_int, C.POINTER(CompactLayoutStruct)]),
+    "frw_witness_ntt_verify_compact_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_expand_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_diag_launch_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_int32 * 4)]),
     "frw_layout_dual": (C.c_int, [C.c_int, C.POINTER(LayoutDualStruct)]),
     "frw_witness_dual_ntt_verify_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

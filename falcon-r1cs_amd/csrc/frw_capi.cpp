@@ -368,6 +368,61 @@ int frw_witness_dual_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const 
     return FRW_OK;
 }
 
+int frw_compact_layout(int logn, frw_compact_layout_t *out)
+{
+    if (!out || (logn != 9 && logn != 10)) return FRW_E_INVALID_ARG;
+    const frw::CompactLayout c = frw::compact_layout(logn);
+    const uint64_t n = (uint64_t)1 << logn, seg = 27 * n;
+    out->logn = logn;
+    out->n = (int32_t)n;
+    out->bytes_per_signature = c.bytes;
+    out->values_off = 0;
+    out->num_values = c.num_values;
+    out->bits_off = c.bits_off;
+    out->num_bit_words = c.bit_words;
+    for (int i = 0; i < 5; i++) out->bit_seg_off[i] = (uint64_t)i * seg;
+    out->bit_seg_off[5] = 4 * seg + 32 * n;
+    out->instance_off = c.instance_off;
+    out->num_instance_values = c.num_instance;
+    return FRW_OK;
+}
+
+int frw_witness_ntt_verify_compact_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_sig, const uint16_t *d_pk,
+                                       const uint16_t *d_hm, void *d_compact, int32_t *d_status, void *stream)
+{
+    if (bad_common(ctx, logn, FRW_ENC_MONTGOMERY)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!d_sig || !d_pk || !d_hm || !d_compact || !d_status || ((uintptr_t)d_compact & 15)) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    int slot;
+    unsigned long long *q = queue_for(ctx, (hipStream_t)stream, &slot);
+    if (!q) return FRW_E_OUT_OF_MEMORY;
+    FRW_HIP(frw::launch_witness_ntt_verify_compact(ctx->d_tables, q, ctx->num_cu, logn, batch, d_sig, d_pk, d_hm, d_compact,
+                                                   d_status, (hipStream_t)stream));
+    queue_launched(ctx, (hipStream_t)stream, slot);
+    return FRW_OK;
+}
+
+int frw_expand_dev(frw_ctx *ctx, int logn, size_t batch, const void *d_compact, uint64_t *d_witness, uint64_t *d_instance,
+                   void *stream)
+{
+    if (bad_common(ctx, logn, FRW_ENC_MONTGOMERY)) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (!d_compact || !d_witness || !d_instance || ((uintptr_t)d_compact & 15)) return FRW_E_INVALID_ARG;
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(frw::launch_expand(ctx->num_cu, logn, batch, d_compact, d_witness, d_instance, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+int frw_diag_launch_shape(frw_ctx *ctx, int logn, int encoding, size_t batch, int32_t out[4])
+{
+    if (!ctx || !out || (logn != 9 && logn != 10) || encoding < 0 || encoding > 2) return FRW_E_INVALID_ARG;
+    int o[4];
+    frw::launch_shape_witness_ntt_verify(ctx->num_cu, logn, encoding, batch, o);
+    for (int i = 0; i < 4; i++) out[i] = o[i];
+    return FRW_OK;
+}
+
 int frw_layout_dual(int logn, frw_layout_dual_t *out)
 {
     if (!out || (logn != 9 && logn != 10)) return FRW_E_INVALID_ARG;

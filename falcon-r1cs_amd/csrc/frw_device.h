@@ -26,7 +26,35 @@ struct Tables {
     uint32_t ck[11][5];     // C_k = 2^k q^(k+1), 32-bit limbs (falcon_ntt.rs:31-39)
 };
 
+// FRW_ENC_COMPACT: one signature = the 13 N non-boolean witness elements as 32-byte Montgomery values (witness order:
+// S0, S1, then per block the values of S3, S4, S5, S6), the 140 N + nb boolean elements as a bit array (witness order:
+// S2, the boolean parts of S3, S4, S5, S6, then S7 in two words), and the 2 N instance values (without the leading one).
+// 0.51 MB instead of 5.08 MB per Falcon-1024 signature; frw_expand_dev rebuilds the arkworks buffers from it.
+struct CompactLayout {
+    size_t num_values, bits_off, bit_words, instance_off, num_instance, bytes;
+    size_t seg_words;      // bit words of one enforce_less_than_q segment (27 N / 32)
+};
+constexpr CompactLayout compact_layout(int logn)
+{
+    const size_t n = (size_t)1 << logn;
+    CompactLayout c{};
+    c.num_values = 13 * n;
+    c.bits_off = c.num_values * 32;
+    c.seg_words = 27 * n / 32;
+    c.bit_words = 4 * c.seg_words + n + 2;
+    c.instance_off = c.bits_off + (c.bit_words * 4 + 15) / 16 * 16;
+    c.num_instance = 2 * n;
+    c.bytes = (c.instance_off + c.num_instance * 32 + 127) / 128 * 128;
+    return c;
+}
+
 void init_launch_config();
+hipError_t launch_witness_ntt_verify_compact(const Tables *tab, unsigned long long *queue, int num_cu, int logn, size_t batch,
+                                             const uint16_t *sig, const uint16_t *pk, const uint16_t *hm, void *compact,
+                                             int32_t *status, hipStream_t st);
+hipError_t launch_expand(int num_cu, int logn, size_t batch, const void *compact, uint64_t *wit, uint64_t *inst, hipStream_t st);
+// grid / resident workgroups per CU / split flag the witness launcher would use for `batch` (diagnostics for bench.py)
+void launch_shape_witness_ntt_verify(int num_cu, int logn, int enc, size_t batch, int out[4]);
 hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch,
                                      const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st);

@@ -638,16 +638,16 @@ __device__ __forceinline__ size_t next_item(size_t cur, unsigned long long ticke
 // array is dead until then, so they share memory: behind the third value slot (first SLAB_SLOT bytes of `lad`) as many
 // of them as fit live inside `lad`.  Falcon-1024: 50.3 KB -> 3 workgroups per CU; Falcon-512: 40.1 KB -> 4.
 // ------------------------------------------------------------------------------------------------
-template <int LOGN>
+template <int LOGN, bool COMPACT = false>
 struct alignas(16) Smem {
     static constexpr int N = 1 << LOGN;
     static constexpr int IN_LAD = (5 * N * 4 - SLAB_SLOT) / (2 * N) < 4 ? (5 * N * 4 - SLAB_SLOT) / (2 * N) : 4;   // 4 | 1
-    unsigned char slab[SLAB_BYTES];      // value slots 0, 1 of the four waves + their constant areas
+    unsigned char slab[COMPACT ? 16 : SLAB_BYTES];   // value slots 0, 1 of the four waves + their constants (no tile writer in compact mode)
     uint32_t lad[5 * N];                 // ladder integers, limb-major; before the ladders: slot 2, then NTT-domain arrays
     uint16_t tw[N];
     uint16_t sig[N], v[N];               // coefficient domain
     uint16_t ntt_rest[(4 - IN_LAD) * N + 8];     // the NTT-domain arrays that do not fit inside `lad`
-    uint16_t vtab[VTAB_ROWS * WAVE];
+    uint16_t vtab[COMPACT ? 8 : VTAB_ROWS * WAVE];
     unsigned long long norm;
     unsigned long long next;              // next signature index taken from the launch's work queue
     int bad;
@@ -693,7 +693,10 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
     constexpr size_t I = 2 * (size_t)N + 1;
     constexpr int TILES = N / WAVE;
     constexpr uint32_t TILE1 = WAVE * 32;            // bytes of a tile of one-element blocks
-    __shared__ Smem<LOGN> sm;
+    constexpr bool COMPACT = ENC == 2;               // FRW_ENC_COMPACT: g_wit is the compact buffer, g_inst unused
+    constexpr int VENC = COMPACT ? 1 : ENC;          // compact values are Montgomery
+    constexpr CompactLayout CL = compact_layout(LOGN);
+    __shared__ Smem<LOGN, COMPACT> sm;
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -705,8 +708,15 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
     wc.lane = lane;
 
     for (int j = tid; j < N; j += BLOCK) sm.tw[j] = tab->tw[j];
-    init_vtab(sm.vtab, VTAB_ROWS, tid);
-    init_slab_const<ENC>(wc.slab, lane);
+    if constexpr (!COMPACT) {
+        init_vtab(sm.vtab, VTAB_ROWS, tid);
+        init_slab_const<ENC>(wc.slab, lane);
+    }
+    // compact mode: element `elem` of a 32-byte-element array
+    auto put = [](v4u *base, size_t elem, const uint32_t (&e)[8]) {
+        base[elem * 2] = mk4(e[0], e[1], e[2], e[3]);
+        base[elem * 2 + 1] = mk4(e[4], e[5], e[6], e[7]);
+    };
 
     constexpr int PARTS = SPLIT ? 5 : 1;
     unsigned long long ticket = 0;
@@ -716,8 +726,12 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         const size_t s = SPLIT ? item / PARTS : item;
         const int part = SPLIT ? (int)(item % PARTS) : -1;
         auto does = [&](int p) { return !SPLIT || part == p; };             // workgroup-uniform
-        v4u *wit = g_wit + s * W * 2;
-        v4u *inst = g_inst + s * I * 2;
+        v4u *wit = COMPACT ? nullptr : g_wit + s * W * 2;
+        v4u *inst = COMPACT ? nullptr : g_inst + s * I * 2;
+        unsigned char *const cbase = COMPACT ? (unsigned char *)g_wit + s * CL.bytes : nullptr;
+        v4u *const cv = (v4u *)cbase;                                       // compact: values
+        uint32_t *const cb = (uint32_t *)(cbase + CL.bits_off);             //          boolean bit words
+        v4u *const ci = (v4u *)(cbase + CL.instance_off);                   //          instance values
         // ---- 1. load + range check ----------------------------------------------------------
         if (tid == 0) { sm.norm = 0; sm.bad = 0; }
         __syncthreads();
@@ -731,7 +745,10 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         __syncthreads();
         if (sm.bad) {                                    // uniform across the workgroup
             if (tid == 0 && does(2)) g_status[s] = ST_COEFF_RANGE;
-            if (does(0)) { zero_fill(wit, W * 2, tid); zero_fill(inst, I * 2, tid); }
+            if (does(0)) {
+                if constexpr (COMPACT) zero_fill(cv, CL.bytes / 16, tid);
+                else { zero_fill(wit, W * 2, tid); zero_fill(inst, I * 2, tid); }
+            }
             __syncthreads();
             continue;
         }
@@ -750,13 +767,13 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
             if (does(0) || does(2) || does(4)) intt_modq_lds<LOGN>(sm.v, tab->itw, tid);   // v = hm - sig*pk   :48-49
         }
 
-        const __amdgpu_buffer_rsrc_t rw = make_rsrc(wit, (uint32_t)(W * 32));
-        const __amdgpu_buffer_rsrc_t ri = make_rsrc(inst, (uint32_t)(I * 32));
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(wit, COMPACT ? 0u : (uint32_t)(W * 32));
+        const __amdgpu_buffer_rsrc_t ri = make_rsrc(inst, COMPACT ? 0u : (uint32_t)(I * 32));
 
         // ---- 3. small segments ---------------------------------------------------------------
         uint32_t e8[8];
         // instance_assignment[0] = 1; then pk_ntt, hm_ntt                                   :63,:67
-        if (tid < 2 && does(0)) {
+        if (!COMPACT && tid < 2 && does(0)) {
             constexpr uint32_t R[8] = FRW_R32;
             v4u one = ENC == 0 ? (tid ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0))
                                  : (tid ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]));
@@ -766,28 +783,45 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         for (int t = wave; t < TILES; t += WAVES) {
             const int k = t * WAVE + lane;
             if (does(0)) {
-            encode_u32<ENC>(s_npk[k], e8); slab_put(wc.slab, 0, lane, e8);
+            const uint32_t vk = sm.v[k];
+            if constexpr (COMPACT) {
+                encode_u32<VENC>(s_npk[k], e8); put(ci, k, e8);
+                encode_u32<VENC>(s_nhm[k], e8); put(ci, N + k, e8);
+                encode_u32<VENC>(sm.sig[k], e8); put(cv, k, e8);
+                encode_u32<VENC>(vk, e8); put(cv, N + k, e8);
+                const uint32_t wd = pack_bits<27>(ltq_mask(vk), lane);
+                if (lane < 54) cb[t * 54 + lane] = wd;
+            } else {
+            encode_u32<VENC>(s_npk[k], e8); slab_put(wc.slab, 0, lane, e8);
             emit_values(ri, 32 + t * TILE1, wc);
-            encode_u32<ENC>(s_nhm[k], e8); slab_put(wc.slab, 0, lane, e8);
+            encode_u32<VENC>(s_nhm[k], e8); slab_put(wc.slab, 0, lane, e8);
             emit_values(ri, 32 + (N / WAVE + t) * TILE1, wc);
             // S0 sig, S1 v                                                                  :58-59,:71
-            encode_u32<ENC>(sm.sig[k], e8); slab_put(wc.slab, 0, lane, e8);
+            encode_u32<VENC>(sm.sig[k], e8); slab_put(wc.slab, 0, lane, e8);
             emit_values(rw, t * TILE1, wc);
-            const uint32_t vk = sm.v[k];
-            encode_u32<ENC>(vk, e8); slab_put(wc.slab, 0, lane, e8);
+            encode_u32<VENC>(vk, e8); slab_put(wc.slab, 0, lane, e8);
             emit_values(rw, (N / WAVE + t) * TILE1, wc);
             // S2 enforce_less_than_q(v[k])                                                  :73-77
             emit_tile<27>(rw, (2 * N + t * WAVE * 27) * 32, ltq_mask(vk), wc);
+            }
             }
             // S5 pointwise: [prod, t, c, ltq(c)]                                            :94-111
             if (does(1)) {
                 const uint32_t prod = (uint32_t)s_nsig[k] * s_npk[k];
                 const uint32_t ab = s_nv[k] + prod;                       // arithmetics.rs:238
                 const uint32_t tq = ab / Q, c = ab - tq * Q;              // :242-243
-                encode_u32<ENC>(prod, e8); slab_put(wc.slab, 0, lane, e8);
-                encode_u32<ENC>(tq, e8);   slab_put(wc.slab, 1, lane, e8);
-                encode_u32<ENC>(c, e8);    slab_put(wc.slab, 2, lane, e8);
+                if constexpr (COMPACT) {
+                    encode_u32<VENC>(prod, e8); put(cv, 6 * N + 3 * k, e8);
+                    encode_u32<VENC>(tq, e8);   put(cv, 6 * N + 3 * k + 1, e8);
+                    encode_u32<VENC>(c, e8);    put(cv, 6 * N + 3 * k + 2, e8);
+                    const uint32_t wd = pack_bits<27>(ltq_mask(c), lane);
+                    if (lane < 54) cb[3 * CL.seg_words + t * 54 + lane] = wd;
+                } else {
+                encode_u32<VENC>(prod, e8); slab_put(wc.slab, 0, lane, e8);
+                encode_u32<VENC>(tq, e8);   slab_put(wc.slab, 1, lane, e8);
+                encode_u32<VENC>(c, e8);    slab_put(wc.slab, 2, lane, e8);
                 emit_tile<30>(rw, (87 * N + t * WAVE * 30) * 32, ltq_mask(c) << 3, wc);
+                }
             }
         }
         // S6 l2_norm_var over v || sig: [a0..a13, w0, w1, r, sq]                             :116-120
@@ -800,9 +834,16 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
             const uint32_t r = (m >> 15) & 1u ? a : Q - a;                // misc.rs:35-46
             const uint32_t sq = r * r;
             nrm += sq;
-            encode_u32<ENC>(r, e8);  slab_put(wc.slab, 0, lane, e8);
-            encode_u32<ENC>(sq, e8); slab_put(wc.slab, 1, lane, e8);
+            if constexpr (COMPACT) {
+                encode_u32<VENC>(r, e8);  put(cv, 9 * N + 2 * k, e8);
+                encode_u32<VENC>(sq, e8); put(cv, 9 * N + 2 * k + 1, e8);
+                const uint32_t wd = pack_bits<16>(m, lane);
+                if (lane < 32) cb[4 * CL.seg_words + t * 32 + lane] = wd;
+            } else {
+            encode_u32<VENC>(r, e8);  slab_put(wc.slab, 0, lane, e8);
+            encode_u32<VENC>(sq, e8); slab_put(wc.slab, 1, lane, e8);
             emit_tile<18>(rw, (117 * N + t * WAVE * 18) * 32, m, wc);
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor((unsigned long long)nrm, off, WAVE);
@@ -812,6 +853,9 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         if (wave == 0 && does(2)) {
             const unsigned long long norm = sm.norm;
             const unsigned long long nm = LOGN == 9 ? norm_mask_512(norm) : norm_mask_1024(norm);
+            if constexpr (COMPACT) {
+                if (lane < 2) cb[4 * CL.seg_words + N + lane] = (uint32_t)(nm >> (32 * lane));
+            } else {
             constexpr uint32_t R[8] = FRW_R32;
             const int half = lane & 1;
             v4u one = ENC == 0 ? (half ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0))
@@ -820,6 +864,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
             for (int c = lane; c < NB * 2; c += WAVE) {
                 const int pos = c >> 1;
                 o[c] = (nm >> pos) & 1ull ? one : mk4(0, 0, 0, 0);
+            }
             }
             if (lane == 0) g_status[s] = norm >= (LOGN == 9 ? 34034726ull : 70265242ull) ? ST_NORM_BOUND : ST_OK;
         }
@@ -836,9 +881,17 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
 #pragma unroll
                 for (int i = 0; i < 5; i++) a[i] = sm.lad[i * N + k];
                 const uint32_t b = divmod_q_u160(a, q5);                  // arithmetics.rs:127-134
-                encode_u160<ENC>(q5, e8); slab_put(wc.slab, 0, lane, e8);    // t_var :137
-                encode_u32<ENC>(b, e8);   slab_put(wc.slab, 1, lane, e8);    // b_var :138
+                if constexpr (COMPACT) {
+                    const size_t ve = (size_t)(which ? 4 : 2) * N + 2 * k;
+                    encode_u160<VENC>(q5, e8); put(cv, ve, e8);
+                    encode_u32<VENC>(b, e8);   put(cv, ve + 1, e8);
+                    const uint32_t wd = pack_bits<27>(ltq_mask(b), lane);
+                    if (lane < 54) cb[(which ? 2 : 1) * CL.seg_words + t * 54 + lane] = wd;
+                } else {
+                encode_u160<VENC>(q5, e8); slab_put(wc.slab, 0, lane, e8);    // t_var :137
+                encode_u32<VENC>(b, e8);   slab_put(wc.slab, 1, lane, e8);    // b_var :138
                 emit_tile<29>(rw, seg + t * WAVE * 29 * 32, ltq_mask(b) << 2, wc);
+                }
             }
             __syncthreads();
         }
@@ -1099,6 +1152,116 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// kernel: FRW_ENC_COMPACT -> the arkworks buffers (witness_assignment / instance_assignment, Montgomery), i.e. exactly
+// what witness_ntt_verify_kernel<LOGN, 1> writes.  Pure data movement through the same tile writer: values are loaded
+// from the compact buffer into the wave's slab, the booleans of a tile are cut out of the bit array (two ds_bpermute
+// per lane) and handed to emit_tile as the per-block mask.  A receiver of an all-gathered compact chunk runs this
+// locally: 0.51 MB cross the fabric per Falcon-1024 signature instead of 5.08 MB.
+// ------------------------------------------------------------------------------------------------
+struct alignas(16) SmemExpand {
+    unsigned char slab[3 * SLAB_SLOT];
+    uint16_t vtab[VTAB_ROWS * WAVE];
+};
+
+// bits [k NB, k NB + NB) of a tile's bit words (lane i holds word i, lanes >= 2 NB hold zero)
+template <int NB>
+__device__ __forceinline__ uint32_t unpack_bits(uint32_t word, int lane)
+{
+    const int off = lane * NB, i0 = off >> 5, o = off & 31;
+    const uint32_t lo = (uint32_t)__shfl((int)word, i0, WAVE), hi = (uint32_t)__shfl((int)word, (i0 + 1) & 63, WAVE);
+    const uint64_t both = (uint64_t)lo | ((uint64_t)hi << 32);
+    return (uint32_t)(both >> o) & ((1u << NB) - 1u);
+}
+
+__device__ __forceinline__ void slab_put16(uint32_t slab_w, int slot, int lane, v4u lo, v4u hi)
+{
+    const uint32_t a = slab_w + slot * SLAB_SLOT + slab_addr(lane);
+    *(FRW_LDS v4u *)(uintptr_t)a = lo;
+    *(FRW_LDS v4u *)(uintptr_t)(a + SLAB_HALF) = hi;
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(BLOCK) void expand_kernel(size_t batch, const unsigned char *__restrict__ g_compact,
+                                                       v4u *__restrict__ g_wit, v4u *__restrict__ g_inst)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int NB = LOGN == 9 ? 50 : 52;
+    constexpr size_t W = 153 * (size_t)N + NB;
+    constexpr size_t I = 2 * (size_t)N + 1;
+    constexpr int TILES = N / WAVE;
+    constexpr CompactLayout CL = compact_layout(LOGN);
+    __shared__ SmemExpand sm;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WaveCtx wc;
+    wc.slab = (uint32_t)(uintptr_t)(FRW_LDS void *)sm.slab + wave * SLAB_WBLK;
+    wc.vtab = (uint32_t)(uintptr_t)(FRW_LDS void *)sm.vtab + lane * 2;
+    wc.lane = lane;
+    init_vtab(sm.vtab, VTAB_ROWS, tid);
+    init_slab_const<1>(wc.slab, lane);
+    __syncthreads();
+    constexpr uint32_t R[8] = FRW_R32;
+    const v4u one = lane & 1 ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]);
+
+    for (size_t s = blockIdx.x; s < batch; s += gridDim.x) {
+        const unsigned char *cbase = g_compact + s * CL.bytes;
+        const v4u *cv = (const v4u *)cbase;
+        const uint32_t *cb = (const uint32_t *)(cbase + CL.bits_off);
+        const v4u *ci = (const v4u *)(cbase + CL.instance_off);
+        v4u *wit = g_wit + s * W * 2;
+        v4u *inst = g_inst + s * I * 2;
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(wit, (uint32_t)(W * 32));
+        // instance: [one, pk_ntt, hm_ntt]; S0, S1: contiguous copies of 32-byte elements
+        if (tid < 2) inst[tid] = one;
+        for (int c = tid; c < 4 * N; c += BLOCK) inst[2 + c] = ci[c];
+        for (int c = tid; c < 4 * N; c += BLOCK) wit[c] = cv[c];
+        // S2: booleans only
+        for (int t = wave; t < TILES; t += WAVES) {
+            const uint32_t wd = lane < 54 ? cb[t * 54 + lane] : 0u;
+            emit_tile<27>(rw, (2 * N + t * WAVE * 27) * 32, unpack_bits<27>(wd, lane), wc);
+        }
+        // S3, S4: [t, b, ltq(b)]
+#pragma unroll 1
+        for (int which = 0; which < 2; which++) {
+            for (int t = wave; t < TILES; t += WAVES) {
+                const int k = t * WAVE + lane;
+                const v4u *v = cv + ((size_t)(which ? 4 : 2) * N + 2 * k) * 2;
+                slab_put16(wc.slab, 0, lane, v[0], v[1]);
+                slab_put16(wc.slab, 1, lane, v[2], v[3]);
+                const uint32_t wd = lane < 54 ? cb[(which ? 2 : 1) * CL.seg_words + t * 54 + lane] : 0u;
+                emit_tile<29>(rw, ((which ? 58 : 29) * N + t * WAVE * 29) * 32, unpack_bits<27>(wd, lane) << 2, wc);
+            }
+        }
+        // S5: [prod, t, c, ltq(c)]
+        for (int t = wave; t < TILES; t += WAVES) {
+            const int k = t * WAVE + lane;
+            const v4u *v = cv + ((size_t)6 * N + 3 * k) * 2;
+            slab_put16(wc.slab, 0, lane, v[0], v[1]);
+            slab_put16(wc.slab, 1, lane, v[2], v[3]);
+            slab_put16(wc.slab, 2, lane, v[4], v[5]);
+            const uint32_t wd = lane < 54 ? cb[3 * CL.seg_words + t * 54 + lane] : 0u;
+            emit_tile<30>(rw, (87 * N + t * WAVE * 30) * 32, unpack_bits<27>(wd, lane) << 3, wc);
+        }
+        // S6: [a0..a13, w0, w1, r, sq]
+        for (int t = wave; t < 2 * TILES; t += WAVES) {
+            const int k = t * WAVE + lane;
+            const v4u *v = cv + ((size_t)9 * N + 2 * k) * 2;
+            slab_put16(wc.slab, 0, lane, v[0], v[1]);
+            slab_put16(wc.slab, 1, lane, v[2], v[3]);
+            const uint32_t wd = lane < 32 ? cb[4 * CL.seg_words + t * 32 + lane] : 0u;
+            emit_tile<18>(rw, (117 * N + t * WAVE * 18) * 32, unpack_bits<16>(wd, lane), wc);
+        }
+        // S7
+        if (wave == 0) {
+            const unsigned long long nm = (unsigned long long)cb[4 * CL.seg_words + N] |
+                                          ((unsigned long long)cb[4 * CL.seg_words + N + 1] << 32);
+            v4u *o = wit + (size_t)153 * N * 2;
+            for (int c = lane; c < NB * 2; c += WAVE) o[c] = (nm >> (c >> 1)) & 1ull ? one : mk4(0, 0, 0, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernel: stand-alone gadget blocks (the reference's gadget API called outside the full circuit, as its unit tests
 // do): one block of BLK field elements per item, 64 items per wavefront tile.
 //   G_LESS_THAN_Q   a:u64            -> ltq block, 27            range_proofs.rs:42-94
@@ -1241,6 +1404,7 @@ hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int n
 // Filled exactly once per process (std::call_once in init_launch_config, which every context creation calls before
 // any launch), read-only afterwards: contexts on several devices / threads share it safely.
 static int g_occ_verify[4], g_occ_dual[4], g_occ_ntt[4];       // resident workgroups per CU, [(LOGN-9)*2 + ENC]
+static int g_occ_compact[2], g_occ_expand[2];                  // [LOGN - 9]
 static std::once_flag g_occ_once;
 
 template <typename K>
@@ -1284,6 +1448,10 @@ void init_launch_config()
         FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 1);
         FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 1);
 #undef FRW_Q
+        query_residency(witness_ntt_verify_kernel<9, 2, false>, g_occ_compact[0]);
+        query_residency(witness_ntt_verify_kernel<10, 2, false>, g_occ_compact[1]);
+        query_residency(expand_kernel<9>, g_occ_expand[0]);
+        query_residency(expand_kernel<10>, g_occ_expand[1]);
     });
 }
 
@@ -1316,6 +1484,48 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queu
     else if (enc == 0) FRW_LAUNCH(10, 0);
     else FRW_LAUNCH(10, 1);
 #undef FRW_LAUNCH
+    return hipGetLastError();
+}
+
+void launch_shape_witness_ntt_verify(int num_cu, int logn, int enc, size_t batch, int out[4])
+{
+    const int occ = enc == 2 ? g_occ_compact[logn - 9] : g_occ_verify[(logn - 9) * 2 + (enc & 1)];
+    const size_t cap = (size_t)(occ > 0 ? occ : 2) * (size_t)num_cu;
+    const bool split = enc != 2 && batch * 5 <= cap;
+    out[0] = split ? (int)(batch * 5 < cap ? batch * 5 : cap) : resident_grid(batch, num_cu, occ);
+    out[1] = occ;
+    out[2] = num_cu;
+    out[3] = split ? 1 : 0;
+}
+
+hipError_t launch_witness_ntt_verify_compact(const Tables *tab, unsigned long long *queue, int num_cu, int logn, size_t batch,
+                                             const uint16_t *sig, const uint16_t *pk, const uint16_t *hm, void *compact,
+                                             int32_t *status, hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    if (!queue) return hipErrorOutOfMemory;
+    hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+    if (qe != hipSuccess) return qe;
+    const int grid = resident_grid(batch, num_cu, g_occ_compact[logn - 9]);
+    if (logn == 9)
+        hipLaunchKernelGGL((witness_ntt_verify_kernel<9, 2, false>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, batch, sig, pk,
+                           hm, (v4u *)compact, (v4u *)nullptr, status);
+    else
+        hipLaunchKernelGGL((witness_ntt_verify_kernel<10, 2, false>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, batch, sig, pk,
+                           hm, (v4u *)compact, (v4u *)nullptr, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand(int num_cu, int logn, size_t batch, const void *compact, uint64_t *wit, uint64_t *inst, hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    const int grid = resident_grid(batch, num_cu, g_occ_expand[logn - 9]);
+    if (logn == 9)
+        hipLaunchKernelGGL((expand_kernel<9>), dim3(grid), dim3(BLOCK), 0, st, batch, (const unsigned char *)compact, (v4u *)wit,
+                           (v4u *)inst);
+    else
+        hipLaunchKernelGGL((expand_kernel<10>), dim3(grid), dim3(BLOCK), 0, st, batch, (const unsigned char *)compact, (v4u *)wit,
+                           (v4u *)inst);
     return hipGetLastError();
 }
 

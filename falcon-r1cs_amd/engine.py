@@ -11,9 +11,9 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from ._lib import FrwError, LayoutDualStruct, LayoutStruct, check, load_library
+from ._lib import CompactLayoutStruct, FrwError, LayoutDualStruct, LayoutStruct, check, load_library
 
-ENC_CANONICAL, ENC_MONTGOMERY = 0, 1
+ENC_CANONICAL, ENC_MONTGOMERY, ENC_COMPACT = 0, 1, 2
 ST_OK, ST_COEFF_RANGE, ST_NORM_BOUND, ST_DECODE = 0, 1, 2, 3
 NONCE_LEN = 40
 PK_LEN = {9: 897, 10: 1793}
@@ -44,6 +44,28 @@ def layout_dual(logn) -> Layout:
     s = LayoutDualStruct()
     check(load_library().frw_layout_dual(int(logn), C.byref(s)), "frw_layout_dual")
     return Layout(s.logn, s.n, s.num_witness, s.num_instance, s.num_constraints, tuple(s.seg_off), tuple(s.seg_len))
+
+
+@dataclass(frozen=True)
+class CompactLayout:
+    logn: int
+    n: int
+    bytes_per_signature: int
+    values_off: int
+    num_values: int
+    bits_off: int
+    num_bit_words: int
+    bit_seg_off: tuple
+    instance_off: int
+    num_instance_values: int
+
+
+def compact_layout(logn) -> CompactLayout:
+    """Layout of FRW_ENC_COMPACT (frw_compact_layout): 13N Montgomery values + boolean bit array + 2N instance values."""
+    s = CompactLayoutStruct()
+    check(load_library().frw_compact_layout(int(logn), C.byref(s)), "frw_compact_layout")
+    return CompactLayout(s.logn, s.n, s.bytes_per_signature, s.values_off, s.num_values, s.bits_off, s.num_bit_words,
+                         tuple(s.bit_seg_off), s.instance_off, s.num_instance_values)
 
 
 def synth_triples(logn, batch, seed=0x46414C434F4E, first_index=0):
@@ -210,6 +232,23 @@ class WitnessEngine:
                                                    self._ptr(d_hm), encoding, self._ptr(d_wit), self._ptr(d_inst),
                                                    self._ptr(d_status), C.c_void_p(stream)),
               "frw_witness_ntt_verify_dev")
+
+    def witness_ntt_verify_compact_dev(self, logn, batch, d_sig, d_pk, d_hm, d_compact, d_status, stream=0):
+        """FRW_ENC_COMPACT producer: d_compact = batch x compact_layout(logn).bytes_per_signature bytes."""
+        check(self._lib.frw_witness_ntt_verify_compact_dev(self._ctx, logn, batch, self._ptr(d_sig), self._ptr(d_pk),
+                                                           self._ptr(d_hm), self._ptr(d_compact), self._ptr(d_status),
+                                                           C.c_void_p(stream)), "frw_witness_ntt_verify_compact_dev")
+
+    def expand_dev(self, logn, batch, d_compact, d_wit, d_inst, stream=0):
+        """compact -> the arkworks witness / instance buffers (FRW_ENC_MONTGOMERY bytes)."""
+        check(self._lib.frw_expand_dev(self._ctx, logn, batch, self._ptr(d_compact), self._ptr(d_wit), self._ptr(d_inst),
+                                       C.c_void_p(stream)), "frw_expand_dev")
+
+    def launch_shape(self, logn, batch, encoding=ENC_MONTGOMERY):
+        """{grid, resident workgroups per CU, CUs, split} of a witness launch of `batch` signatures."""
+        out = (C.c_int32 * 4)()
+        check(self._lib.frw_diag_launch_shape(self._ctx, logn, encoding, batch, C.byref(out)), "frw_diag_launch_shape")
+        return {"grid": out[0], "resident_per_cu": out[1], "cus": out[2], "split": bool(out[3])}
 
     def witness_dual_ntt_verify_dev(self, logn, batch, d_sig, d_pk, d_hm, d_wit, d_inst, d_status,
                                     encoding=ENC_MONTGOMERY, stream=0):

@@ -129,6 +129,37 @@ int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
 int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int encoding,
                  uint64_t *witness, uint16_t *ntt_out, int32_t *status);
 
+/* ---- compact device-side encoding (no counterpart in the reference; for GPU-side consumers and the multi-GPU gather) ----
+ * 140 N + nb of the W witness elements of falcon_ntt.rs:58-122 are booleans, i.e. 32-byte field elements that are 0 or
+ * the Montgomery form of 1.  FRW_ENC_COMPACT keeps, per signature (frw_compact_layout):
+ *   values    13 N x 32 bytes   the non-boolean witness elements, Montgomery form, in witness order:
+ *                               sig[N], v[N], then per NTT coefficient [t, b] of ntt_circuit(sig), [t, b] of ntt_circuit(v),
+ *                               [prod, t, c] of the pointwise add_mod, then [r, sq] of the 2N l2-norm elements
+ *   bits      uint32_t words    the boolean elements as a bit array in witness order (bit i of the array = bit i%32 of
+ *                               word i/32): enforce_less_than_q(v[i]) 27 N bits, then the 27-bit enforce_less_than_q
+ *                               blocks of the S3, S4, S5 segments (27 N each), the 16 booleans of every l2-norm element
+ *                               (32 N), and the norm-bound block (50 | 52 bits, in two words of their own)
+ *   instance  2 N x 32 bytes    pk_ntt, hm_ntt (the leading constant one is implied)
+ * = 509,568 bytes per Falcon-1024 signature instead of 5,080,736.  frw_expand_dev rebuilds, bit for bit, the buffers
+ * frw_witness_ntt_verify_dev(..., FRW_ENC_MONTGOMERY, ...) writes.  A signature with FRW_ST_COEFF_RANGE is all zeros. */
+#define FRW_ENC_COMPACT     2
+typedef struct frw_compact_layout {
+    int32_t logn, n;
+    uint64_t bytes_per_signature;     /* stride of the compact buffer, a multiple of 128 */
+    uint64_t values_off, num_values;  /* byte offset (0) and number of 32-byte values (13 N) */
+    uint64_t bits_off, num_bit_words; /* byte offset and number of uint32_t words of the bit array */
+    uint64_t bit_seg_off[6];          /* first bit of S2, S3, S4, S5, S6, S7 booleans inside the bit array */
+    uint64_t instance_off, num_instance_values;
+} frw_compact_layout_t;
+int frw_compact_layout(int logn, frw_compact_layout_t *out);
+/* d_compact: batch x bytes_per_signature bytes, 16-byte aligned.  Same statuses as frw_witness_ntt_verify_dev. */
+int frw_witness_ntt_verify_compact_dev(frw_ctx *ctx, int logn, size_t batch,
+                                       const uint16_t *d_sig, const uint16_t *d_pk, const uint16_t *d_hm,
+                                       void *d_compact, int32_t *d_status, void *stream);
+/* compact -> witness uint64_t[batch][W][4], instance uint64_t[batch][I][4] (FRW_ENC_MONTGOMERY bytes) */
+int frw_expand_dev(frw_ctx *ctx, int logn, size_t batch, const void *d_compact,
+                   uint64_t *d_witness, uint64_t *d_instance, void *stream);
+
 /* ---- the signed-split variant: FalconDualNTTVerificationCircuit (circuits/falcon_dual_ntt.rs:26-132) -----------
  * Same statement, signature and v split into non-negative (pos, neg) parts (gadgets/dual_poly.rs:15-31), four
  * ntt_circuits, two mod_q per NTT coefficient, squares without range checks (gadgets/misc.rs:55-65).
@@ -244,6 +275,10 @@ int frw_gadget(frw_ctx *ctx, int kind, size_t count, const void *a, const uint64
  * Lets a host compare whole HBM-resident witness batches without copying them back. */
 int frw_digest_dev(frw_ctx *ctx, const uint64_t *d_buf, size_t words_per_item, size_t items,
                    uint64_t *d_out, void *stream);
+
+/* What a witness launch of `batch` signatures looks like on this device: out = {workgroups launched, resident
+ * workgroups per CU the grid was sized for, CUs, 1 if a signature is split into five work items (small batches)}. */
+int frw_diag_launch_shape(frw_ctx *ctx, int logn, int encoding, size_t batch, int32_t out[4]);
 
 /* Roofline calibration: overwrites d_buf[0, bytes) with a compute-free write stream of the witness kernel's store
  * shape (workgroup-contiguous slabs of slab_bytes, 16 B per lane).  Timed by bench.py on the same device and

@@ -42,13 +42,18 @@ class Oracle:
         assert self.lib.frw_oracle_layout(logn, C.byref(L)) == 0
         return L
 
-    def witness_ntt_verify(self, logn, sig, pk, hm, encoding=1, threads=1):
+    def witness_ntt_verify(self, logn, sig, pk, hm, encoding=1, threads=1, out=None):
+        """out = (wit, inst, st) reuses caller-owned (already touched) buffers of at least the batch size; slots of
+        rejected signatures are then left as they were."""
         L = self.layout(logn)
         sig, pk, hm = (np.ascontiguousarray(a, dtype=np.uint16).reshape(-1, L.n) for a in (sig, pk, hm))
         batch = sig.shape[0]
-        wit = np.zeros((batch, L.num_witness, 4), dtype=np.uint64)
-        inst = np.zeros((batch, L.num_instance, 4), dtype=np.uint64)
-        st = np.zeros(batch, dtype=np.int32)
+        if out is not None:
+            wit, inst, st = (a[:batch] for a in out)
+        else:
+            wit = np.zeros((batch, L.num_witness, 4), dtype=np.uint64)
+            inst = np.zeros((batch, L.num_instance, 4), dtype=np.uint64)
+            st = np.zeros(batch, dtype=np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         rc = self.lib.frw_oracle_witness_ntt_verify(logn, batch, p(sig), p(pk), p(hm), encoding, p(wit), p(inst),
                                                     p(st), threads)
@@ -127,3 +132,39 @@ def centred_norm(*polys):
         x = np.where(x < 6144, x, Q - x)
         tot += int((x * x).sum())
     return tot
+
+
+def compact_from_witness(logn, wit, inst, CL):
+    """FRW_ENC_COMPACT restated as a re-layout of one arkworks witness/instance pair (uint64 [W,4] / [I,4], Montgomery):
+    the non-boolean elements in witness order, the boolean elements as a bit array in witness order, the instance
+    values without the leading one (include/frw.h).  CL = falcon_r1cs_amd.compact_layout(logn).  Returns bytes."""
+    n = 1 << logn
+    nb = 50 if logn == 9 else 52
+    off = np.cumsum([0, n, n, 27 * n, 29 * n, 29 * n, 30 * n, 36 * n])
+    S2, S3, S4, S5, S6, S7 = (int(off[i]) for i in (2, 3, 4, 5, 6, 7))
+    k = np.arange(n)
+    k2 = np.arange(2 * n)
+    vals = np.concatenate([
+        np.arange(0, 2 * n),
+        (S3 + 29 * k[:, None] + np.arange(2)).ravel(),
+        (S4 + 29 * k[:, None] + np.arange(2)).ravel(),
+        (S5 + 30 * k[:, None] + np.arange(3)).ravel(),
+        (S6 + 18 * k2[:, None] + 16 + np.arange(2)).ravel()])
+    bools = np.concatenate([
+        np.arange(S2, S2 + 27 * n),
+        (S3 + 29 * k[:, None] + 2 + np.arange(27)).ravel(),
+        (S4 + 29 * k[:, None] + 2 + np.arange(27)).ravel(),
+        (S5 + 30 * k[:, None] + 3 + np.arange(27)).ravel(),
+        (S6 + 18 * k2[:, None] + np.arange(16)).ravel()])
+    assert len(vals) == CL.num_values and len(bools) == 140 * n
+    out = np.zeros(CL.bytes_per_signature, dtype=np.uint8)
+    out[: CL.num_values * 32] = np.ascontiguousarray(wit[vals]).view(np.uint8).ravel()
+    bits = (wit[bools] != 0).any(axis=1)
+    words = np.packbits(bits.astype(np.uint8), bitorder="little").view(np.uint32)
+    tail = (wit[S7:S7 + nb] != 0).any(axis=1)
+    tail = np.packbits(np.concatenate([tail, np.zeros(64 - nb, dtype=bool)]).astype(np.uint8), bitorder="little").view(np.uint32)
+    allw = np.concatenate([words, tail])
+    assert len(allw) == CL.num_bit_words
+    out[CL.bits_off: CL.bits_off + 4 * len(allw)] = allw.view(np.uint8)
+    out[CL.instance_off: CL.instance_off + 2 * n * 32] = np.ascontiguousarray(inst[1:]).view(np.uint8).ravel()
+    return out.tobytes()

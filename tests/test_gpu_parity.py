@@ -705,3 +705,89 @@ def test_rejected_signatures_scattered_through_a_large_batch(engine, oracle, log
         assert dig[lo:lo + step] == want
         assert all(want[j] == zero_digest for j in np.nonzero(bad[sl])[0])
         assert np.array_equal(inst[sl].cpu().numpy().view(np.uint64), oinst)
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_compact_encoding_matches_relayout_of_oracle_witness(engine, oracle, logn):
+    """FRW_ENC_COMPACT straight from the kernel == the oracle's arkworks witness re-laid out on the host (values in
+    witness order, booleans as a bit array, instance without the leading one), byte for byte; a rejected signature is
+    all zeros; and frw_expand_dev turns the compact buffer back into exactly the oracle's witness / instance bytes."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    CL, L = frw.compact_layout(logn), frw.layout(logn)
+    batch = 9
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=0xC0 + logn)
+    big = T.random_triple(logn, random.Random(12), scale=1.6)            # norm above the bound: truncated bits, status 2
+    sig[4], pk[4], hm[4] = big[0], big[1], big[2]
+    sig[7, 5] = T.Q                                                       # rejected
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    comp = torch.full((batch, CL.bytes_per_signature), 0x5A, dtype=torch.uint8, device=dev)
+    st = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    engine.witness_ntt_verify_compact_dev(logn, batch, d[0], d[1], d[2], comp, st, s0)
+    engine.expand_dev(logn, batch, comp, wit, inst, s0)
+    torch.cuda.synchronize()
+    owit, oinst, ost = oracle.witness_ntt_verify(logn, sig, pk, hm, 1)
+    assert st.cpu().numpy().tolist() == ost.tolist() == [0, 0, 0, 0, 2, 0, 0, 1, 0]
+    got = comp.cpu().numpy()
+    used = CL.instance_off + CL.num_instance_values * 32
+    for i in range(batch):
+        if ost[i] == 1:
+            assert not got[i].any()
+            continue
+        want = np.frombuffer(T.compact_from_witness(logn, owit[i], oinst[i], CL), dtype=np.uint8)
+        bits_end = CL.bits_off + 4 * CL.num_bit_words                 # then alignment padding up to instance_off
+        assert np.array_equal(got[i, :bits_end], want[:bits_end]), i
+        assert np.array_equal(got[i, CL.instance_off:used], want[CL.instance_off:used]), i
+        assert np.array_equal(wit[i].cpu().numpy().view(np.uint64), owit[i]), i
+        assert np.array_equal(inst[i].cpu().numpy().view(np.uint64), oinst[i]), i
+
+
+def test_expand_of_compact_equals_direct_output_full_launch(engine):
+    """expand(compact(x)) == the FRW_ENC_MONTGOMERY launch, digest by digest, for a full 4,096-signature Falcon-1024
+    launch and a 2,048-signature Falcon-512 one (plus the committed golden fixtures through the compact path)."""
+    import glob
+    import hashlib
+    import json
+    import os
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    s0 = torch.cuda.current_stream().cuda_stream
+    for logn, batch in ((10, 4096), (9, 2048)):
+        CL, L = frw.compact_layout(logn), frw.layout(logn)
+        sig, pk, hm = frw.synth_triples(logn, batch, seed=0xE0 + logn)
+        wit, inst, st, dig = _launch_and_digest(engine, logn, sig, pk, hm)
+        d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+        comp = torch.empty((batch, CL.bytes_per_signature), dtype=torch.uint8, device=dev)
+        st2 = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        wit2 = torch.full_like(wit, 0x33)
+        inst2 = torch.full_like(inst, 0x33)
+        dig2 = torch.zeros(batch, dtype=torch.int64, device=dev)
+        engine.witness_ntt_verify_compact_dev(logn, batch, d[0], d[1], d[2], comp, st2, s0)
+        engine.expand_dev(logn, batch, comp, wit2, inst2, s0)
+        engine.digest_dev(wit2, L.num_witness * 4, batch, dig2, s0)
+        torch.cuda.synchronize()
+        assert int((st2 != 0).sum()) == 0
+        assert [int(x) for x in dig2.cpu().numpy().view(np.uint64)] == dig
+        assert torch.equal(inst, inst2)
+        assert torch.equal(wit[::257], wit2[::257])
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for path in sorted(glob.glob(os.path.join(gold, "witness_*.json"))):
+        fx = json.load(open(path))
+        logn = fx["logn"]
+        CL, L = frw.compact_layout(logn), frw.layout(logn)
+        arrs = [np.frombuffer(bytes.fromhex(fx[k]), dtype=np.uint16).reshape(1, -1) for k in ("sig", "pk", "hm")]
+        d = [torch.from_numpy(a.view(np.int16).copy()).to(dev) for a in arrs]
+        comp = torch.empty((1, CL.bytes_per_signature), dtype=torch.uint8, device=dev)
+        st = torch.zeros(1, dtype=torch.int32, device=dev)
+        wit = torch.empty((1, L.num_witness, 4), dtype=torch.int64, device=dev)
+        inst = torch.empty((1, L.num_instance, 4), dtype=torch.int64, device=dev)
+        engine.witness_ntt_verify_compact_dev(logn, 1, d[0], d[1], d[2], comp, st, s0)
+        engine.expand_dev(logn, 1, comp, wit, inst, s0)
+        torch.cuda.synchronize()
+        assert hashlib.sha256(wit.cpu().numpy().tobytes()).hexdigest() == fx["witness_sha256"]["montgomery"]
+        assert hashlib.sha256(inst.cpu().numpy().tobytes()).hexdigest() == fx["instance_sha256"]["montgomery"]

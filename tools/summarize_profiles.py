@@ -11,6 +11,7 @@ the read side here is 0.1 % of the traffic, so the uncertainty does not matter).
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -46,6 +47,8 @@ def main():
     stats = [r for r in csv.DictReader(open(find(trace, "_kernel_stats.csv"))) if kern in r["Name"]][0]
     summary = {
         "kernel": kern + ("" if kern.endswith(">") else ", ...>"), "logn": logn, "signatures_per_launch": chunk,
+        # bench.py only quotes this summary while the kernel source is the one that was profiled
+        "kernel_source_sha256_16": hashlib.sha256(open(os.path.join(ROOT, "falcon-r1cs_amd", "csrc", "frw_kernels.hip"), "rb").read()).hexdigest()[:16],
         "avg_launch_ns": float(stats["AverageNs"]), "calls": int(stats["Calls"]),
         "WRITE_SIZE_KiB_avg": w, "WRITE_SIZE_launches": nw, "FETCH_SIZE_KiB_avg_raw": f, "FETCH_SIZE_launches": nf,
         "write_bytes_per_launch": w * 1024, "read_bytes_per_launch": f * 1024 * 2,
