@@ -122,11 +122,11 @@ def cpu_baseline(logn, sig, pk, hm, sample_idx, gpu_digest_of, budget_s=9.0):
         if t_all > budget_s:
             break
     return {"value": round(nall / t_all, 1), "unit": "signatures/s", "cores": nproc, "kind": "port",
-            "sample": "%d Falcon-%d signatures, a strided sample of the last timed launch, %d threads on %d host cores "
+            "sample": "%d Falcon-%d signatures, a strided sample of the buffer the timed launches left, %d threads on %d host cores "
                       "(oracle/frw_oracle.c, a C restatement; the Rust reference cannot be built here); output buffers "
                       "pre-touched and reused" % (nall, 1 << logn, nproc, nproc),
             "nproc": nproc, "threads": nproc, "single_thread": round(n1 / t1, 1), "single_thread_sample": n1,
-            "gpu_witnesses_checked_by_digest": checked, "checked_witnesses_are_from": "the last timed launch"}
+            "gpu_witnesses_checked_by_digest": checked, "checked_witnesses_are_from": "the buffer the timed launches left"}
 
 
 def time_ntt_modq(eng, dev, logn, batch, launches, warm):
@@ -385,9 +385,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="signatures per GPU per step (default: 65,536 = BASELINE configs[2]; with --gpus 8: 131,072 = "
                          "configs[3], 1 M signatures over the node)")
-    ap.add_argument("--chunk", type=int, default=16384,
-                    help="signatures per kernel launch = size of the reused HBM witness buffer (16,384 Falcon-1024 "
-                         "witnesses = 82 GB of the 288 GB; tools/time_chunk_sizes.py)")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="signatures per kernel launch = size of the reused HBM witness buffer.  Default: 21 rounds of the "
+                         "resident grid (21 x 768 = 16,128 Falcon-1024 witnesses = 81 GB of the 288 GB): launches that are "
+                         "an exact multiple of the grid run fastest (profiles/r02_scheduling_ab.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-r1cs-check", action="store_true",
                     help="skip the untimed on-device check that every witness of the last timed launch satisfies the "
@@ -450,10 +451,11 @@ def main():
         return bench_prepare(args, world, rank, dev)
     logn = args.logn
     batch = args.batch or (131072 if world == 8 else 65536)
-    chunk = min(args.chunk, batch)
     dual = args.circuit == "dual"
     L = frw.layout_dual(logn) if dual else frw.layout(logn)
     eng = frw.WitnessEngine(dev_index)
+    resident_grid = eng.launch_shape(logn, 1 << 24)["grid"]
+    chunk = min(args.chunk or (16384 if logn == 10 else 32768) // resident_grid * resident_grid, batch)   # 21 x 768 = 16,128
     launch = eng.witness_dual_ntt_verify_dev if dual else eng.witness_ntt_verify_dev
     threads = max(1, (os.cpu_count() or 1) // world)
 
@@ -502,34 +504,44 @@ def main():
     assert n_bad == 0, "%d of the synthetic signatures failed their range checks: the throughput would not be that of " \
                        "valid witnesses" % n_bad
 
-    # ---- what the LAST timed launch left in HBM: digest all of it, check all of it (untimed) -------------------------
-    last_a = (nchunks - 1) * chunk                       # rank-local index of the first signature in the buffer
+    # ---- what the timed launches left in HBM: digest all of it, check all of it (untimed) ----------------------------
+    # The buffer is reused by every launch of a step, so after the timed region slots [0, last_cnt) hold the witnesses of
+    # the LAST timed launch and, when that one was the step's ragged remainder, slots [last_cnt, chunk) still hold what
+    # the launch before it (a full-size one) wrote.  slot_sig = rank-local signature index behind every slot.
+    last_a = (nchunks - 1) * chunk
     last_cnt = batch - last_a
-    d_dig = torch.zeros(last_cnt, dtype=torch.int64, device=dev)
-    eng.digest_dev(d_wit, L.num_witness * 4, last_cnt, d_dig, stream.cuda_stream)
+    held = chunk if nchunks >= 2 else last_cnt
+    slot_sig = np.arange(held, dtype=np.int64) + last_a
+    if held > last_cnt:
+        slot_sig[last_cnt:] = np.arange(last_cnt, held) + (nchunks - 2) * chunk
+    d_dig = torch.zeros(held, dtype=torch.int64, device=dev)
+    eng.digest_dev(d_wit, L.num_witness * 4, held, d_dig, stream.cuda_stream)
     torch.cuda.synchronize()
-    last_dig = d_dig.cpu().numpy().view(np.uint64)
-    shape = eng.launch_shape(logn, last_cnt) if not dual else {}
-    checked = {"signatures": last_cnt, "is_the_last_timed_launch": True, "distinct_digests": int(len(np.unique(last_dig)))}
-    if shape:
-        checked.update(grid=shape["grid"], resident_workgroups_per_cu=shape["resident_per_cu"],
-                       rounds=round(last_cnt / max(1, shape["grid"]), 2), split=shape["split"])
+    held_dig = d_dig.cpu().numpy().view(np.uint64)
+    checked = {"signatures": held, "from_the_last_timed_launch": last_cnt,
+               "from_the_full_size_launch_before_it": held - last_cnt, "distinct_digests": int(len(np.unique(held_dig)))}
+    if not dual:
+        for name, cnt in (("full_size_launch", chunk), ("remainder_launch", last_cnt if last_cnt != chunk else 0)):
+            if cnt:
+                sh = eng.launch_shape(logn, cnt)
+                checked[name] = {"signatures": cnt, "grid": sh["grid"], "resident_workgroups_per_cu": sh["resident_per_cu"],
+                                 "rounds": round(cnt / max(1, sh["grid"]), 2), "split_signatures": sh["split_signatures"]}
     r1cs = None
     if not args.no_r1cs_check:
-        # the reference's assert!(cs.is_satisfied()) (falcon_ntt.rs:159) for every signature of that launch, on the
-        # device, in place, against matrices emitted from the gadget definitions by the host mirror (not the closed form)
+        # the reference's assert!(cs.is_satisfied()) (falcon_ntt.rs:159) for every witness in the buffer, on the device,
+        # in place, against matrices emitted from the gadget definitions by the host mirror (not the kernels' closed form)
         h = eng.r1cs_load(1 if dual else 0, logn)
-        badrows = torch.zeros(last_cnt, dtype=torch.int32, device=dev)
+        badrows = torch.zeros(held, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         tc = time.perf_counter()
-        eng.r1cs_check_dev(h, last_cnt, d_wit, d_inst, badrows, stream.cuda_stream)
+        eng.r1cs_check_dev(h, held, d_wit, d_inst, badrows, stream.cuda_stream)
         torch.cuda.synchronize()
         tc = time.perf_counter() - tc
         eng.r1cs_free(h)
         n_unsat = sharding.sum_over_ranks(int((badrows != 0).sum().item()), cdev)
-        assert n_unsat == 0, "%d witnesses of the last timed launch violate the constraint system" % n_unsat
-        r1cs = {"witnesses_checked": last_cnt * world, "per_rank": last_cnt, "unsatisfied": n_unsat,
-                "constraints_each": L.num_constraints, "seconds": round(tc, 3), "buffer": "as left by the last timed launch"}
+        assert n_unsat == 0, "%d witnesses left by the timed launches violate the constraint system" % n_unsat
+        r1cs = {"witnesses_checked": held * world, "per_rank": held, "unsatisfied": n_unsat,
+                "constraints_each": L.num_constraints, "seconds": round(tc, 3), "buffer": "as left by the timed launches"}
 
     # ---- roofline of the dominant kernel, from HIP events on the launch stream ------------------
     full = [(e0.elapsed_time(e1), cnt) for e0, e1, cnt in events if cnt == chunk]
@@ -623,9 +635,9 @@ def main():
                 "ntt_modq_falcon512_batch4096": time_ntt_modq(eng, dev, 9, 4096, 200, 20),
                 "verify_falcon512_8192_per_launch": time_verify(eng, dev, 9, 8192, 12, 3, threads)}
         if world == 1 and not args.no_cpu_baseline and not dual:
-            stride = max(1, last_cnt // 4096)
-            sample = np.arange(0, last_cnt, stride)[:4096] + last_a
-            result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, sample, lambda i: int(last_dig[i - last_a]))
+            slots = np.arange(0, held, max(1, held // 4096))[:4096]        # strided over the whole buffer
+            digest_of = {int(slot_sig[j]): int(held_dig[j]) for j in slots}
+            result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, slot_sig[slots], lambda i: digest_of[int(i)])
         emit(result)
     if use_pg:
         dist.destroy_process_group()

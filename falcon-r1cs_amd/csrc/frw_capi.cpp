@@ -7,7 +7,6 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
-#include <mutex>
 #include <new>
 #include <vector>
 
@@ -18,18 +17,6 @@ struct frw_ctx {
     int device;
     int num_cu;
     frw::Tables *d_tables;
-    // Work-queue heads (one 128-byte line each), all allocated with the context -- a launch never allocates.
-    // Slots [0, QUEUE_SLOTS): one per stream the context launches on, recycled least-recently-used; every launch first
-    // makes its stream wait for the event of the slot's previous launch, so a slot that changes hands (eviction, or a
-    // destroyed stream whose handle value comes back) is never reset while its last kernel is still draining.
-    // Slots [QUEUE_SLOTS, QUEUE_SLOTS + CAPTURE_SLOTS): one per launch recorded into a stream capture, never reused
-    // (a captured launch may be replayed on any stream at any time); exhausted -> FRW_E_OUT_OF_MEMORY.
-    unsigned long long *queue_heads;
-    struct StreamSlot { hipStream_t stream; hipEvent_t last; unsigned long long used; bool live; };
-    StreamSlot slots[frw::QUEUE_SLOTS];
-    unsigned long long use_clock;
-    int capture_used;
-    std::mutex queue_mu;
     hipStream_t host_compute, host_copy;                            // streams of the host-buffer entry points
 };
 
@@ -82,40 +69,6 @@ void build_tables(frw::Tables &t)
         }
         memcpy(t.ck[k], c, sizeof c);
     }
-}
-
-// The work-queue head for one launch on `stream`; *slot_out >= 0 names the stream slot whose event queue_launched
-// must record after the launch.  nullptr when the capture pool is exhausted.
-unsigned long long *queue_for(frw_ctx *ctx, hipStream_t stream, int *slot_out)
-{
-    std::lock_guard<std::mutex> lock(ctx->queue_mu);
-    *slot_out = -1;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
-        if (ctx->capture_used >= frw::CAPTURE_SLOTS) return nullptr;
-        return ctx->queue_heads + (size_t)(frw::QUEUE_SLOTS + ctx->capture_used++) * 16;
-    }
-    int pick = -1;
-    for (int i = 0; i < frw::QUEUE_SLOTS; i++)
-        if (ctx->slots[i].live && ctx->slots[i].stream == stream) { pick = i; break; }
-    if (pick < 0) {
-        for (int i = 0; i < frw::QUEUE_SLOTS; i++) {
-            if (!ctx->slots[i].live) { pick = i; break; }
-            if (pick < 0 || ctx->slots[i].used < ctx->slots[pick].used) pick = i;      // least recently used
-        }
-        ctx->slots[pick].stream = stream;
-    }
-    frw_ctx::StreamSlot &sl = ctx->slots[pick];
-    if (sl.live) (void)hipStreamWaitEvent(stream, sl.last, 0);    // no-op for the stream that recorded it
-    sl.live = true;
-    sl.used = ++ctx->use_clock;
-    *slot_out = pick;
-    return ctx->queue_heads + (size_t)pick * 16;
-}
-
-void queue_launched(frw_ctx *ctx, hipStream_t stream, int slot)
-{
-    if (slot >= 0) (void)hipEventRecord(ctx->slots[slot].last, stream);
 }
 
 bool bad_common(const frw_ctx *ctx, int logn, int encoding)
@@ -185,10 +138,6 @@ int frw_ctx_create(int device, frw_ctx **out)
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
     ctx->d_tables = nullptr;
-    ctx->queue_heads = nullptr;
-    ctx->use_clock = 0;
-    ctx->capture_used = 0;
-    for (auto &sl : ctx->slots) sl = {nullptr, nullptr, 0, false};
     ctx->host_compute = ctx->host_copy = nullptr;
     frw::Tables host;
     build_tables(host);
@@ -196,17 +145,12 @@ int frw_ctx_create(int device, frw_ctx **out)
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tables, &host, sizeof host, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->host_compute, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->host_copy, hipStreamNonBlocking);
-    const size_t heads = (size_t)(frw::QUEUE_SLOTS + frw::CAPTURE_SLOTS) * 16 * sizeof(unsigned long long);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->queue_heads, heads);
-    if (e == hipSuccess) e = hipMemset(ctx->queue_heads, 0, heads);
-    for (auto &sl : ctx->slots)
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.last, hipEventDisableTiming);
     if (e != hipSuccess) {
         frw_ctx_destroy(ctx);
         return hip_fail(e, "context setup");
     }
-    // everything a launch needs is set up now (residency of the persistent kernels, every queue head), so the _dev
-    // entry points never allocate or query and are stream-capture safe
+    // everything a launch needs is known now (residency of the persistent kernels): the _dev entry points are one
+    // kernel launch each -- no allocation, no query, no per-launch device state -- and therefore stream-capture safe
     frw::init_launch_config();
     *out = ctx;
     return FRW_OK;
@@ -217,9 +161,6 @@ void frw_ctx_destroy(frw_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
-    if (ctx->queue_heads) (void)hipFree(ctx->queue_heads);
-    for (auto &sl : ctx->slots)
-        if (sl.last) (void)hipEventDestroy(sl.last);
     if (ctx->host_compute) (void)hipStreamDestroy(ctx->host_compute);
     if (ctx->host_copy) (void)hipStreamDestroy(ctx->host_copy);
     delete ctx;
@@ -233,12 +174,8 @@ int frw_witness_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const uint1
     if (batch == 0) return FRW_OK;
     if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    int slot;
-    unsigned long long *q = queue_for(ctx, (hipStream_t)stream, &slot);
-    if (!q) return FRW_E_OUT_OF_MEMORY;
-    FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, q, ctx->num_cu, logn, encoding, batch, d_sig, d_pk, d_hm,
+    FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, batch, d_sig, d_pk, d_hm,
                                            d_witness, d_instance, d_status, (hipStream_t)stream));
-    queue_launched(ctx, (hipStream_t)stream, slot);
     return FRW_OK;
 }
 
@@ -249,12 +186,8 @@ int frw_ntt_modq_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_pol
     if (batch == 0) return FRW_OK;
     if (!d_poly || !d_witness || !d_ntt_out || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    int slot;
-    unsigned long long *q = queue_for(ctx, (hipStream_t)stream, &slot);
-    if (!q) return FRW_E_OUT_OF_MEMORY;
-    FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, q, ctx->num_cu, logn, encoding, batch, d_poly, d_witness, d_ntt_out,
+    FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, ctx->num_cu, logn, encoding, batch, d_poly, d_witness, d_ntt_out,
                                  d_status, (hipStream_t)stream));
-    queue_launched(ctx, (hipStream_t)stream, slot);
     return FRW_OK;
 }
 
@@ -308,20 +241,16 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
         if (k >= 2) FRW_HIP(hipStreamWaitEvent(compute.s, drained[b].e, 0));      // buffer b has been copied out
         for (int j = 0; j < 3; j++)
             FRW_HIP(hipMemcpyAsync(d_in[b][j].p, src[j] + lo * n, cnt * n * 2, hipMemcpyHostToDevice, compute.s));
-        int slot;
-        unsigned long long *q = queue_for(ctx, compute.s, &slot);
-        if (!q) return FRW_E_OUT_OF_MEMORY;
         if (dual)
-            FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, q, ctx->num_cu, logn, encoding, cnt,
+            FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, cnt,
                                                         (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
                                                         (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
                                                         (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
         else
-            FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, q, ctx->num_cu, logn, encoding, cnt,
+            FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, cnt,
                                                    (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
                                                    (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
                                                    (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
-        queue_launched(ctx, compute.s, slot);
         FRW_HIP(hipEventRecord(done[b].e, compute.s));
         FRW_HIP(hipStreamWaitEvent(copy.s, done[b].e, 0));
         FRW_HIP(hipMemcpyAsync(status + lo, d_st[b].p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, copy.s));
@@ -359,12 +288,8 @@ int frw_witness_dual_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const 
     if (batch == 0) return FRW_OK;
     if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    int slot;
-    unsigned long long *q = queue_for(ctx, (hipStream_t)stream, &slot);
-    if (!q) return FRW_E_OUT_OF_MEMORY;
-    FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, q, ctx->num_cu, logn, encoding, batch, d_sig,
+    FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, batch, d_sig,
                                                 d_pk, d_hm, d_witness, d_instance, d_status, (hipStream_t)stream));
-    queue_launched(ctx, (hipStream_t)stream, slot);
     return FRW_OK;
 }
 
@@ -394,12 +319,8 @@ int frw_witness_ntt_verify_compact_dev(frw_ctx *ctx, int logn, size_t batch, con
     if (batch == 0) return FRW_OK;
     if (!d_sig || !d_pk || !d_hm || !d_compact || !d_status || ((uintptr_t)d_compact & 15)) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
-    int slot;
-    unsigned long long *q = queue_for(ctx, (hipStream_t)stream, &slot);
-    if (!q) return FRW_E_OUT_OF_MEMORY;
-    FRW_HIP(frw::launch_witness_ntt_verify_compact(ctx->d_tables, q, ctx->num_cu, logn, batch, d_sig, d_pk, d_hm, d_compact,
+    FRW_HIP(frw::launch_witness_ntt_verify_compact(ctx->d_tables, ctx->num_cu, logn, batch, d_sig, d_pk, d_hm, d_compact,
                                                    d_status, (hipStream_t)stream));
-    queue_launched(ctx, (hipStream_t)stream, slot);
     return FRW_OK;
 }
 
@@ -470,12 +391,8 @@ int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int
         const int b = (int)(k & 1);
         if (k >= 2) FRW_HIP(hipStreamWaitEvent(compute, drained[b].e, 0));
         FRW_HIP(hipMemcpyAsync(d_in[b].p, poly + lo * n, cnt * n * 2, hipMemcpyHostToDevice, compute));
-        int slot;
-        unsigned long long *q = queue_for(ctx, compute, &slot);
-        if (!q) return FRW_E_OUT_OF_MEMORY;
-        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, q, ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in[b].p,
+        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in[b].p,
                                      (uint64_t *)d_wit[b].p, (uint16_t *)d_out[b].p, (int32_t *)d_st[b].p, compute));
-        queue_launched(ctx, compute, slot);
         FRW_HIP(hipEventRecord(done[b].e, compute));
         FRW_HIP(hipStreamWaitEvent(copy, done[b].e, 0));
         FRW_HIP(hipMemcpyAsync(status + lo, d_st[b].p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, copy));

@@ -11,9 +11,6 @@ constexpr int WAVE = 64;               // CDNA wavefront
 constexpr int BLOCK = 256;             // one workgroup = 4 wavefronts = one signature
 constexpr int WAVES = BLOCK / WAVE;
 
-constexpr int QUEUE_SLOTS = 64;        // work-queue heads per context for ordinary launches: one per stream, recycled LRU
-constexpr int CAPTURE_SLOTS = 448;     // heads for launches recorded into stream captures (one each, never reused)
-
 constexpr int ST_OK = 0, ST_COEFF_RANGE = 1, ST_NORM_BOUND = 2, ST_DECODE = 3;    // == FRW_ST_* of include/frw.h
 
 // stand-alone gadget kinds == FRW_G_* of include/frw.h
@@ -49,19 +46,19 @@ constexpr CompactLayout compact_layout(int logn)
 }
 
 void init_launch_config();
-hipError_t launch_witness_ntt_verify_compact(const Tables *tab, unsigned long long *queue, int num_cu, int logn, size_t batch,
+hipError_t launch_witness_ntt_verify_compact(const Tables *tab, int num_cu, int logn, size_t batch,
                                              const uint16_t *sig, const uint16_t *pk, const uint16_t *hm, void *compact,
                                              int32_t *status, hipStream_t st);
 hipError_t launch_expand(int num_cu, int logn, size_t batch, const void *compact, uint64_t *wit, uint64_t *inst, hipStream_t st);
 // grid / resident workgroups per CU / split flag the witness launcher would use for `batch` (diagnostics for bench.py)
 void launch_shape_witness_ntt_verify(int num_cu, int logn, int enc, size_t batch, int out[4]);
-hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch,
+hipError_t launch_witness_ntt_verify(const Tables *tab, int num_cu, int logn, int enc, size_t batch,
                                      const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st);
-hipError_t launch_witness_dual_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc,
+hipError_t launch_witness_dual_ntt_verify(const Tables *tab, int num_cu, int logn, int enc,
                                           size_t batch, const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                           uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st);
-hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
+hipError_t launch_ntt_modq(const Tables *tab, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
                            uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st);
 hipError_t launch_gadget(int kind, int enc, size_t count, const void *a, const uint64_t *b, uint64_t *out,
                          int32_t *status, hipStream_t st);

@@ -100,7 +100,11 @@ __device__ __forceinline__ void cond_sub_p(uint32_t (&T)[9], uint32_t (&out)[8])
 template <int ENC>
 __device__ __forceinline__ void encode_u32(uint32_t x, uint32_t (&out)[8])
 {
+#if defined(FRW_FAKE_ENCODE)      // timing experiments only (tools/ab_variants.py): what would cheaper encodes buy?
+    if (true) {
+#else
     if (ENC == 0) {
+#endif
         out[0] = x;
 #pragma unroll
         for (int j = 1; j < 8; j++) out[j] = 0;
@@ -116,7 +120,11 @@ __device__ __forceinline__ void encode_u32(uint32_t x, uint32_t (&out)[8])
 template <int ENC>
 __device__ __forceinline__ void encode_u160(const uint32_t (&x)[5], uint32_t (&out)[8])
 {
+#if defined(FRW_FAKE_ENCODE)
+    if (true) {
+#else
     if (ENC == 0) {
+#endif
 #pragma unroll
         for (int j = 0; j < 5; j++) out[j] = x[j];
         out[5] = out[6] = out[7] = 0;
@@ -598,40 +606,17 @@ __device__ __forceinline__ void emit_tile_generic(v4u *__restrict__ out, const v
 }
 
 // ------------------------------------------------------------------------------------------------
-// work distribution.  A launch is a persistent grid; which workgroup takes which signature is decided at run time
-// from one 64-bit queue head per launch (zeroed by a memset node in front of the launch): a workgroup's first
-// item is its blockIdx, later ones are gridDim.x + atomicAdd(head, 1).  Workgroups that get less HBM bandwidth
-// (placement, neighbours) simply take fewer signatures, and the tail of a launch drains at full chip bandwidth
-// instead of waiting for the slowest static stripe.  Measured (tools/ab_variants.py, one process, interleaved):
-// +1.4...2.5 % at N=1024, -2.4 % at N=512 (smaller items, 3 workgroups/CU), so the queue is used for LOGN=10 only.
-// FRW_DYNAMIC_SCHED=0 / =2 force static / dynamic for both parameter sets in A/B builds.
+// work distribution.  A launch is a persistent grid (the resident workgroups) with STATIC striding: workgroup b takes
+// signatures b, b + grid, b + 2 grid, ...  All workgroups then advance through their 2.5 / 5 MB units in step, which is
+// the access pattern the HBM write path likes best: measured in round 2 (profiles/r02_scheduling_ab.txt, one process,
+// interleaved) a 15,360-signature Falcon-1024 launch (20 exact rounds of 768) runs at 6,412 GB/s = 0.99 of the
+// compute-free write stream on the same device, the per-launch atomic work queue of round 1 at 5,987 GB/s.
+// What static striding cannot absorb is a ragged last round, so the signatures beyond the last full round (and every
+// signature of a batch too small to fill the grid five times over) are cut into five work items of ~30 N elements
+// each -- {instance, S0, S1, S2}, {S5}, {S6, S7, status}, {S3}, {S4} -- strided over the grid the same way, each
+// recomputing the part of the clear arithmetic it needs (a single Falcon-1024 witness: 167 us -> ~60 us).
 // ------------------------------------------------------------------------------------------------
-#ifndef FRW_DYNAMIC_SCHED
-#define FRW_DYNAMIC_SCHED 1
-#endif
-// The ticket for the NEXT item is drawn (by thread 0) when the current item starts, so the atomic's round trip is
-// hidden behind the whole item; `publish` hands it to the other waves at the item's end.
-template <int LOGN>
-constexpr bool use_queue() { return FRW_DYNAMIC_SCHED == 2 || (FRW_DYNAMIC_SCHED == 1 && LOGN == 10); }
-
-template <int LOGN>
-__device__ __forceinline__ unsigned long long draw_ticket(unsigned long long *queue, int tid)
-{
-    if constexpr (use_queue<LOGN>()) return tid == 0 ? (unsigned long long)gridDim.x + atomicAdd(queue, 1ull) : 0ull;
-    else return 0ull;
-}
-template <int LOGN>
-__device__ __forceinline__ size_t next_item(size_t cur, unsigned long long ticket, unsigned long long *lds_slot, int tid)
-{
-    if constexpr (use_queue<LOGN>()) {
-        __syncthreads();                              // all waves are done with the previous item (and with *lds_slot)
-        if (tid == 0) *lds_slot = ticket;
-        __syncthreads();
-        return (size_t)*lds_slot;
-    } else {
-        return cur + gridDim.x;
-    }
-}
+constexpr int PARTS = 5;
 
 // ------------------------------------------------------------------------------------------------
 // LDS carve-up of one workgroup.  The NTT-domain arrays are dead once the small segments are written and the ladder
@@ -649,7 +634,6 @@ struct alignas(16) Smem {
     uint16_t ntt_rest[(4 - IN_LAD) * N + 8];     // the NTT-domain arrays that do not fit inside `lad`
     uint16_t vtab[COMPACT ? 8 : VTAB_ROWS * WAVE];
     unsigned long long norm;
-    unsigned long long next;              // next signature index taken from the launch's work queue
     int bad;
 #if defined(FRW_LDS_PAD) && FRW_LDS_PAD > 0
     uint32_t pad[FRW_LDS_PAD / 4];        // occupancy experiments only (tools/ab_variants.py)
@@ -662,12 +646,6 @@ struct alignas(16) Smem {
     }
 };
 
-__device__ __forceinline__ size_t uniform_index(size_t x)
-{
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-    return (size_t)lo | ((size_t)hi << 32);
-}
-
 // a rejected signature (coefficient >= q: the reference panics, range_proofs.rs:57-60) leaves zeros, not stale memory
 __device__ __forceinline__ void zero_fill(v4u *p, size_t chunks, int tid)
 {
@@ -677,13 +655,10 @@ __device__ __forceinline__ void zero_fill(v4u *p, size_t chunks, int tid)
 // ------------------------------------------------------------------------------------------------
 // kernel: full verify-with-ntt witness (falcon_ntt.rs:26-123)
 // ------------------------------------------------------------------------------------------------
-// SPLIT = false: one work item = one signature (the throughput form).  SPLIT = true (small batches, chosen by the
-// launcher when five items per signature still fit the resident grid, batch <= 153): one signature = five items of
-// ~30 N elements each -- {instance, S0, S1, S2}, {S5}, {S6, S7, status}, {S3}, {S4} -- taken by different workgroups,
-// each recomputing the part of the clear arithmetic it needs (a single Falcon-1024 witness: 167 us -> ~60 us).
-template <int LOGN, int ENC, bool SPLIT>
+// Work items [0, full) are whole signatures; items full + j are part j % 5 of signature full + j / 5 (see above).
+template <int LOGN, int ENC>
 __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
-    const Tables *__restrict__ tab, unsigned long long *__restrict__ queue, size_t batch,
+    const Tables *__restrict__ tab, size_t batch, size_t full,
     const uint16_t *__restrict__ g_sig, const uint16_t *__restrict__ g_pk, const uint16_t *__restrict__ g_hm,
     v4u *__restrict__ g_wit, v4u *__restrict__ g_inst, int32_t *__restrict__ g_status)
 {
@@ -718,14 +693,12 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         base[elem * 2 + 1] = mk4(e[4], e[5], e[6], e[7]);
     };
 
-    constexpr int PARTS = SPLIT ? 5 : 1;
-    unsigned long long ticket = 0;
-    for (size_t item_v = blockIdx.x; item_v < batch * PARTS; item_v = next_item<LOGN>(item_v, ticket, &sm.next, tid)) {
-        ticket = draw_ticket<LOGN>(queue, tid);
-        const size_t item = uniform_index(item_v);
-        const size_t s = SPLIT ? item / PARTS : item;
-        const int part = SPLIT ? (int)(item % PARTS) : -1;
-        auto does = [&](int p) { return !SPLIT || part == p; };             // workgroup-uniform
+    const size_t items = full + (batch - full) * PARTS;
+    for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const bool whole = item < full;
+        const size_t s = whole ? item : full + (item - full) / PARTS;
+        const int part = whole ? -1 : (int)((item - full) % PARTS);
+        auto does = [&](int p) { return part < 0 || part == p; };             // workgroup-uniform
         v4u *wit = COMPACT ? nullptr : g_wit + s * W * 2;
         v4u *inst = COMPACT ? nullptr : g_inst + s * I * 2;
         unsigned char *const cbase = COMPACT ? (unsigned char *)g_wit + s * CL.bytes : nullptr;
@@ -920,13 +893,12 @@ struct alignas(16) SmemDual {
     uint16_t nsp[N], nsn[N], nvp[N], nvn[N], npk[N], nhm[N];   // NTT domain
     uint16_t vtab[TileShape<18>::ROW0 * WAVE];   // shapes 29 and 30 only
     unsigned long long norm;
-    unsigned long long next;
     int bad;
 };
 
 template <int LOGN, int ENC>
 __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
-    const Tables *__restrict__ tab, unsigned long long *__restrict__ queue, size_t batch,
+    const Tables *__restrict__ tab, size_t batch,
     const uint16_t *__restrict__ g_sig, const uint16_t *__restrict__ g_pk, const uint16_t *__restrict__ g_hm,
     v4u *__restrict__ g_wit, v4u *__restrict__ g_inst, int32_t *__restrict__ g_status)
 {
@@ -952,10 +924,7 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
     const v4u one = ENC == 0 ? (half ? mk4(0, 0, 0, 0) : mk4(1, 0, 0, 0))
                              : (half ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]));
 
-    unsigned long long ticket = 0;
-    for (size_t s_v = blockIdx.x; s_v < batch; s_v = next_item<LOGN>(s_v, ticket, &sm.next, tid)) {
-        ticket = draw_ticket<LOGN>(queue, tid);
-        const size_t s = uniform_index(s_v);
+    for (size_t s = blockIdx.x; s < batch; s += gridDim.x) {
         v4u *wit = g_wit + s * W * 2;
         v4u *inst = g_inst + s * I * 2;
         if (tid == 0) { sm.norm = 0; sm.bad = 0; }
@@ -1089,13 +1058,12 @@ struct alignas(16) SmemNtt {
     uint16_t tw[N];
     uint16_t in[N];
     uint16_t vtab[TileShape<30>::ROW0 * WAVE];    // shape 29 only
-    unsigned long long next;
     int bad;
 };
 
 template <int LOGN, int ENC>
 __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
-    const Tables *__restrict__ tab, unsigned long long *__restrict__ queue, size_t batch,
+    const Tables *__restrict__ tab, size_t batch,
     const uint16_t *__restrict__ g_poly,
     v4u *__restrict__ g_wit, uint16_t *__restrict__ g_ntt, int32_t *__restrict__ g_status)
 {
@@ -1113,10 +1081,7 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
     init_vtab(sm.vtab, TileShape<30>::ROW0, tid);
     init_slab_const<ENC>(wc.slab, lane);
 
-    unsigned long long ticket = 0;
-    for (size_t s_v = blockIdx.x; s_v < batch; s_v = next_item<LOGN>(s_v, ticket, &sm.next, tid)) {
-        ticket = draw_ticket<LOGN>(queue, tid);
-        const size_t s = uniform_index(s_v);
+    for (size_t s = blockIdx.x; s < batch; s += gridDim.x) {
         if (tid == 0) sm.bad = 0;
         __syncthreads();
         int bad = 0;
@@ -1419,6 +1384,9 @@ static int resident_grid(size_t batch, int num_cu, int per_cu)
 {
     const size_t cap = (size_t)(per_cu > 0 ? per_cu : 2) * (size_t)num_cu;
     if (batch <= cap) return (int)batch;
+#if defined(FRW_FORCE_GRID)          // A/B builds only
+    return FRW_FORCE_GRID;
+#endif
 #ifndef FRW_BALANCED_GRID
 #define FRW_BALANCED_GRID 1
 #endif
@@ -1440,7 +1408,7 @@ void init_launch_config()
 {
     std::call_once(g_occ_once, [] {
 #define FRW_Q(K, CACHE, LOGN, ENC) query_residency(K<LOGN, ENC>, CACHE[(LOGN - 9) * 2 + ENC])
-#define FRW_QV(LOGN, ENC) query_residency(witness_ntt_verify_kernel<LOGN, ENC, false>, g_occ_verify[(LOGN - 9) * 2 + ENC])
+#define FRW_QV(LOGN, ENC) query_residency(witness_ntt_verify_kernel<LOGN, ENC>, g_occ_verify[(LOGN - 9) * 2 + ENC])
         FRW_QV(9, 0); FRW_QV(9, 1); FRW_QV(10, 0); FRW_QV(10, 1);
 #undef FRW_QV
         FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 0); FRW_Q(witness_dual_ntt_verify_kernel, g_occ_dual, 9, 1);
@@ -1448,37 +1416,50 @@ void init_launch_config()
         FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 9, 1);
         FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 0); FRW_Q(ntt_modq_kernel, g_occ_ntt, 10, 1);
 #undef FRW_Q
-        query_residency(witness_ntt_verify_kernel<9, 2, false>, g_occ_compact[0]);
-        query_residency(witness_ntt_verify_kernel<10, 2, false>, g_occ_compact[1]);
+        query_residency(witness_ntt_verify_kernel<9, 2>, g_occ_compact[0]);
+        query_residency(witness_ntt_verify_kernel<10, 2>, g_occ_compact[1]);
         query_residency(expand_kernel<9>, g_occ_expand[0]);
         query_residency(expand_kernel<10>, g_occ_expand[1]);
     });
 }
 
-hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch,
+// (grid, full) of a witness launch: all-split for small batches, one workgroup per signature up to the resident capacity,
+// else the resident grid (or, for short launches, a divisor of the batch close to it) with the ragged tail split.
+static void verify_shape(size_t batch, int num_cu, int occ, bool may_split, int &grid, size_t &full)
+{
+    const size_t cap = (size_t)(occ > 0 ? occ : 2) * (size_t)num_cu;
+    if (may_split && batch * PARTS <= cap) {     // measured: 1 signature 167 -> 56 us, 64 signatures 172 -> 95 us; at 256 it loses
+        grid = (int)(batch * PARTS);
+        full = 0;
+        return;
+    }
+    grid = resident_grid(batch, num_cu, occ);
+    full = may_split ? batch / (size_t)grid * (size_t)grid : batch;
+}
+
+void launch_shape_witness_ntt_verify(int num_cu, int logn, int enc, size_t batch, int out[4])
+{
+    const int occ = enc == 2 ? g_occ_compact[logn - 9] : g_occ_verify[(logn - 9) * 2 + (enc & 1)];
+    int grid;
+    size_t full;
+    verify_shape(batch, num_cu, occ, true, grid, full);
+    out[0] = grid;
+    out[1] = occ;
+    out[2] = num_cu;
+    out[3] = (int)(batch - full);          // signatures cut into five work items
+}
+
+hipError_t launch_witness_ntt_verify(const Tables *tab, int num_cu, int logn, int enc, size_t batch,
                                      const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                      uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
-    if (!queue) return hipErrorOutOfMemory;
-    hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
-    if (qe != hipSuccess) return qe;
-#define FRW_LAUNCH(LOGN, ENC)                                                                                        \
-    do {                                                                                                             \
-        const int occ = g_occ_verify[(LOGN - 9) * 2 + ENC];                                                          \
-        const size_t cap = (size_t)(occ > 0 ? occ : 2) * (size_t)num_cu;                                             \
-        if (batch * 5 <= cap) { /* small batch: five items per signature, all resident at once (measured: 1 sig    \
-                                   167 -> 56 us, 64 sigs 172 -> 95 us; at 256 signatures the split already loses) */ \
-            const size_t items = batch * 5;                                                                          \
-            const int grid = (int)(items < cap ? items : cap);                                                       \
-            hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC, true>), dim3(grid), dim3(BLOCK), 0, st, tab,    \
-                               queue, batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                          \
-        } else {                                                                                                     \
-            const int grid = resident_grid(batch, num_cu, occ);                                                      \
-            hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC, false>), dim3(grid), dim3(BLOCK), 0, st, tab,   \
-                               queue, batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                          \
-        }                                                                                                            \
-    } while (0)
+    int grid;
+    size_t full;
+    verify_shape(batch, num_cu, g_occ_verify[(logn - 9) * 2 + enc], true, grid, full);
+#define FRW_LAUNCH(LOGN, ENC)                                                                                              \
+    hipLaunchKernelGGL((witness_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, batch, full, sig, pk, hm, \
+                       (v4u *)wit, (v4u *)inst, status)
     if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);
     else if (logn == 9) FRW_LAUNCH(9, 1);
     else if (enc == 0) FRW_LAUNCH(10, 0);
@@ -1487,32 +1468,20 @@ hipError_t launch_witness_ntt_verify(const Tables *tab, unsigned long long *queu
     return hipGetLastError();
 }
 
-void launch_shape_witness_ntt_verify(int num_cu, int logn, int enc, size_t batch, int out[4])
-{
-    const int occ = enc == 2 ? g_occ_compact[logn - 9] : g_occ_verify[(logn - 9) * 2 + (enc & 1)];
-    const size_t cap = (size_t)(occ > 0 ? occ : 2) * (size_t)num_cu;
-    const bool split = enc != 2 && batch * 5 <= cap;
-    out[0] = split ? (int)(batch * 5 < cap ? batch * 5 : cap) : resident_grid(batch, num_cu, occ);
-    out[1] = occ;
-    out[2] = num_cu;
-    out[3] = split ? 1 : 0;
-}
-
-hipError_t launch_witness_ntt_verify_compact(const Tables *tab, unsigned long long *queue, int num_cu, int logn, size_t batch,
+hipError_t launch_witness_ntt_verify_compact(const Tables *tab, int num_cu, int logn, size_t batch,
                                              const uint16_t *sig, const uint16_t *pk, const uint16_t *hm, void *compact,
                                              int32_t *status, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
-    if (!queue) return hipErrorOutOfMemory;
-    hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
-    if (qe != hipSuccess) return qe;
-    const int grid = resident_grid(batch, num_cu, g_occ_compact[logn - 9]);
+    int grid;
+    size_t full;
+    verify_shape(batch, num_cu, g_occ_compact[logn - 9], true, grid, full);
     if (logn == 9)
-        hipLaunchKernelGGL((witness_ntt_verify_kernel<9, 2, false>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, batch, sig, pk,
-                           hm, (v4u *)compact, (v4u *)nullptr, status);
+        hipLaunchKernelGGL((witness_ntt_verify_kernel<9, 2>), dim3(grid), dim3(BLOCK), 0, st, tab, batch, full, sig, pk, hm,
+                           (v4u *)compact, (v4u *)nullptr, status);
     else
-        hipLaunchKernelGGL((witness_ntt_verify_kernel<10, 2, false>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, batch, sig, pk,
-                           hm, (v4u *)compact, (v4u *)nullptr, status);
+        hipLaunchKernelGGL((witness_ntt_verify_kernel<10, 2>), dim3(grid), dim3(BLOCK), 0, st, tab, batch, full, sig, pk, hm,
+                           (v4u *)compact, (v4u *)nullptr, status);
     return hipGetLastError();
 }
 
@@ -1529,18 +1498,15 @@ hipError_t launch_expand(int num_cu, int logn, size_t batch, const void *compact
     return hipGetLastError();
 }
 
-hipError_t launch_witness_dual_ntt_verify(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc,
+hipError_t launch_witness_dual_ntt_verify(const Tables *tab, int num_cu, int logn, int enc,
                                           size_t batch, const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
                                           uint64_t *wit, uint64_t *inst, int32_t *status, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
-    if (!queue) return hipErrorOutOfMemory;
-    hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
-    if (qe != hipSuccess) return qe;
 #define FRW_LAUNCH(LOGN, ENC)                                                                                       \
     do {                                                                                                            \
         const int grid = resident_grid(batch, num_cu, g_occ_dual[(LOGN - 9) * 2 + ENC]);                            \
-        hipLaunchKernelGGL((witness_dual_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, \
+        hipLaunchKernelGGL((witness_dual_ntt_verify_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab,        \
                            batch, sig, pk, hm, (v4u *)wit, (v4u *)inst, status);                                    \
     } while (0)
     if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);
@@ -1551,17 +1517,14 @@ hipError_t launch_witness_dual_ntt_verify(const Tables *tab, unsigned long long 
     return hipGetLastError();
 }
 
-hipError_t launch_ntt_modq(const Tables *tab, unsigned long long *queue, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
+hipError_t launch_ntt_modq(const Tables *tab, int num_cu, int logn, int enc, size_t batch, const uint16_t *poly,
                            uint64_t *wit, uint16_t *ntt_out, int32_t *status, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
-    if (!queue) return hipErrorOutOfMemory;
-    hipError_t qe = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
-    if (qe != hipSuccess) return qe;
 #define FRW_LAUNCH(LOGN, ENC)                                                                                  \
     do {                                                                                                       \
         const int grid = resident_grid(batch, num_cu, g_occ_ntt[(LOGN - 9) * 2 + ENC]);                        \
-        hipLaunchKernelGGL((ntt_modq_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, queue, batch,    \
+        hipLaunchKernelGGL((ntt_modq_kernel<LOGN, ENC>), dim3(grid), dim3(BLOCK), 0, st, tab, batch,           \
                            poly, (v4u *)wit, ntt_out, status);                                                 \
     } while (0)
     if (logn == 9 && enc == 0) FRW_LAUNCH(9, 0);

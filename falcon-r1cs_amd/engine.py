@@ -245,10 +245,11 @@ class WitnessEngine:
                                        C.c_void_p(stream)), "frw_expand_dev")
 
     def launch_shape(self, logn, batch, encoding=ENC_MONTGOMERY):
-        """{grid, resident workgroups per CU, CUs, split} of a witness launch of `batch` signatures."""
+        """{grid, resident workgroups per CU, CUs, split_signatures} of a witness launch of `batch` signatures
+        (split_signatures = the ragged tail beyond the last full round of the grid, cut into five work items each)."""
         out = (C.c_int32 * 4)()
         check(self._lib.frw_diag_launch_shape(self._ctx, logn, encoding, batch, C.byref(out)), "frw_diag_launch_shape")
-        return {"grid": out[0], "resident_per_cu": out[1], "cus": out[2], "split": bool(out[3])}
+        return {"grid": out[0], "resident_per_cu": out[1], "cus": out[2], "split_signatures": out[3]}
 
     def witness_dual_ntt_verify_dev(self, logn, batch, d_sig, d_pk, d_hm, d_wit, d_inst, d_status,
                                     encoding=ENC_MONTGOMERY, stream=0):

@@ -277,7 +277,9 @@ int frw_digest_dev(frw_ctx *ctx, const uint64_t *d_buf, size_t words_per_item, s
                    uint64_t *d_out, void *stream);
 
 /* What a witness launch of `batch` signatures looks like on this device: out = {workgroups launched, resident
- * workgroups per CU the grid was sized for, CUs, 1 if a signature is split into five work items (small batches)}. */
+ * workgroups per CU the grid was sized for, CUs, number of signatures (the ragged tail beyond the last full round of
+ * the grid, or a whole small batch) that are cut into five work items each}.  Launches whose batch is a multiple of
+ * out[0] run fastest (static striding, no tail). */
 int frw_diag_launch_shape(frw_ctx *ctx, int logn, int encoding, size_t batch, int32_t out[4]);
 
 /* Roofline calibration: overwrites d_buf[0, bytes) with a compute-free write stream of the witness kernel's store

@@ -2,7 +2,7 @@
 """Interleaved A/B timing of kernel build variants in ONE process (methodology rule 24 of the CDNA guide).
 
     python tools/ab_variants.py NAME=FLAGS [NAME=FLAGS ...] [--logn 10] [--chunk 4096] [--rounds 6]
-    e.g. python tools/ab_variants.py plain=-DFRW_NT_STORE=0 nt=-DFRW_NT_STORE=1
+    e.g. python tools/ab_variants.py plain= nt=-DFRW_STORE_AUX=2 nostore=-DFRW_NO_STORE g512=-DFRW_FORCE_GRID=512
 
 Each variant is compiled to its own shared object under gpurun_out/variants/, loaded with ctypes next to the
 others, and the full verify-with-ntt launch is timed with HIP events, round-robin over the variants.

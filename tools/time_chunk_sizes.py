@@ -24,6 +24,7 @@ inst = torch.empty((cap, L.num_instance, 4), dtype=torch.int64, device=dev)
 st = torch.empty(cap, dtype=torch.int32, device=dev)
 sizes = [b for b in (1024, 2048, 3072, 4096, 4608, 6144, 8192, 12288, 16384, 24576, 32768, 49152) if b <= cap]
 res = {b: [] for b in sizes}
+ws = {b: [] for b in sizes}
 bytes_per = 32 * (L.num_witness + 2 * L.n) + 6 * L.n
 for rnd in range(6):
     for b in sizes:
@@ -36,7 +37,17 @@ for rnd in range(6):
         e1.synchronize()
         if rnd:
             res[b].append(e0.elapsed_time(e1) / reps)
+        # compute-free write stream over the same footprint
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            eng.diag_write_stream_dev(wit, b * L.num_witness * 32, L.num_witness * 32, stream.cuda_stream)
+        e1.record(stream)
+        e1.synchronize()
+        if rnd:
+            ws[b].append(e0.elapsed_time(e1) / reps)
 for b in sizes:
     ms = statistics.median(res[b])
-    print("falcon-%d  %6d signatures/launch: %.4f ms  %.1f GB/s  %.0f signatures/s" %
-          (1 << logn, b, ms, b * bytes_per / ms / 1e6, b / ms * 1e3))
+    wms = statistics.median(ws[b])
+    print("falcon-%d  %6d signatures/launch: %.4f ms  %.1f GB/s  %.0f signatures/s   | write stream, same footprint: %.1f GB/s" %
+          (1 << logn, b, ms, b * bytes_per / ms / 1e6, b / ms * 1e3, b * L.num_witness * 32 / wms / 1e6))
