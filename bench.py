@@ -386,9 +386,10 @@ def main():
                     help="signatures per GPU per step (default: 65,536 = BASELINE configs[2]; with --gpus 8: 131,072 = "
                          "configs[3], 1 M signatures over the node)")
     ap.add_argument("--chunk", type=int, default=0,
-                    help="signatures per kernel launch = size of the reused HBM witness buffer.  Default: 21 rounds of the "
-                         "resident grid (21 x 768 = 16,128 Falcon-1024 witnesses = 81 GB of the 288 GB): launches that are "
-                         "an exact multiple of the grid run fastest (profiles/r02_scheduling_ab.txt)")
+                    help="signatures per kernel launch = size of the reused HBM witness buffer.  Default: 32,768 Falcon-1024 "
+                         "witnesses = 164 GB of the 288 GB (a step = two launches): sized for the HBM, and measured -- the "
+                         "write stream itself sustains 6.5 TB/s over a buffer of this size, 6.0 TB/s over 82 GB "
+                         "(profiles/r02_chunk_sizes.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-r1cs-check", action="store_true",
                     help="skip the untimed on-device check that every witness of the last timed launch satisfies the "
@@ -454,8 +455,7 @@ def main():
     dual = args.circuit == "dual"
     L = frw.layout_dual(logn) if dual else frw.layout(logn)
     eng = frw.WitnessEngine(dev_index)
-    resident_grid = eng.launch_shape(logn, 1 << 24)["grid"]
-    chunk = min(args.chunk or (16384 if logn == 10 else 32768) // resident_grid * resident_grid, batch)   # 21 x 768 = 16,128
+    chunk = min(args.chunk or (32768 if logn == 10 else 65536), batch)
     launch = eng.witness_dual_ntt_verify_dev if dual else eng.witness_ntt_verify_dev
     threads = max(1, (os.cpu_count() or 1) // world)
 

@@ -140,6 +140,24 @@ __device__ __forceinline__ void encode_u160(const uint32_t (&x)[5], uint32_t (&o
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
+// Workgroup barrier.  __syncthreads() also drains the wave's outstanding global stores (s_waitcnt vmcnt(0)) before every
+// s_barrier, although nothing in these kernels hands global data from one wave to another; FRW_FULL_BARRIER=0 swaps in
+// an LDS-only barrier (s_waitcnt lgkmcnt(0); s_barrier) that lets a tile's stores drain behind the next ladder.
+// Measured (round 2, tools/ab_variants.py lds= full=-DFRW_FULL_BARRIER=1: 32,768 Falcon-1024, 8,192 Falcon-512 signatures,
+// 4,096 ntt_modq polynomials): no difference beyond 0.1 % -- the kernels wait for HBM either way -- so the plain
+// __syncthreads() stays.
+#ifndef FRW_FULL_BARRIER
+#define FRW_FULL_BARRIER 1
+#endif
+__device__ __forceinline__ void lds_barrier()
+{
+#if FRW_FULL_BARRIER
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ uint32_t mod_q_u32(uint32_t x) { return x % Q; }   // constant divisor: mul_hi + fixups
 
 // a (five limbs) = t*q + b: schoolbook short division in 16-bit steps (arithmetics.rs:127-134)
@@ -261,7 +279,7 @@ __device__ __forceinline__ void ntt_modq_lds(uint16_t *const (&a)[NPOLY], const 
                 a[p][j + ht] = (uint16_t)(y >= Q ? y - Q : y);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -284,10 +302,10 @@ __device__ __forceinline__ void intt_modq_lds(uint16_t *a, const uint16_t *itw, 
             a[j] = (uint16_t)(u >= Q ? u - Q : u);
             a[j + ht] = (uint16_t)w;
         }
-        __syncthreads();
+        lds_barrier();
     }
     for (int j = tid; j < N; j += BLOCK) a[j] = (uint16_t)mod_q_u32(a[j] * NINV);
-    __syncthreads();
+    lds_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -334,7 +352,7 @@ __device__ __forceinline__ void ladder_round(uint32_t *lad, const uint16_t *tw, 
             lad[k * N + j + ht] = (uint32_t)y;
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 template <int LOGN>
@@ -342,7 +360,7 @@ __device__ __forceinline__ void ladder_lds(uint32_t *lad, const uint16_t *in, co
 {
     constexpr int N = 1 << LOGN;
     for (int j = tid; j < N; j += BLOCK) lad[j] = in[j];
-    __syncthreads();
+    lds_barrier();
     ladder_round<LOGN, 0, 1, 1>(lad, tw, ck, tid);
     ladder_round<LOGN, 1, 1, 2>(lad, tw, ck, tid);
     ladder_round<LOGN, 2, 2, 2>(lad, tw, ck, tid);
@@ -707,7 +725,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         v4u *const ci = (v4u *)(cbase + CL.instance_off);                   //          instance values
         // ---- 1. load + range check ----------------------------------------------------------
         if (tid == 0) { sm.norm = 0; sm.bad = 0; }
-        __syncthreads();
+        lds_barrier();
         int bad = 0;
         for (int j = tid; j < N; j += BLOCK) {
             uint32_t a = g_sig[s * N + j], b = g_pk[s * N + j], c = g_hm[s * N + j];
@@ -715,14 +733,14 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
             sm.sig[j] = (uint16_t)a; s_nsig[j] = (uint16_t)a; s_npk[j] = (uint16_t)b; s_nhm[j] = (uint16_t)c;
         }
         if (bad) sm.bad = 1;
-        __syncthreads();
+        lds_barrier();
         if (sm.bad) {                                    // uniform across the workgroup
             if (tid == 0 && does(2)) g_status[s] = ST_COEFF_RANGE;
             if (does(0)) {
                 if constexpr (COMPACT) zero_fill(cv, CL.bytes / 16, tid);
                 else { zero_fill(wit, W * 2, tid); zero_fill(inst, I * 2, tid); }
             }
-            __syncthreads();
+            lds_barrier();
             continue;
         }
         // ---- 2. clear arithmetic (only what this item's segments need) ---------------------------
@@ -736,7 +754,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
                 x = x >= Q ? x - Q : x;
                 s_nv[j] = (uint16_t)x; sm.v[j] = (uint16_t)x;
             }
-            __syncthreads();
+            lds_barrier();
             if (does(0) || does(2) || does(4)) intt_modq_lds<LOGN>(sm.v, tab->itw, tid);   // v = hm - sig*pk   :48-49
         }
 
@@ -821,7 +839,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor((unsigned long long)nrm, off, WAVE);
         if (lane == 0) atomicAdd(&sm.norm, nrm);
-        __syncthreads();
+        lds_barrier();
         // S7 enforce_less_than_norm_bound                                                   :122
         if (wave == 0 && does(2)) {
             const unsigned long long norm = sm.norm;
@@ -866,7 +884,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
                 emit_tile<29>(rw, seg + t * WAVE * 29 * 32, ltq_mask(b) << 2, wc);
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
@@ -928,7 +946,7 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
         v4u *wit = g_wit + s * W * 2;
         v4u *inst = g_inst + s * I * 2;
         if (tid == 0) { sm.norm = 0; sm.bad = 0; }
-        __syncthreads();
+        lds_barrier();
         int bad = 0;
         for (int j = tid; j < N; j += BLOCK) {
             const uint32_t a = g_sig[s * N + j], b = g_pk[s * N + j], c = g_hm[s * N + j];
@@ -938,12 +956,12 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
             sm.npk[j] = (uint16_t)b; sm.nhm[j] = (uint16_t)c;
         }
         if (bad) sm.bad = 1;
-        __syncthreads();
+        lds_barrier();
         if (sm.bad) {
             if (tid == 0) g_status[s] = ST_COEFF_RANGE;
             zero_fill(wit, W * 2, tid);
             zero_fill(inst, I * 2, tid);
-            __syncthreads();                  // every wave has read sm.bad before thread 0 clears it for the next item
+            lds_barrier();                  // every wave has read sm.bad before thread 0 clears it for the next item
             continue;
         }
         {
@@ -955,14 +973,14 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
             uint32_t x = sm.nhm[j] + Q - mod_q_u32(mod_q_u32(sg) * sm.npk[j]);
             sm.vp[j] = (uint16_t)(x >= Q ? x - Q : x);
         }
-        __syncthreads();
+        lds_barrier();
         intt_modq_lds<LOGN>(sm.vp, tab->itw, tid);
         for (int j = tid; j < N; j += BLOCK) {                                     // DualPolynomial::from(&v)   :51
             const uint32_t a = sm.vp[j];
             const uint16_t p = (uint16_t)(a < HALF_Q ? a : 0), m = (uint16_t)(a < HALF_Q ? 0 : Q - a);
             sm.vp[j] = p; sm.vn[j] = m; sm.nvp[j] = p; sm.nvn[j] = m;
         }
-        __syncthreads();
+        lds_barrier();
         {
             uint16_t *const polys[2] = {sm.nvp, sm.nvn};
             ntt_modq_lds<LOGN, 2>(polys, sm.tw, tid);
@@ -1018,7 +1036,7 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor((unsigned long long)nrm, off, WAVE);
         if (lane == 0) atomicAdd(&sm.norm, nrm);
-        __syncthreads();
+        lds_barrier();
         if (wave == 0) {                                                           // :131
             const unsigned long long norm = sm.norm;
             const unsigned long long nm = LOGN == 9 ? norm_mask_512(norm) : norm_mask_1024(norm);
@@ -1042,7 +1060,7 @@ __global__ __launch_bounds__(BLOCK) void witness_dual_ntt_verify_kernel(
                 encode_u32<ENC>(b, e8);   slab_put(wc.slab, 1, lane, e8);
                 emit_tile<29>(rw, seg + t * WAVE * 29 * 32, ltq_mask(b) << 2, wc);
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
@@ -1083,7 +1101,7 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
 
     for (size_t s = blockIdx.x; s < batch; s += gridDim.x) {
         if (tid == 0) sm.bad = 0;
-        __syncthreads();
+        lds_barrier();
         int bad = 0;
         for (int j = tid; j < N; j += BLOCK) {
             uint32_t a = g_poly[s * N + j];
@@ -1091,12 +1109,12 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
             sm.in[j] = (uint16_t)a;
         }
         if (bad) sm.bad = 1;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) g_status[s] = sm.bad ? ST_COEFF_RANGE : ST_OK;
         if (sm.bad) {
             zero_fill(g_wit + s * WN * 2, WN * 2, tid);
             for (int j = tid; j < N; j += BLOCK) g_ntt[s * N + j] = 0;
-            __syncthreads();
+            lds_barrier();
             continue;
         }
         ladder_lds<LOGN>(sm.lad, sm.in, sm.tw, &tab->ck[0][0], tid);
@@ -1112,7 +1130,7 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
             encode_u32<ENC>(b, e8);   slab_put(wc.slab, 1, lane, e8);
             emit_tile<29>(rw, t * WAVE * 29 * 32, ltq_mask(b) << 2, wc);
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -1164,7 +1182,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(size_t batch, const unsig
     wc.lane = lane;
     init_vtab(sm.vtab, VTAB_ROWS, tid);
     init_slab_const<1>(wc.slab, lane);
-    __syncthreads();
+    lds_barrier();
     constexpr uint32_t R[8] = FRW_R32;
     const v4u one = lane & 1 ? mk4(R[4], R[5], R[6], R[7]) : mk4(R[0], R[1], R[2], R[3]);
 

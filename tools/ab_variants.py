@@ -36,6 +36,7 @@ def build(name, flags):
     lib.frw_witness_ntt_verify_dev.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int] + \
         [C.c_void_p] * 4
     lib.frw_diag_write_stream_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    lib.frw_ntt_modq_dev.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int] + [C.c_void_p] * 4
     ctx = C.c_void_p()
     assert lib.frw_ctx_create(0, C.byref(ctx)) == 0
     return lib, ctx
@@ -47,6 +48,7 @@ def main():
     ap.add_argument("--logn", type=int, default=10)
     ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=6)
+    ap.add_argument("--workload", default="verify", choices=["verify", "ntt_modq"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
@@ -62,11 +64,18 @@ def main():
         name, _, flags = v.partition("=")
         libs.append((name, flags) + build(name, flags))
     bytes_per = a.chunk * (32 * (L.num_witness + 2 * L.n) + 6 * L.n)
+    if a.workload == "ntt_modq":
+        bytes_per = a.chunk * (32 * 29 * L.n + 2 * L.n)
     times = {name: [] for name, *_ in libs}
+    reps = 4 if a.workload == "verify" else 50
 
     def launch(lib, ctx):
-        rc = lib.frw_witness_ntt_verify_dev(ctx, a.logn, a.chunk, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 1,
-                                            wit.data_ptr(), inst.data_ptr(), st.data_ptr(), stream.cuda_stream)
+        if a.workload == "ntt_modq":      # d[1] doubles as the input polynomial, d[2] as the reduced-NTT output
+            rc = lib.frw_ntt_modq_dev(ctx, a.logn, a.chunk, d[1].data_ptr(), 1, wit.data_ptr(), d[2].data_ptr(), st.data_ptr(),
+                                      stream.cuda_stream)
+        else:
+            rc = lib.frw_witness_ntt_verify_dev(ctx, a.logn, a.chunk, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 1,
+                                                wit.data_ptr(), inst.data_ptr(), st.data_ptr(), stream.cuda_stream)
         assert rc == 0
     for name, _, lib, ctx in libs:
         launch(lib, ctx)
@@ -75,11 +84,11 @@ def main():
         for name, _, lib, ctx in libs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            for _ in range(4):
+            for _ in range(reps):
                 launch(lib, ctx)
             e1.record(stream)
             e1.synchronize()
-            times[name].append(e0.elapsed_time(e1) / 4)
+            times[name].append(e0.elapsed_time(e1) / reps)
     # compute-free write stream over the same buffer, interleaved the same way (first variant's library)
     lib0, ctx0 = libs[0][2], libs[0][3]
     wbytes = wit.numel() * 8

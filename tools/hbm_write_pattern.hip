@@ -3,6 +3,8 @@
 //   B  wave-private tiles:   every wavefront walks its own 58 KiB tile 1 KiB per step, the four tiles adjacent
 //                            (what the witness kernel's tile writer does)
 //   D  interleaved:          the four wavefronts share one tile, wavefront w writes the 1 KiB steps w, w+4, w+8, ...
+//   E  blocked hand-out:     as A, but workgroup b owns the contiguous run of units [b R, (b+1) R) instead of the stride
+//                            b, b + grid, ...: the chip's concurrent writes are spread over the whole buffer at all times
 // Same bytes, same grid, static hand-out of units, interleaved rounds, medians.
 // Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/wp tools/hbm_write_pattern.hip
 #include <hip/hip_runtime.h>
@@ -21,9 +23,13 @@ __global__ __launch_bounds__(256) void fill(v4u *__restrict__ out, size_t nunits
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v4u v = {blockIdx.x, threadIdx.x, 3, 4};
-    for (size_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+    const size_t per = (nunits + gridDim.x - 1) / gridDim.x;
+    const size_t first = PATTERN == 3 ? blockIdx.x * per : blockIdx.x;
+    const size_t last = PATTERN == 3 ? (first + per < nunits ? first + per : nunits) : nunits;
+    const size_t step = PATTERN == 3 ? 1 : gridDim.x;
+    for (size_t u = first; u < last; u += step) {
         v4u *o = out + u * UNIT16;
-        if (PATTERN == 0) {
+        if (PATTERN == 0 || PATTERN == 3) {
             for (size_t i = threadIdx.x; i < UNIT16; i += 256) o[i] = v;
         } else {
             const size_t ntiles = UNIT16 / TILE16;            // 84 full tiles; the remainder is written A-style
@@ -49,21 +55,22 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct Cfg { int pat; int grid; std::vector<float> ms; };
     std::vector<Cfg> cfgs;
-    for (int grid : {512, 768, 1024})
-        for (int pat : {0, 1, 2}) cfgs.push_back({pat, grid, {}});
+    for (int grid : {768})
+        for (int pat : {0, 1, 2, 3}) cfgs.push_back({pat, grid, {}});
     for (int round = 0; round < 7; round++)
         for (auto &c : cfgs) {
             CK(hipEventRecord(e0));
             for (int k = 0; k < 2; k++) {
                 if (c.pat == 0) hipLaunchKernelGGL(fill<0>, dim3(c.grid), dim3(256), 0, 0, buf, nunits);
                 else if (c.pat == 1) hipLaunchKernelGGL(fill<1>, dim3(c.grid), dim3(256), 0, 0, buf, nunits);
-                else hipLaunchKernelGGL(fill<2>, dim3(c.grid), dim3(256), 0, 0, buf, nunits);
+                else if (c.pat == 2) hipLaunchKernelGGL(fill<2>, dim3(c.grid), dim3(256), 0, 0, buf, nunits);
+                else hipLaunchKernelGGL(fill<3>, dim3(c.grid), dim3(256), 0, 0, buf, nunits);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (round) c.ms.push_back(ms / 2);
         }
-    const char *names[3] = {"A workgroup-contiguous", "B wave-private tiles  ", "D interleaved         "};
+    const char *names[4] = {"A workgroup-contiguous", "B wave-private tiles  ", "D interleaved         ", "E blocked hand-out    "};
     for (auto &c : cfgs) {
         std::sort(c.ms.begin(), c.ms.end());
         printf("units=%zu %s grid=%5d  median %.3f ms  %.1f GB/s\n", nunits, names[c.pat], c.grid, c.ms[c.ms.size() / 2],
