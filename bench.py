@@ -191,6 +191,38 @@ def time_verify(eng, dev, logn, batch, launches, warm, threads):
             "launch_shape": eng.launch_shape(logn, batch)}
 
 
+def time_compact(eng, dev, logn, batch, launches, warm, d_in, d_wit):
+    """FRW_ENC_COMPACT producer and frw_expand_dev on a resident batch (reusing the benchmark's inputs and, for the
+    expansion, its witness buffer): the two halves of the multi-GPU gather path, timed on one GPU."""
+    L, CL = frw.layout(logn), frw.compact_layout(logn)
+    d_sig, d_pk, d_hm = (t[:batch] for t in d_in)
+    comp = torch.empty((batch, CL.bytes_per_signature), dtype=torch.uint8, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.empty(batch, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    out = {}
+    for name, run, nbytes in (
+            ("generate_compact", lambda: eng.witness_ntt_verify_compact_dev(logn, batch, d_sig, d_pk, d_hm, comp, st, stream.cuda_stream),
+             batch * CL.bytes_per_signature),
+            ("expand", lambda: eng.expand_dev(logn, batch, comp, d_wit[:batch], inst, stream.cuda_stream),
+             batch * 32 * (L.num_witness + L.num_instance))):
+        for _ in range(warm):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(launches):
+            run()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / launches
+        out[name] = {"avg_launch_ms": round(ms, 4), "signatures_per_s": round(batch / (ms * 1e-3), 1),
+                     "bytes_written_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1), "signatures_per_launch": batch}
+    assert int((st != 0).sum().item()) == 0
+    out["bytes_per_signature"] = {"compact": CL.bytes_per_signature, "arkworks": 32 * (L.num_witness + L.num_instance)}
+    return out
+
+
 def bench_ntt_modq(args, world, rank, dev):
     """--workload ntt_modq: BASELINE configs[1] as the primary line."""
     eng = frw.WitnessEngine(dev.index)
@@ -633,7 +665,8 @@ def main():
             # untimed w.r.t. `value`: the other two rooflines BASELINE / north_star name, measured in this process
             result["secondary"] = {
                 "ntt_modq_falcon512_batch4096": time_ntt_modq(eng, dev, 9, 4096, 200, 20),
-                "verify_falcon512_8192_per_launch": time_verify(eng, dev, 9, 8192, 12, 3, threads)}
+                "verify_falcon512_8192_per_launch": time_verify(eng, dev, 9, 8192, 12, 3, threads),
+                "compact_encoding_falcon%d" % n: time_compact(eng, dev, logn, chunk, 4, 1, (d_sig, d_pk, d_hm), d_wit)}
         if world == 1 and not args.no_cpu_baseline and not dual:
             slots = np.arange(0, held, max(1, held // 4096))[:4096]        # strided over the whole buffer
             digest_of = {int(slot_sig[j]): int(held_dig[j]) for j in slots}

@@ -284,19 +284,47 @@ def test_input_preparation_matches_codec_oracle(engine, oracle, logn):
     assert st.tolist() == [0] * len(lens) + [frw.ST_DECODE] * 3
     for i, (ws, wp, wh) in enumerate(want):
         assert sig[i].tolist() == ws and pk[i].tolist() == wp and hm[i].tolist() == wh, i
-    # chain: a VALID statement built from encoded inputs -> witness
-    s, p, h = frw.synth_triples(logn, 2, seed=5)
-    # re-encode: sig coefficients are centred small values, pk uniform; hm comes from hashing, so instead of the
-    # synthetic hm use the hashed one and accept a (probably) violated norm bound: permissive mode
-    cent = [[int(x) if x < 6144 else int(x) - T.Q for x in row] for row in s]
-    enc_sig = [K.comp_encode(c, logn, bytes([i]) * 40) for i, c in enumerate(cent)]
-    enc_pk = [K.modq_encode(row.tolist(), logn) for row in p]
-    ms = [b"testing message", b""]
-    sig2, pk2, hm2, st2 = engine.prepare_inputs(logn, enc_pk, ms, enc_sig)
-    assert not st2.any() and np.array_equal(sig2, s) and np.array_equal(pk2, p)
-    wit, inst, stw = engine.witness_ntt_verify(logn, sig2, pk2, hm2, 1, strict=False)
-    owit, oinst, ost = oracle.witness_ntt_verify(logn, sig2, pk2, hm2, 1)
-    assert stw.tolist() == ost.tolist() and np.array_equal(wit, owit) and np.array_equal(inst, oinst)
+
+
+def test_genuine_falcon_signatures_end_to_end(engine, oracle):
+    """The reference's end-to-end test (falcon_ntt.rs:133-160: keygen -> sign -> verify -> generate_constraints ->
+    is_satisfied) on genuine Falcon signatures (tests/golden/falcon_signed.json, produced by oracle/falcon_sign.py and
+    accepted by the specification's Verify): encoded (pk, msg, sig) -> frw_prepare_inputs on the GPU -> strict witness call
+    (a genuine signature passes the norm bound, as in the reference's non-test build) -> bytes equal the oracle's and the
+    fixture's -> every constraint of the independently emitted system holds on the device."""
+    import hashlib
+    import json
+    import os
+    import torch
+    import falcon_r1cs_amd as frw
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "falcon_signed.json")))["cases"]
+    dev = torch.device("cuda:0")
+    for logn in (9, 10):
+        cs = [c for c in cases if c["logn"] == logn]
+        assert len(cs) == 2
+        pks, msgs, sigs = ([bytes.fromhex(c[k]) for c in cs] for k in ("pk_bytes", "msg", "sig_bytes"))
+        sig, pk, hm, st = engine.prepare_inputs(logn, pks, msgs, sigs)
+        assert not st.any()
+        for i, c in enumerate(cs):
+            assert hashlib.sha256(sig[i].tobytes()).hexdigest() == c["sig_sha256"]
+            assert hashlib.sha256(pk[i].tobytes()).hexdigest() == c["pk_sha256"]
+            assert hashlib.sha256(hm[i].tobytes()).hexdigest() == c["hm_sha256"]
+        wit, inst, stw = engine.witness_ntt_verify(logn, sig, pk, hm, frw.ENC_MONTGOMERY, strict=True)
+        owit, oinst, ost = oracle.witness_ntt_verify(logn, sig, pk, hm, 1)
+        assert stw.tolist() == ost.tolist() == [0, 0]
+        assert np.array_equal(wit, owit) and np.array_equal(inst, oinst)
+        for i, c in enumerate(cs):
+            assert hashlib.sha256(wit[i].tobytes()).hexdigest() == c["witness_sha256_montgomery"]
+            assert hashlib.sha256(inst[i].tobytes()).hexdigest() == c["instance_sha256_montgomery"]
+        d_wit = torch.from_numpy(wit.view(np.int64)).to(dev)
+        d_inst = torch.from_numpy(inst.view(np.int64)).to(dev)
+        assert _r1cs_all_satisfied(engine, 0, logn, d_wit, d_inst) == 0
+        # the dual circuit on the same genuine statements (falcon_dual_ntt.rs:142-169)
+        dwit, dinst, dst = engine.witness_dual_ntt_verify(logn, sig, pk, hm, frw.ENC_MONTGOMERY, strict=True)
+        odw, odi, ods = oracle.witness_dual_ntt_verify(logn, sig, pk, hm, 1)
+        assert dst.tolist() == ods.tolist() == [0, 0] and np.array_equal(dwit, odw) and np.array_equal(dinst, odi)
+        assert _r1cs_all_satisfied(engine, 1, logn, torch.from_numpy(dwit.view(np.int64)).to(dev),
+                                   torch.from_numpy(dinst.view(np.int64)).to(dev)) == 0
 
 
 @pytest.mark.parametrize("logn", [9, 10])
