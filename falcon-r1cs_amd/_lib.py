@@ -60,6 +60,7 @@ PROTOTYPES = {
     "frw_witness_ntt_verify_compact_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_expand_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_expand_host": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_diag_launch_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_int32 * 4)]),
     "frw_layout_dual": (C.c_int, [C.c_int, C.POINTER(LayoutDualStruct)]),
     "frw_witness_dual_ntt_verify_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -170,6 +170,8 @@ int frw_witness_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const uint1
                                const uint16_t *d_hm, int encoding, uint64_t *d_witness, uint64_t *d_instance,
                                int32_t *d_status, void *stream)
 {
+    if (encoding == FRW_ENC_COMPACT)       // d_witness = compact buffer, d_instance unused (may be NULL)
+        return frw_witness_ntt_verify_compact_dev(ctx, logn, batch, d_sig, d_pk, d_hm, d_witness, d_status, stream);
     if (bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
     if (!d_sig || !d_pk || !d_hm || !d_witness || !d_instance || !d_status) return FRW_E_INVALID_ARG;
@@ -213,14 +215,16 @@ struct Event {
 int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t *sig, const uint16_t *pk,
                  const uint16_t *hm, int encoding, uint64_t *witness, uint64_t *instance, int32_t *status, int strict)
 {
-    if (bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
+    const bool compact = !dual && encoding == FRW_ENC_COMPACT;    // `witness` = compact buffer, `instance` unused
+    if (compact ? bad_common(ctx, logn, FRW_ENC_MONTGOMERY) : bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
-    if (!sig || !pk || !hm || !witness || !instance || !status) return FRW_E_INVALID_ARG;
+    if (!sig || !pk || !hm || !witness || (!instance && !compact) || !status) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << logn;
     const size_t nb = logn == 9 ? 50 : 52;
-    const size_t wbytes = (dual ? 186 * n + 4 + nb : 153 * n + nb) * 32, ibytes = (2 * n + 1) * 32;
-    const size_t chunk = std::min<size_t>(batch, 256);            // 2 x (<= 1.6 GB) of device witness
+    const size_t wbytes = compact ? frw::compact_layout(logn).bytes : (dual ? 186 * n + 4 + nb : 153 * n + nb) * 32;
+    const size_t ibytes = compact ? 16 : (2 * n + 1) * 32;
+    const size_t chunk = std::min<size_t>(batch, compact ? 2048 : 256);      // 2 x (<= 1.6 GB) of device witness
     DevBuf d_in[2][3], d_wit[2], d_inst[2], d_st[2];
     struct { hipStream_t s; } compute{ctx->host_compute}, copy{ctx->host_copy};
     Event done[2], drained[2];
@@ -246,6 +250,11 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
                                                         (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
                                                         (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
                                                         (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
+        else if (compact)
+            FRW_HIP(frw::launch_witness_ntt_verify_compact(ctx->d_tables, ctx->num_cu, logn, cnt,
+                                                           (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
+                                                           (const uint16_t *)d_in[b][2].p, d_wit[b].p, (int32_t *)d_st[b].p,
+                                                           compute.s));
         else
             FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, cnt,
                                                    (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
@@ -255,7 +264,8 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
         FRW_HIP(hipStreamWaitEvent(copy.s, done[b].e, 0));
         FRW_HIP(hipMemcpyAsync(status + lo, d_st[b].p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, copy.s));
         FRW_HIP(hipMemcpyAsync((char *)witness + lo * wbytes, d_wit[b].p, cnt * wbytes, hipMemcpyDeviceToHost, copy.s));
-        FRW_HIP(hipMemcpyAsync((char *)instance + lo * ibytes, d_inst[b].p, cnt * ibytes, hipMemcpyDeviceToHost, copy.s));
+        if (!compact)
+            FRW_HIP(hipMemcpyAsync((char *)instance + lo * ibytes, d_inst[b].p, cnt * ibytes, hipMemcpyDeviceToHost, copy.s));
         FRW_HIP(hipEventRecord(drained[b].e, copy.s));
     }
     FRW_HIP(hipStreamSynchronize(compute.s));
@@ -332,6 +342,42 @@ int frw_expand_dev(frw_ctx *ctx, int logn, size_t batch, const void *d_compact, 
     if (!d_compact || !d_witness || !d_instance || ((uintptr_t)d_compact & 15)) return FRW_E_INVALID_ARG;
     FRW_HIP(hipSetDevice(ctx->device));
     FRW_HIP(frw::launch_expand(ctx->num_cu, logn, batch, d_compact, d_witness, d_instance, (hipStream_t)stream));
+    return FRW_OK;
+}
+
+// Host-side expansion of compact signatures received over PCIe: data movement only (which 32-byte pattern goes where),
+// no arithmetic -- the counterpart of frw_expand_dev for a consumer that wants arkworks' vectors in host memory.
+int frw_expand_host(int logn, size_t batch, const void *compact, uint64_t *witness, uint64_t *instance)
+{
+    if ((logn != 9 && logn != 10) || (batch && (!compact || !witness || !instance))) return FRW_E_INVALID_ARG;
+    static const uint64_t ONE[4] = {0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull, 0x1824b159acc5056full};
+    const frw::CompactLayout c = frw::compact_layout(logn);
+    const size_t n = (size_t)1 << logn, nb = logn == 9 ? 50 : 52, W = 153 * n + nb, I = 2 * n + 1;
+    for (size_t s = 0; s < batch; s++) {
+        const unsigned char *base = (const unsigned char *)compact + s * c.bytes;
+        const uint64_t *val = (const uint64_t *)base;                     // next value element
+        const uint32_t *bits = (const uint32_t *)(base + c.bits_off);
+        size_t bit = 0;
+        uint64_t *w = witness + s * W * 4, *in = instance + s * I * 4;
+        auto value = [&](int count) { memcpy(w, val, (size_t)count * 32); w += count * 4; val += count * 4; };
+        auto booleans = [&](int count) {
+            for (int i = 0; i < count; i++, bit++, w += 4) {
+                if ((bits[bit >> 5] >> (bit & 31)) & 1u) memcpy(w, ONE, 32);
+                else memset(w, 0, 32);
+            }
+        };
+        memcpy(in, ONE, 32);
+        memcpy(in + 4, base + c.instance_off, 2 * n * 32);
+        value((int)(2 * n));                                              // S0, S1
+        booleans((int)(27 * n));                                          // S2
+        for (int seg = 0; seg < 2; seg++)                                 // S3, S4: [t, b, 27 booleans]
+            for (size_t k = 0; k < n; k++) { value(2); booleans(27); }
+        for (size_t k = 0; k < n; k++) { value(3); booleans(27); }         // S5: [prod, t, c, 27 booleans]
+        // S6: [16 booleans, r, sq]; its values follow the S5 values, its booleans follow the S5 booleans
+        for (size_t k = 0; k < 2 * n; k++) { booleans(16); value(2); }
+        bit = (4 * c.seg_words + n) * 32;                                 // S7 has two words of its own
+        booleans((int)nb);
+    }
     return FRW_OK;
 }
 

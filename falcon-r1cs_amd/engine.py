@@ -147,6 +147,32 @@ class WitnessEngine:
         check(rc, "frw_witness_ntt_verify")
         return wit, inst, st
 
+    def witness_ntt_verify_compact(self, logn, sig, pk, hm, strict=True, pinned=False):
+        """Host-buffer entry point with FRW_ENC_COMPACT: -> (compact u8[batch, bytes_per_signature], status)."""
+        CL = compact_layout(logn)
+        sig, pk, hm = (_u16(a, CL.n) for a in (sig, pk, hm))
+        batch = sig.shape[0]
+        mk = (lambda shape, dt: self.pinned_empty(shape, dt)) if pinned else (lambda shape, dt: np.zeros(shape, dtype=dt))
+        comp, st = mk((batch, CL.bytes_per_signature), np.uint8), mk((batch,), np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = self._lib.frw_witness_ntt_verify(self._ctx, logn, batch, p(sig), p(pk), p(hm), ENC_COMPACT, p(comp), None, p(st),
+                                              1 if strict else 0)
+        if rc == E_RANGE:
+            raise FrwError(rc, "frw_witness_ntt_verify", "Invalid input: a signature failed its range checks")
+        check(rc, "frw_witness_ntt_verify")
+        return comp, st
+
+    def expand_host(self, logn, compact):
+        """frw_expand_host: compact u8[batch, bytes_per_signature] -> (witness u64[batch, W, 4], instance u64[batch, I, 4])."""
+        L = layout(logn)
+        compact = np.ascontiguousarray(compact, dtype=np.uint8)
+        batch = compact.shape[0]
+        wit = np.empty((batch, L.num_witness, 4), dtype=np.uint64)
+        inst = np.empty((batch, L.num_instance, 4), dtype=np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(self._lib.frw_expand_host(logn, batch, p(compact), p(wit), p(inst)), "frw_expand_host")
+        return wit, inst
+
     def aggregate(self, items, encoding=ENC_MONTGOMERY, strict=True):
         """Aggregate driver (the reference's falcon-aggregate-sig is an empty stub, so the behaviour
         is defined here): a mixed batch of Falcon-512 / Falcon-1024 statements, each ``(logn, sig, pk, hm)``, is

@@ -92,3 +92,25 @@ def test_header_is_plain_c99(tmp_path):
                            "-Wl,-rpath," + os.path.join(ROOT, "falcon-r1cs_amd")])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+
+
+def test_expand_host_inverts_the_compact_relayout(oracle):
+    """frw_expand_host (host-side, no device): compact bytes built by re-laying out the oracle's witness
+    (tests/frw_testlib.compact_from_witness, written from include/frw.h's description) expand back to exactly that
+    witness / instance -- two independent statements of FRW_ENC_COMPACT agree."""
+    import ctypes as C
+    import numpy as np
+    import falcon_r1cs_amd as frw
+    import frw_testlib as T
+    lib = frw.load_library()
+    for logn in (9, 10):
+        CL = frw.compact_layout(logn)
+        assert CL.bytes_per_signature % 128 == 0 and CL.num_values == 13 << logn
+        sig, pk, hm = frw.synth_triples(logn, 3, seed=77)
+        wit, inst, st = oracle.witness_ntt_verify(logn, sig, pk, hm, 1)
+        comp = np.stack([np.frombuffer(T.compact_from_witness(logn, wit[k], inst[k], CL), dtype=np.uint8) for k in range(3)])
+        w2, i2 = np.empty_like(wit), np.empty_like(inst)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert lib.frw_expand_host(logn, 3, p(comp), p(w2), p(i2)) == 0
+        assert np.array_equal(w2, wit) and np.array_equal(i2, inst)
+    assert lib.frw_expand_host(11, 1, None, None, None) == -1

@@ -819,3 +819,22 @@ def test_expand_of_compact_equals_direct_output_full_launch(engine):
         torch.cuda.synchronize()
         assert hashlib.sha256(wit.cpu().numpy().tobytes()).hexdigest() == fx["witness_sha256"]["montgomery"]
         assert hashlib.sha256(inst.cpu().numpy().tobytes()).hexdigest() == fx["instance_sha256"]["montgomery"]
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_compact_host_path_and_host_expansion(engine, oracle, logn):
+    """frw_witness_ntt_verify(..., FRW_ENC_COMPACT, ...) through host buffers (more signatures than one pipeline chunk,
+    so both device buffers and both streams are in play), expanded on the host: == the oracle's witness for a sample,
+    == the direct host path for all statuses."""
+    import falcon_r1cs_amd as frw
+    batch = 2300
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=0x40 + logn)
+    sig[1234, 7] = T.Q
+    comp, st = engine.witness_ntt_verify_compact(logn, sig, pk, hm, strict=False)
+    assert st[1234] == frw.ST_COEFF_RANGE and int((st != 0).sum()) == 1 and not comp[1234].any()
+    idx = [0, 1, 255, 256, 2047, 2048, 2049, 2299]
+    wit, inst = engine.expand_host(logn, comp[idx])
+    owit, oinst, ost = oracle.witness_ntt_verify(logn, sig[idx], pk[idx], hm[idx], 1)
+    assert not ost.any() and np.array_equal(wit, owit) and np.array_equal(inst, oinst)
+    with pytest.raises(frw.FrwError):
+        engine.witness_ntt_verify_compact(logn, sig, pk, hm, strict=True)
