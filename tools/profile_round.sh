@@ -17,3 +17,6 @@ cd $REPO
 python3 tools/summarize_profiles.py $TAG $OUT/${TAG}_trace $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_f 32768 10 witness_ntt_verify_kernel
 python3 tools/summarize_profiles.py ${TAG}_verify512 $OUT/${TAG}_trace $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_f 8192 9 witness_ntt_verify_kernel
 python3 tools/summarize_profiles.py ${TAG}_cfg2 $OUT/${TAG}_trace $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_f 4096 9 ntt_modq_kernel
+# gpurun merges only gpurun_out/ back: leave copies of the summaries there
+mkdir -p $OUT/profiles_$TAG && cp $REPO/profiles/${TAG}_*hbm_traffic.json $REPO/profiles/${TAG}_*kernel_stats.csv $OUT/profiles_$TAG/
+cp $OUT/${TAG}_trace.json $OUT/profiles_$TAG/${TAG}_bench_under_rocprof.json

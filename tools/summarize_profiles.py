@@ -40,7 +40,8 @@ def main():
     kname = sys.argv[7] if len(sys.argv) > 7 else "witness_ntt_verify_kernel"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    shutil.copy(find(trace, "_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
+    if "_" not in tag:                         # the per-kernel tags (r02_verify512, ...) share the round's one trace
+        shutil.copy(find(trace, "_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
     kern = "%s<%d, 1" % (kname, logn)          # prefix: the hot kernel carries a third template argument (SPLIT)
     w, nw, _ = pmc_avg(pmc_w, "WRITE_SIZE", kern)
     f, nf, _ = pmc_avg(pmc_f, "FETCH_SIZE", kern)
