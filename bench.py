@@ -318,7 +318,9 @@ def gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d
     every GPU, so this curve is bounded by HBM write bandwidth at ~1/world of `value` per GPU -- not by xGMI."""
     CL = frw.compact_layout(logn)
     d_sig, d_pk, d_hm = d_in
-    gc = max(1, min(args.allgather_chunk or (chunk // world), chunk // world))
+    # signatures per rank per collective: 4,096 (2.1 GB of compact witnesses per rank, world x 2.1 GB gathered, twice for
+    # the double buffer) unless asked otherwise; the expansion target must fit the benchmark's witness buffer
+    gc = max(1, min(args.allgather_chunk or 4096, chunk // world))
     nk = batch // gc
     loc = [torch.empty((gc, CL.bytes_per_signature), dtype=torch.uint8, device=dev) for _ in range(2)]
     gathered = [torch.empty((world, gc, CL.bytes_per_signature), dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -358,13 +360,18 @@ def gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d
     eng.digest_dev(exp_wit, L.num_witness * 4, world * gc, dig, stream.cuda_stream)
     torch.cuda.synchronize()
     a = (nk - 1) * gc
-    own_wit = torch.empty((gc, L.num_witness, 4), dtype=torch.int64, device=dev)
     own_dig = torch.zeros(gc, dtype=torch.int64, device=dev)
-    eng.witness_ntt_verify_dev(logn, gc, d_sig[a:a + gc], d_pk[a:a + gc], d_hm[a:a + gc], own_wit, exp_inst[:gc], st,
+    own_inst = torch.empty((gc, L.num_instance, 4), dtype=torch.int64, device=dev)
+    # the direct launch goes into the part of the witness buffer the expansion does not occupy when there is room
+    # (world * gc <= chunk - gc), else into a buffer of its own
+    own_wit = d_wit[world * gc:(world + 1) * gc] if (world + 1) * gc <= d_wit.shape[0] else \
+        torch.empty((gc, L.num_witness, 4), dtype=torch.int64, device=dev)
+    eng.witness_ntt_verify_dev(logn, gc, d_sig[a:a + gc], d_pk[a:a + gc], d_hm[a:a + gc], own_wit, own_inst, st,
                                frw.ENC_MONTGOMERY, stream.cuda_stream)
     eng.digest_dev(own_wit, L.num_witness * 4, gc, own_dig, stream.cuda_stream)
     torch.cuda.synchronize()
-    own_ok = bool(torch.equal(own_dig, dig[rank * gc:(rank + 1) * gc]))
+    own_ok = bool(torch.equal(own_dig, dig[rank * gc:(rank + 1) * gc])) and \
+        bool(torch.equal(own_inst, exp_inst[rank * gc:(rank + 1) * gc]))
     all_dig = sharding.gather_per_signature(dig.to(cdev), world * world * gc, rank, world) if world > 1 else dig.to(cdev)
     same = all(bool(torch.equal(all_dig[r * world * gc:(r + 1) * world * gc], all_dig[:world * gc])) for r in range(world))
     del own_wit
