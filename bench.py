@@ -223,6 +223,45 @@ def time_compact(eng, dev, logn, batch, launches, warm, d_in, d_wit):
     return out
 
 
+def time_aggregate(eng, dev, total, reps, threads):
+    """BASELINE configs[4] shape on one GPU: one aggregate statement of `total` signatures, Falcon-512 and Falcon-1024
+    mixed (parameter set drawn from the seed), = one engine launch per parameter set (the reference's
+    falcon-aggregate-sig is an empty stub).  Latency of the whole aggregate witness."""
+    import random
+    rng = random.Random(SEED)
+    logns = [rng.choice([9, 10]) for _ in range(total)]
+    stream = torch.cuda.current_stream()
+    groups = []
+    for logn in (9, 10):
+        cnt = sum(1 for l in logns if l == logn)
+        L = frw.layout(logn)
+        sig, pk, hm = synth(logn, cnt, 1 << 41, threads)
+        d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+        groups.append((logn, cnt, d, torch.empty((cnt, L.num_witness, 4), dtype=torch.int64, device=dev),
+                       torch.empty((cnt, L.num_instance, 4), dtype=torch.int64, device=dev),
+                       torch.empty(cnt, dtype=torch.int32, device=dev), L))
+
+    def run():
+        for logn, cnt, d, wit, inst, st, _ in groups:
+            eng.witness_ntt_verify_dev(logn, cnt, d[0], d[1], d[2], wit, inst, st, frw.ENC_MONTGOMERY, stream.cuda_stream)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    assert all(int((g[5] != 0).sum().item()) == 0 for g in groups)
+    nbytes = sum(g[1] * 32 * (g[6].num_witness + g[6].num_instance) for g in groups)
+    return {"workload": "one aggregate statement of %d mixed signatures (%d Falcon-512 + %d Falcon-1024), two launches"
+                        % (total, groups[0][1], groups[1][1]),
+            "ms_per_aggregate": round(ms, 4), "signatures_per_s": round(total / (ms * 1e-3), 1),
+            "bytes_written_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1), "aggregates_timed": reps}
+
+
 def bench_ntt_modq(args, world, rank, dev):
     """--workload ntt_modq: BASELINE configs[1] as the primary line."""
     eng = frw.WitnessEngine(dev.index)
@@ -673,7 +712,8 @@ def main():
             result["secondary"] = {
                 "ntt_modq_falcon512_batch4096": time_ntt_modq(eng, dev, 9, 4096, 200, 20),
                 "verify_falcon512_8192_per_launch": time_verify(eng, dev, 9, 8192, 12, 3, threads),
-                "compact_encoding_falcon%d" % n: time_compact(eng, dev, logn, chunk, 4, 1, (d_sig, d_pk, d_hm), d_wit)}
+                "compact_encoding_falcon%d" % n: time_compact(eng, dev, logn, chunk, 4, 1, (d_sig, d_pk, d_hm), d_wit),
+                "aggregate_1024_mixed": time_aggregate(eng, dev, 1024, 50, threads)}
         if world == 1 and not args.no_cpu_baseline and not dual:
             slots = np.arange(0, held, max(1, held // 4096))[:4096]        # strided over the whole buffer
             digest_of = {int(slot_sig[j]): int(held_dig[j]) for j in slots}

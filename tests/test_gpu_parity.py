@@ -649,10 +649,11 @@ def _r1cs_all_satisfied(engine, circuit, logn, wit, inst):
     return int((bad != 0).sum().item())
 
 
-@pytest.mark.parametrize("logn,batch", [(10, 16384), (9, 8192)])
+@pytest.mark.parametrize("logn,batch", [(10, 32768), (9, 8192)])
 def test_benchmark_launch_shape_is_checked(engine, oracle, logn, batch):
-    """The launch shape bench.py times (BASELINE configs[2]: 16,384 Falcon-1024 signatures per launch = persistent grid at
-    its residency cap, ~21 rounds, work-queue tail; and the Falcon-512 counterpart, 8,192 per launch, static striding):
+    """The launch shapes bench.py times (BASELINE configs[2]: 32,768 Falcon-1024 signatures per launch = persistent grid at
+    its residency cap, 42 full rounds of static striding + 512 signatures cut into five work items each; and the
+    Falcon-512 launch of its `secondary` block, 8,192 signatures = 10 rounds + 512 split):
     every witness of the launch satisfies the independently emitted constraint system on the device
     (falcon_ntt.rs:159), a strided sample of 256 + the last one equals the oracle's witness by digest, all statuses OK."""
     import falcon_r1cs_amd as frw
