@@ -425,6 +425,58 @@ def gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d
             "expanded_own_shard_equals_direct_output": own_ok, "expanded_digests_identical_on_all_ranks": same}
 
 
+def regenerate_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d_wit, d_inst, stream):
+    """Third curve, the recompute-instead-of-communicate form of 'every GPU holds every witness': all-gather the 6 KB
+    INPUTS of a chunk and let every GPU run the witness kernel over all `world` shards itself.  The fabric carries
+    0.1 % of the bytes; each GPU writes world x 5 MB per signature of its shard size, so like the compact curve this is
+    bounded by one GPU's HBM write rate for the whole node -- with the generator's rate instead of the expander's."""
+    d_sig, d_pk, d_hm = d_in
+    n = L.n
+    gc = max(1, min(args.allgather_chunk or 4096, chunk // world))
+    nk = batch // gc
+    loc = [torch.empty((3, gc, n), dtype=torch.int16, device=dev) for _ in range(2)]
+    gathered = [torch.empty((world, 3, gc, n), dtype=torch.int16, device=dev) for _ in range(2)]
+    st = torch.empty(world * gc, dtype=torch.int32, device=dev)
+    nccl = args.backend == "nccl"
+
+    def generate(g):
+        for r in range(world):
+            eng.witness_ntt_verify_dev(logn, gc, g[r, 0], g[r, 1], g[r, 2], d_wit[r * gc:(r + 1) * gc], d_inst[r * gc:(r + 1) * gc],
+                                       st[r * gc:(r + 1) * gc], frw.ENC_MONTGOMERY, stream.cuda_stream)
+
+    def run(k_count):
+        works = [None, None]
+        for k in range(k_count):
+            b = k & 1
+            a = k * gc
+            loc[b][0].copy_(d_sig[a:a + gc])          # the gather that read loc[b] two iterations ago has been waited for
+            loc[b][1].copy_(d_pk[a:a + gc])
+            loc[b][2].copy_(d_hm[a:a + gc])
+            works[b] = sharding.all_gather_chunks(loc[b], gathered[b], async_op=nccl)
+            if k >= 1:
+                if works[1 - b] is not None:
+                    works[1 - b].wait()
+                generate(gathered[1 - b])
+        b = (k_count - 1) & 1
+        if works[b] is not None:
+            works[b].wait()
+        generate(gathered[b])
+
+    run(min(2, nk))
+    torch.cuda.synchronize()
+    sharding.barrier()
+    t0 = time.perf_counter()
+    run(nk)
+    torch.cuda.synchronize()
+    sharding.barrier()
+    t = sharding.max_over_ranks(time.perf_counter() - t0, cdev)
+    ok = int((st != 0).sum().item()) == 0
+    return {"signatures_per_s_node": round(world * nk * gc / t, 1), "seconds": round(t, 4), "chunk_per_rank": gc, "chunks": nk,
+            "wire_format": "the (sig, pk, hm) coefficient vectors, %d bytes per signature" % (6 * n),
+            "witness_bytes_written_GBs_per_gpu": round(world * nk * gc * 32 * (L.num_witness + L.num_instance) / t / 1e9, 1),
+            "all_statuses_ok": ok}
+
+
 def arkworks_gather_probe(args, eng, dev, cdev, world, rank, logn, L, d_in, d_wit, d_inst, d_st, stream, chunk):
     """Bounded probe of the naive form (32-byte elements over the wire), for the xGMI ceiling it runs into."""
     d_sig, d_pk, d_hm = d_in
@@ -649,6 +701,8 @@ def main():
         try:
             gather_info = gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit, d_st,
                                      stream)
+            gather_info["allgather_inputs_and_regenerate"] = regenerate_leg(
+                args, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit, d_inst, stream)
             gather_info["naive_32_byte_elements_probe"] = arkworks_gather_probe(
                 args, eng, dev, cdev, world, rank, logn, L, (d_sig, d_pk, d_hm), d_wit, d_inst, d_st, stream, chunk)
         except Exception as ex:      # the primary metric must not depend on this leg

@@ -65,10 +65,13 @@ def all_gather_chunks(local, gathered, async_op=False):
     if not is_dist():
         gathered[0].copy_(local)
         return None
+    # the collectives move bytes: 16-bit tensors (the input polynomials) are not a type every backend accepts
+    lb, gb = local.reshape(-1).view(torch.uint8), gathered.reshape(-1).view(torch.uint8)
     if dist.get_backend() == "nccl":
-        return dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), async_op=async_op)
-    host = [torch.empty(local.shape, dtype=local.dtype) for _ in range(dist.get_world_size())]
-    dist.all_gather(host, local.cpu())
+        return dist.all_gather_into_tensor(gb, lb, async_op=async_op)
+    host = [torch.empty(lb.shape, dtype=torch.uint8) for _ in range(dist.get_world_size())]
+    dist.all_gather(host, lb.cpu())
+    n = lb.numel()
     for r, h in enumerate(host):
-        gathered[r].copy_(h)
+        gb[r * n:(r + 1) * n].copy_(h)
     return None

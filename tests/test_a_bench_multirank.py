@@ -44,5 +44,6 @@ def test_two_ranks_reproduce_the_one_rank_run(tmp_path):
     assert "error" not in g, g
     assert g["expanded_own_shard_equals_direct_output"] and g["expanded_digests_identical_on_all_ranks"]
     assert g["signatures_per_rank"] == 256
+    assert g["allgather_inputs_and_regenerate"]["all_statuses_ok"] and g["naive_32_byte_elements_probe"]["signatures_per_s_node"] > 0
     assert j1["launch_shape_checked"]["signatures"] == 256 and j1["r1cs_check"]["witnesses_checked"] == 256
     assert j1["launch_shape_checked"]["from_the_last_timed_launch"] == 256
