@@ -1,0 +1,196 @@
+//! `FalconNTTVerificationCircuit` with its witness assignment computed on the GPU.
+//!
+//! The reference circuit (`falcon-r1cs/src/circuits/falcon_ntt.rs:8-123`) is used as it is: in prove mode
+//! [`AcceleratedNTTCircuit`] runs it with the constraint system switched to `SynthesisMode::Setup`, so that arkworks
+//! allocates every variable and records every constraint but evaluates no value closure (the gadgets substitute
+//! `F::one()` themselves in that mode: `arithmetics.rs:121-125`, `range_proofs.rs:49-53`, `:106-110`, `:197-201`,
+//! `:295-299`), then switches back and installs the two assignment vectors from the engine.  The engine's buffers
+//! are in arkworks' allocation order and in `Fp256`'s in-memory (Montgomery) representation, so installing them is a
+//! reinterpretation, not a conversion.
+//!
+//! Not compiled in the repository this file ships in (no Rust toolchain there); see `rust/README.md`.
+
+use std::os::raw::c_int;
+
+use ark_bls12_381::Fr;
+use ark_ff::{BigInteger256, Fp256};
+use ark_relations::r1cs::{ConstraintSynthesizer, ConstraintSystemRef, Result as R1csResult, SynthesisError, SynthesisMode};
+use falcon_r1cs::FalconNTTVerificationCircuit;
+use falcon_rust::{NTTPolynomial, Polynomial, PublicKey, Signature, LOG_N, N};
+use frw_sys as sys;
+
+/// A failed engine call: the negative `FRW_E_*` code and its text.
+#[derive(Debug)]
+pub struct EngineError {
+    pub code: i32,
+    pub what: String,
+}
+
+fn check(code: c_int) -> Result<(), EngineError> {
+    if code == sys::FRW_OK {
+        return Ok(());
+    }
+    let what = unsafe { std::ffi::CStr::from_ptr(sys::frw_strerror(code)).to_string_lossy().into_owned() };
+    Err(EngineError { code, what })
+}
+
+/// One context on one HIP device.  Like a `ConstraintSystemRef` it is used by one thread at a time.
+pub struct Engine {
+    ctx: *mut sys::frw_ctx,
+}
+
+impl Engine {
+    pub fn new(device: i32) -> Result<Self, EngineError> {
+        let mut ctx = std::ptr::null_mut();
+        check(unsafe { sys::frw_ctx_create(device, &mut ctx) })?;
+        Ok(Self { ctx })
+    }
+}
+
+impl Drop for Engine {
+    fn drop(&mut self) {
+        unsafe { sys::frw_ctx_destroy(self.ctx) }
+    }
+}
+
+/// The two assignment vectors of one signature's constraint system, exactly as arkworks would hold them.
+#[derive(Clone, Debug)]
+pub struct Assignment {
+    /// `cs.witness_assignment`: W = 153 N + {50 | 52} elements, allocation order of falcon_ntt.rs:58-122
+    pub witness: Vec<Fr>,
+    /// `cs.instance_assignment`: [1, pk_ntt, hm_ntt] (falcon_ntt.rs:63,67)
+    pub instance: Vec<Fr>,
+    /// FRW_ST_OK | FRW_ST_COEFF_RANGE | FRW_ST_NORM_BOUND
+    pub status: i32,
+}
+
+#[inline]
+fn fr_from_montgomery_limbs(l: &[u64]) -> Fr {
+    // ark-ff 0.3: `pub struct Fp256<P>(pub BigInteger256, pub PhantomData<P>)`; `Fp256::new` takes the limbs verbatim
+    Fp256::new(BigInteger256([l[0], l[1], l[2], l[3]]))
+}
+
+impl Engine {
+    /// Witness and instance assignment of a batch of statements in ONE engine call.
+    /// `strict` mirrors the reference's non-test build: a signature whose norm reaches the bound is an error there
+    /// (`range_proofs.rs:114-117,205-208` panic), `FRW_E_RANGE` here.
+    pub fn witness_ntt_verify(
+        &self,
+        statements: &[(&PublicKey, &[u8], &Signature)],
+        strict: bool,
+    ) -> Result<Vec<Assignment>, EngineError> {
+        let batch = statements.len();
+        let (mut sig, mut pk, mut hm) = (Vec::with_capacity(batch * N), Vec::with_capacity(batch * N), Vec::with_capacity(batch * N));
+        for (p, msg, s) in statements {
+            // the same three coefficient vectors the reference derives at falcon_ntt.rs:27-28,44
+            let sig_poly: Polynomial = (*s).into();
+            let pk_poly: Polynomial = (*p).into();
+            let hm_poly = Polynomial::from_hash_of_message(msg, s.nonce());
+            sig.extend_from_slice(sig_poly.coeff());
+            pk.extend_from_slice(pk_poly.coeff());
+            hm.extend_from_slice(hm_poly.coeff());
+        }
+        let mut layout = sys::frw_layout_t::default();
+        check(unsafe { sys::frw_layout(LOG_N as c_int, &mut layout) })?;
+        let (w, i) = (layout.num_witness as usize, layout.num_instance as usize);
+        let mut wit = vec![0u64; batch * w * 4];
+        let mut inst = vec![0u64; batch * i * 4];
+        let mut status = vec![0i32; batch];
+        check(unsafe {
+            sys::frw_witness_ntt_verify(self.ctx, LOG_N as c_int, batch, sig.as_ptr(), pk.as_ptr(), hm.as_ptr(),
+                                        sys::FRW_ENC_MONTGOMERY, wit.as_mut_ptr(), inst.as_mut_ptr(),
+                                        status.as_mut_ptr(), strict as c_int)
+        })?;
+        Ok((0..batch)
+            .map(|k| Assignment {
+                witness: wit[k * w * 4..(k + 1) * w * 4].chunks_exact(4).map(fr_from_montgomery_limbs).collect(),
+                instance: inst[k * i * 4..(k + 1) * i * 4].chunks_exact(4).map(fr_from_montgomery_limbs).collect(),
+                status: status[k],
+            })
+            .collect())
+    }
+}
+
+/// The reference circuit plus the assignment the engine computed for it.
+pub struct AcceleratedNTTCircuit {
+    inner: FalconNTTVerificationCircuit,
+    assignment: Assignment,
+}
+
+impl AcceleratedNTTCircuit {
+    /// `assignment` must come from [`Engine::witness_ntt_verify`] for the same `(pk, msg, sig)`.
+    pub fn build_circuit(pk: PublicKey, msg: Vec<u8>, sig: Signature, assignment: Assignment) -> Self {
+        Self { inner: FalconNTTVerificationCircuit::build_circuit(pk, msg, sig), assignment }
+    }
+}
+
+impl ConstraintSynthesizer<Fr> for AcceleratedNTTCircuit {
+    fn generate_constraints(self, cs: ConstraintSystemRef<Fr>) -> R1csResult<()> {
+        if cs.is_in_setup_mode() {
+            // circuit_specific_setup: structure only, nothing to accelerate (examples/pok_sig.rs:30-31)
+            return self.inner.generate_constraints(cs);
+        }
+        // prove mode: structure pass without value closures ...
+        let construct_matrices = cs.should_construct_matrices();
+        cs.set_mode(SynthesisMode::Setup);
+        let structure = self.inner.generate_constraints(cs.clone());
+        cs.set_mode(SynthesisMode::Prove { construct_matrices });
+        structure?;
+        // ... then the values, wholesale
+        let mut sys = cs.borrow_mut().ok_or(SynthesisError::MissingCS)?;
+        if sys.num_witness_variables != self.assignment.witness.len()
+            || sys.num_instance_variables != self.assignment.instance.len()
+        {
+            return Err(SynthesisError::Unsatisfiable); // the engine was asked for another parameter set
+        }
+        sys.witness_assignment = self.assignment.witness;
+        sys.instance_assignment = self.assignment.instance;
+        Ok(())
+    }
+}
+
+/// The public inputs a verifier feeds `verify_proof` with, as examples/pok_sig.rs:33-45 computes them.
+pub fn public_inputs(pk: &PublicKey, msg: &[u8], sig: &Signature) -> Vec<Fr> {
+    let pk_ntt = NTTPolynomial::from(&Polynomial::from(pk));
+    let hm_ntt = NTTPolynomial::from(&Polynomial::from_hash_of_message(msg, sig.nonce()));
+    pk_ntt.coeff().iter().chain(hm_ntt.coeff().iter()).map(|e| Fr::from(*e)).collect()
+}
+
+#[cfg(test)]
+mod tests {
+    use super::*;
+    use ark_relations::r1cs::ConstraintSystem;
+    use falcon_rust::KeyPair;
+
+    /// The reference's own end-to-end test (falcon_ntt.rs:133-160) on the accelerated circuit, plus the one check that
+    /// would PIN the engine's parity: its witness equals, element by element, the one arkworks computes on the CPU.
+    #[test]
+    fn accelerated_circuit_is_satisfied_and_equals_the_cpu_witness() {
+        let keypair = KeyPair::keygen();
+        let msg = "testing message";
+        let sig = keypair.secret_key.sign_with_seed("test seed".as_ref(), msg.as_ref());
+        assert!(keypair.public_key.verify(msg.as_ref(), &sig));
+
+        let engine = Engine::new(0).expect("an MI355X and libfrw.so");
+        let a = engine.witness_ntt_verify(&[(&keypair.public_key, msg.as_bytes(), &sig)], true).unwrap().remove(0);
+        assert_eq!(a.status, frw_sys::FRW_ST_OK);
+
+        // CPU: the reference as it is
+        let cpu = ConstraintSystem::<Fr>::new_ref();
+        FalconNTTVerificationCircuit::build_circuit(keypair.public_key, msg.as_bytes().to_vec(), sig)
+            .generate_constraints(cpu.clone())
+            .unwrap();
+        assert!(cpu.is_satisfied().unwrap());
+
+        // GPU values, same structure
+        let gpu = ConstraintSystem::<Fr>::new_ref();
+        AcceleratedNTTCircuit::build_circuit(keypair.public_key, msg.as_bytes().to_vec(), sig, a)
+            .generate_constraints(gpu.clone())
+            .unwrap();
+        assert!(gpu.is_satisfied().unwrap());
+        assert_eq!(gpu.num_constraints(), cpu.num_constraints());
+        let (g, c) = (gpu.borrow().unwrap(), cpu.borrow().unwrap());
+        assert_eq!(g.instance_assignment, c.instance_assignment);
+        assert_eq!(g.witness_assignment, c.witness_assignment);
+    }
+}

@@ -1,0 +1,143 @@
+//! Raw bindings of `include/frw.h`, one declaration per exported function, same order as the header.
+//! Checked against the header by `tests/test_rust_binding.py` (names and parameter counts).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const FRW_OK: c_int = 0;
+pub const FRW_E_INVALID_ARG: c_int = -1;
+pub const FRW_E_NO_DEVICE: c_int = -2;
+pub const FRW_E_HIP: c_int = -3;
+pub const FRW_E_OUT_OF_MEMORY: c_int = -4;
+pub const FRW_E_RANGE: c_int = -5;
+
+pub const FRW_ENC_CANONICAL: c_int = 0;
+/// x * 2^256 mod p: the in-memory limbs of `ark_ff::Fp256` (ark-ff 0.3)
+pub const FRW_ENC_MONTGOMERY: c_int = 1;
+pub const FRW_ENC_COMPACT: c_int = 2;
+
+pub const FRW_ST_OK: i32 = 0;
+pub const FRW_ST_COEFF_RANGE: i32 = 1;
+pub const FRW_ST_NORM_BOUND: i32 = 2;
+pub const FRW_ST_DECODE: i32 = 3;
+
+pub const FRW_CIRCUIT_NTT: c_int = 0;
+pub const FRW_CIRCUIT_DUAL_NTT: c_int = 1;
+pub const FRW_NONCE_LEN: usize = 40;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct frw_layout_t {
+    pub logn: i32,
+    pub n: i32,
+    pub num_witness: i32,
+    pub num_instance: i32,
+    pub num_constraints: i32,
+    pub seg_off: [i32; 8],
+    pub seg_len: [i32; 8],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct frw_layout_dual_t {
+    pub logn: i32,
+    pub n: i32,
+    pub num_witness: i32,
+    pub num_instance: i32,
+    pub num_constraints: i32,
+    pub seg_off: [i32; 15],
+    pub seg_len: [i32; 15],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct frw_compact_layout_t {
+    pub logn: i32,
+    pub n: i32,
+    pub bytes_per_signature: u64,
+    pub values_off: u64,
+    pub num_values: u64,
+    pub bits_off: u64,
+    pub num_bit_words: u64,
+    pub bit_seg_off: [u64; 6],
+    pub instance_off: u64,
+    pub num_instance_values: u64,
+}
+
+#[repr(C)]
+pub struct frw_ctx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct frw_r1cs {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn frw_layout(logn: c_int, out: *mut frw_layout_t) -> c_int;
+    pub fn frw_strerror(code: c_int) -> *const c_char;
+    pub fn frw_last_error() -> *const c_char;
+    pub fn frw_device_count() -> c_int;
+    pub fn frw_ctx_create(device: c_int, out: *mut *mut frw_ctx) -> c_int;
+    pub fn frw_ctx_destroy(ctx: *mut frw_ctx);
+    pub fn frw_witness_ntt_verify_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_sig: *const u16, d_pk: *const u16,
+                                      d_hm: *const u16, encoding: c_int, d_witness: *mut u64, d_instance: *mut u64,
+                                      d_status: *mut i32, stream: *mut c_void) -> c_int;
+    pub fn frw_ntt_modq_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_poly: *const u16, encoding: c_int,
+                            d_witness: *mut u64, d_ntt_out: *mut u16, d_status: *mut i32, stream: *mut c_void) -> c_int;
+    pub fn frw_witness_ntt_verify(ctx: *mut frw_ctx, logn: c_int, batch: usize, sig: *const u16, pk: *const u16,
+                                  hm: *const u16, encoding: c_int, witness: *mut u64, instance: *mut u64,
+                                  status: *mut i32, strict: c_int) -> c_int;
+    pub fn frw_ntt_modq(ctx: *mut frw_ctx, logn: c_int, batch: usize, poly: *const u16, encoding: c_int,
+                        witness: *mut u64, ntt_out: *mut u16, status: *mut i32) -> c_int;
+    pub fn frw_compact_layout(logn: c_int, out: *mut frw_compact_layout_t) -> c_int;
+    pub fn frw_witness_ntt_verify_compact_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_sig: *const u16,
+                                              d_pk: *const u16, d_hm: *const u16, d_compact: *mut c_void,
+                                              d_status: *mut i32, stream: *mut c_void) -> c_int;
+    pub fn frw_expand_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_compact: *const c_void, d_witness: *mut u64,
+                          d_instance: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn frw_expand_host(logn: c_int, batch: usize, compact: *const c_void, witness: *mut u64,
+                           instance: *mut u64) -> c_int;
+    pub fn frw_layout_dual(logn: c_int, out: *mut frw_layout_dual_t) -> c_int;
+    pub fn frw_witness_dual_ntt_verify_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_sig: *const u16,
+                                           d_pk: *const u16, d_hm: *const u16, encoding: c_int, d_witness: *mut u64,
+                                           d_instance: *mut u64, d_status: *mut i32, stream: *mut c_void) -> c_int;
+    pub fn frw_witness_dual_ntt_verify(ctx: *mut frw_ctx, logn: c_int, batch: usize, sig: *const u16, pk: *const u16,
+                                       hm: *const u16, encoding: c_int, witness: *mut u64, instance: *mut u64,
+                                       status: *mut i32, strict: c_int) -> c_int;
+    pub fn frw_r1cs_export(circuit: c_int, logn: c_int, path: *const c_char, counts: *mut u64) -> c_int;
+    pub fn frw_r1cs_load(device: c_int, circuit: c_int, logn: c_int, out: *mut *mut frw_r1cs) -> c_int;
+    pub fn frw_r1cs_free(r: *mut frw_r1cs);
+    pub fn frw_r1cs_check_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
+                              d_num_unsatisfied: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn frw_r1cs_eval_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
+                             d_num_unsatisfied: *mut u32, d_abc: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn frw_hash_to_point_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_nonces: *const u8, d_msgs: *const u8,
+                                 d_msg_off: *const u64, d_hm: *mut u16, stream: *mut c_void) -> c_int;
+    pub fn frw_decode_public_keys_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_pk_bytes: *const u8,
+                                      d_pk: *mut u16, d_status: *mut i32, stream: *mut c_void) -> c_int;
+    pub fn frw_decode_signatures_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_sig_bytes: *const u8,
+                                     sig_len: usize, d_sig: *mut u16, d_nonce_out: *mut u8, d_status: *mut i32,
+                                     stream: *mut c_void) -> c_int;
+    pub fn frw_prepare_inputs(ctx: *mut frw_ctx, logn: c_int, batch: usize, pk_bytes: *const u8, sig_bytes: *const u8,
+                              sig_len: usize, msgs: *const u8, msg_off: *const u64, sig: *mut u16, pk: *mut u16,
+                              hm: *mut u16, status: *mut i32) -> c_int;
+    pub fn frw_gadget_block_len(kind: c_int) -> c_int;
+    pub fn frw_gadget_dev(ctx: *mut frw_ctx, kind: c_int, count: usize, d_a: *const c_void, d_b: *const u64,
+                          encoding: c_int, d_out: *mut u64, d_status: *mut i32, stream: *mut c_void) -> c_int;
+    pub fn frw_gadget(ctx: *mut frw_ctx, kind: c_int, count: usize, a: *const c_void, b: *const u64, encoding: c_int,
+                      out: *mut u64, status: *mut i32) -> c_int;
+    pub fn frw_digest_dev(ctx: *mut frw_ctx, d_buf: *const u64, words_per_item: usize, items: usize, d_out: *mut u64,
+                          stream: *mut c_void) -> c_int;
+    pub fn frw_diag_launch_shape(ctx: *mut frw_ctx, logn: c_int, encoding: c_int, batch: usize, out: *mut i32) -> c_int;
+    pub fn frw_diag_write_stream_dev(ctx: *mut frw_ctx, d_buf: *mut c_void, bytes: usize, slab_bytes: usize,
+                                     stream: *mut c_void) -> c_int;
+    pub fn frw_synth_triples(logn: c_int, batch: usize, seed: u64, first_index: u64, sig: *mut u16, pk: *mut u16,
+                             hm: *mut u16) -> c_int;
+    pub fn frw_host_alloc(ctx: *mut frw_ctx, bytes: usize, ptr: *mut *mut c_void) -> c_int;
+    pub fn frw_host_free(ctx: *mut frw_ctx, ptr: *mut c_void) -> c_int;
+    pub fn frw_malloc(ctx: *mut frw_ctx, bytes: usize, d_ptr: *mut *mut c_void) -> c_int;
+    pub fn frw_free(ctx: *mut frw_ctx, d_ptr: *mut c_void) -> c_int;
+    pub fn frw_memcpy_h2d(ctx: *mut frw_ctx, d_dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    pub fn frw_memcpy_d2h(ctx: *mut frw_ctx, dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
+    pub fn frw_synchronize(ctx: *mut frw_ctx, stream: *mut c_void) -> c_int;
+}
