@@ -8,15 +8,16 @@
 // (sig, pk, hm); this file evaluates it for a batch, one workgroup (4 wavefronts) per signature.
 //
 // Shape of the work: 6 KB of input becomes 5.0 MB of output per Falcon-1024 signature, 91 % of it
-// field elements that are 0 or 1.  The kernel is an HBM write stream (measured: 97 % of a compute-free
-// write stream on the same device, HBM traffic = 1.0001 x the algorithmic bytes); the integer work (mod-q
-// NTTs, the un-reduced 160-bit butterfly ladder, short divisions, Montgomery conversions, and above all
-// the ~26 instructions per store of the tile writer) lives in LDS/registers and overlaps with the stores
-// of the other resident wavefronts.  No MFMA: nothing here is GEMM-shaped.
+// field elements that are 0 or 1.  The kernel is an HBM write stream (measured in round 2: 0.98-1.01 of a
+// compute-free write stream on the same device, 6.5-6.7 TB/s = 0.81-0.84 of the 8 TB/s spec, HBM traffic =
+// 1.0002 x the algorithmic bytes); the integer work (mod-q NTTs, the un-reduced 160-bit butterfly ladder, short
+// divisions, Montgomery conversions, the tile writer's 3 vector instructions per store) lives in LDS/registers
+// and overlaps with the stores of the other resident wavefronts.  No MFMA: nothing here is GEMM-shaped.
 //
-// Kernels in this file: witness_ntt_verify_kernel (the hot path), witness_dual_ntt_verify_kernel (the
-// signed-split variant, falcon_dual_ntt.rs), ntt_modq_kernel (ntt_circuit alone), gadget_kernel (the gadgets
-// called on their own), digest_kernel and write_stream_kernel (verification / calibration utilities).
+// Kernels in this file: witness_ntt_verify_kernel (the hot path; ENC = 2 writes the compact encoding),
+// witness_dual_ntt_verify_kernel (the signed-split variant, falcon_dual_ntt.rs), ntt_modq_kernel (ntt_circuit alone),
+// expand_kernel (compact -> arkworks layout), gadget_kernel (the gadgets called on their own), digest_kernel and
+// write_stream_kernel (verification / calibration utilities).
 //
 // Data flow of one workgroup
 //   1. inputs -> LDS (u16), range check
@@ -27,7 +28,7 @@
 // A tile = 64 gadget blocks = one wavefront: lane k computes block k's few non-boolean elements
 // (converted to the field encoding, parked in a per-wave LDS slab) and a <=30-bit mask of its
 // boolean elements; the wave then walks the tile's bytes in order, every lane producing 16 B per
-// store instruction, so each global_store_dwordx4 writes 1 KiB of contiguous HBM.
+// store instruction, so each buffer_store_dwordx4 writes 1 KiB of contiguous HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
