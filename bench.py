@@ -527,6 +527,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="N = 1 only: skip the untimed secondary rooflines (NTT + mod_q kernel at BASELINE configs[1], "
                          "Falcon-512 full verify)")
+    ap.add_argument("--no-aggregate", action="store_true",
+                    help="N = 1 only: leave the 1,024-signature mixed aggregate (BASELINE configs[4] shape) out of `secondary` "
+                         "(the profiling passes do: its small launches of the same kernels would blur the per-kernel averages)")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1 only: skip the second curve, 'generate + RCCL all-gather of the witness vectors'")
     ap.add_argument("--allgather-chunk", type=int, default=0, help="signatures per rank per all-gather (default chunk/world)")
@@ -766,8 +769,9 @@ def main():
             result["secondary"] = {
                 "ntt_modq_falcon512_batch4096": time_ntt_modq(eng, dev, 9, 4096, 200, 20),
                 "verify_falcon512_8192_per_launch": time_verify(eng, dev, 9, 8192, 12, 3, threads),
-                "compact_encoding_falcon%d" % n: time_compact(eng, dev, logn, chunk, 4, 1, (d_sig, d_pk, d_hm), d_wit),
-                "aggregate_1024_mixed": time_aggregate(eng, dev, 1024, 50, threads)}
+                "compact_encoding_falcon%d" % n: time_compact(eng, dev, logn, chunk, 4, 1, (d_sig, d_pk, d_hm), d_wit)}
+            if not args.no_aggregate:
+                result["secondary"]["aggregate_1024_mixed"] = time_aggregate(eng, dev, 1024, 50, threads)
         if world == 1 and not args.no_cpu_baseline and not dual:
             slots = np.arange(0, held, max(1, held // 4096))[:4096]        # strided over the whole buffer
             digest_of = {int(slot_sig[j]): int(held_dig[j]) for j in slots}

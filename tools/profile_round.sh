@@ -9,10 +9,10 @@ OUT=$REPO/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 # trace: the default benchmark (all three kernels of the JSON line run in it), without the CPU-side extras
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-r1cs-check > $OUT/${TAG}_trace.json 2> $OUT/${TAG}_trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-r1cs-check --no-aggregate > $OUT/${TAG}_trace.json 2> $OUT/${TAG}_trace.log
 # counters: one step is enough (2 launches of the dominant kernel + the secondary kernels)
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_w -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-r1cs-check > /dev/null 2> $OUT/${TAG}_pmc_w.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_f -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-r1cs-check > /dev/null 2> $OUT/${TAG}_pmc_f.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_w -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-r1cs-check --no-aggregate > /dev/null 2> $OUT/${TAG}_pmc_w.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_f -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-r1cs-check --no-aggregate > /dev/null 2> $OUT/${TAG}_pmc_f.log
 cd $REPO
 python3 tools/summarize_profiles.py $TAG $OUT/${TAG}_trace $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_f 32768 10 witness_ntt_verify_kernel
 python3 tools/summarize_profiles.py ${TAG}_verify512 $OUT/${TAG}_trace $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_f 8192 9 witness_ntt_verify_kernel
