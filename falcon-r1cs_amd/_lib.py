@@ -35,7 +35,8 @@ class LayoutDualStruct(C.Structure):
 
 class CompactLayoutStruct(C.Structure):
     _fields_ = [("logn", C.c_int32), ("n", C.c_int32), ("bytes_per_signature", C.c_uint64),
-                ("values_off", C.c_uint64), ("num_values", C.c_uint64), ("bits_off", C.c_uint64),
+                ("small_off", C.c_uint64), ("num_small", C.c_uint64), ("t_off", C.c_uint64), ("num_t", C.c_uint64),
+                ("bits_off", C.c_uint64),
                 ("num_bit_words", C.c_uint64), ("bit_seg_off", C.c_uint64 * 6), ("instance_off", C.c_uint64),
                 ("num_instance_values", C.c_uint64)]
 

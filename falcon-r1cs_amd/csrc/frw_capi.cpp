@@ -311,8 +311,10 @@ int frw_compact_layout(int logn, frw_compact_layout_t *out)
     out->logn = logn;
     out->n = (int32_t)n;
     out->bytes_per_signature = c.bytes;
-    out->values_off = 0;
-    out->num_values = c.num_values;
+    out->small_off = 0;
+    out->num_small = c.num_small;
+    out->t_off = c.t_off;
+    out->num_t = c.num_t;
     out->bits_off = c.bits_off;
     out->num_bit_words = c.bit_words;
     for (int i = 0; i < 5; i++) out->bit_seg_off[i] = (uint64_t)i * seg;
@@ -345,36 +347,98 @@ int frw_expand_dev(frw_ctx *ctx, int logn, size_t batch, const void *d_compact, 
     return FRW_OK;
 }
 
-// Host-side expansion of compact signatures received over PCIe: data movement only (which 32-byte pattern goes where),
-// no arithmetic -- the counterpart of frw_expand_dev for a consumer that wants arkworks' vectors in host memory.
+// Host-side expansion of compact signatures received over PCIe: a format conversion (integers -> ark-ff's Montgomery
+// representation, bits -> 0 / 1 elements), the counterpart of frw_expand_dev for a consumer that wants arkworks' vectors
+// in host memory.  BLS12-381 scalar field, 64-bit limbs.
+namespace {
+constexpr uint64_t FR_P[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+constexpr uint64_t FR_R2[4] = {0xc999e990f3f29c6dull, 0x2b6cedcb87925c23ull, 0x05d314967254398full, 0x0748d9d99f59ff11ull};
+constexpr uint64_t FR_ONE[4] = {0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull, 0x1824b159acc5056full};
+constexpr uint64_t FR_INV = 0xfffffffeffffffffull;          // -p^-1 mod 2^64
+
+// out = x * 2^256 mod p for x < 2^192 given as three 64-bit limbs: Montgomery product of x and R^2 (CIOS)
+inline void fr_to_montgomery(const uint64_t x[3], uint64_t out[4])
+{
+    typedef unsigned __int128 u128;
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        const uint64_t xi = i < 3 ? x[i] : 0;
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)xi * FR_R2[j] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * FR_INV;
+        c = ((u128)m * FR_P[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * FR_P[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    uint64_t d[4];
+    unsigned borrow = 0;
+    for (int j = 0; j < 4; j++) {
+        const u128 diff = (u128)t[j] - FR_P[j] - borrow;
+        d[j] = (uint64_t)diff;
+        borrow = (unsigned)((diff >> 64) & 1);
+    }
+    const bool ge = t[4] != 0 || !borrow;
+    for (int j = 0; j < 4; j++) out[j] = ge ? d[j] : t[j];
+}
+}  // namespace
+
 int frw_expand_host(int logn, size_t batch, const void *compact, uint64_t *witness, uint64_t *instance)
 {
     if ((logn != 9 && logn != 10) || (batch && (!compact || !witness || !instance))) return FRW_E_INVALID_ARG;
-    static const uint64_t ONE[4] = {0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull, 0x1824b159acc5056full};
     const frw::CompactLayout c = frw::compact_layout(logn);
     const size_t n = (size_t)1 << logn, nb = logn == 9 ? 50 : 52, W = 153 * n + nb, I = 2 * n + 1;
     for (size_t s = 0; s < batch; s++) {
         const unsigned char *base = (const unsigned char *)compact + s * c.bytes;
-        const uint64_t *val = (const uint64_t *)base;                     // next value element
+        const uint32_t *small = (const uint32_t *)base;                   // next small value
+        const uint32_t *tq = (const uint32_t *)(base + c.t_off);           // next 5-limb quotient
         const uint32_t *bits = (const uint32_t *)(base + c.bits_off);
+        const uint32_t *ins = (const uint32_t *)(base + c.instance_off);
         size_t bit = 0;
         uint64_t *w = witness + s * W * 4, *in = instance + s * I * 4;
-        auto value = [&](int count) { memcpy(w, val, (size_t)count * 32); w += count * 4; val += count * 4; };
+        auto value = [&](int count) {
+            for (int i = 0; i < count; i++, w += 4) {
+                const uint64_t x[3] = {*small++, 0, 0};
+                fr_to_montgomery(x, w);
+            }
+        };
+        auto quotient = [&]() {
+            const uint64_t x[3] = {(uint64_t)tq[0] | ((uint64_t)tq[1] << 32), (uint64_t)tq[2] | ((uint64_t)tq[3] << 32), tq[4]};
+            fr_to_montgomery(x, w);
+            tq += 5;
+            w += 4;
+        };
         auto booleans = [&](int count) {
             for (int i = 0; i < count; i++, bit++, w += 4) {
-                if ((bits[bit >> 5] >> (bit & 31)) & 1u) memcpy(w, ONE, 32);
+                if ((bits[bit >> 5] >> (bit & 31)) & 1u) memcpy(w, FR_ONE, 32);
                 else memset(w, 0, 32);
             }
         };
-        memcpy(in, ONE, 32);
-        memcpy(in + 4, base + c.instance_off, 2 * n * 32);
+        memcpy(in, FR_ONE, 32);
+        for (size_t k = 0; k < 2 * n; k++) {
+            const uint64_t x[3] = {ins[k], 0, 0};
+            fr_to_montgomery(x, in + 4 + 4 * k);
+        }
         value((int)(2 * n));                                              // S0, S1
         booleans((int)(27 * n));                                          // S2
-        for (int seg = 0; seg < 2; seg++)                                 // S3, S4: [t, b, 27 booleans]
-            for (size_t k = 0; k < n; k++) { value(2); booleans(27); }
+        // S3, S4: [t, b, 27 booleans]; the b values of S3 (N) and of S4 (N) follow sig and v in `small`, the quotients of
+        // S3 then S4 are in `t`
+        for (int seg = 0; seg < 2; seg++)
+            for (size_t k = 0; k < n; k++) { quotient(); value(1); booleans(27); }
         for (size_t k = 0; k < n; k++) { value(3); booleans(27); }         // S5: [prod, t, c, 27 booleans]
-        // S6: [16 booleans, r, sq]; its values follow the S5 values, its booleans follow the S5 booleans
-        for (size_t k = 0; k < 2 * n; k++) { booleans(16); value(2); }
+        for (size_t k = 0; k < 2 * n; k++) { booleans(16); value(2); }     // S6: [16 booleans, r, sq]
         bit = (4 * c.seg_words + n) * 32;                                 // S7 has two words of its own
         booleans((int)nb);
     }

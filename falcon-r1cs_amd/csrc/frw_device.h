@@ -23,25 +23,29 @@ struct Tables {
     uint32_t ck[11][5];     // C_k = 2^k q^(k+1), 32-bit limbs (falcon_ntt.rs:31-39)
 };
 
-// FRW_ENC_COMPACT: one signature = the 13 N non-boolean witness elements as 32-byte Montgomery values (witness order:
-// S0, S1, then per block the values of S3, S4, S5, S6), the 140 N + nb boolean elements as a bit array (witness order:
-// S2, the boolean parts of S3, S4, S5, S6, then S7 in two words), and the 2 N instance values (without the leading one).
-// 0.51 MB instead of 5.08 MB per Falcon-1024 signature; frw_expand_dev rebuilds the arkworks buffers from it.
+// FRW_ENC_COMPACT: one signature = its non-boolean witness elements as plain integers -- the 11 N that fit 32 bits as
+// uint32_t (witness order: sig, v, then the b of S3, the b of S4, [prod, t, c] of S5, [r, sq] of S6), the 2 N quotients t
+// of the two ntt_circuits as 5 x uint32_t little-endian limbs (S3's, then S4's) -- the 140 N + nb boolean elements as a bit
+// array (witness order: S2, the boolean parts of S3, S4, S5, S6, then S7 in two words), and the 2 N instance values as
+// uint32_t (without the leading one).  110 KB instead of 5.08 MB per Falcon-1024 signature; frw_expand_dev rebuilds the
+// arkworks buffers (Montgomery form) from it.
 struct CompactLayout {
-    size_t num_values, bits_off, bit_words, instance_off, num_instance, bytes;
+    size_t num_small, t_off, num_t, bits_off, bit_words, instance_off, num_instance, bytes;
     size_t seg_words;      // bit words of one enforce_less_than_q segment (27 N / 32)
 };
 constexpr CompactLayout compact_layout(int logn)
 {
     const size_t n = (size_t)1 << logn;
     CompactLayout c{};
-    c.num_values = 13 * n;
-    c.bits_off = c.num_values * 32;
+    c.num_small = 11 * n;
+    c.t_off = c.num_small * 4;
+    c.num_t = 2 * n;
+    c.bits_off = c.t_off + c.num_t * 20;
     c.seg_words = 27 * n / 32;
     c.bit_words = 4 * c.seg_words + n + 2;
     c.instance_off = c.bits_off + (c.bit_words * 4 + 15) / 16 * 16;
     c.num_instance = 2 * n;
-    c.bytes = (c.instance_off + c.num_instance * 32 + 127) / 128 * 128;
+    c.bytes = (c.instance_off + c.num_instance * 4 + 127) / 128 * 128;
     return c;
 }
 

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
     constexpr int TILES = N / WAVE;
     constexpr uint32_t TILE1 = WAVE * 32;            // bytes of a tile of one-element blocks
     constexpr bool COMPACT = ENC == 2;               // FRW_ENC_COMPACT: g_wit is the compact buffer, g_inst unused
-    constexpr int VENC = COMPACT ? 1 : ENC;          // compact values are Montgomery
+    constexpr int VENC = COMPACT ? 1 : ENC;          // (compact mode stores plain integers and encodes nothing)
     constexpr CompactLayout CL = compact_layout(LOGN);
     __shared__ Smem<LOGN, COMPACT> sm;
 
@@ -706,11 +706,6 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         init_vtab(sm.vtab, VTAB_ROWS, tid);
         init_slab_const<ENC>(wc.slab, lane);
     }
-    // compact mode: element `elem` of a 32-byte-element array
-    auto put = [](v4u *base, size_t elem, const uint32_t (&e)[8]) {
-        base[elem * 2] = mk4(e[0], e[1], e[2], e[3]);
-        base[elem * 2 + 1] = mk4(e[4], e[5], e[6], e[7]);
-    };
 
     const size_t items = full + (batch - full) * PARTS;
     for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
@@ -721,9 +716,10 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         v4u *wit = COMPACT ? nullptr : g_wit + s * W * 2;
         v4u *inst = COMPACT ? nullptr : g_inst + s * I * 2;
         unsigned char *const cbase = COMPACT ? (unsigned char *)g_wit + s * CL.bytes : nullptr;
-        v4u *const cv = (v4u *)cbase;                                       // compact: values
+        uint32_t *const cs32 = (uint32_t *)cbase;                           // compact: the 11 N small values
+        uint32_t *const ct = (uint32_t *)(cbase + CL.t_off);                //          the 2 N quotients, 5 limbs each
         uint32_t *const cb = (uint32_t *)(cbase + CL.bits_off);             //          boolean bit words
-        v4u *const ci = (v4u *)(cbase + CL.instance_off);                   //          instance values
+        uint32_t *const ci = (uint32_t *)(cbase + CL.instance_off);         //          instance values
         // ---- 1. load + range check ----------------------------------------------------------
         if (tid == 0) { sm.norm = 0; sm.bad = 0; }
         lds_barrier();
@@ -738,7 +734,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         if (sm.bad) {                                    // uniform across the workgroup
             if (tid == 0 && does(2)) g_status[s] = ST_COEFF_RANGE;
             if (does(0)) {
-                if constexpr (COMPACT) zero_fill(cv, CL.bytes / 16, tid);
+                if constexpr (COMPACT) zero_fill((v4u *)cbase, CL.bytes / 16, tid);
                 else { zero_fill(wit, W * 2, tid); zero_fill(inst, I * 2, tid); }
             }
             lds_barrier();
@@ -777,10 +773,10 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
             if (does(0)) {
             const uint32_t vk = sm.v[k];
             if constexpr (COMPACT) {
-                encode_u32<VENC>(s_npk[k], e8); put(ci, k, e8);
-                encode_u32<VENC>(s_nhm[k], e8); put(ci, N + k, e8);
-                encode_u32<VENC>(sm.sig[k], e8); put(cv, k, e8);
-                encode_u32<VENC>(vk, e8); put(cv, N + k, e8);
+                ci[k] = s_npk[k];
+                ci[N + k] = s_nhm[k];
+                cs32[k] = sm.sig[k];
+                cs32[N + k] = vk;
                 const uint32_t wd = pack_bits<27>(ltq_mask(vk), lane);
                 if (lane < 54) cb[t * 54 + lane] = wd;
             } else {
@@ -803,9 +799,9 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
                 const uint32_t ab = s_nv[k] + prod;                       // arithmetics.rs:238
                 const uint32_t tq = ab / Q, c = ab - tq * Q;              // :242-243
                 if constexpr (COMPACT) {
-                    encode_u32<VENC>(prod, e8); put(cv, 6 * N + 3 * k, e8);
-                    encode_u32<VENC>(tq, e8);   put(cv, 6 * N + 3 * k + 1, e8);
-                    encode_u32<VENC>(c, e8);    put(cv, 6 * N + 3 * k + 2, e8);
+                    cs32[4 * N + 3 * k] = prod;
+                    cs32[4 * N + 3 * k + 1] = tq;
+                    cs32[4 * N + 3 * k + 2] = c;
                     const uint32_t wd = pack_bits<27>(ltq_mask(c), lane);
                     if (lane < 54) cb[3 * CL.seg_words + t * 54 + lane] = wd;
                 } else {
@@ -827,8 +823,8 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
             const uint32_t sq = r * r;
             nrm += sq;
             if constexpr (COMPACT) {
-                encode_u32<VENC>(r, e8);  put(cv, 9 * N + 2 * k, e8);
-                encode_u32<VENC>(sq, e8); put(cv, 9 * N + 2 * k + 1, e8);
+                cs32[7 * N + 2 * k] = r;
+                cs32[7 * N + 2 * k + 1] = sq;
                 const uint32_t wd = pack_bits<16>(m, lane);
                 if (lane < 32) cb[4 * CL.seg_words + t * 32 + lane] = wd;
             } else {
@@ -874,9 +870,9 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
                 for (int i = 0; i < 5; i++) a[i] = sm.lad[i * N + k];
                 const uint32_t b = divmod_q_u160(a, q5);                  // arithmetics.rs:127-134
                 if constexpr (COMPACT) {
-                    const size_t ve = (size_t)(which ? 4 : 2) * N + 2 * k;
-                    encode_u160<VENC>(q5, e8); put(cv, ve, e8);
-                    encode_u32<VENC>(b, e8);   put(cv, ve + 1, e8);
+                    cs32[(which ? 3 : 2) * N + k] = b;
+#pragma unroll
+                    for (int i = 0; i < 5; i++) ct[((size_t)(which ? N : 0) + k) * 5 + i] = q5[i];
                     const uint32_t wd = pack_bits<27>(ltq_mask(b), lane);
                     if (lane < 54) cb[(which ? 2 : 1) * CL.seg_words + t * 54 + lane] = wd;
                 } else {
@@ -1137,10 +1133,10 @@ __global__ __launch_bounds__(BLOCK) void ntt_modq_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // kernel: FRW_ENC_COMPACT -> the arkworks buffers (witness_assignment / instance_assignment, Montgomery), i.e. exactly
-// what witness_ntt_verify_kernel<LOGN, 1> writes.  Pure data movement through the same tile writer: values are loaded
-// from the compact buffer into the wave's slab, the booleans of a tile are cut out of the bit array (two ds_bpermute
-// per lane) and handed to emit_tile as the per-block mask.  A receiver of an all-gathered compact chunk runs this
-// locally: 0.51 MB cross the fabric per Falcon-1024 signature instead of 5.08 MB.
+// what witness_ntt_verify_kernel<LOGN, 1> writes.  The integers of the compact buffer are converted to Montgomery form
+// (the same CIOS rounds the generator uses) into the wave's slab, the booleans of a tile are cut out of the bit array
+// (two ds_bpermute per lane) and handed to emit_tile as the per-block mask.  A receiver of an all-gathered compact chunk
+// runs this locally: 0.11 MB cross the fabric per Falcon-1024 signature instead of 5.08 MB.
 // ------------------------------------------------------------------------------------------------
 struct alignas(16) SmemExpand {
     unsigned char slab[3 * SLAB_SLOT];
@@ -1157,13 +1153,6 @@ __device__ __forceinline__ uint32_t unpack_bits(uint32_t word, int lane)
     return (uint32_t)(both >> o) & ((1u << NB) - 1u);
 }
 
-__device__ __forceinline__ void slab_put16(uint32_t slab_w, int slot, int lane, v4u lo, v4u hi)
-{
-    const uint32_t a = slab_w + slot * SLAB_SLOT + slab_addr(lane);
-    *(FRW_LDS v4u *)(uintptr_t)a = lo;
-    *(FRW_LDS v4u *)(uintptr_t)(a + SLAB_HALF) = hi;
-}
-
 template <int LOGN>
 __global__ __launch_bounds__(BLOCK) void expand_kernel(size_t batch, const unsigned char *__restrict__ g_compact,
                                                        v4u *__restrict__ g_wit, v4u *__restrict__ g_inst)
@@ -1173,6 +1162,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(size_t batch, const unsig
     constexpr size_t W = 153 * (size_t)N + NB;
     constexpr size_t I = 2 * (size_t)N + 1;
     constexpr int TILES = N / WAVE;
+    constexpr uint32_t TILE1 = WAVE * 32;
     constexpr CompactLayout CL = compact_layout(LOGN);
     __shared__ SmemExpand sm;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -1189,18 +1179,27 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(size_t batch, const unsig
 
     for (size_t s = blockIdx.x; s < batch; s += gridDim.x) {
         const unsigned char *cbase = g_compact + s * CL.bytes;
-        const v4u *cv = (const v4u *)cbase;
+        const uint32_t *cs32 = (const uint32_t *)cbase;
+        const uint32_t *ct = (const uint32_t *)(cbase + CL.t_off);
         const uint32_t *cb = (const uint32_t *)(cbase + CL.bits_off);
-        const v4u *ci = (const v4u *)(cbase + CL.instance_off);
+        const uint32_t *ci = (const uint32_t *)(cbase + CL.instance_off);
         v4u *wit = g_wit + s * W * 2;
         v4u *inst = g_inst + s * I * 2;
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(wit, (uint32_t)(W * 32));
-        // instance: [one, pk_ntt, hm_ntt]; S0, S1: contiguous copies of 32-byte elements
+        const __amdgpu_buffer_rsrc_t ri = make_rsrc(inst, (uint32_t)(I * 32));
+        uint32_t e8[8];
+        // instance: [one, pk_ntt, hm_ntt]; S0, S1; S2 (booleans only)
         if (tid < 2) inst[tid] = one;
-        for (int c = tid; c < 4 * N; c += BLOCK) inst[2 + c] = ci[c];
-        for (int c = tid; c < 4 * N; c += BLOCK) wit[c] = cv[c];
-        // S2: booleans only
         for (int t = wave; t < TILES; t += WAVES) {
+            const int k = t * WAVE + lane;
+            encode_u32<1>(ci[k], e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(ri, 32 + t * TILE1, wc);
+            encode_u32<1>(ci[N + k], e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(ri, 32 + (N / WAVE + t) * TILE1, wc);
+            encode_u32<1>(cs32[k], e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(rw, t * TILE1, wc);
+            encode_u32<1>(cs32[N + k], e8); slab_put(wc.slab, 0, lane, e8);
+            emit_values(rw, (N / WAVE + t) * TILE1, wc);
             const uint32_t wd = lane < 54 ? cb[t * 54 + lane] : 0u;
             emit_tile<27>(rw, (2 * N + t * WAVE * 27) * 32, unpack_bits<27>(wd, lane), wc);
         }
@@ -1209,9 +1208,11 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(size_t batch, const unsig
         for (int which = 0; which < 2; which++) {
             for (int t = wave; t < TILES; t += WAVES) {
                 const int k = t * WAVE + lane;
-                const v4u *v = cv + ((size_t)(which ? 4 : 2) * N + 2 * k) * 2;
-                slab_put16(wc.slab, 0, lane, v[0], v[1]);
-                slab_put16(wc.slab, 1, lane, v[2], v[3]);
+                uint32_t q5[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) q5[i] = ct[((size_t)(which ? N : 0) + k) * 5 + i];
+                encode_u160<1>(q5, e8); slab_put(wc.slab, 0, lane, e8);
+                encode_u32<1>(cs32[(which ? 3 : 2) * N + k], e8); slab_put(wc.slab, 1, lane, e8);
                 const uint32_t wd = lane < 54 ? cb[(which ? 2 : 1) * CL.seg_words + t * 54 + lane] : 0u;
                 emit_tile<29>(rw, ((which ? 58 : 29) * N + t * WAVE * 29) * 32, unpack_bits<27>(wd, lane) << 2, wc);
             }
@@ -1219,19 +1220,17 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(size_t batch, const unsig
         // S5: [prod, t, c, ltq(c)]
         for (int t = wave; t < TILES; t += WAVES) {
             const int k = t * WAVE + lane;
-            const v4u *v = cv + ((size_t)6 * N + 3 * k) * 2;
-            slab_put16(wc.slab, 0, lane, v[0], v[1]);
-            slab_put16(wc.slab, 1, lane, v[2], v[3]);
-            slab_put16(wc.slab, 2, lane, v[4], v[5]);
+            encode_u32<1>(cs32[4 * N + 3 * k], e8);     slab_put(wc.slab, 0, lane, e8);
+            encode_u32<1>(cs32[4 * N + 3 * k + 1], e8); slab_put(wc.slab, 1, lane, e8);
+            encode_u32<1>(cs32[4 * N + 3 * k + 2], e8); slab_put(wc.slab, 2, lane, e8);
             const uint32_t wd = lane < 54 ? cb[3 * CL.seg_words + t * 54 + lane] : 0u;
             emit_tile<30>(rw, (87 * N + t * WAVE * 30) * 32, unpack_bits<27>(wd, lane) << 3, wc);
         }
         // S6: [a0..a13, w0, w1, r, sq]
         for (int t = wave; t < 2 * TILES; t += WAVES) {
             const int k = t * WAVE + lane;
-            const v4u *v = cv + ((size_t)9 * N + 2 * k) * 2;
-            slab_put16(wc.slab, 0, lane, v[0], v[1]);
-            slab_put16(wc.slab, 1, lane, v[2], v[3]);
+            encode_u32<1>(cs32[7 * N + 2 * k], e8);     slab_put(wc.slab, 0, lane, e8);
+            encode_u32<1>(cs32[7 * N + 2 * k + 1], e8); slab_put(wc.slab, 1, lane, e8);
             const uint32_t wd = lane < 32 ? cb[4 * CL.seg_words + t * 32 + lane] : 0u;
             emit_tile<18>(rw, (117 * N + t * WAVE * 18) * 32, unpack_bits<16>(wd, lane), wc);
         }

@@ -51,8 +51,10 @@ class CompactLayout:
     logn: int
     n: int
     bytes_per_signature: int
-    values_off: int
-    num_values: int
+    small_off: int
+    num_small: int
+    t_off: int
+    num_t: int
     bits_off: int
     num_bit_words: int
     bit_seg_off: tuple
@@ -61,10 +63,11 @@ class CompactLayout:
 
 
 def compact_layout(logn) -> CompactLayout:
-    """Layout of FRW_ENC_COMPACT (frw_compact_layout): 13N Montgomery values + boolean bit array + 2N instance values."""
+    """Layout of FRW_ENC_COMPACT (frw_compact_layout): 11N u32 values + 2N five-limb quotients + boolean bit array +
+    2N u32 instance values."""
     s = CompactLayoutStruct()
     check(load_library().frw_compact_layout(int(logn), C.byref(s)), "frw_compact_layout")
-    return CompactLayout(s.logn, s.n, s.bytes_per_signature, s.values_off, s.num_values, s.bits_off, s.num_bit_words,
+    return CompactLayout(s.logn, s.n, s.bytes_per_signature, s.small_off, s.num_small, s.t_off, s.num_t, s.bits_off, s.num_bit_words,
                          tuple(s.bit_seg_off), s.instance_off, s.num_instance_values)
 
 

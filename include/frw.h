@@ -131,24 +131,29 @@ int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
 int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int encoding,
                  uint64_t *witness, uint16_t *ntt_out, int32_t *status);
 
-/* ---- compact device-side encoding (no counterpart in the reference; for GPU-side consumers and the multi-GPU gather) ----
- * 140 N + nb of the W witness elements of falcon_ntt.rs:58-122 are booleans, i.e. 32-byte field elements that are 0 or
- * the Montgomery form of 1.  FRW_ENC_COMPACT keeps, per signature (frw_compact_layout):
- *   values    13 N x 32 bytes   the non-boolean witness elements, Montgomery form, in witness order:
- *                               sig[N], v[N], then per NTT coefficient [t, b] of ntt_circuit(sig), [t, b] of ntt_circuit(v),
- *                               [prod, t, c] of the pointwise add_mod, then [r, sq] of the 2N l2-norm elements
+/* ---- compact encoding (no counterpart in the reference; for GPU-side consumers, the multi-GPU gather and PCIe) ----
+ * 140 N + nb of the W witness elements of falcon_ntt.rs:58-122 are booleans, and all but 2 N of the others are integers
+ * below 2^28.  FRW_ENC_COMPACT keeps, per signature (frw_compact_layout), the VALUES as plain integers:
+ *   small     11 N x uint32_t   the non-boolean witness elements that fit 32 bits, in witness order:
+ *                               sig[N], v[N], b of ntt_circuit(sig) [N], b of ntt_circuit(v) [N],
+ *                               [prod, t, c] of the pointwise add_mod [3 N], [r, sq] of the 2 N l2-norm elements [4 N]
+ *   t         2 N x 5 uint32_t  the mod_q quotients t = floor(a / q) of ntt_circuit(sig), then of ntt_circuit(v)
+ *                               (132 / 146 bits; little-endian limbs)
  *   bits      uint32_t words    the boolean elements as a bit array in witness order (bit i of the array = bit i%32 of
  *                               word i/32): enforce_less_than_q(v[i]) 27 N bits, then the 27-bit enforce_less_than_q
  *                               blocks of the S3, S4, S5 segments (27 N each), the 16 booleans of every l2-norm element
  *                               (32 N), and the norm-bound block (50 | 52 bits, in two words of their own)
- *   instance  2 N x 32 bytes    pk_ntt, hm_ntt (the leading constant one is implied)
- * = 509,568 bytes per Falcon-1024 signature instead of 5,080,736.  frw_expand_dev rebuilds, bit for bit, the buffers
- * frw_witness_ntt_verify_dev(..., FRW_ENC_MONTGOMERY, ...) writes.  A signature with FRW_ST_COEFF_RANGE is all zeros. */
+ *   instance  2 N x uint32_t    pk_ntt, hm_ntt (the leading constant one is implied)
+ * = 112,256 bytes per Falcon-1024 signature instead of 5,080,736.  frw_expand_dev / frw_expand_host rebuild, bit for bit,
+ * the buffers frw_witness_ntt_verify_dev(..., FRW_ENC_MONTGOMERY, ...) writes (x -> x * 2^256 mod p for the values, 0 / the
+ * Montgomery form of 1 for the booleans); a Rust host can equally build its Vec<Fr> with Fr::from(u64) / from limbs.
+ * A signature with FRW_ST_COEFF_RANGE is all zeros. */
 #define FRW_ENC_COMPACT     2
 typedef struct frw_compact_layout {
     int32_t logn, n;
     uint64_t bytes_per_signature;     /* stride of the compact buffer, a multiple of 128 */
-    uint64_t values_off, num_values;  /* byte offset (0) and number of 32-byte values (13 N) */
+    uint64_t small_off, num_small;    /* byte offset (0) and number (11 N) of the uint32_t values */
+    uint64_t t_off, num_t;            /* byte offset and number (2 N) of the 5 x uint32_t quotients */
     uint64_t bits_off, num_bit_words; /* byte offset and number of uint32_t words of the bit array */
     uint64_t bit_seg_off[6];          /* first bit of S2, S3, S4, S5, S6, S7 booleans inside the bit array */
     uint64_t instance_off, num_instance_values;
@@ -161,9 +166,10 @@ int frw_witness_ntt_verify_compact_dev(frw_ctx *ctx, int logn, size_t batch,
 /* compact -> witness uint64_t[batch][W][4], instance uint64_t[batch][I][4] (FRW_ENC_MONTGOMERY bytes) */
 int frw_expand_dev(frw_ctx *ctx, int logn, size_t batch, const void *d_compact,
                    uint64_t *d_witness, uint64_t *d_instance, void *stream);
-/* The same expansion in host memory (no device, no arithmetic: it only places 32-byte patterns), for a host that took
- * the compact form over PCIe: frw_witness_ntt_verify(..., FRW_ENC_COMPACT, compact, NULL, status, strict) moves 0.51 MB
- * per Falcon-1024 signature instead of 5.08 MB.  Signatures are independent: callers may split `batch` over threads. */
+/* The same expansion in host memory (no device; a format conversion: integers to Montgomery form, bits to 0 / 1 elements),
+ * for a host that took the compact form over PCIe: frw_witness_ntt_verify(..., FRW_ENC_COMPACT, compact, NULL, status,
+ * strict) moves 0.11 MB per Falcon-1024 signature instead of 5.08 MB.  Signatures are independent: callers may split
+ * `batch` over threads. */
 int frw_expand_host(int logn, size_t batch, const void *compact, uint64_t *witness, uint64_t *instance);
 
 /* ---- the signed-split variant: FalconDualNTTVerificationCircuit (circuits/falcon_dual_ntt.rs:26-132) -----------

@@ -54,8 +54,10 @@ pub struct frw_compact_layout_t {
     pub logn: i32,
     pub n: i32,
     pub bytes_per_signature: u64,
-    pub values_off: u64,
-    pub num_values: u64,
+    pub small_off: u64,
+    pub num_small: u64,
+    pub t_off: u64,
+    pub num_t: u64,
     pub bits_off: u64,
     pub num_bit_words: u64,
     pub bit_seg_off: [u64; 6],

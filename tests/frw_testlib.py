@@ -134,31 +134,46 @@ def centred_norm(*polys):
     return tot
 
 
+P_FR = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+R_INV = pow(1 << 256, -1, P_FR)
+
+
+def _from_montgomery(limbs4):
+    x = int(limbs4[0]) | int(limbs4[1]) << 64 | int(limbs4[2]) << 128 | int(limbs4[3]) << 192
+    return x * R_INV % P_FR
+
+
 def compact_from_witness(logn, wit, inst, CL):
     """FRW_ENC_COMPACT restated as a re-layout of one arkworks witness/instance pair (uint64 [W,4] / [I,4], Montgomery):
-    the non-boolean elements in witness order, the boolean elements as a bit array in witness order, the instance
-    values without the leading one (include/frw.h).  CL = falcon_r1cs_amd.compact_layout(logn).  Returns bytes."""
+    the non-boolean elements as plain integers (11 N of them as uint32, the 2 N mod_q quotients as 5 x uint32), the boolean
+    elements as a bit array in witness order, the instance values without the leading one as uint32 (include/frw.h).
+    CL = falcon_r1cs_amd.compact_layout(logn).  Returns bytes."""
     n = 1 << logn
     nb = 50 if logn == 9 else 52
     off = np.cumsum([0, n, n, 27 * n, 29 * n, 29 * n, 30 * n, 36 * n])
     S2, S3, S4, S5, S6, S7 = (int(off[i]) for i in (2, 3, 4, 5, 6, 7))
     k = np.arange(n)
     k2 = np.arange(2 * n)
-    vals = np.concatenate([
+    small = np.concatenate([
         np.arange(0, 2 * n),
-        (S3 + 29 * k[:, None] + np.arange(2)).ravel(),
-        (S4 + 29 * k[:, None] + np.arange(2)).ravel(),
+        S3 + 29 * k + 1,
+        S4 + 29 * k + 1,
         (S5 + 30 * k[:, None] + np.arange(3)).ravel(),
         (S6 + 18 * k2[:, None] + 16 + np.arange(2)).ravel()])
+    tq = np.concatenate([S3 + 29 * k, S4 + 29 * k])
     bools = np.concatenate([
         np.arange(S2, S2 + 27 * n),
         (S3 + 29 * k[:, None] + 2 + np.arange(27)).ravel(),
         (S4 + 29 * k[:, None] + 2 + np.arange(27)).ravel(),
         (S5 + 30 * k[:, None] + 3 + np.arange(27)).ravel(),
         (S6 + 18 * k2[:, None] + np.arange(16)).ravel()])
-    assert len(vals) == CL.num_values and len(bools) == 140 * n
+    assert len(small) == CL.num_small and len(tq) == CL.num_t and len(bools) == 140 * n
     out = np.zeros(CL.bytes_per_signature, dtype=np.uint8)
-    out[: CL.num_values * 32] = np.ascontiguousarray(wit[vals]).view(np.uint8).ravel()
+    sv = [_from_montgomery(wit[i]) for i in small]
+    assert max(sv) < 1 << 32
+    out[: 4 * len(sv)] = np.array(sv, dtype=np.uint32).view(np.uint8)
+    tv = np.array([[(t >> (32 * j)) & 0xFFFFFFFF for j in range(5)] for t in (_from_montgomery(wit[i]) for i in tq)], dtype=np.uint32)
+    out[CL.t_off: CL.t_off + tv.nbytes] = tv.view(np.uint8).ravel()
     bits = (wit[bools] != 0).any(axis=1)
     words = np.packbits(bits.astype(np.uint8), bitorder="little").view(np.uint32)
     tail = (wit[S7:S7 + nb] != 0).any(axis=1)
@@ -166,5 +181,6 @@ def compact_from_witness(logn, wit, inst, CL):
     allw = np.concatenate([words, tail])
     assert len(allw) == CL.num_bit_words
     out[CL.bits_off: CL.bits_off + 4 * len(allw)] = allw.view(np.uint8)
-    out[CL.instance_off: CL.instance_off + 2 * n * 32] = np.ascontiguousarray(inst[1:]).view(np.uint8).ravel()
+    iv = np.array([_from_montgomery(inst[i]) for i in range(1, 2 * n + 1)], dtype=np.uint32)
+    out[CL.instance_off: CL.instance_off + iv.nbytes] = iv.view(np.uint8)
     return out.tobytes()

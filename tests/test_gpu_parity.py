@@ -738,8 +738,8 @@ def test_rejected_signatures_scattered_through_a_large_batch(engine, oracle, log
 
 @pytest.mark.parametrize("logn", [9, 10])
 def test_compact_encoding_matches_relayout_of_oracle_witness(engine, oracle, logn):
-    """FRW_ENC_COMPACT straight from the kernel == the oracle's arkworks witness re-laid out on the host (values in
-    witness order, booleans as a bit array, instance without the leading one), byte for byte; a rejected signature is
+    """FRW_ENC_COMPACT straight from the kernel == the oracle's arkworks witness re-laid out on the host (values as plain
+    integers in witness order, booleans as a bit array, instance without the leading one), byte for byte; a rejected signature is
     all zeros; and frw_expand_dev turns the compact buffer back into exactly the oracle's witness / instance bytes."""
     import torch
     import falcon_r1cs_amd as frw
@@ -762,7 +762,7 @@ def test_compact_encoding_matches_relayout_of_oracle_witness(engine, oracle, log
     owit, oinst, ost = oracle.witness_ntt_verify(logn, sig, pk, hm, 1)
     assert st.cpu().numpy().tolist() == ost.tolist() == [0, 0, 0, 0, 2, 0, 0, 1, 0]
     got = comp.cpu().numpy()
-    used = CL.instance_off + CL.num_instance_values * 32
+    used = CL.instance_off + CL.num_instance_values * 4
     for i in range(batch):
         if ost[i] == 1:
             assert not got[i].any()
