@@ -16,12 +16,15 @@ import falcon_r1cs_amd as frw  # noqa: E402
 import frw_testlib  # noqa: E402
 
 launches = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+FULL = len(sys.argv) > 2 and sys.argv[2] == "full"       # also: the benchmark's launch shape, one buffer per stream would not fit
 oracle = frw_testlib.load_oracle()
 eng = frw.WitnessEngine(0)
 dev = torch.device("cuda:0")
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-for logn, batch, mode in ((10, 3000, "ntt"), (9, 5000, "ntt"), (10, 1500, "dual"), (9, 2500, "dual"), (10, 3000, "compact"),
-                          (9, 4096, "ntt_modq")):
+CASES = [(10, 3000, "ntt"), (9, 5000, "ntt"), (10, 1500, "dual"), (9, 2500, "dual"), (10, 3000, "compact"), (9, 4096, "ntt_modq")]
+if FULL:
+    CASES = [(10, 16384, "ntt"), (10, 16384, "compact")]     # two 82 GB buffers, 21.33 rounds + split tail per launch
+for logn, batch, mode in CASES:
     dual = mode == "dual"
     L = frw.layout_dual(logn) if dual else frw.layout(logn)
     CL = frw.compact_layout(logn)
