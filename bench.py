@@ -532,7 +532,9 @@ def main():
                          "(the profiling passes do: its small launches of the same kernels would blur the per-kernel averages)")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1 only: skip the second curve, 'generate + RCCL all-gather of the witness vectors'")
-    ap.add_argument("--allgather-chunk", type=int, default=0, help="signatures per rank per all-gather (default chunk/world)")
+    ap.add_argument("--allgather-chunk", type=int, default=0, help="signatures per rank per all-gather (default 4,096)")
+    ap.add_argument("--allgather-deadline", type=int, default=240,
+                    help="seconds the N > 1 gather legs may take before the run reports `value` without them")
     ap.add_argument("--force-pg", action="store_true",
                     help="initialise the process group and run the N > 1 legs even with one rank (rehearses the RCCL "
                          "calls on a single GPU)")
@@ -699,20 +701,38 @@ def main():
         cal_ms = e0.elapsed_time(e1) / cal_reps
     write_stream_gbs = wbytes / (cal_ms * 1e-3) / 1e9
 
-    # ---- second curve (N > 1): generate + all-gather of the witness vectors, full step ------------------------------
-    gather_info = None
-    if use_pg and not args.no_allgather and not dual:
-        try:
-            gather_info = gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit, d_st,
-                                     stream)
-            gather_info["allgather_inputs_and_regenerate"] = regenerate_leg(
-                args, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit, d_inst, stream)
-            gather_info["naive_32_byte_elements_probe"] = arkworks_gather_probe(
-                args, eng, dev, cdev, world, rank, logn, L, (d_sig, d_pk, d_hm), d_wit, d_inst, d_st, stream, chunk)
-        except Exception as ex:      # the primary metric must not depend on this leg
-            gather_info = dict(gather_info or {}, error=repr(ex)[:300])
     ranks_seen = dist.get_world_size() if use_pg else 1
     devs = sharding.gather_per_signature(torch.tensor([dev_index], dtype=torch.int64, device=cdev), world, rank, world)
+
+    # ---- second curve (N > 1): generate + all-gather of the witness vectors, full step ------------------------------
+    # Every collective the primary result needs has happened by now.  The legs run in a worker thread with a deadline:
+    # should a collective of theirs ever hang (they cannot be rehearsed on more than one RCCL rank here), rank 0 still
+    # emits `value` and every rank leaves through os._exit instead of waiting for peers.
+    gather_info, legs_hung = None, False
+    if use_pg and not args.no_allgather and not dual:
+        import threading
+        box = {}
+
+        def legs():
+            torch.cuda.set_device(dev_index)
+            try:
+                box["r"] = gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit,
+                                      d_st, stream)
+                box["r"]["allgather_inputs_and_regenerate"] = regenerate_leg(
+                    args, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit, d_inst, stream)
+                box["r"]["naive_32_byte_elements_probe"] = arkworks_gather_probe(
+                    args, eng, dev, cdev, world, rank, logn, L, (d_sig, d_pk, d_hm), d_wit, d_inst, d_st, stream, chunk)
+            except Exception as ex:      # the primary metric must not depend on these legs
+                box["e"] = repr(ex)[:300]
+        th = threading.Thread(target=legs, daemon=True)
+        th.start()
+        th.join(args.allgather_deadline)
+        legs_hung = th.is_alive()
+        gather_info = dict(box.get("r") or {})
+        if legs_hung:
+            gather_info["error"] = "no result within %d s (a collective did not complete)" % args.allgather_deadline
+        elif "e" in box:
+            gather_info["error"] = box["e"]
 
     if args.dump_digests:
         # one extra, untimed pass with every launch digested: per-signature (global index, status, digest) of this rank
@@ -779,6 +799,11 @@ def main():
             result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, slot_sig[slots], lambda i: digest_of[int(i)])
         emit(result)
     if use_pg:
+        if legs_hung or world > 1:
+            # no further rendezvous with the peers: a rank whose legs timed out must not wait, and the others must not
+            # wait for it
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
