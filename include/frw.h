@@ -25,7 +25,10 @@
  *     (what falcon-rust's Polynomial::coeff() returns; falcon_ntt.rs:27-28,44).
  *   - a field element is 4 x uint64_t little-endian limbs (ark-ff Fp256 over the BLS12-381
  *     scalar field).  encoding FRW_ENC_MONTGOMERY stores x*2^256 mod p -- byte-identical to
- *     what arkworks keeps in witness_assignment; FRW_ENC_CANONICAL stores x itself.
+ *     what arkworks keeps in witness_assignment; FRW_ENC_CANONICAL stores x itself.  The reference is generic
+ *     over F: PrimeField but instantiates it with this one field everywhere (poly.rs:244, examples/pok_sig.rs:3);
+ *     every witness value is an integer below 2^160, so FRW_ENC_CANONICAL and FRW_ENC_COMPACT are field-agnostic
+ *     (a host on another >= 161-bit field converts them itself), only FRW_ENC_MONTGOMERY is BLS12-381-specific.
  *   - witness:  uint64_t[batch][W][4] in arkworks allocation order (layout: frw_layout()).
  *     instance: uint64_t[batch][I][4], I = 2N+1: [1, pk_ntt[0..N), hm_ntt[0..N)]
  *     (falcon_ntt.rs:63,67; public-input order as in examples/pok_sig.rs:38-45).

@@ -134,6 +134,22 @@ def centred_norm(*polys):
     return tot
 
 
+class CompactLayoutPy:
+    """include/frw.h's FRW_ENC_COMPACT layout restated (independent of the library; tests/test_capi.py compares the two)."""
+
+    def __init__(self, logn):
+        n = 1 << logn
+        self.logn, self.n = logn, n
+        self.small_off, self.num_small = 0, 11 * n
+        self.t_off, self.num_t = 4 * self.num_small, 2 * n
+        self.bits_off = self.t_off + 20 * self.num_t
+        self.num_bit_words = 4 * (27 * n // 32) + n + 2
+        self.bit_seg_off = (0, 27 * n, 54 * n, 81 * n, 108 * n, 140 * n)
+        self.instance_off = self.bits_off + (4 * self.num_bit_words + 15) // 16 * 16
+        self.num_instance_values = 2 * n
+        self.bytes_per_signature = (self.instance_off + 4 * self.num_instance_values + 127) // 128 * 128
+
+
 P_FR = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 R_INV = pow(1 << 256, -1, P_FR)
 
@@ -143,11 +159,12 @@ def _from_montgomery(limbs4):
     return x * R_INV % P_FR
 
 
-def compact_from_witness(logn, wit, inst, CL):
+def compact_from_witness(logn, wit, inst, CL=None):
     """FRW_ENC_COMPACT restated as a re-layout of one arkworks witness/instance pair (uint64 [W,4] / [I,4], Montgomery):
     the non-boolean elements as plain integers (11 N of them as uint32, the 2 N mod_q quotients as 5 x uint32), the boolean
     elements as a bit array in witness order, the instance values without the leading one as uint32 (include/frw.h).
-    CL = falcon_r1cs_amd.compact_layout(logn).  Returns bytes."""
+    CL = falcon_r1cs_amd.compact_layout(logn), or None for the restated layout above.  Returns bytes."""
+    CL = CL or CompactLayoutPy(logn)
     n = 1 << logn
     nb = 50 if logn == 9 else 52
     off = np.cumsum([0, n, n, 27 * n, 29 * n, 29 * n, 30 * n, 36 * n])

@@ -76,7 +76,15 @@ def witness_fixture(logn, seed):
         "sample_t": [str(cs.witness_assignment[t_off + 29 * k]) for k in range(4)],
         "sample_b": [cs.witness_assignment[t_off + 29 * k + 1] for k in range(4)],
         "l2_norm": T.centred_norm(sig, v),
+        # FRW_ENC_COMPACT of the same assignment (integers + boolean bit array, include/frw.h), re-laid out on the host
+        **compact_fixture(logn, cs),
     }
+
+
+def compact_fixture(logn, cs):
+    as_u64 = lambda vals: np.frombuffer(G.encode_elements(vals, True), dtype=np.uint64).reshape(-1, 4)
+    comp = T.compact_from_witness(logn, as_u64(cs.witness_assignment), as_u64(cs.instance_assignment))
+    return {"compact_sha256": sha(comp), "compact_bytes": len(comp)}
 
 
 def dual_fixture(logn, seed):

@@ -820,6 +820,11 @@ def test_expand_of_compact_equals_direct_output_full_launch(engine):
         torch.cuda.synchronize()
         assert hashlib.sha256(wit.cpu().numpy().tobytes()).hexdigest() == fx["witness_sha256"]["montgomery"]
         assert hashlib.sha256(inst.cpu().numpy().tobytes()).hexdigest() == fx["instance_sha256"]["montgomery"]
+        # the compact bytes themselves (padding zeroed: the kernel does not write it)
+        got = comp[0].cpu().numpy().copy()
+        got[CL.bits_off + 4 * CL.num_bit_words: CL.instance_off] = 0
+        got[CL.instance_off + 4 * CL.num_instance_values:] = 0
+        assert len(got) == fx["compact_bytes"] and hashlib.sha256(got.tobytes()).hexdigest() == fx["compact_sha256"]
 
 
 @pytest.mark.parametrize("logn", [9, 10])
