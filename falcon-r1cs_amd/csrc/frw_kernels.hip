@@ -31,6 +31,7 @@
 // store instruction, so each buffer_store_dwordx4 writes 1 KiB of contiguous HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <mutex>
 #include "frw_device.h"
 
@@ -1188,51 +1189,91 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(size_t batch, const unsig
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(wit, (uint32_t)(W * 32));
         const __amdgpu_buffer_rsrc_t ri = make_rsrc(inst, (uint32_t)(I * 32));
         uint32_t e8[8];
+        // Every loop below keeps the loads of its NEXT tile in flight while the current tile is emitted (58 stores): under
+        // a saturated write stream an HBM read takes long enough that four waves per SIMD do not hide it otherwise
+        // (measured: +5 % from over-subscribing the grid before this was done, tools/ab_variants.py --workload expand).
         // instance: [one, pk_ntt, hm_ntt]; S0, S1; S2 (booleans only)
         if (tid < 2) inst[tid] = one;
-        for (int t = wave; t < TILES; t += WAVES) {
-            const int k = t * WAVE + lane;
-            encode_u32<1>(ci[k], e8); slab_put(wc.slab, 0, lane, e8);
-            emit_values(ri, 32 + t * TILE1, wc);
-            encode_u32<1>(ci[N + k], e8); slab_put(wc.slab, 0, lane, e8);
-            emit_values(ri, 32 + (N / WAVE + t) * TILE1, wc);
-            encode_u32<1>(cs32[k], e8); slab_put(wc.slab, 0, lane, e8);
-            emit_values(rw, t * TILE1, wc);
-            encode_u32<1>(cs32[N + k], e8); slab_put(wc.slab, 0, lane, e8);
-            emit_values(rw, (N / WAVE + t) * TILE1, wc);
-            const uint32_t wd = lane < 54 ? cb[t * 54 + lane] : 0u;
-            emit_tile<27>(rw, (2 * N + t * WAVE * 27) * 32, unpack_bits<27>(wd, lane), wc);
+        {
+            uint32_t n_pk, n_hm, n_sig, n_v, n_wd;
+            auto ld = [&](int t) {
+                const int k = t * WAVE + lane;
+                n_pk = ci[k]; n_hm = ci[N + k]; n_sig = cs32[k]; n_v = cs32[N + k];
+                n_wd = lane < 54 ? cb[t * 54 + lane] : 0u;
+            };
+            ld(wave);
+            for (int t = wave; t < TILES; t += WAVES) {
+                const uint32_t c_pk = n_pk, c_hm = n_hm, c_sig = n_sig, c_v = n_v, c_wd = n_wd;
+                if (t + WAVES < TILES) ld(t + WAVES);
+                encode_u32<1>(c_pk, e8); slab_put(wc.slab, 0, lane, e8);
+                emit_values(ri, 32 + t * TILE1, wc);
+                encode_u32<1>(c_hm, e8); slab_put(wc.slab, 0, lane, e8);
+                emit_values(ri, 32 + (N / WAVE + t) * TILE1, wc);
+                encode_u32<1>(c_sig, e8); slab_put(wc.slab, 0, lane, e8);
+                emit_values(rw, t * TILE1, wc);
+                encode_u32<1>(c_v, e8); slab_put(wc.slab, 0, lane, e8);
+                emit_values(rw, (N / WAVE + t) * TILE1, wc);
+                emit_tile<27>(rw, (2 * N + t * WAVE * 27) * 32, unpack_bits<27>(c_wd, lane), wc);
+            }
         }
         // S3, S4: [t, b, ltq(b)]
 #pragma unroll 1
         for (int which = 0; which < 2; which++) {
-            for (int t = wave; t < TILES; t += WAVES) {
+            uint32_t n_q[5], n_b, n_wd;
+            auto ld = [&](int t) {
                 const int k = t * WAVE + lane;
+#pragma unroll
+                for (int i = 0; i < 5; i++) n_q[i] = ct[((size_t)(which ? N : 0) + k) * 5 + i];
+                n_b = cs32[(which ? 3 : 2) * N + k];
+                n_wd = lane < 54 ? cb[(which ? 2 : 1) * CL.seg_words + t * 54 + lane] : 0u;
+            };
+            ld(wave);
+            for (int t = wave; t < TILES; t += WAVES) {
                 uint32_t q5[5];
 #pragma unroll
-                for (int i = 0; i < 5; i++) q5[i] = ct[((size_t)(which ? N : 0) + k) * 5 + i];
+                for (int i = 0; i < 5; i++) q5[i] = n_q[i];
+                const uint32_t c_b = n_b, c_wd = n_wd;
+                if (t + WAVES < TILES) ld(t + WAVES);
                 encode_u160<1>(q5, e8); slab_put(wc.slab, 0, lane, e8);
-                encode_u32<1>(cs32[(which ? 3 : 2) * N + k], e8); slab_put(wc.slab, 1, lane, e8);
-                const uint32_t wd = lane < 54 ? cb[(which ? 2 : 1) * CL.seg_words + t * 54 + lane] : 0u;
-                emit_tile<29>(rw, ((which ? 58 : 29) * N + t * WAVE * 29) * 32, unpack_bits<27>(wd, lane) << 2, wc);
+                encode_u32<1>(c_b, e8); slab_put(wc.slab, 1, lane, e8);
+                emit_tile<29>(rw, ((which ? 58 : 29) * N + t * WAVE * 29) * 32, unpack_bits<27>(c_wd, lane) << 2, wc);
             }
         }
         // S5: [prod, t, c, ltq(c)]
-        for (int t = wave; t < TILES; t += WAVES) {
-            const int k = t * WAVE + lane;
-            encode_u32<1>(cs32[4 * N + 3 * k], e8);     slab_put(wc.slab, 0, lane, e8);
-            encode_u32<1>(cs32[4 * N + 3 * k + 1], e8); slab_put(wc.slab, 1, lane, e8);
-            encode_u32<1>(cs32[4 * N + 3 * k + 2], e8); slab_put(wc.slab, 2, lane, e8);
-            const uint32_t wd = lane < 54 ? cb[3 * CL.seg_words + t * 54 + lane] : 0u;
-            emit_tile<30>(rw, (87 * N + t * WAVE * 30) * 32, unpack_bits<27>(wd, lane) << 3, wc);
+        {
+            uint32_t n_a[3], n_wd;
+            auto ld = [&](int t) {
+                const int k = t * WAVE + lane;
+#pragma unroll
+                for (int i = 0; i < 3; i++) n_a[i] = cs32[4 * N + 3 * k + i];
+                n_wd = lane < 54 ? cb[3 * CL.seg_words + t * 54 + lane] : 0u;
+            };
+            ld(wave);
+            for (int t = wave; t < TILES; t += WAVES) {
+                const uint32_t c0 = n_a[0], c1 = n_a[1], c2 = n_a[2], c_wd = n_wd;
+                if (t + WAVES < TILES) ld(t + WAVES);
+                encode_u32<1>(c0, e8); slab_put(wc.slab, 0, lane, e8);
+                encode_u32<1>(c1, e8); slab_put(wc.slab, 1, lane, e8);
+                encode_u32<1>(c2, e8); slab_put(wc.slab, 2, lane, e8);
+                emit_tile<30>(rw, (87 * N + t * WAVE * 30) * 32, unpack_bits<27>(c_wd, lane) << 3, wc);
+            }
         }
         // S6: [a0..a13, w0, w1, r, sq]
-        for (int t = wave; t < 2 * TILES; t += WAVES) {
-            const int k = t * WAVE + lane;
-            encode_u32<1>(cs32[7 * N + 2 * k], e8);     slab_put(wc.slab, 0, lane, e8);
-            encode_u32<1>(cs32[7 * N + 2 * k + 1], e8); slab_put(wc.slab, 1, lane, e8);
-            const uint32_t wd = lane < 32 ? cb[4 * CL.seg_words + t * 32 + lane] : 0u;
-            emit_tile<18>(rw, (117 * N + t * WAVE * 18) * 32, unpack_bits<16>(wd, lane), wc);
+        {
+            uint32_t n_r, n_sq, n_wd;
+            auto ld = [&](int t) {
+                const int k = t * WAVE + lane;
+                n_r = cs32[7 * N + 2 * k]; n_sq = cs32[7 * N + 2 * k + 1];
+                n_wd = lane < 32 ? cb[4 * CL.seg_words + t * 32 + lane] : 0u;
+            };
+            ld(wave);
+            for (int t = wave; t < 2 * TILES; t += WAVES) {
+                const uint32_t c_r = n_r, c_sq = n_sq, c_wd = n_wd;
+                if (t + WAVES < 2 * TILES) ld(t + WAVES);
+                encode_u32<1>(c_r, e8);  slab_put(wc.slab, 0, lane, e8);
+                encode_u32<1>(c_sq, e8); slab_put(wc.slab, 1, lane, e8);
+                emit_tile<18>(rw, (117 * N + t * WAVE * 18) * 32, unpack_bits<16>(c_wd, lane), wc);
+            }
         }
         // S7
         if (wave == 0) {
@@ -1373,7 +1414,10 @@ hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int n
     if (slab16 == 0) return hipErrorInvalidValue;
     const size_t nslabs = bytes / (slab16 * 16);
     if (nslabs == 0) return hipSuccess;
-    size_t grid = (size_t)num_cu * 3;
+    // 24 workgroups per CU: three times what a CU holds of this register-light kernel.  The calibration is meant to be the
+    // best compute-free stream known for the device (tools/hbm_write_pattern.hip, 32,256 units: 768 workgroups 6,615 GB/s,
+    // 3,072 6,736, 6,144 6,947), not a stream handicapped to the witness kernel's occupancy.
+    size_t grid = (size_t)num_cu * 24;
     if (grid > nslabs) grid = nslabs;
     hipLaunchKernelGGL(write_stream_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, st, (v4u *)buf, slab16, nslabs, 7u);
     return hipGetLastError();
@@ -1398,26 +1442,34 @@ static void query_residency(K kernel, int &cache)
     cache = per_cu;
 }
 
-static int resident_grid(size_t batch, int num_cu, int per_cu)
+// Workgroups to launch for `batch` items.  `cap` = what the device keeps resident (per_cu x CUs).  Launches with at least
+// two items per workgroup to spare use up to OVERSUB x cap: with more workgroups than the device holds, the ones that
+// finish are replaced at different moments, which keeps the workgroups' compute and store phases from lining up across
+// the chip (measured, tools/ab_variants.py: 32,768 Falcon-1024 signatures +1.3 ... 3.5 % at 2 x ... 4 x the resident 768,
+// no more at 6 x and 8 x; 8,192 Falcon-512 signatures +2.7 % at 2,048 and +4.4 % at 4,096 workgroups over 1,024, -9 % at
+// one signature per workgroup; the expansion kernel, whose items are all stores behind a few loads, +4.5 % at 8 x:
+// profiles/r02_scheduling_ab.txt).
+#ifndef FRW_OVERSUB
+#define FRW_OVERSUB 4
+#endif
+static int resident_grid(size_t batch, int num_cu, int per_cu, int oversub = FRW_OVERSUB)
 {
     const size_t cap = (size_t)(per_cu > 0 ? per_cu : 2) * (size_t)num_cu;
     if (batch <= cap) return (int)batch;
 #if defined(FRW_FORCE_GRID)          // A/B builds only
     return FRW_FORCE_GRID;
 #endif
-#ifndef FRW_BALANCED_GRID
-#define FRW_BALANCED_GRID 1
-#endif
-#if FRW_BALANCED_GRID
+    // beyond the resident capacity only while every workgroup keeps at least two items
+    size_t top = cap;
+    if (batch >= 2 * cap) top = std::min((size_t)oversub * cap, batch / 2);
     // Every workgroup streams one 2.5-5 MB signature at a time, so a batch that is not a multiple of the grid ends in a
-    // tail where most CUs idle.  For short launches (< 8 rounds) a grid between 5/8 and 8/8 of the resident capacity that
-    // divides the batch wins (4,096 signatures: 512 x 8 rounds beats 768 x 5.33 by 1.1 %); for long ones the tail is
-    // amortised and the third workgroup per CU is worth more (16,384 signatures: 768 beats 512 by 1.1 %).
-    if (batch < 8 * cap)
-        for (size_t g = cap; g * 8 >= cap * 5; g--)
+    // tail where most CUs idle.  For short launches (< 8 rounds) a grid between 5/8 and 8/8 of the target that divides the
+    // batch wins (4,096 signatures: 512 x 8 rounds beats 768 x 5.33 by 1.1 %); long launches amortise the tail, and the
+    // witness kernel splits it besides.
+    if (batch < 8 * top)
+        for (size_t g = top; g * 8 >= top * 5; g--)
             if (batch % g == 0) return (int)g;
-#endif
-    return (int)cap;
+    return (int)top;
 }
 
 // Called once per context: asks the runtime for the residency of every persistent kernel, so that no launch ever
@@ -1506,7 +1558,7 @@ hipError_t launch_witness_ntt_verify_compact(const Tables *tab, int num_cu, int 
 hipError_t launch_expand(int num_cu, int logn, size_t batch, const void *compact, uint64_t *wit, uint64_t *inst, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
-    const int grid = resident_grid(batch, num_cu, g_occ_expand[logn - 9]);
+    const int grid = resident_grid(batch, num_cu, g_occ_expand[logn - 9], 8);
     if (logn == 9)
         hipLaunchKernelGGL((expand_kernel<9>), dim3(grid), dim3(BLOCK), 0, st, batch, (const unsigned char *)compact, (v4u *)wit,
                            (v4u *)inst);

@@ -55,7 +55,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct Cfg { int pat; int grid; std::vector<float> ms; };
     std::vector<Cfg> cfgs;
-    for (int grid : {768})
+    for (int grid : {768, 1536, 3072, 6144})
         for (int pat : {0, 1, 2, 3}) cfgs.push_back({pat, grid, {}});
     for (int round = 0; round < 7; round++)
         for (auto &c : cfgs) {
