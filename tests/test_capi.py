@@ -118,3 +118,56 @@ def test_expand_host_inverts_the_compact_relayout(oracle):
         assert lib.frw_expand_host(logn, 3, p(comp), p(w2), p(i2)) == 0
         assert np.array_equal(w2, wit) and np.array_equal(i2, inst)
     assert lib.frw_expand_host(11, 1, None, None, None) == -1
+
+
+def test_expand_host_montgomery_conversion_on_random_integers():
+    """frw_expand_host on a compact buffer filled with random integers of the full documented ranges (32-bit values,
+    160-bit quotients, random booleans): every output element == x * 2^256 mod p computed with Python integers."""
+    import ctypes as C
+    import random
+    import numpy as np
+    import falcon_r1cs_amd as frw
+    import frw_testlib as T
+    lib = frw.load_library()
+    rng = random.Random(2026)
+    logn = 9
+    CL, L = T.CompactLayoutPy(logn), frw.layout(logn)
+    n = 1 << logn
+    buf = np.zeros(CL.bytes_per_signature, dtype=np.uint8)
+    small = [rng.choice([0, 1, 12288, (1 << 28) - 1, (1 << 32) - 1, rng.getrandbits(32)]) for _ in range(CL.num_small)]
+    tq = [rng.choice([0, 1, (1 << 160) - 1, (1 << 146) - 1, rng.getrandbits(160)]) for _ in range(CL.num_t)]
+    bits = [rng.getrandbits(1) for _ in range(140 * n)] + [rng.getrandbits(1) for _ in range(50)]
+    inst = [rng.getrandbits(32) for _ in range(2 * n)]
+    buf[:4 * len(small)] = np.array(small, dtype=np.uint32).view(np.uint8)
+    buf[CL.t_off:CL.t_off + 20 * len(tq)] = np.array([[(t >> (32 * j)) & 0xFFFFFFFF for j in range(5)] for t in tq], dtype=np.uint32).view(np.uint8).ravel()
+    words = np.packbits(np.array(bits[:140 * n], dtype=np.uint8), bitorder="little").view(np.uint32)
+    tail = np.packbits(np.array(bits[140 * n:] + [0] * 14, dtype=np.uint8), bitorder="little").view(np.uint32)
+    allw = np.concatenate([words, tail])
+    buf[CL.bits_off:CL.bits_off + 4 * len(allw)] = allw.view(np.uint8)
+    buf[CL.instance_off:CL.instance_off + 8 * n] = np.array(inst, dtype=np.uint32).view(np.uint8)
+    wit = np.empty((1, L.num_witness, 4), dtype=np.uint64)
+    ins = np.empty((1, L.num_instance, 4), dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.frw_expand_host(logn, 1, p(buf), p(wit), p(ins)) == 0
+    R = (1 << 256) % T.P_FR
+    to_int = lambda l: int(l[0]) | int(l[1]) << 64 | int(l[2]) << 128 | int(l[3]) << 192
+    mont = lambda x: x * R % T.P_FR
+    # expected element list in witness order
+    it_small, it_t, it_bit = iter(small), iter(tq), iter(bits)
+    want = [mont(next(it_small)) for _ in range(2 * n)]
+    want += [mont(next(it_bit)) for _ in range(27 * n)]
+    seg = []
+    b_s3 = [next(it_small) for _ in range(n)]
+    b_s4 = [next(it_small) for _ in range(n)]
+    for bs in (b_s3, b_s4):
+        for k in range(n):
+            seg += [mont(next(it_t)), mont(bs[k])] + [mont(next(it_bit)) for _ in range(27)]
+    want += seg
+    for k in range(n):
+        want += [mont(next(it_small)) for _ in range(3)] + [mont(next(it_bit)) for _ in range(27)]
+    for k in range(2 * n):
+        want += [mont(next(it_bit)) for _ in range(16)] + [mont(next(it_small)) for _ in range(2)]
+    want += [mont(next(it_bit)) for _ in range(50)]
+    got = [to_int(wit[0, i]) for i in range(L.num_witness)]
+    assert got == want
+    assert [to_int(ins[0, i]) for i in range(L.num_instance)] == [R] + [mont(x) for x in inst]

@@ -844,3 +844,30 @@ def test_compact_host_path_and_host_expansion(engine, oracle, logn):
     assert not ost.any() and np.array_equal(wit, owit) and np.array_equal(inst, oinst)
     with pytest.raises(frw.FrwError):
         engine.witness_ntt_verify_compact(logn, sig, pk, hm, strict=True)
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_expand_dev_equals_expand_host_on_random_compact_buffers(engine, logn):
+    """frw_expand_dev vs frw_expand_host (itself checked against Python integers in tests/test_capi.py) on compact buffers
+    filled with random integers of the full documented ranges -- 32-bit values, 160-bit quotients, random bits -- i.e. far
+    outside what a Falcon witness ever holds: the two expansions are the same function."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    CL, L = frw.compact_layout(logn), frw.layout(logn)
+    batch = 5
+    rng = np.random.default_rng(77 + logn)
+    comp = rng.integers(0, 256, size=(batch, CL.bytes_per_signature), dtype=np.uint8)
+    nb = 50 if logn == 9 else 52
+    for i in range(batch):                                   # the two words of the norm-bound block carry nb bits only
+        w = comp[i, CL.bits_off: CL.bits_off + 4 * CL.num_bit_words].view(np.uint32)
+        tail = (int(w[-2]) | int(w[-1]) << 32) & ((1 << nb) - 1)
+        w[-2], w[-1] = tail & 0xFFFFFFFF, tail >> 32
+    hw, hi = engine.expand_host(logn, comp)
+    d_comp = torch.from_numpy(comp).to(dev)
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    engine.expand_dev(logn, batch, d_comp, wit, inst, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(wit.cpu().numpy().view(np.uint64), hw)
+    assert np.array_equal(inst.cpu().numpy().view(np.uint64), hi)
