@@ -35,7 +35,32 @@ class Oracle:
             [C.c_void_p] * 3
         lib.frw_oracle_digest.argtypes = [C.c_void_p, C.c_size_t]
         lib.frw_oracle_digest.restype = C.c_uint64
+        lib.frw_oracle_qap_domain_log.argtypes = [C.c_uint64, C.c_uint64]
+        lib.frw_oracle_qap_matvec.argtypes = [C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
+        lib.frw_oracle_qap_matvec.restype = None
+        lib.frw_oracle_qap_witness_map.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         self.lib = lib
+
+    def qap_matvec(self, ptr, col, val, z):
+        """One CSR matrix (canonical values) times z (uint64[vars, 4], canonical) -> uint64[rows, 4] canonical."""
+        ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+        col = np.ascontiguousarray(col, dtype=np.uint32)
+        val = np.ascontiguousarray(val, dtype=np.uint64)
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.zeros((len(ptr) - 1, 4), dtype=np.uint64)
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.lib.frw_oracle_qap_matvec(len(ptr) - 1, P(ptr), P(col), P(val), P(z), z.shape[0], P(out))
+        return out
+
+    def qap_witness_map(self, az, bz, cz, num_inputs, z):
+        """ark-groth16's R1CStoQAP::witness_map from the three products on; everything uint64[., 4] canonical."""
+        az, bz, cz, z = (np.ascontiguousarray(a, dtype=np.uint64) for a in (az, bz, cz, z))
+        nc = az.shape[0]
+        lg = self.lib.frw_oracle_qap_domain_log(nc, num_inputs)
+        h = np.zeros((1 << lg, 4), dtype=np.uint64)
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert self.lib.frw_oracle_qap_witness_map(P(az), P(bz), P(cz), nc, num_inputs, P(z), P(h)) == 0
+        return h
 
     def layout(self, logn):
         L = OracleLayout()
@@ -96,10 +121,20 @@ class Oracle:
 
 def load_oracle():
     so = os.path.join(ORACLE_DIR, "libfrw_oracle.so")
-    src = os.path.join(ORACLE_DIR, "frw_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("frw_oracle.c", "qap_oracle.c")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "libfrw_oracle.so"])
     return Oracle(so)
+
+
+def limbs_to_ints(a):
+    """uint64[..., 4] little-endian limbs -> list of Python ints (row-major)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    return [int.from_bytes(r.tobytes(), "little") for r in a]
+
+
+def ints_to_limbs(vals):
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint64).reshape(-1, 4).copy()
 
 
 def negacyclic_mul(a, b):
