@@ -41,6 +41,11 @@ class CompactLayoutStruct(C.Structure):
                 ("num_instance_values", C.c_uint64)]
 
 
+class QapInfoStruct(C.Structure):
+    _fields_ = [("log_domain_size", C.c_int32), ("domain_size", C.c_uint64), ("num_constraints", C.c_uint64),
+                ("num_instance", C.c_uint64), ("workspace_bytes_per_signature", C.c_uint64)]
+
+
 # name -> (restype, argtypes); must list every symbol include/frw.h declares
 PROTOTYPES = {
     "frw_layout": (C.c_int, [C.c_int, C.POINTER(LayoutStruct)]),
@@ -73,6 +78,9 @@ PROTOTYPES = {
     "frw_r1cs_free": (None, [C.c_void_p]),
     "frw_r1cs_check_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_r1cs_eval_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_qap_info": (C.c_int, [C.c_void_p, C.POINTER(QapInfoStruct)]),
+    "frw_qap_witness_map_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]),
     "frw_hash_to_point_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     "frw_decode_public_keys_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -83,7 +83,18 @@ struct R1csDev {
     const uint32_t *order;      // constraint rows by decreasing length
 };
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
-                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st);
+                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st, int qap_log = 0);
+// Tables of the QAP witness map's domain (frw_qap.hip), Montgomery form, built by frw_r1cs_load
+struct QapDev {
+    int log_n;                  // domain = the 2^log_n-th roots of unity, 2^log_n >= num_constraints + num_instance
+    const uint32_t *tw_fwd;     // w^k,  k < n/2
+    const uint32_t *tw_inv;     // w^-k, k < n/2
+    const uint32_t *scale_in;   // g^k / n                  (ifft's 1/n and coset_fft's distribute_powers, fused)
+    const uint32_t *scale_out;  // g^-k / (n (g^n - 1))     (ifft's 1/n, division by the vanishing polynomial, g^-k)
+};
+hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,
+                                  const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,
+                                  size_t workspace_bytes, hipStream_t st);
 hipError_t launch_write_stream(void *buf, size_t bytes, size_t slab_bytes, int num_cu, hipStream_t st);
 hipError_t launch_digest(const uint64_t *buf, size_t words, size_t items, uint64_t *out, hipStream_t st);
 

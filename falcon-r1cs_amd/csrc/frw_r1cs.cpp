@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <cstring>
+#include <stdexcept>
 #include <exception>
 #include <numeric>
 #include <vector>
@@ -31,8 +33,58 @@ frw::host::ConstraintMatrices build_matrices(int circuit, int logn)
 struct frw_r1cs {
     int device;
     frw::R1csDev dev;
+    frw::QapDev qap;
     std::vector<void *> allocs;
 };
+
+namespace {
+using frw::host::Fr;
+Fr pow_limbs(const Fr &b, const uint64_t e[4])
+{
+    Fr r = Fr::one();
+    for (int i = 255; i >= 0; i--) {
+        r = r * r;
+        if ((e[i / 64] >> (i % 64)) & 1) r = r * b;
+    }
+    return r;
+}
+Fr inverse(const Fr &a)
+{
+    const uint64_t e[4] = {Fr::P[0] - 2, Fr::P[1], Fr::P[2], Fr::P[3]};
+    return pow_limbs(a, e);
+}
+int domain_log(uint64_t num_coeffs)
+{
+    int lg = 0;
+    while (((uint64_t)1 << lg) < num_coeffs) lg++;
+    return lg;
+}
+// Tables of Radix2EvaluationDomain::new(num_constraints + num_instance) (ark-poly 0.3.0), Montgomery limbs as the
+// device reads them.  group_gen = two_adic_root_of_unity^(2^(32 - log n)) (ark-ff 0.3.0 get_root_of_unity); the root is
+// ark-bls12-381 0.3.0's TWO_ADIC_ROOT_OF_UNITY = 7^((p-1)/2^32) (tests/test_qap.py derives these limbs from the formula).
+struct QapTables { int log_n; std::vector<uint64_t> tw_fwd, tw_inv, scale_in, scale_out; };
+QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
+{
+    QapTables t;
+    t.log_n = domain_log(num_constraints + num_instance);
+    if (t.log_n > 32) throw std::runtime_error("PolynomialDegreeTooLarge");
+    const size_t n = (size_t)1 << t.log_n;
+    const uint64_t root_limbs[4] = {0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL};
+    Fr w = Fr::from_montgomery(root_limbs);
+    for (int i = t.log_n; i < 32; i++) w = w * w;
+    const Fr winv = inverse(w), g = Fr::from(7), ginv = inverse(g), ninv = inverse(Fr::from(n));
+    const Fr zinv = inverse(g.pow(n) - Fr::one());             // divide_by_vanishing_poly_on_coset
+    auto fill = [](std::vector<uint64_t> &v, size_t count, Fr first, const Fr &step) {
+        v.resize(count * 4);
+        for (size_t k = 0; k < count; k++) { std::memcpy(&v[4 * k], first.l, 32); first = first * step; }
+    };
+    fill(t.tw_fwd, n / 2, Fr::one(), w);
+    fill(t.tw_inv, n / 2, Fr::one(), winv);
+    fill(t.scale_in, n, ninv, g);
+    fill(t.scale_out, n, ninv * zinv, ginv);
+    return t;
+}
+}  // namespace
 
 extern "C" void frw_r1cs_free(frw_r1cs *r)
 {
@@ -87,6 +139,12 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
             return m.a[x].size() + m.b[x].size() + m.c[x].size() > m.a[y].size() + m.b[y].size() + m.c[y].size();
         });
         r->dev.order = (const uint32_t *)upload(order.data(), order.size() * 4);
+        const QapTables qt = build_qap_tables(m.num_constraints, m.num_instance_variables);
+        r->qap.log_n = qt.log_n;
+        r->qap.tw_fwd = (const uint32_t *)upload(qt.tw_fwd.data(), qt.tw_fwd.size() * 8);
+        r->qap.tw_inv = (const uint32_t *)upload(qt.tw_inv.data(), qt.tw_inv.size() * 8);
+        r->qap.scale_in = (const uint32_t *)upload(qt.scale_in.data(), qt.scale_in.size() * 8);
+        r->qap.scale_out = (const uint32_t *)upload(qt.scale_out.data(), qt.scale_out.size() * 8);
         *out = r;
         return FRW_OK;
     } catch (const std::exception &) {
@@ -109,6 +167,28 @@ extern "C" int frw_r1cs_eval_dev(const frw_r1cs *r, size_t batch, const uint64_t
             return FRW_E_HIP;
     }
     return FRW_OK;
+}
+
+extern "C" int frw_qap_info(const frw_r1cs *r, frw_qap_info_t *out)
+{
+    if (!r || !out) return FRW_E_INVALID_ARG;
+    out->log_domain_size = r->qap.log_n;
+    out->domain_size = (uint64_t)1 << r->qap.log_n;
+    out->num_constraints = r->dev.num_constraints;
+    out->num_instance = r->dev.num_instance;
+    out->workspace_bytes_per_signature = 3 * out->domain_size * 32;
+    return FRW_OK;
+}
+
+extern "C" int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                                       uint64_t *d_h, uint32_t *d_num_unsatisfied, void *d_workspace, size_t workspace_bytes,
+                                       void *stream)
+{
+    if (!r || (batch && (!d_witness || !d_instance || !d_h || !d_workspace))) return FRW_E_INVALID_ARG;
+    if (batch && workspace_bytes < 3 * ((size_t)1 << r->qap.log_n) * 32) return FRW_E_INVALID_ARG;
+    if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
+    return frw::launch_qap_witness_map(r->dev, r->qap, batch, d_witness, d_instance, d_h, d_num_unsatisfied, d_workspace,
+                                       workspace_bytes, (hipStream_t)stream) == hipSuccess ? FRW_OK : FRW_E_HIP;
 }
 
 extern "C" int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,

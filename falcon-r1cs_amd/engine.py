@@ -315,6 +315,22 @@ class WitnessEngine:
                                           self._ptr(d_num_unsatisfied), self._ptr(d_abc), C.c_void_p(stream)),
               "frw_r1cs_eval_dev")
 
+    def qap_info(self, handle):
+        """Domain of the QAP witness map for the loaded matrices: (log n, n, C, I, workspace bytes per signature)."""
+        from ._lib import QapInfoStruct
+        q = QapInfoStruct()
+        check(self._lib.frw_qap_info(handle, C.byref(q)), "frw_qap_info")
+        return q
+
+    def qap_witness_map_dev(self, handle, batch, d_wit, d_inst, d_h, d_workspace, workspace_bytes, d_num_unsatisfied=None,
+                            stream=0):
+        """ark-groth16's R1CStoQAP::witness_map for every signature of a resident batch: d_h = int64[batch, n, 4]
+        (Montgomery), coefficient k of h(X) = (A B - C)(X) / (X^n - 1) at index k."""
+        check(self._lib.frw_qap_witness_map_dev(handle, batch, self._ptr(d_wit), self._ptr(d_inst), self._ptr(d_h),
+                                                self._ptr(d_num_unsatisfied) if d_num_unsatisfied is not None else None,
+                                                self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)),
+              "frw_qap_witness_map_dev")
+
     def digest_dev(self, d_buf, words_per_item, items, d_out, stream=0):
         check(self._lib.frw_digest_dev(self._ctx, self._ptr(d_buf), words_per_item, items, self._ptr(d_out),
                                        C.c_void_p(stream)), "frw_digest_dev")

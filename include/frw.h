@@ -228,6 +228,30 @@ int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witnes
 int frw_r1cs_eval_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
                       uint32_t *d_num_unsatisfied, uint64_t *d_abc, void *stream);
 
+/* ---- QAP witness map (the step after the hot path in a Groth16 prover) ------------------------------------------
+ * examples/pok_sig.rs:30-47 hands the circuit to Groth16::<Bls12_381>::prove; after generate_constraints the prover's
+ * first step is ark-groth16 0.3.0's R1CStoQAP::witness_map (r1cs_to_qap.rs): the coefficients of
+ *     h(X) = (A(X) B(X) - C(X)) / (X^n - 1)
+ * over ark-poly's Radix2EvaluationDomain of size n = next_power_of_two(C + I) (2^17 for Falcon-512, 2^18 for
+ * Falcon-1024), computed as  a = A z ++ instance values, b = B z, c = C z;  ifft, coset_fft (generator 7);
+ * a o b - c;  / (7^n - 1);  coset_ifft.  frw_qap_witness_map_dev does exactly that for every signature of an HBM-resident
+ * batch, from the buffers the witness entry points wrote (FRW_ENC_MONTGOMERY):
+ *     d_h               uint64_t[batch][n][4], Montgomery form, coefficient k of h at index k (what the prover feeds,
+ *                       after into_repr, to the MSM over pk.h_query; the last coefficient is zero for a satisfied system)
+ *     d_num_unsatisfied optional uint32_t[batch]: constraint rows the witness violates (h is then not a quotient)
+ *     d_workspace       at least workspace_bytes_per_signature bytes; the batch is processed in chunks of as many
+ *                       signatures as fit. */
+typedef struct {
+    int32_t log_domain_size;
+    uint64_t domain_size;                      /* n */
+    uint64_t num_constraints, num_instance;    /* C, I */
+    uint64_t workspace_bytes_per_signature;    /* 3 n x 32 */
+} frw_qap_info_t;
+int frw_qap_info(const frw_r1cs *r, frw_qap_info_t *out);
+int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                            uint64_t *d_h, uint32_t *d_num_unsatisfied, void *d_workspace, size_t workspace_bytes,
+                            void *stream);
+
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),
  * hm = Polynomial::from_hash_of_message(msg, sig.nonce()).  Formats are the Falcon specification's:

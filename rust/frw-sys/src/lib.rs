@@ -66,6 +66,16 @@ pub struct frw_compact_layout_t {
 }
 
 #[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct frw_qap_info_t {
+    pub log_domain_size: i32,
+    pub domain_size: u64,
+    pub num_constraints: u64,
+    pub num_instance: u64,
+    pub workspace_bytes_per_signature: u64,
+}
+
+#[repr(C)]
 pub struct frw_ctx {
     _private: [u8; 0],
 }
@@ -113,6 +123,10 @@ extern "C" {
                               d_num_unsatisfied: *mut u32, stream: *mut c_void) -> c_int;
     pub fn frw_r1cs_eval_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
                              d_num_unsatisfied: *mut u32, d_abc: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn frw_qap_info(r: *const frw_r1cs, out: *mut frw_qap_info_t) -> c_int;
+    pub fn frw_qap_witness_map_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
+                                   d_h: *mut u64, d_num_unsatisfied: *mut u32, d_workspace: *mut c_void,
+                                   workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_hash_to_point_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_nonces: *const u8, d_msgs: *const u8,
                                  d_msg_off: *const u64, d_hm: *mut u16, stream: *mut c_void) -> c_int;
     pub fn frw_decode_public_keys_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_pk_bytes: *const u8,

@@ -1,0 +1,122 @@
+"""GPU parity of the R1CS -> QAP witness map (frw_qap_witness_map_dev) against the oracle (oracle/qap_oracle.c, which
+tests/test_qap.py pins to oracle/qap.py and to the FFT-free identity).  Bit-exact: h is a vector of field elements."""
+import random
+
+import numpy as np
+import pytest
+
+import frw_testlib as T
+from oracle import qap
+
+pytestmark = pytest.mark.gpu
+P = qap.P
+R_INV = pow(qap.R_MONT, -1, P)
+
+
+def from_montgomery(limbs):
+    return [v * R_INV % P for v in T.limbs_to_ints(limbs)]
+
+
+def oracle_h(oracle, mats, ni, z_limbs):
+    az, bz, cz = (oracle.qap_matvec(*m, z_limbs) for m in mats)
+    return (az, bz, cz), oracle.qap_witness_map(az, bz, cz, ni, z_limbs)
+
+
+@pytest.mark.parametrize("circuit,logn", [(0, 9), (0, 10), (1, 9)])
+def test_witness_map_equals_oracle(engine, oracle, tmp_path, circuit, logn):
+    import torch
+    import falcon_r1cs_amd as frw
+    from test_r1cs_export import export, read_r1cs
+    dev = torch.device("cuda:0")
+    batch = 3
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=4242 + logn)
+    L = frw.layout_dual(logn) if circuit else frw.layout(logn)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.empty(batch, dtype=torch.int32, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    gen = engine.witness_dual_ntt_verify_dev if circuit else engine.witness_ntt_verify_dev
+    gen(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, s0)
+    # signature 2: break the witness (one S1 element + 1) -- h is still a deterministic function of (matrices, z)
+    tamper = L.n + 7
+    one_m = torch.tensor(np.array(T.ints_to_limbs([qap.R_MONT])[0]).view(np.int64), device=dev)
+    w2 = from_montgomery(wit[2, tamper].cpu().numpy().view(np.uint64))[0]
+    wit[2, tamper] = torch.from_numpy(T.ints_to_limbs([(w2 + 1) * qap.R_MONT % P])[0].view(np.int64)).to(dev)
+    del one_m
+    h_r1cs = engine.r1cs_load(circuit, logn)
+    try:
+        q = engine.qap_info(h_r1cs)
+        n = int(q.domain_size)
+        assert n == 1 << int(q.log_domain_size) and n >= q.num_constraints + q.num_instance > n // 2
+        assert q.num_constraints == L.num_constraints and q.num_instance == L.num_instance
+        ws_bytes = 2 * int(q.workspace_bytes_per_signature)              # two signatures per chunk: 3 = 2 + 1
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        h = torch.full((batch, n, 4), -1, dtype=torch.int64, device=dev)
+        bad = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        engine.qap_witness_map_dev(h_r1cs, batch, wit, inst, h, ws, ws_bytes, bad, s0)
+        torch.cuda.synchronize()
+    finally:
+        engine.r1cs_free(h_r1cs)
+    assert bad.tolist()[:2] == [0, 0] and bad.tolist()[2] > 0
+    path = tmp_path / "c.r1cs"
+    export(circuit, logn, path)
+    ni, nw, nc, mats = read_r1cs(path)
+    ofn = oracle.witness_dual_ntt_verify if circuit else oracle.witness_ntt_verify
+    owit, oinst, ost = ofn(logn, sig, pk, hm, 0)
+    for k in (0, 2):
+        z = np.concatenate([oinst[k], owit[k]])
+        if k == 2:
+            z[ni + tamper] = T.ints_to_limbs([(T.limbs_to_ints(z[ni + tamper])[0] + 1) % P])[0]
+        (az, bz, cz), want = oracle_h(oracle, mats, ni, z)
+        got = from_montgomery(h[k].cpu().numpy().view(np.uint64))
+        assert got == T.limbs_to_ints(want), "signature %d" % k
+        if k == 0:
+            assert got[-1] == 0                                          # deg h <= n - 2 for a satisfied system
+
+
+def test_witness_map_full_batch_identity_and_chunking(engine, oracle, tmp_path):
+    """Falcon-1024, 40 signatures through a 16-signature workspace (chunks of 16, 16, 8): every signature's h equals the h
+    of a one-signature call, and a sampled one satisfies A(tau) B(tau) - C(tau) = h(tau) (tau^n - 1) -- evaluated in
+    Python without any FFT from the oracle's A z, B z, C z."""
+    import torch
+    import falcon_r1cs_amd as frw
+    from test_r1cs_export import export, read_r1cs
+    dev = torch.device("cuda:0")
+    logn, batch = 10, 40
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=99)
+    L = frw.layout(logn)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.empty(batch, dtype=torch.int32, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    engine.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, s0)
+    h_r1cs = engine.r1cs_load(0, logn)
+    try:
+        q = engine.qap_info(h_r1cs)
+        n, per = int(q.domain_size), int(q.workspace_bytes_per_signature)
+        ws = torch.empty(16 * per, dtype=torch.uint8, device=dev)
+        h = torch.empty((batch, n, 4), dtype=torch.int64, device=dev)
+        bad = torch.empty(batch, dtype=torch.int32, device=dev)
+        engine.qap_witness_map_dev(h_r1cs, batch, wit, inst, h, ws, 16 * per, bad, s0)
+        torch.cuda.synchronize()
+        assert int(bad.abs().sum()) == 0
+        assert int(h[:, -1].abs().sum()) == 0
+        h1 = torch.empty((1, n, 4), dtype=torch.int64, device=dev)
+        for k in (0, 15, 16, 33, 39):
+            engine.qap_witness_map_dev(h_r1cs, 1, wit[k], inst[k], h1, ws, per, None, s0)
+            torch.cuda.synchronize()
+            assert torch.equal(h1[0], h[k]), k
+    finally:
+        engine.r1cs_free(h_r1cs)
+    k = 33
+    path = tmp_path / "c.r1cs"
+    export(0, logn, path)
+    ni, nw, nc, mats = read_r1cs(path)
+    owit, oinst, _ = oracle.witness_ntt_verify(logn, sig[k:k + 1], pk[k:k + 1], hm[k:k + 1], 0)
+    z = np.concatenate([oinst[0], owit[0]])
+    az, bz, cz = (T.limbs_to_ints(oracle.qap_matvec(*m, z)) for m in mats)
+    got = from_montgomery(h[k].cpu().numpy().view(np.uint64))
+    lhs, rhs = qap.check_identity(az, bz, cz, ni, T.limbs_to_ints(z[:ni]), got, random.Random(7).randrange(P))
+    assert lhs == rhs
