@@ -62,7 +62,7 @@ int domain_log(uint64_t num_coeffs)
 // Tables of Radix2EvaluationDomain::new(num_constraints + num_instance) (ark-poly 0.3.0), Montgomery limbs as the
 // device reads them.  group_gen = two_adic_root_of_unity^(2^(32 - log n)) (ark-ff 0.3.0 get_root_of_unity); the root is
 // ark-bls12-381 0.3.0's TWO_ADIC_ROOT_OF_UNITY = 7^((p-1)/2^32) (tests/test_qap.py derives these limbs from the formula).
-struct QapTables { int log_n; std::vector<uint64_t> tw_fwd, tw_inv, scale_in, scale_out; };
+struct QapTables { int log_n; std::vector<uint32_t> tw_fwd, tw_inv, scale_in, scale_in_a, scale_out; };
 QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
 {
     QapTables t;
@@ -72,15 +72,26 @@ QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
     const uint64_t root_limbs[4] = {0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL};
     Fr w = Fr::from_montgomery(root_limbs);
     for (int i = t.log_n; i < 32; i++) w = w * w;
-    const Fr winv = inverse(w), g = Fr::from(7), ginv = inverse(g), ninv = inverse(Fr::from(n));
+    const Fr winv = inverse(w), g = Fr::from(7), ginv = inverse(g), ninv = inverse(Fr::from(n)), two5 = Fr::from(32);
     const Fr zinv = inverse(g.pow(n) - Fr::one());             // divide_by_vanishing_poly_on_coset
-    auto fill = [](std::vector<uint64_t> &v, size_t count, Fr first, const Fr &step) {
-        v.resize(count * 4);
-        for (size_t k = 0; k < count; k++) { std::memcpy(&v[4 * k], first.l, 32); first = first * step; }
+    // first, first * step, ... as x R' (R' = 2^261 = 2^5 R: the Montgomery limbs of 32 x) in 29-bit limbs, plane per limb
+    auto fill = [&](std::vector<uint32_t> &v, size_t count, Fr first, const Fr &step) {
+        v.resize(count * 9);
+        for (size_t k = 0; k < count; k++) {
+            const Fr x = first * two5;
+            for (int i = 0; i < 9; i++) {
+                const int bit = 29 * i, q = bit >> 6, sft = bit & 63;
+                uint64_t limb = x.l[q] >> sft;
+                if (sft > 35 && q + 1 < 4) limb |= x.l[q + 1] << (64 - sft);
+                v[(size_t)i * count + k] = (uint32_t)(limb & 0x1fffffffu);
+            }
+            first = first * step;
+        }
     };
     fill(t.tw_fwd, n / 2, Fr::one(), w);
     fill(t.tw_inv, n / 2, Fr::one(), winv);
     fill(t.scale_in, n, ninv, g);
+    fill(t.scale_in_a, n, ninv * two5, g);
     fill(t.scale_out, n, ninv * zinv, ginv);
     return t;
 }
@@ -141,10 +152,11 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
         r->dev.order = (const uint32_t *)upload(order.data(), order.size() * 4);
         const QapTables qt = build_qap_tables(m.num_constraints, m.num_instance_variables);
         r->qap.log_n = qt.log_n;
-        r->qap.tw_fwd = (const uint32_t *)upload(qt.tw_fwd.data(), qt.tw_fwd.size() * 8);
-        r->qap.tw_inv = (const uint32_t *)upload(qt.tw_inv.data(), qt.tw_inv.size() * 8);
-        r->qap.scale_in = (const uint32_t *)upload(qt.scale_in.data(), qt.scale_in.size() * 8);
-        r->qap.scale_out = (const uint32_t *)upload(qt.scale_out.data(), qt.scale_out.size() * 8);
+        r->qap.tw_fwd = (const uint32_t *)upload(qt.tw_fwd.data(), qt.tw_fwd.size() * 4);
+        r->qap.tw_inv = (const uint32_t *)upload(qt.tw_inv.data(), qt.tw_inv.size() * 4);
+        r->qap.scale_in = (const uint32_t *)upload(qt.scale_in.data(), qt.scale_in.size() * 4);
+        r->qap.scale_in_a = (const uint32_t *)upload(qt.scale_in_a.data(), qt.scale_in_a.size() * 4);
+        r->qap.scale_out = (const uint32_t *)upload(qt.scale_out.data(), qt.scale_out.size() * 4);
         *out = r;
         return FRW_OK;
     } catch (const std::exception &) {
@@ -176,7 +188,7 @@ extern "C" int frw_qap_info(const frw_r1cs *r, frw_qap_info_t *out)
     out->domain_size = (uint64_t)1 << r->qap.log_n;
     out->num_constraints = r->dev.num_constraints;
     out->num_instance = r->dev.num_instance;
-    out->workspace_bytes_per_signature = 3 * out->domain_size * 32;
+    out->workspace_bytes_per_signature = frw::qap_workspace_bytes_per_signature(r->dev, r->qap);
     return FRW_OK;
 }
 
@@ -185,7 +197,7 @@ extern "C" int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const ui
                                        void *stream)
 {
     if (!r || (batch && (!d_witness || !d_instance || !d_h || !d_workspace))) return FRW_E_INVALID_ARG;
-    if (batch && workspace_bytes < 3 * ((size_t)1 << r->qap.log_n) * 32) return FRW_E_INVALID_ARG;
+    if (batch && workspace_bytes < frw::qap_workspace_bytes_per_signature(r->dev, r->qap)) return FRW_E_INVALID_ARG;
     if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
     return frw::launch_qap_witness_map(r->dev, r->qap, batch, d_witness, d_instance, d_h, d_num_unsatisfied, d_workspace,
                                        workspace_bytes, (hipStream_t)stream) == hipSuccess ? FRW_OK : FRW_E_HIP;

@@ -33,12 +33,10 @@ __device__ __forceinline__ Fr8 row_dot(const R1csMatrixDev &m, uint32_t row, con
 
 // abc != nullptr: also write Az, Bz, Cz (Montgomery form) as [batch][3][num_constraints][8 x u32] -- the inputs of a
 // prover's QAP witness map (what ark-groth16 computes on the CPU right after generate_constraints).
-// qap_log > 0: the layout the QAP witness map starts from instead (frw_qap.hip): [batch][3][2^qap_log][8 x u32], row i at
-// position bitrev(i) (the transforms that follow are decimation-in-time, bit-reversed in, natural out).
 __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
                                                            const uint32_t *__restrict__ instance,
                                                            unsigned int *__restrict__ num_unsatisfied,
-                                                           uint32_t *__restrict__ abc, int qap_log)
+                                                           uint32_t *__restrict__ abc)
 {
     const size_t sig = blockIdx.y;
     if (sig >= batch) return;
@@ -50,13 +48,7 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
         const Fr8 az = row_dot(r.a, row, wit, inst, r.num_instance);
         const Fr8 bz = row_dot(r.b, row, wit, inst, r.num_instance);
         const Fr8 cz = row_dot(r.c, row, wit, inst, r.num_instance);
-        if (abc && qap_log) {
-            const size_t n = (size_t)1 << qap_log, pos = __brev(row) >> (32 - qap_log);
-            uint32_t *o = abc + sig * 3 * n * 8;
-            fr_store(o + pos * 8, az);
-            fr_store(o + (n + pos) * 8, bz);
-            fr_store(o + (2 * n + pos) * 8, cz);
-        } else if (abc) {
+        if (abc) {
             uint32_t *o = abc + sig * (size_t)3 * r.num_constraints * 8;
             fr_store(o + (size_t)row * 8, az);
             fr_store(o + ((size_t)r.num_constraints + row) * 8, bz);
@@ -74,7 +66,7 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
 }
 
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
-                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st, int qap_log)
+                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
     if (batch > 65535) return hipErrorInvalidValue;
@@ -85,7 +77,7 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
     // enough workgroups per signature that the dense ladder rows (first in `order`) spread over many waves
     const unsigned gx = (r.num_constraints + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(r1cs_check_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
-                       (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied, (uint32_t *)abc, qap_log);
+                       (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied, (uint32_t *)abc);
     return hipGetLastError();
 }
 

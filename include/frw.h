@@ -245,7 +245,7 @@ typedef struct {
     int32_t log_domain_size;
     uint64_t domain_size;                      /* n */
     uint64_t num_constraints, num_instance;    /* C, I */
-    uint64_t workspace_bytes_per_signature;    /* 3 n x 32 */
+    uint64_t workspace_bytes_per_signature;    /* 3 C x 32 (A z, B z, C z) + 3 x 36 n (working arrays) */
 } frw_qap_info_t;
 int frw_qap_info(const frw_r1cs *r, frw_qap_info_t *out);
 int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,

@@ -29,7 +29,7 @@ def build(name, flags):
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libfrw_%s.so" % name)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", so] + \
-        flags.split() + [os.path.join(CSRC, f) for f in ("frw_kernels.hip", "frw_prepare.hip", "frw_r1cs_check.hip", "frw_capi.cpp", "frw_synth.cpp", "frw_r1cs.cpp")]
+        flags.split() + [os.path.join(CSRC, f) for f in ("frw_kernels.hip", "frw_prepare.hip", "frw_r1cs_check.hip", "frw_qap.hip", "frw_capi.cpp", "frw_synth.cpp", "frw_r1cs.cpp")]
     subprocess.check_call(cmd)
     lib = C.CDLL(so)
     lib.frw_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
