@@ -77,10 +77,21 @@ struct R1csMatrixDev {
     const uint32_t *col;        // nnz; < num_instance: instance variable (0 = the constant one), else witness
     const uint32_t *val;        // nnz x 8
 };
+// Rows of at least R1CS_LONG_ROW terms (the 2 N un-reduced NTT outputs of the Falcon circuits are linear combinations
+// of all N coefficients once arkworks' finalize() has inlined them) are not walked by one thread: a wavefront takes the
+// row, 64 terms at a time.  Their coefficients are stored per chunk of 64 terms as c R' (R' = 2^261) in nine 29-bit
+// limbs, one plane per limb (frw_fr29.h), padded with zero coefficients.
+constexpr uint32_t R1CS_LONG_ROW = 128;
+struct R1csLongRow { uint32_t matrix, row, first_chunk, num_chunks; };
 struct R1csDev {
     uint32_t num_instance, num_witness, num_constraints;
     R1csMatrixDev a, b, c;
     const uint32_t *order;      // constraint rows by decreasing length
+    uint32_t num_long;
+    const R1csLongRow *long_rows;
+    const uint32_t *long_col;   // [chunks][64]
+    const uint32_t *long_coef;  // [chunks][9][64]
+    const uint8_t *long_mask;   // [num_constraints]: bit m set = row is long in matrix m (0 = A, 1 = B, 2 = C)
 };
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
                              uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st);

@@ -62,6 +62,17 @@ int domain_log(uint64_t num_coeffs)
 // Tables of Radix2EvaluationDomain::new(num_constraints + num_instance) (ark-poly 0.3.0), Montgomery limbs as the
 // device reads them.  group_gen = two_adic_root_of_unity^(2^(32 - log n)) (ark-ff 0.3.0 get_root_of_unity); the root is
 // ark-bls12-381 0.3.0's TWO_ADIC_ROOT_OF_UNITY = 7^((p-1)/2^32) (tests/test_qap.py derives these limbs from the formula).
+// x R' (R' = 2^261 = 2^5 R: the Montgomery limbs of 32 x) in nine 29-bit limbs
+void limbs29(const Fr &v, uint32_t out[9])
+{
+    const Fr x = v * Fr::from(32);
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, q = bit >> 6, sft = bit & 63;
+        uint64_t limb = x.l[q] >> sft;
+        if (sft > 35 && q + 1 < 4) limb |= x.l[q + 1] << (64 - sft);
+        out[i] = (uint32_t)(limb & 0x1fffffffu);
+    }
+}
 struct QapTables { int log_n; std::vector<uint32_t> tw_fwd, tw_inv, scale_in, scale_in_a, scale_out; };
 QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
 {
@@ -78,13 +89,9 @@ QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
     auto fill = [&](std::vector<uint32_t> &v, size_t count, Fr first, const Fr &step) {
         v.resize(count * 9);
         for (size_t k = 0; k < count; k++) {
-            const Fr x = first * two5;
-            for (int i = 0; i < 9; i++) {
-                const int bit = 29 * i, q = bit >> 6, sft = bit & 63;
-                uint64_t limb = x.l[q] >> sft;
-                if (sft > 35 && q + 1 < 4) limb |= x.l[q + 1] << (64 - sft);
-                v[(size_t)i * count + k] = (uint32_t)(limb & 0x1fffffffu);
-            }
+            uint32_t l[9];
+            limbs29(first, l);
+            for (int i = 0; i < 9; i++) v[(size_t)i * count + k] = l[i];
             first = first * step;
         }
     };
@@ -150,6 +157,33 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
             return m.a[x].size() + m.b[x].size() + m.c[x].size() > m.a[y].size() + m.b[y].size() + m.c[y].size();
         });
         r->dev.order = (const uint32_t *)upload(order.data(), order.size() * 4);
+        // long rows: chunked, coefficient planes (see frw_device.h)
+        std::vector<frw::R1csLongRow> lrows;
+        std::vector<uint32_t> lcol, lcoef;
+        std::vector<uint8_t> lmask(m.num_constraints, 0);
+        const std::vector<frw::host::ConstraintMatrices::Row> *mats[3] = {&m.a, &m.b, &m.c};
+        for (uint32_t mi = 0; mi < 3; mi++)
+            for (size_t row = 0; row < m.num_constraints; row++) {
+                const auto &terms = (*mats[mi])[row];
+                if (terms.size() < frw::R1CS_LONG_ROW) continue;
+                const uint32_t chunks = (uint32_t)((terms.size() + 63) / 64), first = (uint32_t)(lcol.size() / 64);
+                lrows.push_back({mi, (uint32_t)row, first, chunks});
+                lmask[row] |= (uint8_t)(1u << mi);
+                lcol.resize((size_t)(first + chunks) * 64, 0u);
+                lcoef.resize((size_t)(first + chunks) * 9 * 64, 0u);
+                for (size_t t = 0; t < terms.size(); t++) {
+                    uint32_t l[9];
+                    limbs29(terms[t].first, l);
+                    const size_t ch = first + t / 64, lane = t % 64;
+                    lcol[ch * 64 + lane] = terms[t].second;
+                    for (int k = 0; k < 9; k++) lcoef[(ch * 9 + k) * 64 + lane] = l[k];
+                }
+            }
+        r->dev.num_long = (uint32_t)lrows.size();
+        r->dev.long_rows = (const frw::R1csLongRow *)upload(lrows.data(), lrows.size() * sizeof(frw::R1csLongRow));
+        r->dev.long_col = (const uint32_t *)upload(lcol.data(), lcol.size() * 4);
+        r->dev.long_coef = (const uint32_t *)upload(lcoef.data(), lcoef.size() * 4);
+        r->dev.long_mask = (const uint8_t *)upload(lmask.data(), lmask.size());
         const QapTables qt = build_qap_tables(m.num_constraints, m.num_instance_variables);
         r->qap.log_n = qt.log_n;
         r->qap.tw_fwd = (const uint32_t *)upload(qt.tw_fwd.data(), qt.tw_fwd.size() * 4);

@@ -12,7 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "frw_device.h"
-#include "frw_fr.h"
+#include "frw_fr29.h"
 
 namespace frw {
 
@@ -33,6 +33,9 @@ __device__ __forceinline__ Fr8 row_dot(const R1csMatrixDev &m, uint32_t row, con
 
 // abc != nullptr: also write Az, Bz, Cz (Montgomery form) as [batch][3][num_constraints][8 x u32] -- the inputs of a
 // prover's QAP witness map (what ark-groth16 computes on the CPU right after generate_constraints).
+// LONG_DONE: the long rows' products are already in abc (r1cs_long_rows_kernel ran first) and are read back instead of
+// recomputed; rows are then visited in constraint order (neighbouring rows touch neighbouring witnesses).
+template <bool LONG_DONE>
 __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
                                                            const uint32_t *__restrict__ instance,
                                                            unsigned int *__restrict__ num_unsatisfied,
@@ -42,17 +45,18 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
     if (sig >= batch) return;
     const uint32_t *wit = witness + sig * (size_t)r.num_witness * 8;
     const uint32_t *inst = instance + sig * (size_t)r.num_instance * 8;
+    uint32_t *o = abc ? abc + sig * (size_t)3 * r.num_constraints * 8 : nullptr;
     unsigned bad = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < r.num_constraints; i += gridDim.x * BLOCK) {
-        const uint32_t row = r.order[i];
-        const Fr8 az = row_dot(r.a, row, wit, inst, r.num_instance);
-        const Fr8 bz = row_dot(r.b, row, wit, inst, r.num_instance);
-        const Fr8 cz = row_dot(r.c, row, wit, inst, r.num_instance);
-        if (abc) {
-            uint32_t *o = abc + sig * (size_t)3 * r.num_constraints * 8;
-            fr_store(o + (size_t)row * 8, az);
-            fr_store(o + ((size_t)r.num_constraints + row) * 8, bz);
-            fr_store(o + ((size_t)2 * r.num_constraints + row) * 8, cz);
+        const uint32_t row = LONG_DONE ? i : r.order[i];
+        const uint32_t mask = LONG_DONE ? r.long_mask[row] : 0u;
+        const Fr8 az = mask & 1u ? fr_load(o + (size_t)row * 8) : row_dot(r.a, row, wit, inst, r.num_instance);
+        const Fr8 bz = mask & 2u ? fr_load(o + ((size_t)r.num_constraints + row) * 8) : row_dot(r.b, row, wit, inst, r.num_instance);
+        const Fr8 cz = mask & 4u ? fr_load(o + ((size_t)2 * r.num_constraints + row) * 8) : row_dot(r.c, row, wit, inst, r.num_instance);
+        if (o) {
+            if (!(mask & 1u)) fr_store(o + (size_t)row * 8, az);
+            if (!(mask & 2u)) fr_store(o + ((size_t)r.num_constraints + row) * 8, bz);
+            if (!(mask & 4u)) fr_store(o + ((size_t)2 * r.num_constraints + row) * 8, cz);
         }
         const Fr8 ab = fr_mul(az, bz);              // (Az R)(Bz R)/R = Az Bz R
         bool eq = true;
@@ -65,6 +69,50 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
     if ((threadIdx.x & (WAVE - 1)) == 0 && bad && num_unsatisfied) atomicAdd(&num_unsatisfied[sig], bad);
 }
 
+// One wavefront per (long row, group of LONG_SIGS signatures): lane l multiplies terms l, l + 64, ... (coefficient loaded
+// once, used for every signature of the group), the 64 partial sums are added across the wavefront, lane 0 stores.
+// Products are f29_mul(z R, c R') = z c R, sums kept < 2 p.
+constexpr int LONG_SIGS = 4;
+__global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
+                                                              const uint32_t *__restrict__ instance, uint32_t *__restrict__ abc)
+{
+    const R1csLongRow d = r.long_rows[blockIdx.x];
+    const int lane = threadIdx.x;
+    const size_t sig0 = (size_t)blockIdx.y * LONG_SIGS;
+    F29 acc[LONG_SIGS];
+#pragma unroll
+    for (int s = 0; s < LONG_SIGS; s++)
+#pragma unroll
+        for (int k = 0; k < NL29; k++) acc[s].l[k] = 0;
+    for (uint32_t ch = 0; ch < d.num_chunks; ch++) {
+        const size_t chunk = (size_t)d.first_chunk + ch;
+        const uint32_t col = r.long_col[chunk * WAVE + lane];
+        F29 c;
+#pragma unroll
+        for (int k = 0; k < NL29; k++) c.l[k] = r.long_coef[(chunk * NL29 + k) * WAVE + lane];
+#pragma unroll
+        for (int s = 0; s < LONG_SIGS; s++) {
+            const size_t sig = sig0 + s < batch ? sig0 + s : batch - 1;       // a ragged last group repeats the last signature
+            const uint32_t *zp = col < r.num_instance ? instance + (sig * r.num_instance + col) * 8
+                                                       : witness + (sig * r.num_witness + (col - r.num_instance)) * 8;
+            const F29 z = f29_unpack(fr_load(zp));
+            acc[s] = f29_reduce_4p(f29_add(acc[s], f29_mul(z, c)));
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < LONG_SIGS; s++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            F29 other;
+#pragma unroll
+            for (int k = 0; k < NL29; k++) other.l[k] = (uint32_t)__shfl_xor((int)acc[s].l[k], off, WAVE);
+            acc[s] = f29_reduce_4p(f29_add(acc[s], other));
+        }
+        if (lane == 0 && sig0 + s < batch)
+            fr_store(abc + (((sig0 + s) * 3 + d.matrix) * (size_t)r.num_constraints + d.row) * 8, f29_pack(f29_canonical(acc[s])));
+    }
+}
+
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
                              uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st)
 {
@@ -74,9 +122,17 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
         hipError_t e = hipMemsetAsync(num_unsatisfied, 0, batch * sizeof(uint32_t), st);
         if (e != hipSuccess) return e;
     }
-    // enough workgroups per signature that the dense ladder rows (first in `order`) spread over many waves
     const unsigned gx = (r.num_constraints + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(r1cs_check_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
+    if (abc && r.num_long) {
+        hipLaunchKernelGGL(r1cs_long_rows_kernel, dim3(r.num_long, (unsigned)((batch + LONG_SIGS - 1) / LONG_SIGS)), dim3(WAVE), 0, st,
+                           r, batch, (const uint32_t *)witness, (const uint32_t *)instance, (uint32_t *)abc);
+        hipLaunchKernelGGL(r1cs_check_kernel<true>, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
+                           (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied, (uint32_t *)abc);
+        return hipGetLastError();
+    }
+    // check only (no buffer to park the long rows' products in): one thread per row, longest rows first, so that the dense
+    // ladder rows spread over many waves
+    hipLaunchKernelGGL(r1cs_check_kernel<false>, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
                        (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied, (uint32_t *)abc);
     return hipGetLastError();
 }
