@@ -75,7 +75,9 @@ hipError_t launch_decode_signatures(int logn, size_t batch, const uint8_t *sig_b
 struct R1csMatrixDev {
     const uint64_t *row_ptr;    // num_constraints + 1
     const uint32_t *col;        // nnz; < num_instance: instance variable (0 = the constant one), else witness
-    const uint32_t *val;        // nnz x 8
+    const uint32_t *val;        // nnz x 8: c R, Montgomery form (the check-only kernel)
+    const uint32_t *col_class;  // nnz: column | class << 30 (0 general, 1 coefficient +1, 2 coefficient -1)
+    const uint32_t *val29;      // nnz x 8: c R' (R' = 2^261) packed, for f29_mul(z R, c R') = z c R
 };
 // Rows of at least R1CS_LONG_ROW terms (the 2 N un-reduced NTT outputs of the Falcon circuits are linear combinations
 // of all N coefficients once arkworks' finalize() has inlined them) are not walked by one thread: a wavefront takes the

@@ -136,17 +136,24 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
         };
         auto put = [&](const std::vector<frw::host::ConstraintMatrices::Row> &rows, frw::R1csMatrixDev &dst) {
             std::vector<uint64_t> ptr{0};
-            std::vector<uint32_t> col, val;
+            std::vector<uint32_t> col, val, cls, val29;
+            const Fr one = Fr::one(), minus_one = -Fr::one(), two5 = Fr::from(32);
             for (const auto &row : rows) {
                 for (const auto &t : row) {
+                    if (t.second >> 30) throw std::runtime_error("too many variables");
                     col.push_back(t.second);
+                    cls.push_back(t.second | (t.first == one ? 1u << 30 : t.first == minus_one ? 2u << 30 : 0u));
+                    const Fr c29 = t.first * two5;                       // Montgomery limbs of 32 c = c R' mod p
                     for (int k = 0; k < 4; k++) { val.push_back((uint32_t)t.first.l[k]); val.push_back((uint32_t)(t.first.l[k] >> 32)); }   // Montgomery limbs
+                    for (int k = 0; k < 4; k++) { val29.push_back((uint32_t)c29.l[k]); val29.push_back((uint32_t)(c29.l[k] >> 32)); }
                 }
                 ptr.push_back(col.size());
             }
             dst.row_ptr = (const uint64_t *)upload(ptr.data(), ptr.size() * 8);
             dst.col = (const uint32_t *)upload(col.data(), col.size() * 4);
             dst.val = (const uint32_t *)upload(val.data(), val.size() * 4);
+            dst.col_class = (const uint32_t *)upload(cls.data(), cls.size() * 4);
+            dst.val29 = (const uint32_t *)upload(val29.data(), val29.size() * 4);
         };
         put(m.a, r->dev.a);
         put(m.b, r->dev.b);

@@ -31,33 +31,83 @@ __device__ __forceinline__ Fr8 row_dot(const R1csMatrixDev &m, uint32_t row, con
     return acc;
 }
 
-// abc != nullptr: also write Az, Bz, Cz (Montgomery form) as [batch][3][num_constraints][8 x u32] -- the inputs of a
-// prover's QAP witness map (what ark-groth16 computes on the CPU right after generate_constraints).
-// LONG_DONE: the long rows' products are already in abc (r1cs_long_rows_kernel ran first) and are read back instead of
-// recomputed; rows are then visited in constraint order (neighbouring rows touch neighbouring witnesses).
-template <bool LONG_DONE>
-__global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
-                                                           const uint32_t *__restrict__ instance,
-                                                           unsigned int *__restrict__ num_unsatisfied,
-                                                           uint32_t *__restrict__ abc)
+// The fast path of frw_r1cs_eval_dev (abc != nullptr): thread per row in nine-limb arithmetic (frw_fr29.h).
+// Term classes (host-computed, top two bits of the column index): coefficient +1 / -1 (55 % of the non-long terms of the
+// Falcon circuits: no product), anything else as f29_mul(z R, c R') with c R' stored packed.  Rows are visited by
+// decreasing length (r.order), so the 64 rows of a wavefront have similar length; matrices in which the row is long
+// (r.long_mask) are skipped -- r1cs_long_rows_kernel has already put their product into abc.
+constexpr uint32_t TERM_PLUS_ONE = 1u, TERM_MINUS_ONE = 2u;      // 0: general coefficient
+__device__ __forceinline__ F29 row_dot29(const R1csMatrixDev &m, uint32_t row, const uint32_t *__restrict__ wit,
+                                         const uint32_t *__restrict__ inst, uint32_t num_instance)
+{
+    F29 acc;
+#pragma unroll
+    for (int i = 0; i < NL29; i++) acc.l[i] = 0;
+    const uint64_t lo = m.row_ptr[row], hi = m.row_ptr[row + 1];
+    for (uint64_t t = lo; t < hi; t++) {
+        const uint32_t cc = m.col_class[t], col = cc & 0x3fffffffu, cls = cc >> 30;
+        const F29 z = f29_unpack(fr_load(col < num_instance ? inst + (size_t)col * 8 : wit + (size_t)(col - num_instance) * 8));
+        if (cls == TERM_PLUS_ONE) acc = f29_reduce_4p(f29_add(acc, z));
+        else if (cls == TERM_MINUS_ONE) acc = f29_reduce_4p(f29_sub_2p(acc, z));
+        else acc = f29_reduce_4p(f29_add(acc, f29_mul(z, f29_unpack(fr_load(m.val29 + t * 8)))));
+    }
+    return acc;                                    // < 2 p
+}
+
+__global__ __launch_bounds__(BLOCK) void r1cs_eval_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
+                                                          const uint32_t *__restrict__ instance,
+                                                          unsigned int *__restrict__ num_unsatisfied,
+                                                          uint32_t *__restrict__ abc)
 {
     const size_t sig = blockIdx.y;
     if (sig >= batch) return;
     const uint32_t *wit = witness + sig * (size_t)r.num_witness * 8;
     const uint32_t *inst = instance + sig * (size_t)r.num_instance * 8;
-    uint32_t *o = abc ? abc + sig * (size_t)3 * r.num_constraints * 8 : nullptr;
+    uint32_t *o = abc + sig * (size_t)3 * r.num_constraints * 8;
+    constexpr uint32_t R32[8] = FRW_R32;
+    Fr8 one_r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) one_r.l[k] = R32[k];
+    const F29 one29 = f29_unpack(one_r);          // R as an integer: f29_mul(x R, R) = x R / 32
     unsigned bad = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < r.num_constraints; i += gridDim.x * BLOCK) {
-        const uint32_t row = LONG_DONE ? i : r.order[i];
-        const uint32_t mask = LONG_DONE ? r.long_mask[row] : 0u;
-        const Fr8 az = mask & 1u ? fr_load(o + (size_t)row * 8) : row_dot(r.a, row, wit, inst, r.num_instance);
-        const Fr8 bz = mask & 2u ? fr_load(o + ((size_t)r.num_constraints + row) * 8) : row_dot(r.b, row, wit, inst, r.num_instance);
-        const Fr8 cz = mask & 4u ? fr_load(o + ((size_t)2 * r.num_constraints + row) * 8) : row_dot(r.c, row, wit, inst, r.num_instance);
-        if (o) {
-            if (!(mask & 1u)) fr_store(o + (size_t)row * 8, az);
-            if (!(mask & 2u)) fr_store(o + ((size_t)r.num_constraints + row) * 8, bz);
-            if (!(mask & 4u)) fr_store(o + ((size_t)2 * r.num_constraints + row) * 8, cz);
-        }
+        const uint32_t row = r.order[i], mask = r.long_mask[row];
+        uint32_t *oa = o + (size_t)row * 8, *ob = o + ((size_t)r.num_constraints + row) * 8, *oc = o + ((size_t)2 * r.num_constraints + row) * 8;
+        F29 az, bz, cz;
+        if (mask & 1u) az = f29_unpack(fr_load(oa));
+        else { az = f29_canonical(row_dot29(r.a, row, wit, inst, r.num_instance)); fr_store(oa, f29_pack(az)); }
+        if (mask & 2u) bz = f29_unpack(fr_load(ob));
+        else { bz = f29_canonical(row_dot29(r.b, row, wit, inst, r.num_instance)); fr_store(ob, f29_pack(bz)); }
+        if (mask & 4u) cz = f29_unpack(fr_load(oc));
+        else { cz = f29_canonical(row_dot29(r.c, row, wit, inst, r.num_instance)); fr_store(oc, f29_pack(cz)); }
+        // (Az R)(Bz R) / R' = Az Bz R / 32  against  (Cz R) R / R' = Cz R / 32
+        const F29 ab = f29_canonical(f29_mul(az, bz)), c32 = f29_canonical(f29_mul(cz, one29));
+        bool eq = true;
+#pragma unroll
+        for (int k = 0; k < NL29; k++) eq &= ab.l[k] == c32.l[k];
+        bad += eq ? 0u : 1u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && bad && num_unsatisfied) atomicAdd(&num_unsatisfied[sig], bad);
+}
+
+// Check only (no buffer to park the long rows' products in): one thread per row in the 8 x 32-bit form, longest rows
+// first, so that the dense ladder rows spread over many waves.
+__global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
+                                                           const uint32_t *__restrict__ instance,
+                                                           unsigned int *__restrict__ num_unsatisfied)
+{
+    const size_t sig = blockIdx.y;
+    if (sig >= batch) return;
+    const uint32_t *wit = witness + sig * (size_t)r.num_witness * 8;
+    const uint32_t *inst = instance + sig * (size_t)r.num_instance * 8;
+    unsigned bad = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < r.num_constraints; i += gridDim.x * BLOCK) {
+        const uint32_t row = r.order[i];
+        const Fr8 az = row_dot(r.a, row, wit, inst, r.num_instance);
+        const Fr8 bz = row_dot(r.b, row, wit, inst, r.num_instance);
+        const Fr8 cz = row_dot(r.c, row, wit, inst, r.num_instance);
         const Fr8 ab = fr_mul(az, bz);              // (Az R)(Bz R)/R = Az Bz R
         bool eq = true;
 #pragma unroll
@@ -123,17 +173,16 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
         if (e != hipSuccess) return e;
     }
     const unsigned gx = (r.num_constraints + BLOCK - 1) / BLOCK;
-    if (abc && r.num_long) {
-        hipLaunchKernelGGL(r1cs_long_rows_kernel, dim3(r.num_long, (unsigned)((batch + LONG_SIGS - 1) / LONG_SIGS)), dim3(WAVE), 0, st,
+    if (abc) {
+        if (r.num_long)
+            hipLaunchKernelGGL(r1cs_long_rows_kernel, dim3(r.num_long, (unsigned)((batch + LONG_SIGS - 1) / LONG_SIGS)), dim3(WAVE), 0, st,
                            r, batch, (const uint32_t *)witness, (const uint32_t *)instance, (uint32_t *)abc);
-        hipLaunchKernelGGL(r1cs_check_kernel<true>, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
+        hipLaunchKernelGGL(r1cs_eval_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
                            (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied, (uint32_t *)abc);
         return hipGetLastError();
     }
-    // check only (no buffer to park the long rows' products in): one thread per row, longest rows first, so that the dense
-    // ladder rows spread over many waves
-    hipLaunchKernelGGL(r1cs_check_kernel<false>, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
-                       (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied, (uint32_t *)abc);
+    hipLaunchKernelGGL(r1cs_check_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
+                       (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied);
     return hipGetLastError();
 }
 
