@@ -98,14 +98,16 @@ struct R1csDev {
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
                              uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st);
 // Tables of the QAP witness map's domain (frw_qap.hip), built by frw_r1cs_load.  Every entry is a field element times
-// R' = 2^261 in nine 29-bit limbs, one plane per limb ([9][count] u32): see frw_fr29.h.
+// R' = 2^261 (frw_fr29.h): the per-index factors packed in 8 x 32 bits (they are < p), the 64-th roots in nine limbs.
 struct QapDev {
-    int log_n;                  // domain = the 2^log_n-th roots of unity, 2^log_n >= num_constraints + num_instance
-    const uint32_t *tw_fwd;     // w^k,  k < n/2
-    const uint32_t *tw_inv;     // w^-k, k < n/2
-    const uint32_t *scale_in;   // g^k / n                  (ifft's 1/n and coset_fft's distribute_powers, fused)
-    const uint32_t *scale_in_a; // 2^5 g^k / n              (for A z: the a b product divides by 2^261, the data carry 2^256)
-    const uint32_t *scale_out;  // g^-k / (n (g^n - 1))     (ifft's 1/n, division by the vanishing polynomial, g^-k)
+    int log_n;                    // domain = the 2^log_n-th roots of unity, 2^log_n >= num_constraints + num_instance
+    const uint32_t *roots_fwd;    // w^(k n/64), k < 32, 12 words apart
+    const uint32_t *roots_inv;    // w^-(k n/64)
+    const uint32_t *twist_fwd[2]; // [n][8]: what a forward pass on bits [6,12) / [12,L) multiplies index i by on its way out
+    const uint32_t *twist_inv[2]; // [n][8]: what an inverse pass multiplies index i by for the NEXT pass on bits [6,12) / [12,L)
+    const uint32_t *scale_in;     // g^k / n                  (ifft's 1/n and coset_fft's distribute_powers, fused)
+    const uint32_t *scale_in_a;   // 2^5 g^k / n              (for A z: the a b product divides by 2^261, the data carry 2^256)
+    const uint32_t *scale_out;    // g^-k / (n (g^n - 1))     (ifft's 1/n, division by the vanishing polynomial, g^-k)
 };
 size_t qap_workspace_bytes_per_signature(const R1csDev &r, const QapDev &q);
 hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,

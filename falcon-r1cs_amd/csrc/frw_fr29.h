@@ -39,6 +39,34 @@ constexpr uint32_t twice_p_word(int k)
 constexpr uint32_t P2_32_[8] = {twice_p_word(0), twice_p_word(1), twice_p_word(2), twice_p_word(3),
                                 twice_p_word(4), twice_p_word(5), twice_p_word(6), twice_p_word(7)};
 constexpr uint32_t p2_29(int i) { return limb29_of(P2_32_, i); }
+// the limbs of K p (K <= 16: K p < 2^259) as a constant table (a constexpr FUNCTION of the loop index is not folded in
+// device code: it was evaluated at run time through scratch memory)
+struct Limbs29 { uint32_t l[NL29]; };
+constexpr Limbs29 make_kp29(uint32_t K)
+{
+    uint32_t w[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t carry = 0;
+    for (int k = 0; k < 8; k++) {
+        const uint64_t t = (uint64_t)K * P32_[k] + carry;
+        w[k] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    w[8] = (uint32_t)carry;
+    Limbs29 r{};
+    for (int i = 0; i < NL29; i++) {
+        const int bit = 29 * i, k = bit >> 5, s = bit & 31;
+        const uint64_t both = (uint64_t)w[k] | ((uint64_t)w[k + 1] << 32);
+        r.l[i] = (uint32_t)(both >> s) & (i == NL29 - 1 ? 0xffffffffu : M29);
+    }
+    return r;
+}
+constexpr Limbs29 KP29_1 = make_kp29(1), KP29_2 = make_kp29(2), KP29_4 = make_kp29(4), KP29_8 = make_kp29(8);
+template <uint32_t K> constexpr const Limbs29 &kp29_table()
+{
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "table missing");
+    return K == 1 ? KP29_1 : K == 2 ? KP29_2 : K == 4 ? KP29_4 : KP29_8;
+}
+static_assert(KP29_2.l[0] == p2_29(0) && KP29_2.l[8] == p2_29(8) && KP29_1.l[3] == p29(3), "K p limbs");
 static_assert(p29(0) == 1u, "p = 1 mod 2^29: the Montgomery factor -p^-1 mod 2^29 is 2^29 - 1");
 
 __device__ __forceinline__ F29 f29_unpack(const Fr8 &w)
@@ -118,6 +146,17 @@ __device__ __forceinline__ F29 f29_sub_2p(const F29 &a, const F29 &b)
     return r;
 }
 
+// a - b + K p  (b < K p), normalised
+template <uint32_t K>
+__device__ __forceinline__ F29 f29_sub_kp(const F29 &a, const F29 &b)
+{
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < NL29; i++) r.l[i] = a.l[i] - b.l[i] + kp29_table<K>().l[i];
+    (void)f29_normalise_signed(r);
+    return r;
+}
+
 // a < 4 p  ->  a or a - 2 p, < 2 p
 __device__ __forceinline__ F29 f29_reduce_4p(const F29 &a)
 {
@@ -144,34 +183,42 @@ __device__ __forceinline__ F29 f29_canonical(const F29 &a)
     return r;
 }
 
-// Montgomery product a b / 2^261 mod p, product scanning, columns in 64 bits.
+// Montgomery product a b / 2^261 mod p, columns in 64 bits.
 // a: limbs < 2^31 (need not be normalised); b: normalised limbs.  Result: normalised, < a b / 2^261 + p
 // (< 2 p whenever a b < 2^261 p, e.g. b < p and a < 2^261).
+// Shaped for instruction-level parallelism: v_mad_u64_u32 issues every ~5 cycles but a dependent one waits several times
+// that, and the transforms run two wavefronts per SIMD.  So: first all 81 partial products into their 17 columns (17
+// independent chains), then the reduction by operand scanning -- each m[i] feeds eight independent multiply-adds
+// (m[i] p[j] into column i + j); the only serial thread is carry -> m[i] -> column i + 1.  (The first form accumulated one
+// column at a time, 18 dependent multiply-adds in a row: 13 cycles per multiply-add measured, profiles/r02_qap_v3_ab.txt.)
 __device__ __forceinline__ F29 f29_mul(const F29 &a, const F29 &b)
 {
-    uint32_t m[NL29];
-    F29 r;
-    uint64_t acc = 0;
+    uint64_t col[2 * NL29];
 #pragma unroll
-    for (int k = 0; k < NL29; k++) {
+    for (int k = 0; k < 2 * NL29 - 1; k++) {
+        uint64_t even = 0, odd = 0;                                  // two chains per column
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p29(k - i);
-        m[k] = (0u - (uint32_t)acc) & M29;          // -p^-1 = -1 mod 2^29
-        acc += m[k];                                // m[k] p29(0), p29(0) = 1
-        acc >>= 29;
+        for (int i = (k < NL29 ? 0 : k - (NL29 - 1)); i <= (k < NL29 ? k : NL29 - 1); i++) {
+            if (i & 1) odd += (uint64_t)a.l[i] * b.l[k - i];
+            else even += (uint64_t)a.l[i] * b.l[k - i];
+        }
+        col[k] = even + odd;
     }
+    col[2 * NL29 - 1] = 0;
+#pragma unroll
+    for (int i = 0; i < NL29; i++) {
+        const uint32_t m = (0u - (uint32_t)col[i]) & M29;          // -p^-1 = -1 mod 2^29
+#pragma unroll
+        for (int j = 1; j < NL29; j++) col[i + j] += (uint64_t)m * p29(j);
+        col[i + 1] += (col[i] + m) >> 29;                           // m p29(0) = m clears the low 29 bits of column i
+    }
+    F29 r;
 #pragma unroll
     for (int k = NL29; k < 2 * NL29 - 1; k++) {
-#pragma unroll
-        for (int i = k - (NL29 - 1); i < NL29; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-        for (int i = k - (NL29 - 1); i < NL29; i++) acc += (uint64_t)m[i] * p29(k - i);
-        r.l[k - NL29] = (uint32_t)acc & M29;
-        acc >>= 29;
+        r.l[k - NL29] = (uint32_t)col[k] & M29;
+        col[k + 1] += col[k] >> 29;
     }
-    r.l[NL29 - 1] = (uint32_t)acc;
+    r.l[NL29 - 1] = (uint32_t)col[2 * NL29 - 1];
     return r;
 }
 

@@ -5,258 +5,369 @@
 //     a = A z (+ the instance values in rows C .. C+I), b = B z, c = C z       over the domain of n-th roots of unity
 //     a, b, c <- coset_fft(ifft(.));   ab = a o b - c;   ab /= (g^n - 1);   h = coset_ifft(ab)
 // Here, with the transforms arranged so that no permutation pass and no scattered access is needed:
-//     r1cs_check_kernel writes A z, B z, C z in constraint order (ark-ff's 8 x 32-bit Montgomery form)
+//     r1cs_eval_kernel writes A z, B z, C z in constraint order (ark-ff's 8 x 32-bit Montgomery form)
 //     inverse transform, decimation in time; its first pass reads that order through the bit-reversed tile
-//         (64 rows 2^(L-6) apart x 16 adjacent rows), appends the instance rows and the zero padding on the fly, and
-//         writes the working form; its last pass multiplies by g^k / n on the way out
+//         (64 rows 2^(L-6) apart x 16 adjacent rows), appends the instance rows and the zero padding on the fly;
+//         its last pass multiplies by g^k / n on the way out
 //     forward transform, decimation in frequency (natural in, bit-reversed out)      -> values on the coset
-//     inverse transform, decimation in time, first pass fused with a b - c, last pass with g^-k / (n (g^n - 1)),
-//         canonical reduction and re-packing                                          -> h, ark-ff form, natural order
-// Working form (frw_fr29.h): nine 29-bit limbs per element, one plane per limb ([9][n] u32 per array), values lazily
-// reduced (< 2^261).  Every transform is three passes over HBM (6 + 6 + (L - 12) butterfly stages), a workgroup taking a
-// tile of 2^T rows x 16 adjacent elements through LDS.  Field arithmetic is exact, so the result is the same element
-// for element as any other schedule's.
+//     inverse transform, decimation in time, first pass fused with a b - c, last pass with g^-k / (n (g^n - 1)) and the
+//         canonical reduction                                                        -> h, ark-ff form, natural order
 //
-// Cost per signature (n = 2^18): 7 transforms x 9 n + 5 n Montgomery products (~17.8 M): bound by VALU issue
-// (~290 instructions per butterfly), not by HBM (~0.5 GB of traffic per signature).
+// Every transform is three passes over HBM (6 + 6 + (L - 12) butterfly stages) in four-step form: a pass is a set of
+// plain 2^T-point transforms that need the 64-th roots of unity only, followed by ONE multiplication per element by a
+// per-index factor read alongside the data (the twist towards the next pass, or the scale factor of the witness map).
+// A workgroup of 128 threads takes a tile of 2^T rows x 2^(10-T) adjacent elements; a thread holds 8 elements in
+// registers and does three stages on them (radix 8), the tile is exchanged once through LDS, three (or two) more stages,
+// the multiplication, and out.  A/B timing of the first version (one LDS round trip and one gathered twiddle per stage)
+// showed the passes waiting for LDS and for the gathers, not for the multiplier (profiles/r02_qap_v2_ab.txt).
+// tools/dev/qap_fourstep_model.py and qap_radix8_model.py are exact-integer models of the index and twiddle arithmetic.
+//
+// Arithmetic: nine 29-bit limbs, lazily reduced (frw_fr29.h); between passes elements are < 2 p and travel packed in
+// 8 x 32 bits, the same form the sparse products arrive in and h leaves in.  Field arithmetic is exact, so the result is
+// the same element for element as any other schedule's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "frw_device.h"
 #include "frw_fr29.h"
 
 namespace frw {
 
-constexpr int QAP_COLS = 16;            // adjacent elements per tile row
-constexpr int QAP_MAX_T = 6;            // butterfly stages per pass
-constexpr int QAP_TILE = (1 << QAP_MAX_T) * QAP_COLS;
+constexpr int QAP_TILE = 1024;          // elements per tile
+constexpr int QAP_THREADS = 128;        // 8 elements per thread
+constexpr int QAP_LDS_PLANE = QAP_TILE + 16;      // memory-order tiles are stored 65 apart per column (see below)
 
 enum { PASS_FIRST = 0, PASS_DIT_SH0 = 1, PASS_DIT = 2, PASS_DIF = 3, PASS_DIF_SH0 = 4 };
 enum { LOAD_PLAIN = 0, LOAD_AB_MINUS_C = 1 };
-enum { STORE_PLAIN = 0, STORE_SCALE = 1, STORE_SCALE_PACK = 2 };
+enum { STORE_PLAIN = 0, STORE_FACTOR = 1, STORE_FACTOR_A = 2, STORE_FACTOR_CANONICAL = 3 };
 
 struct NttPass {
-    uint32_t *x;                // working arrays: [arrays][9][n] u32
-    size_t x_stride;            // words between consecutive arrays of this launch
-    const uint32_t *tw;         // root^k in R' form, planes [9][n/2]
-    const uint32_t *scale;      // STORE_SCALE*: factor per natural index, planes [9][n]
-    const uint32_t *scale0;     // STORE_SCALE: the table for arrays 0, 3, 6, ... (A z carries an extra 2^5, see below)
-    uint32_t *out_packed;       // STORE_SCALE_PACK: [arrays][n][8] u32 (ark-ff form)
+    const uint32_t *src;        // [arrays][n][8] u32, working order (PASS_FIRST: unused)
+    uint32_t *dst;              // [arrays][n][8] u32 (may be src: every tile reads all it needs before it writes)
+    size_t src_stride, dst_stride;    // words between consecutive arrays
+    const uint32_t *factor;     // STORE_FACTOR*: [n][8], the multiplier of each working index as x R' packed
+    const uint32_t *factor_a;   // STORE_FACTOR_A: the table for arrays 0, 3, 6, ... instead
+    const uint32_t *roots;      // 64-th roots of unity ^k, k < 32, x R' in nine limbs, 12 words apart
     // PASS_FIRST sources
     const uint32_t *abc;        // [signatures][3][C][8] u32
     const uint32_t *instance;   // [signatures][I][8] u32
     uint32_t num_constraints, num_instance;
-    int L, sh, T;               // log n; lowest index bit this pass transforms; stages in this pass
+    int L, sh;                  // log n; lowest index bit this pass transforms
 };
 
-// A/B builds (tools/ab_qap.py): -DFRW_QAP_NO_TW reads one fixed twiddle, -DFRW_QAP_NO_MUL replaces the products by additions,
-// -DFRW_QAP_NO_STAGES skips the butterflies (passes become copies).  Results are then wrong, timings tell what a pass waits for.
+// A/B builds (tools/ab_qap.py): -DFRW_QAP_NO_MUL replaces the products by additions, -DFRW_QAP_NO_STAGES skips the
+// butterflies (passes become copies + the element-wise factor).  Results are then wrong; timings tell what a pass waits for.
 #if defined(FRW_QAP_NO_MUL)
 #define QAP_MUL(a, b) f29_add(a, b)
 #else
 #define QAP_MUL(a, b) f29_mul(a, b)
 #endif
-#if defined(FRW_QAP_NO_TW)
-#define QAP_TW(p, n, idx) planes_get((p).tw, (n) / 2, 1)
-#else
-#define QAP_TW(p, n, idx) planes_get((p).tw, (n) / 2, idx)
-#endif
 
-__device__ __forceinline__ F29 planes_get(const uint32_t *base, size_t plane_words, size_t idx)
+// compile-time loop: `#pragma unroll` is a request, and a loop over a thread's eight elements that stays a loop puts the
+// register array into scratch memory (it did, for the loop that multiplies by the factor and stores)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
 {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+__device__ __forceinline__ F29 root_get(const uint32_t *roots, int idx)
+{
+    const uint4 a = *(const uint4 *)(roots + idx * 12), b = *(const uint4 *)(roots + idx * 12 + 4);
     F29 r;
-#pragma unroll
-    for (int k = 0; k < NL29; k++) r.l[k] = base[k * plane_words + idx];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = roots[idx * 12 + 8];
     return r;
 }
-__device__ __forceinline__ void planes_put(uint32_t *base, size_t plane_words, size_t idx, const F29 &v)
+
+// decimation in time: (u, v) -> (u + w v, u - w v).  KV = bound of v in units of p when there is no product (w == 1).
+template <uint32_t KV>
+__device__ __forceinline__ void dit_one(F29 &u, F29 &v)
 {
-#pragma unroll
-    for (int k = 0; k < NL29; k++) base[k * plane_words + idx] = v.l[k];
+    const F29 s = f29_add(u, v);
+    v = f29_sub_kp<KV>(u, v);
+    u = s;
+}
+__device__ __forceinline__ void dit_mul(F29 &u, F29 &v, const F29 &w)
+{
+    v = QAP_MUL(v, w);                    // < 2 p
+    const F29 s = f29_add(u, v);
+    v = f29_sub_kp<2>(u, v);
+    u = s;
+}
+// decimation in frequency: (u, v) -> (u + v, (u - v) w), everything < 2 p
+__device__ __forceinline__ void dif_one(F29 &u, F29 &v)
+{
+    const F29 s = f29_reduce_4p(f29_add(u, v));
+    v = f29_reduce_4p(f29_sub_kp<2>(u, v));
+    u = s;
+}
+__device__ __forceinline__ void dif_mul(F29 &u, F29 &v, const F29 &w)
+{
+    const F29 s = f29_reduce_4p(f29_add(u, v));
+    v = QAP_MUL(f29_sub_kp<2>(u, v), w);
+    u = s;
 }
 
-// One pass = T consecutive radix-2 stages on the index bits [sh, sh + T) of the working order.
-//   decimation in time (PASS_FIRST, PASS_DIT_SH0, PASS_DIT): stages bottom-up, (u, v) -> (u + w v, u - w v); values grow
-//       by < 2 p per stage and are reduced only by the products (and by the scale factor of the last pass);
-//   decimation in frequency (PASS_DIF, PASS_DIF_SH0): stages top-down, (u, v) -> (u + v, (u - v) w), everything kept < 2 p.
-// Tile geometry: *_SH0 (sh == 0): 16 2^T consecutive elements, tile-linear order = memory order (row = low bits);
-// otherwise the 16 columns are the index bits [0, 4) and the rows the bits [sh, sh + T).
-// PASS_FIRST is the sh == 0 pass of a decimation-in-time transform whose input is still in natural order in the packed
-// buffers: working index pos = bitrev(i), so the 64 rows are the natural-index bits [L - 6, L) reversed and the 16
-// columns the natural-index bits [0, 4): 512-byte runs on the way in, 256-byte runs per plane on the way out.
-// LOAD / STORE (the element-wise steps fused into the first / last pass of a transform) are compile-time: a run-time
-// `store_op` made the compiler thread the scale-table select through the store loop and leave the pointer undefined on
-// one path (memory fault on the first GPU run of this file).
-template <int MODE, int LOAD, int STORE>
-__global__ __launch_bounds__(BLOCK) void ntt_pass_kernel(const NttPass p)
+// Stages 1..3 of a 2^T-point transform on the 8 elements x[e] = row 8 g + e: the twiddle of stage t for the pair whose
+// lower row is r is (2^t-th root)^(r mod 2^(t-1)), i.e. a 64-th root with exponent (e mod 2^(t-1)) 2^(6-t) -- the same
+// three constants (w8, w16, w24) for every thread.
+template <bool DIF>
+__device__ __forceinline__ void round_low(F29 (&x)[8], const F29 &w8, const F29 &w16, const F29 &w24)
+{
+    if (!DIF) {
+        dit_one<2>(x[0], x[1]); dit_one<2>(x[2], x[3]); dit_one<2>(x[4], x[5]); dit_one<2>(x[6], x[7]);      // -> < 4 p
+        dit_one<4>(x[0], x[2]); dit_mul(x[1], x[3], w16); dit_one<4>(x[4], x[6]); dit_mul(x[5], x[7], w16);  // -> < 8 p
+        dit_one<8>(x[0], x[4]); dit_mul(x[1], x[5], w8); dit_mul(x[2], x[6], w16); dit_mul(x[3], x[7], w24); // -> < 16 p
+    } else {
+        dif_one(x[0], x[4]); dif_mul(x[1], x[5], w8); dif_mul(x[2], x[6], w16); dif_mul(x[3], x[7], w24);
+        dif_one(x[0], x[2]); dif_mul(x[1], x[3], w16); dif_one(x[4], x[6]); dif_mul(x[5], x[7], w16);
+        dif_one(x[0], x[1]); dif_one(x[2], x[3]); dif_one(x[4], x[5]); dif_one(x[6], x[7]);
+    }
+}
+
+// Stages 4..T on the 8 elements x[e]: T == 6: row 8 e + g (three stages over e); T == 5: row 8 (e & 3) + g + 4 (e >> 2)
+// (two stages over the low two bits of e, two independent groups).  Twiddles depend on the thread (g): table look-ups.
+template <bool DIF, int T>
+__device__ __forceinline__ void round_high(F29 (&x)[8], const uint32_t *roots, int g)
+{
+    if (T == 6) {
+        if (!DIF) {
+            { const F29 w = root_get(roots, g << 2);                                         // stage 4
+              dit_mul(x[0], x[1], w); dit_mul(x[2], x[3], w); dit_mul(x[4], x[5], w); dit_mul(x[6], x[7], w); }
+            { const F29 w0 = root_get(roots, g << 1), w1 = root_get(roots, (g + 8) << 1);    // stage 5
+              dit_mul(x[0], x[2], w0); dit_mul(x[1], x[3], w1); dit_mul(x[4], x[6], w0); dit_mul(x[5], x[7], w1); }
+            dit_mul(x[0], x[4], root_get(roots, g)); dit_mul(x[1], x[5], root_get(roots, g + 8));                  // stage 6
+            dit_mul(x[2], x[6], root_get(roots, g + 16)); dit_mul(x[3], x[7], root_get(roots, g + 24));
+        } else {
+            dif_mul(x[0], x[4], root_get(roots, g)); dif_mul(x[1], x[5], root_get(roots, g + 8));
+            dif_mul(x[2], x[6], root_get(roots, g + 16)); dif_mul(x[3], x[7], root_get(roots, g + 24));
+            { const F29 w0 = root_get(roots, g << 1), w1 = root_get(roots, (g + 8) << 1);
+              dif_mul(x[0], x[2], w0); dif_mul(x[1], x[3], w1); dif_mul(x[4], x[6], w0); dif_mul(x[5], x[7], w1); }
+            { const F29 w = root_get(roots, g << 2);
+              dif_mul(x[0], x[1], w); dif_mul(x[2], x[3], w); dif_mul(x[4], x[5], w); dif_mul(x[6], x[7], w); }
+        }
+    } else {
+        const F29 wa = root_get(roots, g << 2), wb = root_get(roots, (g + 4) << 2);                   // stage 4, the two groups
+        const F29 wa0 = root_get(roots, g << 1), wa1 = root_get(roots, (g + 8) << 1);                 // stage 5
+        const F29 wb0 = root_get(roots, (g + 4) << 1), wb1 = root_get(roots, (g + 12) << 1);
+        if (!DIF) {
+            dit_mul(x[0], x[1], wa); dit_mul(x[2], x[3], wa); dit_mul(x[4], x[5], wb); dit_mul(x[6], x[7], wb);
+            dit_mul(x[0], x[2], wa0); dit_mul(x[1], x[3], wa1); dit_mul(x[4], x[6], wb0); dit_mul(x[5], x[7], wb1);
+        } else {
+            dif_mul(x[0], x[2], wa0); dif_mul(x[1], x[3], wa1); dif_mul(x[4], x[6], wb0); dif_mul(x[5], x[7], wb1);
+            dif_mul(x[0], x[1], wa); dif_mul(x[2], x[3], wa); dif_mul(x[4], x[5], wb); dif_mul(x[6], x[7], wb);
+        }
+    }
+}
+
+// One pass = T consecutive radix-2 stages on the index bits [sh, sh + T) of the working order, then the per-index factor.
+// Tile geometry: PASS_DIT / PASS_DIF (sh > 0): rows = index bits [sh, sh + T), columns = index bits [0, 10 - T): runs of
+// 512 / 1024 bytes in memory, threads read and write their elements directly.  PASS_DIT_SH0 / PASS_DIF_SH0 (sh == 0,
+// T == 6): 1,024 consecutive elements, row = low six bits: they go through LDS on both sides (memory order <-> the rows a
+// thread holds), since a thread's eight rows would be adjacent in memory on one of them.  PASS_FIRST: the sh == 0 pass of
+// a decimation-in-time transform whose input is still in constraint order in the products' buffers: working index =
+// bitrev(natural index), so the 64 rows are the natural-index bits [L - 6, L) reversed and the 16 columns the
+// natural-index bits [0, 4) (512-byte runs on the way in); the output is a memory-order tile of the working array.
+template <int MODE, int T, int LOAD, int STORE>
+__global__ __launch_bounds__(QAP_THREADS, 2) void ntt_pass_kernel(const NttPass p)
 {
     constexpr bool DIF = MODE == PASS_DIF || MODE == PASS_DIF_SH0;
-    constexpr bool SH0 = MODE == PASS_DIT_SH0 || MODE == PASS_DIF_SH0;      // memory-order tile
-    constexpr bool LOWJ = MODE == PASS_DIT || MODE == PASS_DIF;             // twiddle exponent includes the low index bits
-    __shared__ uint32_t tile[NL29 * QAP_TILE];
-    const int tid = threadIdx.x;
-    const int R = 1 << p.T, elems = R * QAP_COLS;
+    constexpr bool MEMORDER = MODE == PASS_DIT_SH0 || MODE == PASS_DIF_SH0;     // tile = 1,024 consecutive elements
+    constexpr int R = 1 << T, CB = 10 - T, COLS = 1 << CB;
+    static_assert(T == 6 || (T == 5 && (MODE == PASS_DIT || MODE == PASS_DIF)), "five-stage passes only above bit 0");
+    __shared__ uint32_t lds[NL29 * QAP_LDS_PLANE];
+    const int tid = threadIdx.x, c = tid & (COLS - 1), g = tid >> CB;
     const uint32_t tileid = blockIdx.x;
     const size_t n = (size_t)1 << p.L;
-    uint32_t *xa = p.x + (size_t)blockIdx.y * p.x_stride;
-    const uint32_t *sc = STORE == STORE_SCALE && blockIdx.y % 3 == 0 ? p.scale0 : p.scale;
+    const uint32_t *src = p.src + (size_t)blockIdx.y * p.src_stride;
+    uint32_t *dst = p.dst + (size_t)blockIdx.y * p.dst_stride;
+    const uint32_t *factor = STORE == STORE_FACTOR_A && blockIdx.y % 3 == 0 ? p.factor_a : p.factor;
 
-    // ---- tile-linear index -> LDS slot and working index ---------------------------------------------------------------
-    // slots: SH0: lin (= c R + r);  otherwise r 16 + c
+    // rows of the eight elements a thread holds in the low round (stages 1..3) and in the high round (stages 4..T)
+    auto row_low = [&](int e) { return g * 8 + e; };
+    auto row_high = [&](int e) { return T == 6 ? e * 8 + g : (e & 3) * 8 + g + 4 * (e >> 2); };
+    // LDS slot of (row, column): sh > 0 tiles: row-major with bit 4 flipped by bit 3 of the row (T == 6), which keeps both
+    // register patterns conflict-free; memory-order tiles: column-major, columns 65 apart
+    auto slot = [&](int row, int col) {
+        if (MEMORDER || MODE == PASS_FIRST) return col * (R + 1) + row;
+        return T == 6 ? (row * COLS + col) ^ ((row & 8) << 1) : row * COLS + col;
+    };
+    // working index of (row, column)
     uint32_t lowmid = 0, high = 0;
-    if (MODE == PASS_FIRST) {
-        // tileid = natural-index bits [4, L - 6); working index = r | rev(tileid) << 6 | rev4(c) << (L - 4)
-        high = (__brev(tileid) >> (32 - (p.L - 10))) << 6;
-    } else if (SH0) {
-        high = tileid * (uint32_t)elems;
-    } else {
-        lowmid = (tileid & ((1u << (p.sh - 4)) - 1u)) << 4;
-        high = (tileid >> (p.sh - 4)) << (p.sh + p.T);
+    if (MODE == PASS_FIRST) high = (__brev(tileid) >> (32 - (p.L - 10))) << 6;
+    else if (MEMORDER) high = tileid * (uint32_t)QAP_TILE;
+    else {
+        lowmid = (tileid & ((1u << (p.sh - CB)) - 1u)) << CB;
+        high = (tileid >> (p.sh - CB)) << (p.sh + T);
     }
-    auto widx = [&](int lin) -> uint32_t {          // working index of the element in LDS slot `lin`
-        if (MODE == PASS_FIRST) return (uint32_t)(lin >> 4) | high | ((__brev((uint32_t)(lin & 15)) >> 28) << (p.L - 4));
-        if (SH0) return high + (uint32_t)lin;
-        return high | ((uint32_t)(lin >> 4) << p.sh) | lowmid | (uint32_t)(lin & 15);
+    auto widx = [&](int row, int col) -> uint32_t {
+        if (MODE == PASS_FIRST) return (uint32_t)row | high | ((__brev((uint32_t)col) >> 28) << (p.L - 4));
+        if (MEMORDER) return high + (uint32_t)(col * R + row);
+        return high | ((uint32_t)row << p.sh) | lowmid | (uint32_t)col;
+    };
+    auto load_elem = [&](uint32_t gidx) -> F29 {
+        F29 v = f29_unpack(fr_load(src + (size_t)gidx * 8));
+        if (LOAD == LOAD_AB_MINUS_C) {
+            // the three arrays of a signature lie n elements apart: (a 2^5 R)(b R) / R' - c R = (a b - c) R, < 2 p
+            const F29 b = f29_unpack(fr_load(src + (n + gidx) * 8)), cc = f29_unpack(fr_load(src + (2 * n + gidx) * 8));
+            v = f29_reduce_4p(f29_sub_kp<2>(QAP_MUL(v, b), cc));
+        }
+        return v;
+    };
+    auto store_elem = [&](uint32_t gidx, F29 v) {
+        if (STORE != STORE_PLAIN) v = QAP_MUL(v, f29_unpack(fr_load(factor + (size_t)gidx * 8)));     // < 2 p
+        if (STORE == STORE_FACTOR_CANONICAL) v = f29_canonical(v);
+        fr_store(dst + (size_t)gidx * 8, f29_pack(v));
+    };
+    auto lds_put = [&](int s, const F29 &v) {
+#pragma unroll
+        for (int k = 0; k < NL29; k++) lds[k * QAP_LDS_PLANE + s] = v.l[k];
+    };
+    auto lds_get = [&](int s) -> F29 {
+        F29 v;
+#pragma unroll
+        for (int k = 0; k < NL29; k++) v.l[k] = lds[k * QAP_LDS_PLANE + s];
+        return v;
     };
 
-    // ---- load ------------------------------------------------------------------------------------------------------------
+    F29 x[8];
+    const F29 w8 = root_get(p.roots, 8), w16 = root_get(p.roots, 16), w24 = root_get(p.roots, 24);
+
+    // ---- in: the eight elements of the first round -----------------------------------------------------------------------
     if (MODE == PASS_FIRST) {
         const size_t sig = blockIdx.y / 3, which = blockIdx.y % 3;
-        const uint32_t *src = p.abc + (sig * 3 + which) * (size_t)p.num_constraints * 8;
+        const uint32_t *rows = p.abc + (sig * 3 + which) * (size_t)p.num_constraints * 8;
         const uint32_t *inst = p.instance + sig * (size_t)p.num_instance * 8;
-        for (int lin = tid; lin < elems; lin += BLOCK) {
-            const uint32_t ihi = (uint32_t)(lin >> 4), c = (uint32_t)(lin & 15);
-            const uint32_t i = (ihi << (p.L - 6)) | (tileid << 4) | c;          // natural (constraint) index
+        static_for<8>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const uint32_t ihi = __brev((uint32_t)row_low(e)) >> 26;                 // row = rev6(natural bits [L - 6, L))
+            const uint32_t i = (ihi << (p.L - 6)) | (tileid << 4) | (uint32_t)c;     // natural (constraint) index
             Fr8 w;
-            if (i < p.num_constraints) w = fr_load(src + (size_t)i * 8);
+            if (i < p.num_constraints) w = fr_load(rows + (size_t)i * 8);
             else if (which == 0 && i - p.num_constraints < p.num_instance) w = fr_load(inst + (size_t)(i - p.num_constraints) * 8);
             else {
 #pragma unroll
                 for (int k = 0; k < 8; k++) w.l[k] = 0;
             }
-            const F29 v = f29_unpack(w);
-            const int slot = (int)(__brev(ihi) >> 26) * QAP_COLS + (int)c;     // row r = rev6(ihi)
+            x[e] = f29_unpack(w);
+        });
+    } else if (MEMORDER) {
+        // memory order -> LDS -> the rows of the first round
 #pragma unroll
-            for (int k = 0; k < NL29; k++) tile[k * QAP_TILE + slot] = v.l[k];
-        }
-    } else {
-        for (int lin = tid; lin < elems; lin += BLOCK) {
-            const uint32_t g = widx(lin);
-            F29 v = planes_get(xa, n, g);
-            if (LOAD == LOAD_AB_MINUS_C) {
-                // arrays of one signature lie 9 n words apart: (a 2^5 R)(b R) / R' - c R = (a b - c) R
-                const F29 b = planes_get(xa + NL29 * n, n, g), c = planes_get(xa + 2 * NL29 * n, n, g);
-                v = f29_reduce_4p(f29_sub_2p(f29_mul(v, b), c));                 // < 2 p
-            }
-#pragma unroll
-            for (int k = 0; k < NL29; k++) tile[k * QAP_TILE + lin] = v.l[k];
-        }
-    }
-    __syncthreads();
-
-    // ---- stages ----------------------------------------------------------------------------------------------------------
-#if !defined(FRW_QAP_NO_STAGES)
-    for (int ti = 0; ti < p.T; ti++) {
-        const int t = DIF ? p.T - ti : ti + 1, s = p.sh + t, hr = 1 << (t - 1);
-        for (int k = tid; k < elems / 2; k += BLOCK) {
-            const int b = SH0 ? k & (R / 2 - 1) : k >> 4, c = SH0 ? k >> (p.T - 1) : k & 15;
-            const int r_lo = b & (hr - 1), r = ((b >> (t - 1)) << t) | r_lo;
-            const int s0 = SH0 ? c * R + r : r * QAP_COLS + c, s1 = s0 + (SH0 ? hr : hr * QAP_COLS);
-            const uint32_t j = LOWJ ? ((uint32_t)r_lo << p.sh) | lowmid | (uint32_t)c : (uint32_t)r_lo;
-            F29 u, v;
-#pragma unroll
-            for (int q = 0; q < NL29; q++) { u.l[q] = tile[q * QAP_TILE + s0]; v.l[q] = tile[q * QAP_TILE + s1]; }
-            F29 nu, nv;
-            if (DIF) {
-                nu = f29_reduce_4p(f29_add(u, v));
-                nv = f29_sub_2p(u, v);                                       // < 4 p
-                if (s == 1) nv = f29_reduce_4p(nv);                          // the twiddle is one
-                else nv = QAP_MUL(nv, QAP_TW(p, n, (size_t)j << (p.L - s)));
-            } else {
-                if (s != 1) v = QAP_MUL(v, QAP_TW(p, n, (size_t)j << (p.L - s)));      // < 2 p
-                nu = f29_add(u, v);
-                nv = f29_sub_2p(u, v);
-            }
-#pragma unroll
-            for (int q = 0; q < NL29; q++) { tile[q * QAP_TILE + s0] = nu.l[q]; tile[q * QAP_TILE + s1] = nv.l[q]; }
+        for (int k = 0; k < 8; k++) {
+            const int lin = tid + QAP_THREADS * k;                                   // = col * 64 + row
+            lds_put(slot(lin & 63, lin >> 6), load_elem(high + (uint32_t)lin));
         }
         __syncthreads();
+        static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = lds_get(slot(DIF ? row_high(e) : row_low(e), c)); });
+        __syncthreads();
+    } else {
+        static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = load_elem(widx(DIF ? row_high(e) : row_low(e), c)); });
     }
+
+#if !defined(FRW_QAP_NO_STAGES)
+    // ---- first round, exchange, second round ---------------------------------------------------------------------------------
+    if (DIF) round_high<true, T>(x, p.roots, g);
+    else round_low<false>(x, w8, w16, w24);
+    static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; lds_put(slot(DIF ? row_high(e) : row_low(e), c), x[e]); });
+    __syncthreads();
+    static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = lds_get(slot(DIF ? row_low(e) : row_high(e), c)); });
+    if (DIF) round_low<true>(x, w8, w16, w24);
+    else round_high<false, T>(x, p.roots, g);
 #endif
 
-    // ---- store -----------------------------------------------------------------------------------------------------------
-    for (int lin = tid; lin < elems; lin += BLOCK) {
-        const uint32_t g = widx(lin);
-        F29 v;
+    // ---- out ---------------------------------------------------------------------------------------------------------------------
+    if (MODE == PASS_FIRST || MEMORDER) {
+        // rows of the last round -> LDS -> memory order
+        __syncthreads();
+        static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; lds_put(slot(DIF ? row_low(e) : row_high(e), c), x[e]); });
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NL29; k++) v.l[k] = tile[k * QAP_TILE + lin];
-        if (STORE != STORE_PLAIN) v = f29_mul(v, planes_get(sc, n, g));     // < 2 p
-        if (STORE == STORE_SCALE_PACK)
-            fr_store(p.out_packed + ((size_t)blockIdx.y * n + g) * 8, f29_pack(f29_canonical(v)));
-        else
-            planes_put(xa, n, g, v);
+        for (int k = 0; k < 8; k++) {
+            const int lin = tid + QAP_THREADS * k, row = lin & 63, col = lin >> 6;
+            store_elem(widx(row, col), lds_get(slot(row, col)));
+        }
+    } else {
+        static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; store_elem(widx(DIF ? row_low(e) : row_high(e), c), x[e]); });
     }
 }
 
 namespace {
-template <int MODE, int LOAD, int STORE>
+template <int MODE, int T, int LOAD, int STORE>
 hipError_t launch_pass(const NttPass &p, unsigned arrays, hipStream_t st)
 {
-    const unsigned tiles = (unsigned)(((size_t)1 << p.L) >> (p.T + 4));
-    hipLaunchKernelGGL((ntt_pass_kernel<MODE, LOAD, STORE>), dim3(tiles, arrays), dim3(BLOCK), 0, st, p);
+    const unsigned tiles = (unsigned)(((size_t)1 << p.L) >> 10);
+    hipLaunchKernelGGL((ntt_pass_kernel<MODE, T, LOAD, STORE>), dim3(tiles, arrays), dim3(QAP_THREADS), 0, st, p);
     return hipGetLastError();
 }
 
-enum { XF_IFFT_FROM_PACKED, XF_FFT, XF_IFFT_POINTWISE_TO_PACKED };
+enum { XF_IFFT_FROM_PRODUCTS, XF_FFT, XF_IFFT_POINTWISE_TO_H };
 
-// One transform over `arrays` working arrays, in place, with the element-wise steps of the witness map fused into its
-// first and last pass:
-//   XF_IFFT_FROM_PACKED          bit-reversed -> natural; reads A z, B z, C z (packed, natural order); x g^k / n at the end
-//   XF_FFT                       natural -> bit-reversed
-//   XF_IFFT_POINTWISE_TO_PACKED  bit-reversed -> natural; a b - c at the start; x g^-k / (n (g^n - 1)), packed, at the end
-hipError_t transform(int kind, const QapDev &q, const NttPass &base, unsigned arrays, hipStream_t st)
+// One transform over `arrays` arrays with the element-wise steps of the witness map fused into its first and last pass:
+//   XF_IFFT_FROM_PRODUCTS     bit-reversed -> natural; reads A z, B z, C z (constraint order); x g^k / n at the end
+//   XF_FFT                    natural -> bit-reversed, in place
+//   XF_IFFT_POINTWISE_TO_H    bit-reversed -> natural; a b - c at the start; x g^-k / (n (g^n - 1)), canonical, into h
+// L = 6 + 6 + T3 with T3 = 5 or 6 (domains 2^17 and 2^18).
+hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *work, size_t work_stride, uint32_t *h,
+                     unsigned arrays, hipStream_t st)
 {
-    const int L = q.log_n;
-    const bool dif = kind == XF_FFT;
-    int shs[8], ts[8], np = 0;
-    for (int sh = 0; sh < L; sh += QAP_MAX_T) { shs[np] = sh; ts[np] = L - sh < QAP_MAX_T ? L - sh : QAP_MAX_T; np++; }
-    for (int i = 0; i < np; i++) {
-        const int k = dif ? np - 1 - i : i;
-        const bool last = i == np - 1;
-        NttPass p = base;
-        p.tw = dif ? q.tw_fwd : q.tw_inv;
-        p.L = L; p.sh = shs[k]; p.T = ts[k];
-        hipError_t e;
-        if (kind == XF_FFT)
-            e = p.sh == 0 ? launch_pass<PASS_DIF_SH0, LOAD_PLAIN, STORE_PLAIN>(p, arrays, st)
-                          : launch_pass<PASS_DIF, LOAD_PLAIN, STORE_PLAIN>(p, arrays, st);
-        else if (kind == XF_IFFT_FROM_PACKED)
-            e = p.sh == 0 ? launch_pass<PASS_FIRST, LOAD_PLAIN, STORE_PLAIN>(p, arrays, st)
-                : last    ? launch_pass<PASS_DIT, LOAD_PLAIN, STORE_SCALE>(p, arrays, st)
-                          : launch_pass<PASS_DIT, LOAD_PLAIN, STORE_PLAIN>(p, arrays, st);
-        else
-            e = p.sh == 0 ? launch_pass<PASS_DIT_SH0, LOAD_AB_MINUS_C, STORE_PLAIN>(p, arrays, st)
-                : last    ? launch_pass<PASS_DIT, LOAD_PLAIN, STORE_SCALE_PACK>(p, arrays, st)
-                          : launch_pass<PASS_DIT, LOAD_PLAIN, STORE_PLAIN>(p, arrays, st);
+    const int L = q.log_n, T3 = L - 12;
+    NttPass p = base;
+    p.L = L;
+    hipError_t e;
+    if (kind == XF_FFT) {
+        p.roots = q.roots_fwd;
+        p.src = work; p.dst = work; p.src_stride = p.dst_stride = work_stride;
+        p.sh = 12; p.factor = q.twist_fwd[1];
+        e = T3 == 6 ? launch_pass<PASS_DIF, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
+                    : launch_pass<PASS_DIF, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
         if (e != hipSuccess) return e;
+        p.sh = 6; p.factor = q.twist_fwd[0];
+        if ((e = launch_pass<PASS_DIF, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        p.sh = 0; p.factor = nullptr;
+        return launch_pass<PASS_DIF_SH0, 6, LOAD_PLAIN, STORE_PLAIN>(p, arrays, st);
     }
-    return hipSuccess;
+    p.roots = q.roots_inv;
+    if (kind == XF_IFFT_FROM_PRODUCTS) {
+        p.src = work; p.dst = work; p.src_stride = p.dst_stride = work_stride;
+        p.sh = 0; p.factor = q.twist_inv[0];
+        if ((e = launch_pass<PASS_FIRST, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        p.sh = 6; p.factor = q.twist_inv[1];
+        if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        p.sh = 12; p.factor = q.scale_in; p.factor_a = q.scale_in_a;
+        return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st)
+                       : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st);
+    }
+    // a b - c from the three arrays of each signature, in place on the first of them; the last pass writes h
+    p.src = work; p.src_stride = 3 * work_stride; p.dst = work; p.dst_stride = 3 * work_stride;
+    p.sh = 0; p.factor = q.twist_inv[0];
+    if ((e = launch_pass<PASS_DIT_SH0, 6, LOAD_AB_MINUS_C, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+    p.sh = 6; p.factor = q.twist_inv[1];
+    if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+    p.sh = 12; p.factor = q.scale_out; p.dst = h; p.dst_stride = work_stride;
+    return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR_CANONICAL>(p, arrays, st)
+                   : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR_CANONICAL>(p, arrays, st);
 }
 }  // namespace
 
 size_t qap_workspace_bytes_per_signature(const R1csDev &r, const QapDev &q)
 {
-    return 3 * (size_t)r.num_constraints * 32 + 3 * (size_t)NL29 * 4 * ((size_t)1 << q.log_n);
+    return 3 * (size_t)r.num_constraints * 32 + 3 * 32 * ((size_t)1 << q.log_n);
 }
 
-// workspace per signature in flight: A z, B z, C z packed (3 C x 32 B) + three working arrays (3 x 36 n B); the batch is
-// cut into chunks that fit
+// workspace per signature in flight: A z, B z, C z (3 C x 32 B) + three working arrays (3 n x 32 B); the batch is cut into
+// chunks that fit
 hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,
                                   const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,
                                   size_t workspace_bytes, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
     const int L = q.log_n;
-    if (L < 12 || L > 30) return hipErrorInvalidValue;          // tiles of 2^10 elements, at least two passes; 32-bit indices
+    if (L != 17 && L != 18) return hipErrorInvalidValue;         // three passes of 6 + 6 + (5 | 6) stages
     const size_t n = (size_t)1 << L, per_sig = qap_workspace_bytes_per_signature(r, q);
     size_t chunk = workspace_bytes / per_sig;
     if (chunk == 0) return hipErrorInvalidValue;
@@ -269,23 +380,17 @@ hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batc
         hipError_t e = launch_r1cs_check(r, cnt, wit, inst, num_unsatisfied ? num_unsatisfied + lo : nullptr, (uint64_t *)abc, st);
         if (e != hipSuccess) return e;
         NttPass p{};
-        p.x = work;
-        p.x_stride = NL29 * n;
         p.abc = abc;
         p.instance = (const uint32_t *)inst;
         p.num_constraints = r.num_constraints;
         p.num_instance = r.num_instance;
-        p.scale = q.scale_in;
-        p.scale0 = q.scale_in_a;
         // ifft + distribute_powers(g) (A z with an extra 2^5, which the a b product in R' = 2^261 arithmetic takes out again)
-        if ((e = transform(XF_IFFT_FROM_PACKED, q, p, (unsigned)(3 * cnt), st)) != hipSuccess) return e;
+        if ((e = transform(XF_IFFT_FROM_PRODUCTS, q, p, work, n * 8, nullptr, (unsigned)(3 * cnt), st)) != hipSuccess) return e;
         // fft: a, b, c on the coset (bit-reversed order)
-        if ((e = transform(XF_FFT, q, p, (unsigned)(3 * cnt), st)) != hipSuccess) return e;
-        // (a b - c) / Z on the coset, coset_ifft: one array per signature (in place on a's), packed into h at the end
-        p.x_stride = 3 * NL29 * n;
-        p.scale = q.scale_out;
-        p.out_packed = (uint32_t *)(h + lo * n * 4);
-        if ((e = transform(XF_IFFT_POINTWISE_TO_PACKED, q, p, (unsigned)cnt, st)) != hipSuccess) return e;
+        if ((e = transform(XF_FFT, q, p, work, n * 8, nullptr, (unsigned)(3 * cnt), st)) != hipSuccess) return e;
+        // (a b - c) / Z on the coset, coset_ifft
+        if ((e = transform(XF_IFFT_POINTWISE_TO_H, q, p, work, n * 8, (uint32_t *)(h + lo * n * 4), (unsigned)cnt, st)) != hipSuccess)
+            return e;
     }
     return hipSuccess;
 }

@@ -73,33 +73,65 @@ void limbs29(const Fr &v, uint32_t out[9])
         out[i] = (uint32_t)(limb & 0x1fffffffu);
     }
 }
-struct QapTables { int log_n; std::vector<uint32_t> tw_fwd, tw_inv, scale_in, scale_in_a, scale_out; };
+// x R' packed in 8 x 32 bits (x R' mod p < p)
+void packed29(const Fr &v, uint32_t out[8])
+{
+    const Fr x = v * Fr::from(32);
+    for (int k = 0; k < 4; k++) { out[2 * k] = (uint32_t)x.l[k]; out[2 * k + 1] = (uint32_t)(x.l[k] >> 32); }
+}
+uint32_t bitrev(uint32_t x, int bits)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+struct QapTables { int log_n; std::vector<uint32_t> roots_fwd, roots_inv, twist_fwd[2], twist_inv[2], scale_in, scale_in_a, scale_out; };
 QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
 {
     QapTables t;
     t.log_n = domain_log(num_constraints + num_instance);
     if (t.log_n > 32) throw std::runtime_error("PolynomialDegreeTooLarge");
-    const size_t n = (size_t)1 << t.log_n;
+    if (t.log_n < 13) return t;                                 // no device witness map for such a domain (frw_qap.hip)
+    const int L = t.log_n;
+    const size_t n = (size_t)1 << L;
     const uint64_t root_limbs[4] = {0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL};
     Fr w = Fr::from_montgomery(root_limbs);
-    for (int i = t.log_n; i < 32; i++) w = w * w;
+    for (int i = L; i < 32; i++) w = w * w;
     const Fr winv = inverse(w), g = Fr::from(7), ginv = inverse(g), ninv = inverse(Fr::from(n)), two5 = Fr::from(32);
     const Fr zinv = inverse(g.pow(n) - Fr::one());             // divide_by_vanishing_poly_on_coset
-    // first, first * step, ... as x R' (R' = 2^261 = 2^5 R: the Montgomery limbs of 32 x) in 29-bit limbs, plane per limb
+    // first, first * step, ... packed
     auto fill = [&](std::vector<uint32_t> &v, size_t count, Fr first, const Fr &step) {
-        v.resize(count * 9);
-        for (size_t k = 0; k < count; k++) {
-            uint32_t l[9];
-            limbs29(first, l);
-            for (int i = 0; i < 9; i++) v[(size_t)i * count + k] = l[i];
-            first = first * step;
-        }
+        v.resize(count * 8);
+        for (size_t k = 0; k < count; k++) { packed29(first, &v[8 * k]); first = first * step; }
     };
-    fill(t.tw_fwd, n / 2, Fr::one(), w);
-    fill(t.tw_inv, n / 2, Fr::one(), winv);
     fill(t.scale_in, n, ninv, g);
     fill(t.scale_in_a, n, ninv * two5, g);
     fill(t.scale_out, n, ninv * zinv, ginv);
+    // powers of w and w^-1, then the twist tables: a pass on the index bits [sh, sh + T) goes with the factor
+    // root^((i mod 2^sh) * bitrev_T((i >> sh) mod 2^T) * 2^(L - sh - T)) on index i (tools/dev/qap_fourstep_model.py)
+    std::vector<uint32_t> pw_fwd, pw_inv;
+    fill(pw_fwd, n, Fr::one(), w);
+    fill(pw_inv, n, Fr::one(), winv);
+    const int shs[2] = {6, 12}, ts[2] = {6, L - 12 < 6 ? L - 12 : 6};
+    for (int k = 0; k < 2; k++) {
+        t.twist_fwd[k].resize(n * 8);
+        t.twist_inv[k].resize(n * 8);
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t low = i & (((uint64_t)1 << shs[k]) - 1), r = (i >> shs[k]) & (((uint64_t)1 << ts[k]) - 1);
+            const size_t e = (size_t)((low * bitrev((uint32_t)r, ts[k])) << (L - shs[k] - ts[k]));
+            std::memcpy(&t.twist_fwd[k][8 * i], &pw_fwd[8 * e], 32);
+            std::memcpy(&t.twist_inv[k][8 * i], &pw_inv[8 * e], 32);
+        }
+    }
+    // 64-th roots, nine 29-bit limbs, 12 words apart
+    auto roots = [&](std::vector<uint32_t> &v, const Fr &root) {
+        v.assign(32 * 12, 0u);
+        const Fr step = root.pow(n >> 6);
+        Fr x = Fr::one();
+        for (int k = 0; k < 32; k++) { limbs29(x, &v[12 * k]); x = x * step; }
+    };
+    roots(t.roots_fwd, w);
+    roots(t.roots_inv, winv);
     return t;
 }
 }  // namespace
@@ -192,12 +224,15 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
         r->dev.long_coef = (const uint32_t *)upload(lcoef.data(), lcoef.size() * 4);
         r->dev.long_mask = (const uint8_t *)upload(lmask.data(), lmask.size());
         const QapTables qt = build_qap_tables(m.num_constraints, m.num_instance_variables);
+        r->qap = frw::QapDev{};
         r->qap.log_n = qt.log_n;
-        r->qap.tw_fwd = (const uint32_t *)upload(qt.tw_fwd.data(), qt.tw_fwd.size() * 4);
-        r->qap.tw_inv = (const uint32_t *)upload(qt.tw_inv.data(), qt.tw_inv.size() * 4);
-        r->qap.scale_in = (const uint32_t *)upload(qt.scale_in.data(), qt.scale_in.size() * 4);
-        r->qap.scale_in_a = (const uint32_t *)upload(qt.scale_in_a.data(), qt.scale_in_a.size() * 4);
-        r->qap.scale_out = (const uint32_t *)upload(qt.scale_out.data(), qt.scale_out.size() * 4);
+        auto up = [&](const std::vector<uint32_t> &v) { return (const uint32_t *)upload(v.data(), v.size() * 4); };
+        r->qap.roots_fwd = up(qt.roots_fwd);
+        r->qap.roots_inv = up(qt.roots_inv);
+        for (int k = 0; k < 2; k++) { r->qap.twist_fwd[k] = up(qt.twist_fwd[k]); r->qap.twist_inv[k] = up(qt.twist_inv[k]); }
+        r->qap.scale_in = up(qt.scale_in);
+        r->qap.scale_in_a = up(qt.scale_in_a);
+        r->qap.scale_out = up(qt.scale_out);
         *out = r;
         return FRW_OK;
     } catch (const std::exception &) {
