@@ -223,6 +223,36 @@ def time_compact(eng, dev, logn, batch, launches, warm, d_in, d_wit):
     return out
 
 
+def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps):
+    """The step after the hot path in a Groth16 prover (SURVEY 8-f row 4): ark-groth16's R1CStoQAP::witness_map -- A z, B z,
+    C z, three inverse + three coset-forward + one coset-inverse transform over the 2^17 / 2^18 domain -- for `nsig` of the
+    witnesses the timed launches left in HBM.  Bound by VALU issue (field multiplications), not by HBM."""
+    q = eng.qap_info(handle)
+    n, per = int(q.domain_size), int(q.workspace_bytes_per_signature)
+    ws = torch.empty(nsig * per, dtype=torch.uint8, device=dev)
+    h = torch.empty((nsig, n, 4), dtype=torch.int64, device=dev)
+    bad = torch.empty(nsig, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    run = lambda: eng.qap_witness_map_dev(handle, nsig, d_wit, d_inst, h, ws, nsig * per, bad, stream.cuda_stream)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    assert int(bad.abs().sum()) == 0, "witness map: unsatisfied rows"
+    assert int(h[:, -1].abs().sum()) == 0, "witness map: deg h must be <= n - 2 for satisfied systems"
+    products = 7 * (n // 2) * int(q.log_domain_size) + 5 * n
+    return {"workload": "R1CS->QAP witness map (h = (A B - C) / Z, domain 2^%d) of %d resident witnesses per call" %
+                        (int(q.log_domain_size), nsig),
+            "ms_per_call": round(ms, 3), "signatures_per_s": round(nsig / (ms * 1e-3), 1), "calls_timed": reps,
+            "field_products_per_signature_transforms": products,
+            "bytes_out_per_signature": n * 32, "checked": "no unsatisfied rows; top coefficient of every h is zero"}
+
+
 def time_aggregate(eng, dev, total, reps, threads):
     """BASELINE configs[4] shape on one GPU: one aggregate statement of `total` signatures, Falcon-512 and Falcon-1024
     mixed (parameter set drawn from the seed), = one engine launch per parameter set (the reference's
@@ -670,6 +700,7 @@ def main():
                 checked[name] = {"signatures": cnt, "grid": sh["grid"], "resident_workgroups_per_cu": sh["resident_per_cu"],
                                  "rounds": round(cnt / max(1, sh["grid"]), 2), "split_signatures": sh["split_signatures"]}
     r1cs = None
+    qap_result = None
     if not args.no_r1cs_check:
         # the reference's assert!(cs.is_satisfied()) (falcon_ntt.rs:159) for every witness in the buffer, on the device,
         # in place, against matrices emitted from the gadget definitions by the host mirror (not the kernels' closed form)
@@ -680,6 +711,8 @@ def main():
         eng.r1cs_check_dev(h, held, d_wit, d_inst, badrows, stream.cuda_stream)
         torch.cuda.synchronize()
         tc = time.perf_counter() - tc
+        if world == 1 and not args.no_secondary and not dual:
+            qap_result = time_qap(eng, h, dev, d_wit, d_inst, min(64, held), 3)
         eng.r1cs_free(h)
         n_unsat = sharding.sum_over_ranks(int((badrows != 0).sum().item()), cdev)
         assert n_unsat == 0, "%d witnesses left by the timed launches violate the constraint system" % n_unsat
@@ -799,6 +832,8 @@ def main():
                 "ntt_modq_falcon512_batch4096": time_ntt_modq(eng, dev, 9, 4096, 200, 20),
                 "verify_falcon512_8192_per_launch": time_verify(eng, dev, 9, 8192, 12, 3, threads),
                 "compact_encoding_falcon%d" % n: time_compact(eng, dev, logn, chunk, 4, 1, (d_sig, d_pk, d_hm), d_wit)}
+            if qap_result is not None:
+                result["secondary"]["qap_witness_map_falcon%d" % n] = qap_result
             if not args.no_aggregate:
                 result["secondary"]["aggregate_1024_mixed"] = time_aggregate(eng, dev, 1024, 50, threads)
                 result["secondary"]["input_preparation_falcon%d" % n] = time_prepare(eng, dev, logn, 65536, 5, 1)
