@@ -121,7 +121,8 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
 
 // One wavefront per (long row, group of LONG_SIGS signatures): lane l multiplies terms l, l + 64, ... (coefficient loaded
 // once, used for every signature of the group), the 64 partial sums are added across the wavefront, lane 0 stores.
-// Products are f29_mul(z R, c R') = z c R, sums kept < 2 p.
+// Products are f29_mul(z R, c R') = z c R (< 2 p); they are summed limb-wise with a carry pass every four and a reduction
+// (a product with R' mod p) every sixteen, so the running value stays far below 2^261 = 70 p.
 constexpr int LONG_SIGS = 4;
 __global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
                                                               const uint32_t *__restrict__ instance, uint32_t *__restrict__ abc)
@@ -134,6 +135,15 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t 
     for (int s = 0; s < LONG_SIGS; s++)
 #pragma unroll
         for (int k = 0; k < NL29; k++) acc[s].l[k] = 0;
+    // R' mod p = 2^5 R mod p as an integer: f29_mul(x, R' mod p) = x mod p, brought under 2 p
+    constexpr uint32_t R32[8] = FRW_R32;
+    Fr8 r_words;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r_words.l[k] = R32[k];
+    F29 one_rp = f29_unpack(r_words);
+#pragma unroll
+    for (int k = 0; k < 5; k++) one_rp = f29_reduce_4p(f29_add(one_rp, one_rp));       // x 32, kept < 2 p
+    one_rp = f29_canonical(one_rp);
     for (uint32_t ch = 0; ch < d.num_chunks; ch++) {
         const size_t chunk = (size_t)d.first_chunk + ch;
         const uint32_t col = r.long_col[chunk * WAVE + lane];
@@ -146,11 +156,23 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t 
             const uint32_t *zp = col < r.num_instance ? instance + (sig * r.num_instance + col) * 8
                                                        : witness + (sig * r.num_witness + (col - r.num_instance)) * 8;
             const F29 z = f29_unpack(fr_load(zp));
-            acc[s] = f29_reduce_4p(f29_add(acc[s], f29_mul(z, c)));
+            const F29 prod = f29_mul(z, c);                       // < 2 p, normalised
+#pragma unroll
+            for (int k = 0; k < NL29; k++) acc[s].l[k] += prod.l[k];          // lazily: limbs < 4 x 2^29 between carries
+        }
+        if ((ch & 3u) == 3u) {
+#pragma unroll
+            for (int s = 0; s < LONG_SIGS; s++) f29_normalise(acc[s]);
+        }
+        if ((ch & 15u) == 15u) {                                  // every 16 terms bring the sum (< 34 p) back under 2 p
+#pragma unroll
+            for (int s = 0; s < LONG_SIGS; s++) acc[s] = f29_mul(acc[s], one_rp);
         }
     }
 #pragma unroll
     for (int s = 0; s < LONG_SIGS; s++) {
+        f29_normalise(acc[s]);
+        acc[s] = f29_mul(acc[s], one_rp);                         // x R' / R' = x, < 2 p
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             F29 other;
