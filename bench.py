@@ -365,6 +365,55 @@ def bench_prepare(args, world, rank, dev):
           "config": {"workload": r["workload"], "logn": args.logn, "batch_per_gpu": args.batch}})
 
 
+def bench_qap(args, world, rank, dev):
+    """--workload qap: witnesses of `--batch` signatures generated on the device, then the R1CS->QAP witness map of all of
+    them per step (the step after the hot path in a Groth16 prover); signatures are independent, ranks too."""
+    logn, batch = args.logn, args.batch
+    eng = frw.WitnessEngine(dev.index)
+    L = frw.layout(logn)
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=SEED + rank)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.empty(batch, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    eng.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, frw.ENC_MONTGOMERY, stream.cuda_stream)
+    handle = eng.r1cs_load(0, logn)
+    q = eng.qap_info(handle)
+    n, per = int(q.domain_size), int(q.workspace_bytes_per_signature)
+    chunk = min(batch, 128)                                      # signatures in flight: 128 x 41 MB of workspace
+    ws = torch.empty(chunk * per, dtype=torch.uint8, device=dev)
+    h = torch.empty((batch, n, 4), dtype=torch.int64, device=dev)
+    bad = torch.empty(batch, dtype=torch.int32, device=dev)
+    run = lambda: eng.qap_witness_map_dev(handle, batch, wit, inst, h, ws, chunk * per, bad, stream.cuda_stream)
+    for _ in range(max(1, args.warmup)):
+        run()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    t0 = time.perf_counter()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(args.steps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    sharding.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev if dist.is_initialized() and dist.get_backend() == "nccl" else torch.device("cpu"))
+    ms = e0.elapsed_time(e1) / args.steps
+    assert int(bad.abs().sum()) == 0 and int(h[:, -1].abs().sum()) == 0
+    eng.r1cs_free(handle)
+    products = 7 * (n // 2) * int(q.log_domain_size) + 5 * n
+    emit({"metric": "falcon%d_qap_witness_maps_per_sec" % (1 << logn), "value": round(batch * world * args.steps / elapsed, 1),
+          "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (BLS12-381 Fr in 29-bit limbs)",
+          "data": "synthetic",
+          "config": {"workload": "R1CS->QAP witness map of resident witnesses (ark-groth16 witness_map), domain 2^%d" %
+                                 int(q.log_domain_size), "logn": logn, "batch_per_gpu": batch, "signatures_in_flight": chunk},
+          "field_products_per_s": round(products * batch * world * args.steps / elapsed / 1e9, 1),
+          "field_products_unit": "G Montgomery products/s (transforms only counted)",
+          "checked": "no unsatisfied rows; top coefficient of every h is zero"})
+
+
 _REAL_STDOUT = None
 
 
@@ -582,7 +631,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL over xGMI, the default) or gloo (rehearsal of "
                          "the N > 1 code path with several ranks sharing one GPU)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "ntt_modq", "prepare"],
+    ap.add_argument("--workload", default="verify", choices=["verify", "ntt_modq", "prepare", "qap"],
                     help="verify = full verify-with-ntt witness (default, BASELINE configs[2]); ntt_modq = the "
                          "NTT + mod_q witness kernel alone (BASELINE configs[1]: --logn 9 --batch 4096)")
     ap.add_argument("--dump-digests", default="",
@@ -623,6 +672,10 @@ def main():
         if not args.batch:
             args.batch = 65536
         return bench_prepare(args, world, rank, dev)
+    if args.workload == "qap":
+        if not args.batch:
+            args.batch = 256
+        return bench_qap(args, world, rank, dev)
     logn = args.logn
     batch = args.batch or (131072 if world == 8 else 65536)
     dual = args.circuit == "dual"

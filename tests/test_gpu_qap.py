@@ -120,3 +120,39 @@ def test_witness_map_full_batch_identity_and_chunking(engine, oracle, tmp_path):
     got = from_montgomery(h[k].cpu().numpy().view(np.uint64))
     lhs, rhs = qap.check_identity(az, bz, cz, ni, T.limbs_to_ints(z[:ni]), got, random.Random(7).randrange(P))
     assert lhs == rhs
+
+
+def test_witness_map_matches_committed_golden(engine):
+    """tests/golden/qap.json: the digest of h (ark-ff's Montgomery bytes, as frw_qap_witness_map_dev writes them) for the
+    committed witness fixtures, Falcon-512 and Falcon-1024."""
+    import hashlib
+    import json
+    import os
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for fx in json.load(open(os.path.join(gold, "qap.json")))["cases"]:
+        wfx = json.load(open(os.path.join(gold, fx["witness_fixture"])))
+        logn = fx["logn"]
+        L = frw.layout(logn)
+        d = [torch.from_numpy(np.frombuffer(bytes.fromhex(wfx[k]), dtype=np.uint16).copy().view(np.int16)).to(dev)
+             for k in ("sig", "pk", "hm")]
+        wit = torch.empty((1, L.num_witness, 4), dtype=torch.int64, device=dev)
+        inst = torch.empty((1, L.num_instance, 4), dtype=torch.int64, device=dev)
+        st = torch.empty(1, dtype=torch.int32, device=dev)
+        engine.witness_ntt_verify_dev(logn, 1, d[0], d[1], d[2], wit, inst, st, 1, 0)
+        r = engine.r1cs_load(0, logn)
+        try:
+            q = engine.qap_info(r)
+            assert int(q.log_domain_size) == fx["log_domain_size"]
+            per = int(q.workspace_bytes_per_signature)
+            ws = torch.empty(per, dtype=torch.uint8, device=dev)
+            h = torch.empty((1, int(q.domain_size), 4), dtype=torch.int64, device=dev)
+            bad = torch.empty(1, dtype=torch.int32, device=dev)
+            engine.qap_witness_map_dev(r, 1, wit, inst, h, ws, per, bad, 0)
+            torch.cuda.synchronize()
+        finally:
+            engine.r1cs_free(r)
+        assert bad.tolist() == [0]
+        assert hashlib.sha256(h[0].cpu().numpy().tobytes()).hexdigest() == fx["h_sha256"]["montgomery"]
