@@ -94,6 +94,13 @@ struct R1csDev {
     const uint32_t *long_col;   // [chunks][64]
     const uint32_t *long_coef;  // [chunks][9][64]
     const uint8_t *long_mask;   // [num_constraints]: bit m set = row is long in matrix m (0 = A, 1 = B, 2 = C)
+    // the distinct variables the long rows read (the N signature coefficients, the N coefficients of v, ... -- small
+    // integers in a Falcon witness): their plain values are extracted once per signature, and a long-row term whose
+    // variable is below 2^28 is one multiply-add per limb instead of a field product
+    uint32_t num_long_vars;
+    const uint32_t *long_vars;  // [num_long_vars] column
+    const uint32_t *long_cidx;  // [chunks][64] index into long_vars
+    uint32_t k_rrp[9];          // R R' mod p (R = 2^256, R' = 2^261) as an integer, 29-bit limbs
 };
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
                              uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st);

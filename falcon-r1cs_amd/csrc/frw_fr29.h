@@ -191,20 +191,9 @@ __device__ __forceinline__ F29 f29_canonical(const F29 &a)
 // independent chains), then the reduction by operand scanning -- each m[i] feeds eight independent multiply-adds
 // (m[i] p[j] into column i + j); the only serial thread is carry -> m[i] -> column i + 1.  (The first form accumulated one
 // column at a time, 18 dependent multiply-adds in a row: 13 cycles per multiply-add measured, profiles/r02_qap_v3_ab.txt.)
-__device__ __forceinline__ F29 f29_mul(const F29 &a, const F29 &b)
+// the Montgomery reduction of 18 columns (column k has weight 2^(29 k)): sum / 2^261 mod p, normalised, < sum / 2^261 + p
+__device__ __forceinline__ F29 f29_reduce_columns(uint64_t (&col)[2 * NL29])
 {
-    uint64_t col[2 * NL29];
-#pragma unroll
-    for (int k = 0; k < 2 * NL29 - 1; k++) {
-        uint64_t even = 0, odd = 0;                                  // two chains per column
-#pragma unroll
-        for (int i = (k < NL29 ? 0 : k - (NL29 - 1)); i <= (k < NL29 ? k : NL29 - 1); i++) {
-            if (i & 1) odd += (uint64_t)a.l[i] * b.l[k - i];
-            else even += (uint64_t)a.l[i] * b.l[k - i];
-        }
-        col[k] = even + odd;
-    }
-    col[2 * NL29 - 1] = 0;
 #pragma unroll
     for (int i = 0; i < NL29; i++) {
         const uint32_t m = (0u - (uint32_t)col[i]) & M29;          // -p^-1 = -1 mod 2^29
@@ -220,6 +209,31 @@ __device__ __forceinline__ F29 f29_mul(const F29 &a, const F29 &b)
     }
     r.l[NL29 - 1] = (uint32_t)col[2 * NL29 - 1];
     return r;
+}
+
+__device__ __forceinline__ F29 f29_mul(const F29 &a, const F29 &b)
+{
+    uint64_t col[2 * NL29];
+#pragma unroll
+    for (int k = 0; k < 2 * NL29 - 1; k++) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = (k < NL29 ? 0 : k - (NL29 - 1)); i <= (k < NL29 ? k : NL29 - 1); i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+        col[k] = acc;
+    }
+    col[2 * NL29 - 1] = 0;
+    return f29_reduce_columns(col);
+}
+
+// x / 2^261 mod p for an integer x < 2^261 p given in 29-bit limbs (x[10] may hold the excess), < 2 p
+template <int N>
+__device__ __forceinline__ F29 f29_redc_wide(const uint32_t (&x)[N])
+{
+    static_assert(N <= 2 * NL29, "too wide");
+    uint64_t col[2 * NL29];
+#pragma unroll
+    for (int k = 0; k < 2 * NL29; k++) col[k] = k < N ? x[k] : 0;
+    return f29_reduce_columns(col);
 }
 
 }  // namespace frw

@@ -62,6 +62,16 @@ int domain_log(uint64_t num_coeffs)
 // Tables of Radix2EvaluationDomain::new(num_constraints + num_instance) (ark-poly 0.3.0), Montgomery limbs as the
 // device reads them.  group_gen = two_adic_root_of_unity^(2^(32 - log n)) (ark-ff 0.3.0 get_root_of_unity); the root is
 // ark-bls12-381 0.3.0's TWO_ADIC_ROOT_OF_UNITY = 7^((p-1)/2^32) (tests/test_qap.py derives these limbs from the formula).
+// 4 x 64-bit limbs -> nine 29-bit limbs
+void split29(const uint64_t l[4], uint32_t out[9])
+{
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, q = bit >> 6, sft = bit & 63;
+        uint64_t limb = l[q] >> sft;
+        if (sft > 35 && q + 1 < 4) limb |= l[q + 1] << (64 - sft);
+        out[i] = (uint32_t)(limb & 0x1fffffffu);
+    }
+}
 // x R' (R' = 2^261 = 2^5 R: the Montgomery limbs of 32 x) in nine 29-bit limbs
 void limbs29(const Fr &v, uint32_t out[9])
 {
@@ -218,6 +228,21 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
                     for (int k = 0; k < 9; k++) lcoef[(ch * 9 + k) * 64 + lane] = l[k];
                 }
             }
+        // the variables the long rows read, and each term's index into that list
+        std::vector<uint32_t> lvars(lcol);
+        std::sort(lvars.begin(), lvars.end());
+        lvars.erase(std::unique(lvars.begin(), lvars.end()), lvars.end());
+        std::vector<uint32_t> lcidx(lcol.size());
+        for (size_t t = 0; t < lcol.size(); t++)
+            lcidx[t] = (uint32_t)(std::lower_bound(lvars.begin(), lvars.end(), lcol[t]) - lvars.begin());
+        r->dev.num_long_vars = (uint32_t)lvars.size();
+        r->dev.long_vars = (const uint32_t *)upload(lvars.data(), lvars.size() * 4);
+        r->dev.long_cidx = (const uint32_t *)upload(lcidx.data(), lcidx.size() * 4);
+        {
+            const Fr rp = Fr::from(32);                        // limbs: R' mod p as an integer
+            const Fr k = Fr::from_canonical(rp.l);             // value R' mod p; limbs: R' R mod p
+            split29(k.l, r->dev.k_rrp);
+        }
         r->dev.num_long = (uint32_t)lrows.size();
         r->dev.long_rows = (const frw::R1csLongRow *)upload(lrows.data(), lrows.size() * sizeof(frw::R1csLongRow));
         r->dev.long_col = (const uint32_t *)upload(lcol.data(), lcol.size() * 4);

@@ -185,6 +185,114 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t 
     }
 }
 
+// The plain value of every variable the long rows read, when it is below 2^28 (else ~0): f29_mul(z R, 32) = z.
+__global__ __launch_bounds__(BLOCK) void r1cs_zsmall_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
+                                                            const uint32_t *__restrict__ instance, uint32_t *__restrict__ zs)
+{
+    const size_t sig = blockIdx.y;
+    const uint32_t u = blockIdx.x * BLOCK + threadIdx.x;
+    if (sig >= batch || u >= r.num_long_vars) return;
+    const uint32_t col = r.long_vars[u];
+    const uint32_t *zp = col < r.num_instance ? instance + (sig * r.num_instance + col) * 8
+                                               : witness + (sig * r.num_witness + (col - r.num_instance)) * 8;
+    F29 c32;
+#pragma unroll
+    for (int k = 0; k < NL29; k++) c32.l[k] = k ? 0u : 32u;
+    const F29 v = f29_canonical(f29_mul(f29_unpack(fr_load(zp)), c32));
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 1; k < NL29; k++) hi |= v.l[k];
+    zs[sig * r.num_long_vars + u] = (hi == 0 && v.l[0] < (1u << 28)) ? v.l[0] : 0xffffffffu;
+}
+
+// The long rows again, for witnesses whose long-row variables are small integers (zs from r1cs_zsmall_kernel): a term is
+// c R' (nine limbs) times a 28-bit integer, accumulated per limb in 64 bits without any reduction -- one multiply-add per
+// limb instead of a field product.  A term whose variable is not small takes the field product and enters the same
+// columns as 32 z c R.  At the end the 64 lanes' columns are carried into 29-bit limbs, added across the wavefront, and
+// X = 32 R sum(c z) becomes sum(c z) R through one Montgomery reduction (X / R') and one product with R R' mod p.
+__global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
+                                                                    const uint32_t *__restrict__ instance,
+                                                                    const uint32_t *__restrict__ zs, uint32_t *__restrict__ abc)
+{
+    const R1csLongRow d = r.long_rows[blockIdx.x];
+    const int lane = threadIdx.x;
+    const size_t sig0 = (size_t)blockIdx.y * LONG_SIGS;
+    uint64_t col[LONG_SIGS][NL29 + 1];                             // column 9 takes the carries of rows of any length
+#pragma unroll
+    for (int s = 0; s < LONG_SIGS; s++)
+#pragma unroll
+        for (int k = 0; k <= NL29; k++) col[s][k] = 0;
+    for (uint32_t ch = 0; ch < d.num_chunks; ch++) {
+        const size_t chunk = (size_t)d.first_chunk + ch;
+        const uint32_t cidx = r.long_cidx[chunk * WAVE + lane];
+        F29 c;
+#pragma unroll
+        for (int k = 0; k < NL29; k++) c.l[k] = r.long_coef[(chunk * NL29 + k) * WAVE + lane];
+        uint32_t zv[LONG_SIGS];
+        bool all_small = true;
+#pragma unroll
+        for (int s = 0; s < LONG_SIGS; s++) {
+            const size_t sig = sig0 + s < batch ? sig0 + s : batch - 1;       // a ragged last group repeats the last signature
+            zv[s] = zs[sig * r.num_long_vars + cidx];
+            all_small &= zv[s] != 0xffffffffu;
+        }
+        if (!__all(all_small)) {
+            // field products for the terms whose variable is large; they enter the columns as 32 (z c R)
+            const uint32_t colv = r.long_col[chunk * WAVE + lane];
+#pragma unroll
+            for (int s = 0; s < LONG_SIGS; s++) {
+                if (zv[s] == 0xffffffffu) {
+                    const size_t sig = sig0 + s < batch ? sig0 + s : batch - 1;
+                    const uint32_t *zp = colv < r.num_instance ? instance + (sig * r.num_instance + colv) * 8
+                                                                : witness + (sig * r.num_witness + (colv - r.num_instance)) * 8;
+                    const F29 prod = f29_mul(f29_unpack(fr_load(zp)), c);
+#pragma unroll
+                    for (int k = 0; k < NL29; k++) col[s][k] += (uint64_t)prod.l[k] << 5;
+                    zv[s] = 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < LONG_SIGS; s++)
+#pragma unroll
+            for (int k = 0; k < NL29; k++) col[s][k] += (uint64_t)c.l[k] * zv[s];      // < 2^57 per term: 64 terms fit
+        if ((ch & 31u) == 31u) {                                   // carry pass every 32 terms (rows of more than 2,048 terms)
+#pragma unroll
+            for (int s = 0; s < LONG_SIGS; s++)
+#pragma unroll
+                for (int k = 0; k < NL29; k++) { col[s][k + 1] += col[s][k] >> 29; col[s][k] &= M29; }
+        }
+    }
+    F29 krrp;
+#pragma unroll
+    for (int k = 0; k < NL29; k++) krrp.l[k] = r.k_rrp[k];
+#pragma unroll
+    for (int s = 0; s < LONG_SIGS; s++) {
+        // this lane's columns -> 29-bit limbs x[0..10]
+        uint32_t x[11];
+        uint64_t carry = 0;
+#pragma unroll
+        for (int k = 0; k <= NL29; k++) { const uint64_t t = col[s][k] + carry; x[k] = (uint32_t)t & M29; carry = t >> 29; }
+        x[10] = (uint32_t)carry;
+        // sum over the 64 lanes, a carry pass every second level (4 x 2^29 < 2^32)
+#pragma unroll
+        for (int level = 0; level < 6; level++) {
+#pragma unroll
+            for (int k = 0; k < 11; k++) x[k] += (uint32_t)__shfl_xor((int)x[k], 32 >> level, WAVE);
+            if (level & 1) {
+                uint32_t cy = 0;
+#pragma unroll
+                for (int k = 0; k < 10; k++) { const uint32_t t = x[k] + cy; x[k] = t & M29; cy = t >> 29; }
+                x[10] += cy;
+            }
+        }
+        const F29 sum = f29_redc_wide(x);                          // X / R' = sum(c z), < 2 p
+        const F29 res = f29_canonical(f29_mul(sum, krrp));         // sum(c z) R
+        if (lane == 0 && sig0 + s < batch)
+            fr_store(abc + (((sig0 + s) * 3 + d.matrix) * (size_t)r.num_constraints + d.row) * 8, f29_pack(res));
+    }
+}
+
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
                              uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st)
 {
@@ -196,9 +304,22 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
     }
     const unsigned gx = (r.num_constraints + BLOCK - 1) / BLOCK;
     if (abc) {
-        if (r.num_long)
-            hipLaunchKernelGGL(r1cs_long_rows_kernel, dim3(r.num_long, (unsigned)((batch + LONG_SIGS - 1) / LONG_SIGS)), dim3(WAVE), 0, st,
-                           r, batch, (const uint32_t *)witness, (const uint32_t *)instance, (uint32_t *)abc);
+        if (r.num_long) {
+            const dim3 grid(r.num_long, (unsigned)((batch + LONG_SIGS - 1) / LONG_SIGS));
+            // stream-ordered scratch for the small values; without it (allocation refused) every term is a field product
+            uint32_t *zs = nullptr;
+            if (hipMallocAsync((void **)&zs, batch * (size_t)r.num_long_vars * sizeof(uint32_t), st) == hipSuccess && zs) {
+                hipLaunchKernelGGL(r1cs_zsmall_kernel, dim3((r.num_long_vars + BLOCK - 1) / BLOCK, (unsigned)batch), dim3(BLOCK), 0, st,
+                                   r, batch, (const uint32_t *)witness, (const uint32_t *)instance, zs);
+                hipLaunchKernelGGL(r1cs_long_rows_small_kernel, grid, dim3(WAVE), 0, st, r, batch, (const uint32_t *)witness,
+                                   (const uint32_t *)instance, zs, (uint32_t *)abc);
+                (void)hipFreeAsync(zs, st);
+            } else {
+                (void)hipGetLastError();
+                hipLaunchKernelGGL(r1cs_long_rows_kernel, grid, dim3(WAVE), 0, st, r, batch, (const uint32_t *)witness,
+                                   (const uint32_t *)instance, (uint32_t *)abc);
+            }
+        }
         hipLaunchKernelGGL(r1cs_eval_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
                            (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied, (uint32_t *)abc);
         return hipGetLastError();

@@ -44,6 +44,10 @@ def test_witness_map_equals_oracle(engine, oracle, tmp_path, circuit, logn):
     w2 = from_montgomery(wit[2, tamper].cpu().numpy().view(np.uint64))[0]
     wit[2, tamper] = torch.from_numpy(T.ints_to_limbs([(w2 + 1) * qap.R_MONT % P])[0].view(np.int64)).to(dev)
     del one_m
+    # signature 1: a ladder input (S0 element 3, read by every long row) replaced by a full-size field element: the long
+    # rows' small-integer path must fall back to field products for that term
+    big = 0x5A5A1234_9E3779B9_7F4A7C15_F39CC060_5CEDC834_1082276B_F3A27251_F86C6A11 % P
+    wit[1, 3] = torch.from_numpy(T.ints_to_limbs([big * qap.R_MONT % P])[0].view(np.int64)).to(dev)
     h_r1cs = engine.r1cs_load(circuit, logn)
     try:
         q = engine.qap_info(h_r1cs)
@@ -58,14 +62,16 @@ def test_witness_map_equals_oracle(engine, oracle, tmp_path, circuit, logn):
         torch.cuda.synchronize()
     finally:
         engine.r1cs_free(h_r1cs)
-    assert bad.tolist()[:2] == [0, 0] and bad.tolist()[2] > 0
+    assert bad.tolist()[0] == 0 and bad.tolist()[1] > 0 and bad.tolist()[2] > 0
     path = tmp_path / "c.r1cs"
     export(circuit, logn, path)
     ni, nw, nc, mats = read_r1cs(path)
     ofn = oracle.witness_dual_ntt_verify if circuit else oracle.witness_ntt_verify
     owit, oinst, ost = ofn(logn, sig, pk, hm, 0)
-    for k in (0, 2):
+    for k in (0, 1, 2):
         z = np.concatenate([oinst[k], owit[k]])
+        if k == 1:
+            z[ni + 3] = T.ints_to_limbs([big])[0]
         if k == 2:
             z[ni + tamper] = T.ints_to_limbs([(T.limbs_to_ints(z[ni + tamper])[0] + 1) % P])[0]
         (az, bz, cz), want = oracle_h(oracle, mats, ni, z)
