@@ -298,6 +298,7 @@ extern "C" int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const ui
                                        void *stream)
 {
     if (!r || (batch && (!d_witness || !d_instance || !d_h || !d_workspace))) return FRW_E_INVALID_ARG;
+    if (r->qap.log_n != 17 && r->qap.log_n != 18) return FRW_E_INVALID_ARG;   // the pass schedule covers the Falcon circuits' domains
     if (batch && workspace_bytes < frw::qap_workspace_bytes_per_signature(r->dev, r->qap)) return FRW_E_INVALID_ARG;
     if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
     return frw::launch_qap_witness_map(r->dev, r->qap, batch, d_witness, d_instance, d_h, d_num_unsatisfied, d_workspace,

@@ -5,10 +5,14 @@
 // `assert!(cs.is_satisfied())` (circuits/falcon_ntt.rs:159) run against an independently derived constraint system,
 // for every signature of a full-size launch, where the witnesses lie (HBM).
 //
-// One thread evaluates one constraint row of one signature: three sparse dot products over BLS12-381 Fr in Montgomery
-// form and one field multiplication.  Rows are visited in order of decreasing length (host-computed permutation), so
-// the 64 rows of a wavefront have similar length (the 2N ladder rows have N+1 terms, everything else a handful).
-// ALU-bound (a 256-bit Montgomery product per term); a verification utility, not a throughput path.
+// Two uses.  (1) frw_r1cs_check_dev, check only: r1cs_check_kernel, one thread per constraint row of one signature --
+// three sparse dot products over BLS12-381 Fr (8 x 32-bit Montgomery form) and one field multiplication; rows visited in
+// order of decreasing length so that the 64 rows of a wavefront have similar length.  A verification utility.
+// (2) frw_r1cs_eval_dev / the QAP witness map (frw_qap.hip), which need A z, B z, C z in HBM: the 2 N + 1 rows that
+// arkworks' finalize() turns into N-term linear combinations go to a wavefront each (r1cs_long_rows_small_kernel: plain
+// values of their variables extracted once per signature by r1cs_zsmall_kernel, one multiply-add per limb per term;
+// r1cs_long_rows_kernel: field products, when no scratch is to be had), everything else to r1cs_eval_kernel (thread per
+// row, nine-limb arithmetic of frw_fr29.h, +1 / -1 coefficients without a product).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "frw_device.h"

@@ -240,7 +240,10 @@ int frw_r1cs_eval_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness
  *                       after into_repr, to the MSM over pk.h_query; the last coefficient is zero for a satisfied system)
  *     d_num_unsatisfied optional uint32_t[batch]: constraint rows the witness violates (h is then not a quotient)
  *     d_workspace       at least workspace_bytes_per_signature bytes; the batch is processed in chunks of as many
- *                       signatures as fit. */
+ *                       signatures as fit.
+ * Returns FRW_E_INVALID_ARG for a null pointer, a workspace smaller than one signature's, or a domain other than 2^17 /
+ * 2^18 (the transform schedule is built for the four Falcon circuits).  Stream-ordered: everything is enqueued on
+ * `stream`; the sparse products take a stream-ordered scratch allocation (hipMallocAsync) for the duration of the call. */
 typedef struct {
     int32_t log_domain_size;
     uint64_t domain_size;                      /* n */
