@@ -305,6 +305,43 @@ extern "C" int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const ui
                                        workspace_bytes, (hipStream_t)stream) == hipSuccess ? FRW_OK : FRW_E_HIP;
 }
 
+// Host buffers in, host buffers out: the same map for a caller that holds `Vec<Fr>`s (arkworks' witness_assignment /
+// instance_assignment bytes) -- copies in, frw_qap_witness_map_dev in chunks of 64 signatures, copies out.
+extern "C" int frw_qap_witness_map(const frw_r1cs *r, size_t batch, const uint64_t *witness, const uint64_t *instance,
+                                   uint64_t *h, uint32_t *num_unsatisfied)
+{
+    if (!r || (batch && (!witness || !instance || !h))) return FRW_E_INVALID_ARG;
+    if (r->qap.log_n != 17 && r->qap.log_n != 18) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
+    const size_t n = (size_t)1 << r->qap.log_n, W = r->dev.num_witness, I = r->dev.num_instance;
+    const size_t chunk = std::min<size_t>(batch, 64), per = frw::qap_workspace_bytes_per_signature(r->dev, r->qap);
+    void *d_wit = nullptr, *d_inst = nullptr, *d_h = nullptr, *d_ws = nullptr, *d_bad = nullptr;
+    hipStream_t st = nullptr;
+    int rc = FRW_OK;
+    if (hipStreamCreate(&st) != hipSuccess) return FRW_E_HIP;
+    if (hipMalloc(&d_wit, chunk * W * 32) != hipSuccess || hipMalloc(&d_inst, chunk * I * 32) != hipSuccess ||
+        hipMalloc(&d_h, chunk * n * 32) != hipSuccess || hipMalloc(&d_ws, chunk * per) != hipSuccess ||
+        hipMalloc(&d_bad, chunk * sizeof(uint32_t)) != hipSuccess)
+        rc = FRW_E_OUT_OF_MEMORY;
+    for (size_t lo = 0; rc == FRW_OK && lo < batch; lo += chunk) {
+        const size_t cnt = std::min(chunk, batch - lo);
+        bool ok = hipMemcpyAsync(d_wit, witness + lo * W * 4, cnt * W * 32, hipMemcpyHostToDevice, st) == hipSuccess &&
+                  hipMemcpyAsync(d_inst, instance + lo * I * 4, cnt * I * 32, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && frw::launch_qap_witness_map(r->dev, r->qap, cnt, (const uint64_t *)d_wit, (const uint64_t *)d_inst, (uint64_t *)d_h,
+                                               (uint32_t *)d_bad, d_ws, chunk * per, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(h + lo * n * 4, d_h, cnt * n * 32, hipMemcpyDeviceToHost, st) == hipSuccess;
+        if (ok && num_unsatisfied)
+            ok = hipMemcpyAsync(num_unsatisfied + lo, d_bad, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        if (!ok) rc = FRW_E_HIP;
+    }
+    for (void *p : {d_wit, d_inst, d_h, d_ws, d_bad})
+        if (p) (void)hipFree(p);
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+
 extern "C" int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
                                   uint32_t *d_num_unsatisfied, void *stream)
 {

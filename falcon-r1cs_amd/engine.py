@@ -331,6 +331,19 @@ class WitnessEngine:
                                                 self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)),
               "frw_qap_witness_map_dev")
 
+    def qap_witness_map(self, handle, witness, instance):
+        """Host arrays (uint64[batch, W, 4], uint64[batch, I, 4], Montgomery, as witness_ntt_verify returns them) ->
+        (h uint64[batch, n, 4], unsatisfied rows uint32[batch])."""
+        witness = np.ascontiguousarray(witness, dtype=np.uint64)
+        instance = np.ascontiguousarray(instance, dtype=np.uint64)
+        batch = witness.shape[0]
+        n = int(self.qap_info(handle).domain_size)
+        h = np.empty((batch, n, 4), dtype=np.uint64)
+        bad = np.empty(batch, dtype=np.uint32)
+        check(self._lib.frw_qap_witness_map(handle, batch, witness.ctypes.data_as(C.c_void_p), instance.ctypes.data_as(C.c_void_p),
+                                            h.ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p)), "frw_qap_witness_map")
+        return h, bad
+
     def digest_dev(self, d_buf, words_per_item, items, d_out, stream=0):
         check(self._lib.frw_digest_dev(self._ctx, self._ptr(d_buf), words_per_item, items, self._ptr(d_out),
                                        C.c_void_p(stream)), "frw_digest_dev")

@@ -254,6 +254,11 @@ int frw_qap_info(const frw_r1cs *r, frw_qap_info_t *out);
 int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
                             uint64_t *d_h, uint32_t *d_num_unsatisfied, void *d_workspace, size_t workspace_bytes,
                             void *stream);
+/* Host buffers: witness uint64_t[batch][W][4], instance uint64_t[batch][I][4] (the constant one first) -- the bytes of
+ * arkworks' witness_assignment / instance_assignment -- to h uint64_t[batch][n][4]; num_unsatisfied may be NULL.
+ * Synchronous; device buffers are allocated and freed inside (64 signatures in flight). */
+int frw_qap_witness_map(const frw_r1cs *r, size_t batch, const uint64_t *witness, const uint64_t *instance,
+                        uint64_t *h, uint32_t *num_unsatisfied);
 
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),

@@ -149,6 +149,55 @@ impl ConstraintSynthesizer<Fr> for AcceleratedNTTCircuit {
     }
 }
 
+/// The constraint matrices of one circuit on the device plus the tables of its evaluation domain: what
+/// `frw_qap_witness_map` needs.  Built once per (circuit, parameter set), like a proving key.
+pub struct R1cs {
+    raw: *mut sys::frw_r1cs,
+    info: sys::frw_qap_info_t,
+}
+
+impl R1cs {
+    /// `circuit`: `sys::FRW_CIRCUIT_NTT` or `sys::FRW_CIRCUIT_DUAL_NTT`.
+    pub fn load(device: i32, circuit: i32) -> Result<Self, EngineError> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { sys::frw_r1cs_load(device, circuit, LOG_N as c_int, &mut raw) })?;
+        let mut info = sys::frw_qap_info_t::default();
+        check(unsafe { sys::frw_qap_info(raw, &mut info) })?;
+        Ok(Self { raw, info })
+    }
+
+    /// Size of ark-poly's `Radix2EvaluationDomain::new(num_constraints + num_instance_variables)`.
+    pub fn domain_size(&self) -> usize {
+        self.info.domain_size as usize
+    }
+
+    /// ark-groth16's `R1CStoQAP::witness_map` for each `(instance_assignment, witness_assignment)` pair: the coefficients
+    /// of h(X) = (A(X) B(X) - C(X)) / (X^n - 1), `domain_size()` of them, computed on the GPU.
+    pub fn witness_map(&self, full: &[(&[Fr], &[Fr])]) -> Result<Vec<Vec<Fr>>, EngineError> {
+        let (ni, n) = (self.info.num_instance as usize, self.domain_size());
+        let mut wit: Vec<u64> = Vec::new();
+        let mut inst: Vec<u64> = Vec::new();
+        for (i, w) in full {
+            assert_eq!(i.len(), ni, "instance_assignment with the constant one first");
+            inst.extend(i.iter().flat_map(|e| (e.0).0));          // Fp256(BigInteger256([u64; 4]), _): Montgomery limbs
+            wit.extend(w.iter().flat_map(|e| (e.0).0));
+        }
+        let mut h = vec![0u64; full.len() * n * 4];
+        check(unsafe {
+            sys::frw_qap_witness_map(self.raw, full.len(), wit.as_ptr(), inst.as_ptr(), h.as_mut_ptr(), std::ptr::null_mut())
+        })?;
+        Ok(h.chunks_exact(n * 4)
+            .map(|one| one.chunks_exact(4).map(|l| Fp256::new(BigInteger256([l[0], l[1], l[2], l[3]]))).collect())
+            .collect())
+    }
+}
+
+impl Drop for R1cs {
+    fn drop(&mut self) {
+        unsafe { sys::frw_r1cs_free(self.raw) }
+    }
+}
+
 /// The public inputs a verifier feeds `verify_proof` with, as examples/pok_sig.rs:33-45 computes them.
 pub fn public_inputs(pk: &PublicKey, msg: &[u8], sig: &Signature) -> Vec<Fr> {
     let pk_ntt = NTTPolynomial::from(&Polynomial::from(pk));
@@ -192,5 +241,54 @@ mod tests {
         let (g, c) = (gpu.borrow().unwrap(), cpu.borrow().unwrap());
         assert_eq!(g.instance_assignment, c.instance_assignment);
         assert_eq!(g.witness_assignment, c.witness_assignment);
+    }
+
+    /// What would pin the QAP witness map: h from the GPU satisfies, at a random point, the identity that defines
+    /// ark-groth16's `R1CStoQAP::witness_map` output -- A(tau) B(tau) - C(tau) = h(tau) Z(tau) with the Lagrange
+    /// coefficients, the matrices and the assignment all taken from arkworks itself (ark-poly 0.3 `EvaluationDomain`,
+    /// `cs.to_matrices()` after `finalize()`), none from this repository.
+    #[test]
+    fn gpu_witness_map_satisfies_arkworks_qap_identity() {
+        use ark_ff::{One, UniformRand, Zero};
+        use ark_poly::{EvaluationDomain, GeneralEvaluationDomain};
+        let keypair = KeyPair::keygen();
+        let msg = "testing message";
+        let sig = keypair.secret_key.sign_with_seed("test seed".as_ref(), msg.as_ref());
+        let cs = ConstraintSystem::<Fr>::new_ref();
+        FalconNTTVerificationCircuit::build_circuit(keypair.public_key, msg.as_bytes().to_vec(), sig)
+            .generate_constraints(cs.clone())
+            .unwrap();
+        cs.finalize();
+        let m = cs.to_matrices().unwrap();
+        let (inst, wit) = {
+            let c = cs.borrow().unwrap();
+            (c.instance_assignment.clone(), c.witness_assignment.clone())
+        };
+        let r1cs = R1cs::load(0, frw_sys::FRW_CIRCUIT_NTT).expect("an MI355X and libfrw.so");
+        let h = r1cs.witness_map(&[(&inst, &wit)]).unwrap().remove(0);
+
+        let domain = GeneralEvaluationDomain::<Fr>::new(cs.num_constraints() + cs.num_instance_variables()).unwrap();
+        assert_eq!(domain.size(), h.len());
+        let tau = Fr::rand(&mut ark_std::test_rng());
+        let lag = domain.evaluate_all_lagrange_coefficients(tau);
+        let z: Vec<Fr> = inst.iter().chain(wit.iter()).cloned().collect();
+        let dot = |rows: &Vec<Vec<(Fr, usize)>>, extra: &[Fr]| -> Fr {
+            let mut acc = Fr::zero();
+            for (i, row) in rows.iter().enumerate() {
+                acc += lag[i] * row.iter().map(|(c, j)| *c * z[*j]).sum::<Fr>();
+            }
+            for (j, e) in extra.iter().enumerate() {
+                acc += lag[rows.len() + j] * e;
+            }
+            acc
+        };
+        let (a, b, c) = (dot(&m.a, &inst), dot(&m.b, &[]), dot(&m.c, &[]));
+        let mut h_tau = Fr::zero();
+        let mut p = Fr::one();
+        for coeff in &h {
+            h_tau += *coeff * p;
+            p *= tau;
+        }
+        assert_eq!(a * b - c, h_tau * domain.evaluate_vanishing_polynomial(tau));
     }
 }

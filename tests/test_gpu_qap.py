@@ -162,3 +162,29 @@ def test_witness_map_matches_committed_golden(engine):
             engine.r1cs_free(r)
         assert bad.tolist() == [0]
         assert hashlib.sha256(h[0].cpu().numpy().tobytes()).hexdigest() == fx["h_sha256"]["montgomery"]
+
+
+def test_host_entry_point_equals_device_entry_point(engine):
+    """frw_qap_witness_map (host buffers, what a holder of arkworks' Vec<Fr>s calls) == frw_qap_witness_map_dev, for a
+    batch that spans two internal chunks (70 = 64 + 6 Falcon-512 signatures)."""
+    import torch
+    import falcon_r1cs_amd as frw
+    logn, batch = 9, 70
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=31337)
+    wit, inst, st = engine.witness_ntt_verify(logn, sig, pk, hm, frw.ENC_MONTGOMERY, strict=True)
+    r = engine.r1cs_load(0, logn)
+    try:
+        h, bad = engine.qap_witness_map(r, wit, inst)
+        assert not bad.any() and not h[:, -1].any()
+        dev = torch.device("cuda:0")
+        q = engine.qap_info(r)
+        per = int(q.workspace_bytes_per_signature)
+        dw = torch.from_numpy(wit.view(np.int64)).to(dev)
+        di = torch.from_numpy(inst.view(np.int64)).to(dev)
+        dh = torch.empty((batch, int(q.domain_size), 4), dtype=torch.int64, device=dev)
+        ws = torch.empty(8 * per, dtype=torch.uint8, device=dev)
+        engine.qap_witness_map_dev(r, batch, dw, di, dh, ws, 8 * per, None, 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(dh.cpu().numpy().view(np.uint64), h)
+    finally:
+        engine.r1cs_free(r)
