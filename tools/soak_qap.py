@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Soak of the QAP witness map: many back-to-back calls on fixed witnesses, two streams at once (each with its own
+workspace and output), the digest of every call's h compared with the first call's -- a race in the LDS exchange or the
+staging of the memory-order tiles would show up as a mismatch.   python tools/soak_qap.py [calls=200] [logn=10] [batch=48]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import falcon_r1cs_amd as frw  # noqa: E402
+
+calls = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+logn = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 48
+dev = torch.device("cuda:0")
+eng = frw.WitnessEngine(0)
+L = frw.layout(logn)
+sig, pk, hm = frw.synth_triples(logn, batch, seed=4711)
+d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+st = torch.empty(batch, dtype=torch.int32, device=dev)
+eng.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, 0)
+torch.cuda.synchronize()
+r = eng.r1cs_load(0, logn)
+q = eng.qap_info(r)
+n, per = int(q.domain_size), int(q.workspace_bytes_per_signature)
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+bufs = [{"ws": torch.empty(batch * per, dtype=torch.uint8, device=dev), "h": torch.empty((batch, n, 4), dtype=torch.int64, device=dev),
+         "bad": torch.empty(batch, dtype=torch.int32, device=dev)} for _ in streams]
+weights = torch.arange(1, 4 * n + 1, dtype=torch.int64, device=dev).reshape(n, 4) * 0x9E3779B97F4A7C15 % (1 << 62)
+
+
+def digest(h):                       # order-sensitive per-signature digest, wrapping int64 arithmetic
+    return (h * weights).sum(dim=(1, 2))
+
+
+ref = None
+t0 = time.time()
+for i in range(calls):
+    for s, b in zip(streams, bufs):
+        with torch.cuda.stream(s):
+            b["h"].fill_(-1)
+            eng.qap_witness_map_dev(r, batch, wit, inst, b["h"], b["ws"], batch * per, b["bad"], s.cuda_stream)
+            b["dig"] = digest(b["h"])
+    torch.cuda.synchronize()
+    for b in bufs:
+        assert int(b["bad"].abs().sum()) == 0
+        if ref is None:
+            ref = b["dig"].clone()
+        elif not torch.equal(ref, b["dig"]):
+            raise SystemExit("MISMATCH in call %d, signatures %s" % (i, torch.nonzero(ref != b["dig"]).flatten().tolist()[:10]))
+eng.r1cs_free(r)
+print("Falcon-%d witness map: %d calls x 2 streams x %d signatures, every h identical to the first call's (%.1f s)"
+      % (1 << logn, calls, batch, time.time() - t0))
