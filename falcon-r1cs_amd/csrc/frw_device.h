@@ -94,6 +94,7 @@ struct R1csDev {
     const uint32_t *long_col;   // [chunks][64]
     const uint32_t *long_coef;  // [chunks][9][64]
     const uint8_t *long_mask;   // [num_constraints]: bit m set = row is long in matrix m (0 = A, 1 = B, 2 = C)
+    const uint32_t *long_slot;  // [3][num_constraints]: index into long_rows of (matrix, row), where long
     // the distinct variables the long rows read (the N signature coefficients, the N coefficients of v, ... -- small
     // integers in a Falcon witness): their plain values are extracted once per signature, and a long-row term whose
     // variable is below 2^28 is one multiply-add per limb instead of a field product

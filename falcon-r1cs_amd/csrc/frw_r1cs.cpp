@@ -210,12 +210,14 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
         std::vector<frw::R1csLongRow> lrows;
         std::vector<uint32_t> lcol, lcoef;
         std::vector<uint8_t> lmask(m.num_constraints, 0);
+        std::vector<uint32_t> lslot(3 * m.num_constraints, 0u);
         const std::vector<frw::host::ConstraintMatrices::Row> *mats[3] = {&m.a, &m.b, &m.c};
         for (uint32_t mi = 0; mi < 3; mi++)
             for (size_t row = 0; row < m.num_constraints; row++) {
                 const auto &terms = (*mats[mi])[row];
                 if (terms.size() < frw::R1CS_LONG_ROW) continue;
                 const uint32_t chunks = (uint32_t)((terms.size() + 63) / 64), first = (uint32_t)(lcol.size() / 64);
+                lslot[(size_t)mi * m.num_constraints + row] = (uint32_t)lrows.size();
                 lrows.push_back({mi, (uint32_t)row, first, chunks});
                 lmask[row] |= (uint8_t)(1u << mi);
                 lcol.resize((size_t)(first + chunks) * 64, 0u);
@@ -248,6 +250,7 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
         r->dev.long_col = (const uint32_t *)upload(lcol.data(), lcol.size() * 4);
         r->dev.long_coef = (const uint32_t *)upload(lcoef.data(), lcoef.size() * 4);
         r->dev.long_mask = (const uint8_t *)upload(lmask.data(), lmask.size());
+        r->dev.long_slot = (const uint32_t *)upload(lslot.data(), lslot.size() * 4);
         const QapTables qt = build_qap_tables(m.num_constraints, m.num_instance_variables);
         r->qap = frw::QapDev{};
         r->qap.log_n = qt.log_n;

@@ -58,16 +58,20 @@ __device__ __forceinline__ F29 row_dot29(const R1csMatrixDev &m, uint32_t row, c
     return acc;                                    // < 2 p
 }
 
+// STORE: write A z, B z, C z to abc (and read the long rows' products from there).  !STORE: check only -- nothing is
+// written; the long rows' products are read from `long_out` ([signature][long row], r.long_slot maps (matrix, row) to it).
+template <bool STORE>
 __global__ __launch_bounds__(BLOCK) void r1cs_eval_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
                                                           const uint32_t *__restrict__ instance,
                                                           unsigned int *__restrict__ num_unsatisfied,
-                                                          uint32_t *__restrict__ abc)
+                                                          uint32_t *__restrict__ abc, const uint32_t *__restrict__ long_out)
 {
     const size_t sig = blockIdx.y;
     if (sig >= batch) return;
     const uint32_t *wit = witness + sig * (size_t)r.num_witness * 8;
     const uint32_t *inst = instance + sig * (size_t)r.num_instance * 8;
-    uint32_t *o = abc + sig * (size_t)3 * r.num_constraints * 8;
+    uint32_t *o = STORE ? abc + sig * (size_t)3 * r.num_constraints * 8 : nullptr;
+    const uint32_t *lo = STORE ? nullptr : long_out + sig * (size_t)r.num_long * 8;
     constexpr uint32_t R32[8] = FRW_R32;
     Fr8 one_r;
 #pragma unroll
@@ -76,16 +80,20 @@ __global__ __launch_bounds__(BLOCK) void r1cs_eval_kernel(R1csDev r, size_t batc
     unsigned bad = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < r.num_constraints; i += gridDim.x * BLOCK) {
         const uint32_t row = r.order[i], mask = r.long_mask[row];
-        uint32_t *oa = o + (size_t)row * 8, *ob = o + ((size_t)r.num_constraints + row) * 8, *oc = o + ((size_t)2 * r.num_constraints + row) * 8;
-        F29 az, bz, cz;
-        if (mask & 1u) az = f29_unpack(fr_load(oa));
-        else { az = f29_canonical(row_dot29(r.a, row, wit, inst, r.num_instance)); fr_store(oa, f29_pack(az)); }
-        if (mask & 2u) bz = f29_unpack(fr_load(ob));
-        else { bz = f29_canonical(row_dot29(r.b, row, wit, inst, r.num_instance)); fr_store(ob, f29_pack(bz)); }
-        if (mask & 4u) cz = f29_unpack(fr_load(oc));
-        else { cz = f29_canonical(row_dot29(r.c, row, wit, inst, r.num_instance)); fr_store(oc, f29_pack(cz)); }
+        F29 v[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const R1csMatrixDev &mat = m == 0 ? r.a : m == 1 ? r.b : r.c;
+            uint32_t *om = STORE ? o + ((size_t)m * r.num_constraints + row) * 8 : nullptr;
+            if (mask & (1u << m)) {
+                v[m] = f29_unpack(fr_load(STORE ? om : lo + (size_t)r.long_slot[(size_t)m * r.num_constraints + row] * 8));
+            } else {
+                v[m] = f29_canonical(row_dot29(mat, row, wit, inst, r.num_instance));
+                if (STORE) fr_store(om, f29_pack(v[m]));
+            }
+        }
         // (Az R)(Bz R) / R' = Az Bz R / 32  against  (Cz R) R / R' = Cz R / 32
-        const F29 ab = f29_canonical(f29_mul(az, bz)), c32 = f29_canonical(f29_mul(cz, one29));
+        const F29 ab = f29_canonical(f29_mul(v[0], v[1])), c32 = f29_canonical(f29_mul(v[2], one29));
         bool eq = true;
 #pragma unroll
         for (int k = 0; k < NL29; k++) eq &= ab.l[k] == c32.l[k];
@@ -96,8 +104,8 @@ __global__ __launch_bounds__(BLOCK) void r1cs_eval_kernel(R1csDev r, size_t batc
     if ((threadIdx.x & (WAVE - 1)) == 0 && bad && num_unsatisfied) atomicAdd(&num_unsatisfied[sig], bad);
 }
 
-// Check only (no buffer to park the long rows' products in): one thread per row in the 8 x 32-bit form, longest rows
-// first, so that the dense ladder rows spread over many waves.
+// Check only, when no scratch is to be had for the long rows' products: one thread per row in the 8 x 32-bit form, longest
+// rows first, so that the dense ladder rows spread over many waves.
 __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
                                                            const uint32_t *__restrict__ instance,
                                                            unsigned int *__restrict__ num_unsatisfied)
@@ -128,8 +136,15 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
 // Products are f29_mul(z R, c R') = z c R (< 2 p); they are summed limb-wise with a carry pass every four and a reduction
 // (a product with R' mod p) every sixteen, so the running value stays far below 2^261 = 70 p.
 constexpr int LONG_SIGS = 4;
+// where a long row's product goes: its slot in abc, or (check only) [signature][long row] of the scratch
+__device__ __forceinline__ uint32_t *long_row_out(const R1csDev &r, const R1csLongRow &d, uint32_t *abc, uint32_t *long_out, size_t sig)
+{
+    return abc ? abc + ((sig * 3 + d.matrix) * (size_t)r.num_constraints + d.row) * 8 : long_out + (sig * r.num_long + blockIdx.x) * 8;
+}
+
 __global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
-                                                              const uint32_t *__restrict__ instance, uint32_t *__restrict__ abc)
+                                                              const uint32_t *__restrict__ instance, uint32_t *__restrict__ abc,
+                                                              uint32_t *__restrict__ long_out)
 {
     const R1csLongRow d = r.long_rows[blockIdx.x];
     const int lane = threadIdx.x;
@@ -184,8 +199,7 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t 
             for (int k = 0; k < NL29; k++) other.l[k] = (uint32_t)__shfl_xor((int)acc[s].l[k], off, WAVE);
             acc[s] = f29_reduce_4p(f29_add(acc[s], other));
         }
-        if (lane == 0 && sig0 + s < batch)
-            fr_store(abc + (((sig0 + s) * 3 + d.matrix) * (size_t)r.num_constraints + d.row) * 8, f29_pack(f29_canonical(acc[s])));
+        if (lane == 0 && sig0 + s < batch) fr_store(long_row_out(r, d, abc, long_out, sig0 + s), f29_pack(f29_canonical(acc[s])));
     }
 }
 
@@ -216,7 +230,8 @@ __global__ __launch_bounds__(BLOCK) void r1cs_zsmall_kernel(R1csDev r, size_t ba
 // X = 32 R sum(c z) becomes sum(c z) R through one Montgomery reduction (X / R') and one product with R R' mod p.
 __global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
                                                                     const uint32_t *__restrict__ instance,
-                                                                    const uint32_t *__restrict__ zs, uint32_t *__restrict__ abc)
+                                                                    const uint32_t *__restrict__ zs, uint32_t *__restrict__ abc,
+                                                                    uint32_t *__restrict__ long_out)
 {
     const R1csLongRow d = r.long_rows[blockIdx.x];
     const int lane = threadIdx.x;
@@ -292,8 +307,7 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, s
         }
         const F29 sum = f29_redc_wide(x);                          // X / R' = sum(c z), < 2 p
         const F29 res = f29_canonical(f29_mul(sum, krrp));         // sum(c z) R
-        if (lane == 0 && sig0 + s < batch)
-            fr_store(abc + (((sig0 + s) * 3 + d.matrix) * (size_t)r.num_constraints + d.row) * 8, f29_pack(res));
+        if (lane == 0 && sig0 + s < batch) fr_store(long_row_out(r, d, abc, long_out, sig0 + s), f29_pack(res));
     }
 }
 
@@ -307,30 +321,36 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
         if (e != hipSuccess) return e;
     }
     const unsigned gx = (r.num_constraints + BLOCK - 1) / BLOCK;
-    if (abc) {
+    const dim3 egrid(gx > 64 ? 64 : gx, (unsigned)batch);
+    const uint32_t *wit = (const uint32_t *)witness, *inst = (const uint32_t *)instance;
+    // stream-ordered scratch: the small values of the long rows' variables, and (check only) the long rows' products
+    uint32_t *zs = nullptr, *long_out = nullptr;
+    bool scratch = true;
+    if (r.num_long) {
+        scratch = hipMallocAsync((void **)&zs, batch * (size_t)r.num_long_vars * sizeof(uint32_t), st) == hipSuccess && zs;
+        if (scratch && !abc) scratch = hipMallocAsync((void **)&long_out, batch * (size_t)r.num_long * 32, st) == hipSuccess && long_out;
+        if (!scratch) (void)hipGetLastError();
+    }
+    if (abc || scratch) {
         if (r.num_long) {
             const dim3 grid(r.num_long, (unsigned)((batch + LONG_SIGS - 1) / LONG_SIGS));
-            // stream-ordered scratch for the small values; without it (allocation refused) every term is a field product
-            uint32_t *zs = nullptr;
-            if (hipMallocAsync((void **)&zs, batch * (size_t)r.num_long_vars * sizeof(uint32_t), st) == hipSuccess && zs) {
+            if (scratch) {
                 hipLaunchKernelGGL(r1cs_zsmall_kernel, dim3((r.num_long_vars + BLOCK - 1) / BLOCK, (unsigned)batch), dim3(BLOCK), 0, st,
-                                   r, batch, (const uint32_t *)witness, (const uint32_t *)instance, zs);
-                hipLaunchKernelGGL(r1cs_long_rows_small_kernel, grid, dim3(WAVE), 0, st, r, batch, (const uint32_t *)witness,
-                                   (const uint32_t *)instance, zs, (uint32_t *)abc);
-                (void)hipFreeAsync(zs, st);
-            } else {
-                (void)hipGetLastError();
-                hipLaunchKernelGGL(r1cs_long_rows_kernel, grid, dim3(WAVE), 0, st, r, batch, (const uint32_t *)witness,
-                                   (const uint32_t *)instance, (uint32_t *)abc);
+                                   r, batch, wit, inst, zs);
+                hipLaunchKernelGGL(r1cs_long_rows_small_kernel, grid, dim3(WAVE), 0, st, r, batch, wit, inst, zs, (uint32_t *)abc, long_out);
+            } else {                                              // abc given, no scratch: every term a field product
+                hipLaunchKernelGGL(r1cs_long_rows_kernel, grid, dim3(WAVE), 0, st, r, batch, wit, inst, (uint32_t *)abc, long_out);
             }
         }
-        hipLaunchKernelGGL(r1cs_eval_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
-                           (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied, (uint32_t *)abc);
-        return hipGetLastError();
+        if (abc) hipLaunchKernelGGL(r1cs_eval_kernel<true>, egrid, dim3(BLOCK), 0, st, r, batch, wit, inst, num_unsatisfied, (uint32_t *)abc, long_out);
+        else hipLaunchKernelGGL(r1cs_eval_kernel<false>, egrid, dim3(BLOCK), 0, st, r, batch, wit, inst, num_unsatisfied, (uint32_t *)abc, long_out);
+    } else {
+        hipLaunchKernelGGL(r1cs_check_kernel, egrid, dim3(BLOCK), 0, st, r, batch, wit, inst, num_unsatisfied);
     }
-    hipLaunchKernelGGL(r1cs_check_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)batch), dim3(BLOCK), 0, st, r, batch,
-                       (const uint32_t *)witness, (const uint32_t *)instance, num_unsatisfied);
-    return hipGetLastError();
+    const hipError_t e = hipGetLastError();
+    if (zs) (void)hipFreeAsync(zs, st);
+    if (long_out) (void)hipFreeAsync(long_out, st);
+    return e;
 }
 
 }  // namespace frw
