@@ -223,7 +223,41 @@ def time_compact(eng, dev, logn, batch, launches, warm, d_in, d_wit):
     return out
 
 
-def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps):
+def qap_cpu_port(logn, triple, gpu_h0):
+    """The oracle's witness map (oracle/qap_oracle.c, one thread) for one signature: the CPU figure beside the GPU's, and
+    the check of the GPU's h for that signature, element for element.  Matrices: the file frw_r1cs_export writes."""
+    import tempfile
+    oracle = load_oracle()
+    sig, pk, hm = triple
+    wit, inst, st = oracle.witness_ntt_verify(logn, sig, pk, hm, 0)                  # canonical limbs
+    assert st[0] == 0
+    z = np.concatenate([inst[0], wit[0]])
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "c.r1cs")
+        assert frw.load_library().frw_r1cs_export(0, logn, path.encode(), None) == 0
+        raw = open(path, "rb").read()
+    ni, nw, nc, *nnz = np.frombuffer(raw, dtype=np.uint64, count=6, offset=8).tolist()
+    off, mats = 56, []
+    for k in range(3):
+        ptr = np.frombuffer(raw, dtype=np.uint64, count=nc + 1, offset=off); off += 8 * (nc + 1)
+        col = np.frombuffer(raw, dtype=np.uint32, count=nnz[k], offset=off); off += 4 * nnz[k]
+        val = np.frombuffer(raw, dtype=np.uint64, count=4 * nnz[k], offset=off).reshape(-1, 4); off += 32 * nnz[k]
+        mats.append((ptr, col, val))
+    t0 = time.perf_counter()
+    prods = [oracle.qap_matvec(*m, z) for m in mats]
+    h = oracle.qap_witness_map(*prods, ni, z)
+    seconds = time.perf_counter() - t0
+    p_fr = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    r_inv = pow(1 << 256, -1, p_fr)
+    got = [int.from_bytes(row.tobytes(), "little") * r_inv % p_fr for row in gpu_h0]
+    want = [int.from_bytes(row.tobytes(), "little") for row in h]
+    assert got == want, "GPU witness map differs from the oracle"
+    return {"seconds_per_map": round(seconds, 3), "threads": 1, "kind": "port",
+            "what": "oracle/qap_oracle.c (plain radix-2 transforms, 64-bit-limb Montgomery arithmetic); the GPU's h of the same "
+                    "signature compared with it element for element (%d coefficients)" % len(want)}
+
+
+def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps, logn=None, cpu_triple=None):
     """The step after the hot path in a Groth16 prover (SURVEY 8-f row 4): ark-groth16's R1CStoQAP::witness_map -- A z, B z,
     C z, three inverse + three coset-forward + one coset-inverse transform over the 2^17 / 2^18 domain -- for `nsig` of the
     witnesses the timed launches left in HBM.  Bound by VALU issue (field multiplications), not by HBM."""
@@ -246,11 +280,15 @@ def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps):
     assert int(bad.abs().sum()) == 0, "witness map: unsatisfied rows"
     assert int(h[:, -1].abs().sum()) == 0, "witness map: deg h must be <= n - 2 for satisfied systems"
     products = 7 * (n // 2) * int(q.log_domain_size) + 5 * n
-    return {"workload": "R1CS->QAP witness map (h = (A B - C) / Z, domain 2^%d) of %d resident witnesses per call" %
-                        (int(q.log_domain_size), nsig),
-            "ms_per_call": round(ms, 3), "signatures_per_s": round(nsig / (ms * 1e-3), 1), "calls_timed": reps,
-            "field_products_per_signature_transforms": products,
-            "bytes_out_per_signature": n * 32, "checked": "no unsatisfied rows; top coefficient of every h is zero"}
+    out = {"workload": "R1CS->QAP witness map (h = (A B - C) / Z, domain 2^%d) of %d resident witnesses per call" %
+                       (int(q.log_domain_size), nsig),
+           "ms_per_call": round(ms, 3), "signatures_per_s": round(nsig / (ms * 1e-3), 1), "calls_timed": reps,
+           "field_products_per_signature_transforms": products,
+           "bytes_out_per_signature": n * 32, "checked": "no unsatisfied rows; top coefficient of every h is zero"}
+    if cpu_triple is not None:
+        out["cpu_port"] = qap_cpu_port(logn, cpu_triple, h[0].cpu().numpy().view(np.uint64))
+        out["cpu_port"]["gpu_maps_per_cpu_core_map"] = round(out["signatures_per_s"] * out["cpu_port"]["seconds_per_map"], 1)
+    return out
 
 
 def time_aggregate(eng, dev, total, reps, threads):
@@ -765,7 +803,9 @@ def main():
         torch.cuda.synchronize()
         tc = time.perf_counter() - tc
         if world == 1 and not args.no_secondary and not dual:
-            qap_result = time_qap(eng, h, dev, d_wit, d_inst, min(64, held), 3)
+            s0 = int(slot_sig[0])
+            qap_result = time_qap(eng, h, dev, d_wit, d_inst, min(64, held), 3, logn,
+                                  None if args.no_cpu_baseline else (sig[s0:s0 + 1], pk[s0:s0 + 1], hm[s0:s0 + 1]))
         eng.r1cs_free(h)
         n_unsat = sharding.sum_over_ranks(int((badrows != 0).sum().item()), cdev)
         assert n_unsat == 0, "%d witnesses left by the timed launches violate the constraint system" % n_unsat
