@@ -22,7 +22,7 @@ def oracle_h(oracle, mats, ni, z_limbs):
     return (az, bz, cz), oracle.qap_witness_map(az, bz, cz, ni, z_limbs)
 
 
-@pytest.mark.parametrize("circuit,logn", [(0, 9), (0, 10), (1, 9)])
+@pytest.mark.parametrize("circuit,logn", [(0, 9), (0, 10), (1, 9), (1, 10)])
 def test_witness_map_equals_oracle(engine, oracle, tmp_path, circuit, logn):
     import torch
     import falcon_r1cs_amd as frw
