@@ -279,12 +279,27 @@ def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps, logn=None, cpu_triple=
     ms = e0.elapsed_time(e1) / reps
     assert int(bad.abs().sum()) == 0, "witness map: unsatisfied rows"
     assert int(h[:, -1].abs().sum()) == 0, "witness map: deg h must be <= n - 2 for satisfied systems"
+    # the six-transform route to the same h (valid because every witness here satisfies the system): must be identical
+    h6 = torch.empty_like(h)
+    run6 = lambda: eng.qap_quotient_dev(handle, nsig, d_wit, d_inst, h6, ws, nsig * per, bad, stream.cuda_stream)
+    run6()
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        run6()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms6 = e0.elapsed_time(e1) / reps
+    assert torch.equal(h6, h), "six-transform quotient differs from the witness map on satisfied witnesses"
     products = 7 * (n // 2) * int(q.log_domain_size) + 5 * n
     out = {"workload": "R1CS->QAP witness map (h = (A B - C) / Z, domain 2^%d) of %d resident witnesses per call" %
                        (int(q.log_domain_size), nsig),
            "ms_per_call": round(ms, 3), "signatures_per_s": round(nsig / (ms * 1e-3), 1), "calls_timed": reps,
            "field_products_per_signature_transforms": products,
-           "bytes_out_per_signature": n * 32, "checked": "no unsatisfied rows; top coefficient of every h is zero"}
+           "bytes_out_per_signature": n * 32, "checked": "no unsatisfied rows; top coefficient of every h is zero",
+           "six_transform_quotient": {"ms_per_call": round(ms6, 3), "signatures_per_s": round(nsig / (ms6 * 1e-3), 1),
+                                      "what": "frw_qap_quotient_dev: h as the high half of a(X) b(X), six transforms, C z not "
+                                              "transformed; bit-identical to the witness map on these (satisfied) witnesses"}}
     if cpu_triple is not None:
         out["cpu_port"] = qap_cpu_port(logn, cpu_triple, h[0].cpu().numpy().view(np.uint64))
         out["cpu_port"]["gpu_maps_per_cpu_core_map"] = round(out["signatures_per_s"] * out["cpu_port"]["seconds_per_map"], 1)

@@ -116,8 +116,15 @@ struct QapDev {
     const uint32_t *scale_in;     // g^k / n                  (ifft's 1/n and coset_fft's distribute_powers, fused)
     const uint32_t *scale_in_a;   // 2^5 g^k / n              (for A z: the a b product divides by 2^261, the data carry 2^256)
     const uint32_t *scale_out;    // g^-k / (n (g^n - 1))     (ifft's 1/n, division by the vanishing polynomial, g^-k)
+    // the six-transform quotient (launch_qap_quotient): psi = the 2n-th root of unity with psi^2 = w
+    const uint32_t *scale_psi_in; // psi^k / n
+    const uint32_t *scale_psi_out;// -16 psi^-k / n           (-1/2, and 32 for the data x data product in R' arithmetic)
+    uint32_t sixteen_over_n[9];   // 16 / n, x R' in nine limbs
 };
 size_t qap_workspace_bytes_per_signature(const R1csDev &r, const QapDev &q);
+hipError_t launch_qap_quotient(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,
+                               const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,
+                               size_t workspace_bytes, hipStream_t st);
 hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,
                                   const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,
                                   size_t workspace_bytes, hipStream_t st);

@@ -38,8 +38,8 @@ constexpr int QAP_THREADS = 128;        // 8 elements per thread
 constexpr int QAP_LDS_PLANE = QAP_TILE + 16;      // memory-order tiles are stored 65 apart per column (see below)
 
 enum { PASS_FIRST = 0, PASS_DIT_SH0 = 1, PASS_DIT = 2, PASS_DIF = 3, PASS_DIF_SH0 = 4 };
-enum { LOAD_PLAIN = 0, LOAD_AB_MINUS_C = 1 };
-enum { STORE_PLAIN = 0, STORE_FACTOR = 1, STORE_FACTOR_A = 2, STORE_FACTOR_CANONICAL = 3 };
+enum { LOAD_PLAIN = 0, LOAD_AB_MINUS_C = 1, LOAD_AB = 2, LOAD_PRODUCTS_AB = 3 };
+enum { STORE_PLAIN = 0, STORE_FACTOR = 1, STORE_FACTOR_A = 2, STORE_FACTOR_CANONICAL = 3, STORE_CONST_ADD_CANONICAL = 4 };
 
 struct NttPass {
     const uint32_t *src;        // [arrays][n][8] u32, working order (PASS_FIRST: unused)
@@ -53,6 +53,8 @@ struct NttPass {
     const uint32_t *instance;   // [signatures][I][8] u32
     uint32_t num_constraints, num_instance;
     int L, sh;                  // log n; lowest index bit this pass transforms
+    int per_sig;                // PASS_FIRST: arrays per signature in this launch (array y = signature y / per_sig, matrix y % per_sig)
+    uint32_t cfac[9];           // STORE_CONST_ADD_CANONICAL: the constant factor, x R' in nine limbs
 };
 
 // A/B builds (tools/ab_qap.py): -DFRW_QAP_NO_MUL replaces the products by additions, -DFRW_QAP_NO_STAGES skips the
@@ -216,10 +218,20 @@ __global__ __launch_bounds__(QAP_THREADS, 2) void ntt_pass_kernel(const NttPass 
             const F29 b = f29_unpack(fr_load(src + (n + gidx) * 8)), cc = f29_unpack(fr_load(src + (2 * n + gidx) * 8));
             v = f29_reduce_4p(f29_sub_kp<2>(QAP_MUL(v, b), cc));
         }
+        if (LOAD == LOAD_AB) v = QAP_MUL(v, f29_unpack(fr_load(src + (n + gidx) * 8)));     // the two arrays of a signature: a b R / 32, < 2 p
         return v;
     };
     auto store_elem = [&](uint32_t gidx, F29 v) {
-        if (STORE != STORE_PLAIN) v = QAP_MUL(v, f29_unpack(fr_load(factor + (size_t)gidx * 8)));     // < 2 p
+        if (STORE == STORE_CONST_ADD_CANONICAL) {
+            // times a constant, plus what the destination already holds (< 2 p), canonical
+            F29 cf;
+#pragma unroll
+            for (int k = 0; k < NL29; k++) cf.l[k] = p.cfac[k];
+            v = f29_reduce_4p(f29_add(QAP_MUL(v, cf), f29_unpack(fr_load(dst + (size_t)gidx * 8))));
+            v = f29_canonical(v);
+        } else if (STORE != STORE_PLAIN) {
+            v = QAP_MUL(v, f29_unpack(fr_load(factor + (size_t)gidx * 8)));                            // < 2 p
+        }
         if (STORE == STORE_FACTOR_CANONICAL) v = f29_canonical(v);
         fr_store(dst + (size_t)gidx * 8, f29_pack(v));
     };
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(QAP_THREADS, 2) void ntt_pass_kernel(const NttPass 
 
     // ---- in: the eight elements of the first round -----------------------------------------------------------------------
     if (MODE == PASS_FIRST) {
-        const size_t sig = blockIdx.y / 3, which = blockIdx.y % 3;
+        const size_t sig = blockIdx.y / p.per_sig, which = blockIdx.y % p.per_sig;
         const uint32_t *rows = p.abc + (sig * 3 + which) * (size_t)p.num_constraints * 8;
         const uint32_t *inst = p.instance + sig * (size_t)p.num_instance * 8;
         static_for<8>([&](auto ec) {
@@ -247,13 +259,19 @@ __global__ __launch_bounds__(QAP_THREADS, 2) void ntt_pass_kernel(const NttPass 
             const uint32_t ihi = __brev((uint32_t)row_low(e)) >> 26;                 // row = rev6(natural bits [L - 6, L))
             const uint32_t i = (ihi << (p.L - 6)) | (tileid << 4) | (uint32_t)c;     // natural (constraint) index
             Fr8 w;
-            if (i < p.num_constraints) w = fr_load(rows + (size_t)i * 8);
-            else if (which == 0 && i - p.num_constraints < p.num_instance) w = fr_load(inst + (size_t)(i - p.num_constraints) * 8);
-            else {
 #pragma unroll
-                for (int k = 0; k < 8; k++) w.l[k] = 0;
+            for (int k = 0; k < 8; k++) w.l[k] = 0;
+            if (LOAD == LOAD_PRODUCTS_AB) {
+                // (A z)_i (B z)_i for the constraint rows, zero beyond (B z has no instance rows): a b R / 32, < 2 p
+                if (i < p.num_constraints)
+                    x[e] = QAP_MUL(f29_unpack(fr_load(rows + (size_t)i * 8)), f29_unpack(fr_load(rows + ((size_t)p.num_constraints + i) * 8)));
+                else
+                    x[e] = f29_unpack(w);
+            } else {
+                if (i < p.num_constraints) w = fr_load(rows + (size_t)i * 8);
+                else if (which == 0 && i - p.num_constraints < p.num_instance) w = fr_load(inst + (size_t)(i - p.num_constraints) * 8);
+                x[e] = f29_unpack(w);
             }
-            x[e] = f29_unpack(w);
         });
     } else if (MEMORDER) {
         // memory order -> LDS -> the rows of the first round
@@ -305,7 +323,8 @@ hipError_t launch_pass(const NttPass &p, unsigned arrays, hipStream_t st)
     return hipGetLastError();
 }
 
-enum { XF_IFFT_FROM_PRODUCTS, XF_FFT, XF_IFFT_POINTWISE_TO_H };
+enum { XF_IFFT_FROM_PRODUCTS, XF_FFT, XF_IFFT_POINTWISE_TO_H,
+       XF_IFFT_FROM_PRODUCTS_PSI, XF_IFFT_AB_TO_H, XF_IFFT_PRODUCTS_AB_ADD_H };
 
 // One transform over `arrays` arrays with the element-wise steps of the witness map fused into its first and last pass:
 //   XF_IFFT_FROM_PRODUCTS     bit-reversed -> natural; reads A z, B z, C z (constraint order); x g^k / n at the end
@@ -332,7 +351,44 @@ hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *w
         return launch_pass<PASS_DIF_SH0, 6, LOAD_PLAIN, STORE_PLAIN>(p, arrays, st);
     }
     p.roots = q.roots_inv;
+    if (kind == XF_IFFT_FROM_PRODUCTS_PSI) {
+        // the two-array variant of XF_IFFT_FROM_PRODUCTS for the six-transform quotient: x psi^k / n at the end
+        p.src = work; p.dst = work; p.src_stride = p.dst_stride = work_stride;
+        p.per_sig = 2;
+        p.sh = 0; p.factor = q.twist_inv[0];
+        if ((e = launch_pass<PASS_FIRST, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        p.sh = 6; p.factor = q.twist_inv[1];
+        if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        p.sh = 12; p.factor = q.scale_psi_in;
+        return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
+                       : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
+    }
+    if (kind == XF_IFFT_AB_TO_H) {
+        // a b on the coset psi H from the two arrays of each signature, in place on the first; -16 psi^-k / n into h
+        p.src = work; p.src_stride = 2 * work_stride; p.dst = work; p.dst_stride = 2 * work_stride;
+        p.sh = 0; p.factor = q.twist_inv[0];
+        if ((e = launch_pass<PASS_DIT_SH0, 6, LOAD_AB, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        p.sh = 6; p.factor = q.twist_inv[1];
+        if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        p.sh = 12; p.factor = q.scale_psi_out; p.dst = h; p.dst_stride = work_stride;
+        return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
+                       : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
+    }
+    if (kind == XF_IFFT_PRODUCTS_AB_ADD_H) {
+        // (A z)_i (B z)_i on the domain itself -> coefficients of (a b) mod (X^n - 1), x 16 / n, added to what h holds
+        p.src = work; p.src_stride = 2 * work_stride; p.dst = work; p.dst_stride = 2 * work_stride;
+        p.per_sig = 1;
+        p.sh = 0; p.factor = q.twist_inv[0];
+        if ((e = launch_pass<PASS_FIRST, 6, LOAD_PRODUCTS_AB, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        p.sh = 6; p.factor = q.twist_inv[1];
+        if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        p.sh = 12; p.factor = nullptr; p.dst = h; p.dst_stride = work_stride;
+        for (int k = 0; k < 9; k++) p.cfac[k] = q.sixteen_over_n[k];
+        return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_CONST_ADD_CANONICAL>(p, arrays, st)
+                       : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_CONST_ADD_CANONICAL>(p, arrays, st);
+    }
     if (kind == XF_IFFT_FROM_PRODUCTS) {
+        p.per_sig = 3;
         p.src = work; p.dst = work; p.src_stride = p.dst_stride = work_stride;
         p.sh = 0; p.factor = q.twist_inv[0];
         if ((e = launch_pass<PASS_FIRST, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
@@ -391,6 +447,43 @@ hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batc
         // (a b - c) / Z on the coset, coset_ifft
         if ((e = transform(XF_IFFT_POINTWISE_TO_H, q, p, work, n * 8, (uint32_t *)(h + lo * n * 4), (unsigned)cnt, st)) != hipSuccess)
             return e;
+    }
+    return hipSuccess;
+}
+
+// The same quotient with six transforms instead of seven, for witnesses that satisfy the system (num_unsatisfied says):
+// a(X) b(X) = lo + X^n hi;  S = lo + hi from the pointwise products on the domain, N = lo - hi from the pointwise products
+// on the coset psi H (psi^n = -1);  h = hi = (S - N) / 2.  C z is still computed -- for the satisfaction count -- but not
+// transformed.  For a witness that violates the system the result is hi all the same, which is then NOT what ark-groth16
+// returns (nor a quotient of anything).
+hipError_t launch_qap_quotient(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,
+                               const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,
+                               size_t workspace_bytes, hipStream_t st)
+{
+    if (batch == 0) return hipSuccess;
+    const int L = q.log_n;
+    if (L != 17 && L != 18) return hipErrorInvalidValue;
+    const size_t n = (size_t)1 << L, per_sig = qap_workspace_bytes_per_signature(r, q);
+    size_t chunk = workspace_bytes / per_sig;
+    if (chunk == 0) return hipErrorInvalidValue;
+    if (chunk > 16384) chunk = 16384;
+    for (size_t lo = 0; lo < batch; lo += chunk) {
+        const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
+        uint32_t *abc = (uint32_t *)workspace;
+        uint32_t *work = abc + cnt * 3 * (size_t)r.num_constraints * 8;           // two arrays per signature
+        const uint64_t *wit = witness + lo * (size_t)r.num_witness * 4, *inst = instance + lo * (size_t)r.num_instance * 4;
+        uint32_t *hh = (uint32_t *)(h + lo * n * 4);
+        hipError_t e = launch_r1cs_check(r, cnt, wit, inst, num_unsatisfied ? num_unsatisfied + lo : nullptr, (uint64_t *)abc, st);
+        if (e != hipSuccess) return e;
+        NttPass p{};
+        p.abc = abc;
+        p.instance = (const uint32_t *)inst;
+        p.num_constraints = r.num_constraints;
+        p.num_instance = r.num_instance;
+        if ((e = transform(XF_IFFT_FROM_PRODUCTS_PSI, q, p, work, n * 8, nullptr, (unsigned)(2 * cnt), st)) != hipSuccess) return e;
+        if ((e = transform(XF_FFT, q, p, work, n * 8, nullptr, (unsigned)(2 * cnt), st)) != hipSuccess) return e;
+        if ((e = transform(XF_IFFT_AB_TO_H, q, p, work, n * 8, hh, (unsigned)cnt, st)) != hipSuccess) return e;
+        if ((e = transform(XF_IFFT_PRODUCTS_AB_ADD_H, q, p, work, n * 8, hh, (unsigned)cnt, st)) != hipSuccess) return e;
     }
     return hipSuccess;
 }

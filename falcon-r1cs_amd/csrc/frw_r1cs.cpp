@@ -95,7 +95,7 @@ uint32_t bitrev(uint32_t x, int bits)
     for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
     return r;
 }
-struct QapTables { int log_n; std::vector<uint32_t> roots_fwd, roots_inv, twist_fwd[2], twist_inv[2], scale_in, scale_in_a, scale_out; };
+struct QapTables { int log_n; std::vector<uint32_t> roots_fwd, roots_inv, twist_fwd[2], twist_inv[2], scale_in, scale_in_a, scale_out, scale_psi_in, scale_psi_out; uint32_t sixteen_over_n[9]; };
 QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
 {
     QapTables t;
@@ -117,6 +117,15 @@ QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
     fill(t.scale_in, n, ninv, g);
     fill(t.scale_in_a, n, ninv * two5, g);
     fill(t.scale_out, n, ninv * zinv, ginv);
+    {
+        // psi: the primitive 2n-th root of unity whose square is w (get_root_of_unity(2 n))
+        Fr psi = Fr::from_montgomery(root_limbs);
+        for (int i = L + 1; i < 32; i++) psi = psi * psi;
+        const Fr sixteen_n = Fr::from(16) * ninv;
+        fill(t.scale_psi_in, n, ninv, psi);
+        fill(t.scale_psi_out, n, -sixteen_n, inverse(psi));
+        limbs29(sixteen_n, t.sixteen_over_n);
+    }
     // powers of w and w^-1, then the twist tables: a pass on the index bits [sh, sh + T) goes with the factor
     // root^((i mod 2^sh) * bitrev_T((i >> sh) mod 2^T) * 2^(L - sh - T)) on index i (tools/dev/qap_fourstep_model.py)
     std::vector<uint32_t> pw_fwd, pw_inv;
@@ -261,6 +270,9 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
         r->qap.scale_in = up(qt.scale_in);
         r->qap.scale_in_a = up(qt.scale_in_a);
         r->qap.scale_out = up(qt.scale_out);
+        r->qap.scale_psi_in = up(qt.scale_psi_in);
+        r->qap.scale_psi_out = up(qt.scale_psi_out);
+        std::memcpy(r->qap.sixteen_over_n, qt.sixteen_over_n, sizeof(qt.sixteen_over_n));
         *out = r;
         return FRW_OK;
     } catch (const std::exception &) {
@@ -306,6 +318,18 @@ extern "C" int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const ui
     if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
     return frw::launch_qap_witness_map(r->dev, r->qap, batch, d_witness, d_instance, d_h, d_num_unsatisfied, d_workspace,
                                        workspace_bytes, (hipStream_t)stream) == hipSuccess ? FRW_OK : FRW_E_HIP;
+}
+
+extern "C" int frw_qap_quotient_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                                    uint64_t *d_h, uint32_t *d_num_unsatisfied, void *d_workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    if (!r || (batch && (!d_witness || !d_instance || !d_h || !d_workspace))) return FRW_E_INVALID_ARG;
+    if (r->qap.log_n != 17 && r->qap.log_n != 18) return FRW_E_INVALID_ARG;
+    if (batch && workspace_bytes < frw::qap_workspace_bytes_per_signature(r->dev, r->qap)) return FRW_E_INVALID_ARG;
+    if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
+    return frw::launch_qap_quotient(r->dev, r->qap, batch, d_witness, d_instance, d_h, d_num_unsatisfied, d_workspace,
+                                    workspace_bytes, (hipStream_t)stream) == hipSuccess ? FRW_OK : FRW_E_HIP;
 }
 
 // Host buffers in, host buffers out: the same map for a caller that holds `Vec<Fr>`s (arkworks' witness_assignment /

@@ -331,6 +331,13 @@ class WitnessEngine:
                                                 self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)),
               "frw_qap_witness_map_dev")
 
+    def qap_quotient_dev(self, handle, batch, d_wit, d_inst, d_h, d_workspace, workspace_bytes, d_num_unsatisfied=None, stream=0):
+        """h with six transforms instead of seven: equal to qap_witness_map_dev's wherever d_num_unsatisfied is 0."""
+        check(self._lib.frw_qap_quotient_dev(handle, batch, self._ptr(d_wit), self._ptr(d_inst), self._ptr(d_h),
+                                             self._ptr(d_num_unsatisfied) if d_num_unsatisfied is not None else None,
+                                             self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)),
+              "frw_qap_quotient_dev")
+
     def qap_witness_map(self, handle, witness, instance):
         """Host arrays (uint64[batch, W, 4], uint64[batch, I, 4], Montgomery, as witness_ntt_verify returns them) ->
         (h uint64[batch, n, 4], unsatisfied rows uint32[batch])."""

@@ -254,6 +254,15 @@ int frw_qap_info(const frw_r1cs *r, frw_qap_info_t *out);
 int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
                             uint64_t *d_h, uint32_t *d_num_unsatisfied, void *d_workspace, size_t workspace_bytes,
                             void *stream);
+/* The same quotient with six transforms instead of seven, for witnesses that satisfy the system: with
+ * a(X) b(X) = lo(X) + X^n hi(X), h = hi = ((a b mod X^n - 1) - (a b mod X^n + 1)) / 2 -- the first from the pointwise
+ * products on the domain, the second from those on the coset psi H, psi^n = -1; C z is computed for d_num_unsatisfied but
+ * not transformed.  d_num_unsatisfied[i] == 0  =>  d_h[i] is exactly frw_qap_witness_map_dev's (ark-groth16's) h.
+ * Otherwise d_h[i] is still hi, which is NOT what ark-groth16 returns for an unsatisfied system (nor a quotient).
+ * Same arguments and workspace as frw_qap_witness_map_dev. */
+int frw_qap_quotient_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                         uint64_t *d_h, uint32_t *d_num_unsatisfied, void *d_workspace, size_t workspace_bytes,
+                         void *stream);
 /* Host buffers: witness uint64_t[batch][W][4], instance uint64_t[batch][I][4] (the constant one first) -- the bytes of
  * arkworks' witness_assignment / instance_assignment -- to h uint64_t[batch][n][4]; num_unsatisfied may be NULL.
  * Synchronous; device buffers are allocated and freed inside (64 signatures in flight). */

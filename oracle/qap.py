@@ -183,3 +183,46 @@ def check_identity(az, bz, cz, num_inputs, z_inputs, h, tau):
         ht = (ht + c * p) % P
         p = p * tau % P
     return (at * bt - ct) % P, ht * zt % P
+
+
+def product_high_half(az, bz, num_inputs, z_inputs):
+    """hi(X) of a(X) b(X) = lo(X) + X^n hi(X), a and b the interpolants of (A z ++ inputs) and B z on the domain.
+    For a witness that satisfies the system this IS witness_map's output: c(X) = (a b) mod (X^n - 1) = lo + hi, so
+    a b - c = (X^n - 1) hi.  (For one that does not, witness_map returns the interpolant of (a b - c) / Z on the coset,
+    which is not a quotient of anything; hi is still well defined.)  Schoolbook product: small systems only.
+    The device computes it with six transforms instead of seven: S = (a b) mod (X^n - 1) = lo + hi from the pointwise
+    products on the domain, N = (a b) mod (X^n + 1) = lo - hi from the pointwise products on the coset psi H with
+    psi^n = -1, hi = (S - N) / 2."""
+    nc = len(az)
+    d = Domain(nc + num_inputs)
+    n = d.size
+    a = list(az) + [0] * (n - nc)
+    b = list(bz) + [0] * (n - nc)
+    a[nc:nc + num_inputs] = [v % P for v in z_inputs[:num_inputs]]
+    ac, bc = d.ifft(a), d.ifft(b)
+    prod = [0] * (2 * n)
+    for i, x in enumerate(ac):
+        if x:
+            for j, y in enumerate(bc):
+                prod[i + j] = (prod[i + j] + x * y) % P
+    return prod[n:2 * n]
+
+
+def product_high_half_six_transforms(az, bz, num_inputs, z_inputs):
+    """The same through the identity the device uses (any size)."""
+    nc = len(az)
+    d = Domain(nc + num_inputs)
+    n = d.size
+    a = list(az) + [0] * (n - nc)
+    b = list(bz) + [0] * (n - nc)
+    a[nc:nc + num_inputs] = [v % P for v in z_inputs[:num_inputs]]
+    psi = TWO_ADIC_ROOT_OF_UNITY
+    for _ in range(d.log_size + 1, TWO_ADICITY):
+        psi = psi * psi % P
+    assert psi * psi % P == d.group_gen and pow(psi, n, P) == P - 1
+    s = d.ifft([x * y % P for x, y in zip(a, b)])                                   # lo + hi
+    ea = d.fft(d.distribute_powers(d.ifft(a), psi))
+    eb = d.fft(d.distribute_powers(d.ifft(b), psi))
+    neg = d.distribute_powers(d.ifft([x * y % P for x, y in zip(ea, eb)]), pow(psi, P - 2, P))   # lo - hi
+    half = pow(2, P - 2, P)
+    return [(x - y) * half % P for x, y in zip(s, neg)]

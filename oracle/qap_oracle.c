@@ -183,3 +183,31 @@ int frw_oracle_qap_witness_map(const uint64_t *az, const uint64_t *bz, const uin
     free(a); free(b); free(c);
     return 0;
 }
+
+/* hi(X) of a(X) b(X) = lo + X^n hi through the six-transform identity of oracle/qap.py::product_high_half_six_transforms:
+ * S = (a b) mod (X^n - 1) from the pointwise products on the domain, N = (a b) mod (X^n + 1) from those on the coset
+ * psi H (psi^2 = w), hi = (S - N) / 2.  Equals the witness map's h exactly when the system is satisfied. */
+int frw_oracle_qap_product_high_half(const uint64_t *az, const uint64_t *bz, uint64_t nc, uint64_t num_inputs,
+                                     const uint64_t *z, uint64_t *h)
+{
+    const int lg = frw_oracle_qap_domain_log(nc, num_inputs);
+    if (lg > 31) return -1;
+    const dom_t d = make_domain(lg);
+    fe *a = (fe *)calloc(d.n, sizeof(fe)), *b = (fe *)calloc(d.n, sizeof(fe)), *s = (fe *)calloc(d.n, sizeof(fe));
+    if (!a || !b || !s) { free(a); free(b); free(s); return -2; }
+    for (uint64_t i = 0; i < nc; i++) { a[i] = f_from(az + 4 * i); b[i] = f_from(bz + 4 * i); }
+    for (uint64_t j = 0; j < num_inputs; j++) a[nc + j] = f_from(z + 4 * j);
+    for (size_t i = 0; i < d.n; i++) s[i] = f_mul(a[i], b[i]);
+    ifft(&d, s);                                               /* lo + hi */
+    const fe psi = root_of_unity(lg + 1), psi_inv = f_inv(psi);
+    ifft(&d, a); ifft(&d, b);
+    distribute_powers(a, d.n, psi); distribute_powers(b, d.n, psi);
+    transform(a, d.lg, d.w); transform(b, d.lg, d.w);
+    for (size_t i = 0; i < d.n; i++) a[i] = f_mul(a[i], b[i]);
+    ifft(&d, a);
+    distribute_powers(a, d.n, psi_inv);                        /* lo - hi */
+    const fe half = f_inv(f_small(2));
+    for (size_t i = 0; i < d.n; i++) f_to(f_mul(f_sub(s[i], a[i]), half), h + 4 * i);
+    free(a); free(b); free(s);
+    return 0;
+}

@@ -127,6 +127,9 @@ extern "C" {
     pub fn frw_qap_witness_map_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
                                    d_h: *mut u64, d_num_unsatisfied: *mut u32, d_workspace: *mut c_void,
                                    workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn frw_qap_quotient_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
+                                d_h: *mut u64, d_num_unsatisfied: *mut u32, d_workspace: *mut c_void, workspace_bytes: usize,
+                                stream: *mut c_void) -> c_int;
     pub fn frw_qap_witness_map(r: *const frw_r1cs, batch: usize, witness: *const u64, instance: *const u64, h: *mut u64,
                                num_unsatisfied: *mut u32) -> c_int;
     pub fn frw_hash_to_point_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_nonces: *const u8, d_msgs: *const u8,

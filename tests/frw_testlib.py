@@ -39,7 +39,18 @@ class Oracle:
         lib.frw_oracle_qap_matvec.argtypes = [C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
         lib.frw_oracle_qap_matvec.restype = None
         lib.frw_oracle_qap_witness_map.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        lib.frw_oracle_qap_product_high_half.argtypes = [C.c_void_p] * 2 + [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         self.lib = lib
+
+    def qap_product_high_half(self, az, bz, num_inputs, z):
+        """hi of a(X) b(X) = lo + X^n hi (what frw_qap_quotient_dev returns); uint64[., 4] canonical."""
+        az, bz, z = (np.ascontiguousarray(a, dtype=np.uint64) for a in (az, bz, z))
+        nc = az.shape[0]
+        lg = self.lib.frw_oracle_qap_domain_log(nc, num_inputs)
+        h = np.zeros((1 << lg, 4), dtype=np.uint64)
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert self.lib.frw_oracle_qap_product_high_half(P(az), P(bz), nc, num_inputs, P(z), P(h)) == 0
+        return h
 
     def qap_matvec(self, ptr, col, val, z):
         """One CSR matrix (canonical values) times z (uint64[vars, 4], canonical) -> uint64[rows, 4] canonical."""

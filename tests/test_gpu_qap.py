@@ -59,10 +59,17 @@ def test_witness_map_equals_oracle(engine, oracle, tmp_path, circuit, logn):
         h = torch.full((batch, n, 4), -1, dtype=torch.int64, device=dev)
         bad = torch.full((batch,), -1, dtype=torch.int32, device=dev)
         engine.qap_witness_map_dev(h_r1cs, batch, wit, inst, h, ws, ws_bytes, bad, s0)
+        # the six-transform quotient on the same batch
+        hq = torch.full((batch, n, 4), -1, dtype=torch.int64, device=dev)
+        badq = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        engine.qap_quotient_dev(h_r1cs, batch, wit, inst, hq, ws, ws_bytes, badq, s0)
         torch.cuda.synchronize()
     finally:
         engine.r1cs_free(h_r1cs)
     assert bad.tolist()[0] == 0 and bad.tolist()[1] > 0 and bad.tolist()[2] > 0
+    assert badq.tolist() == bad.tolist()
+    assert torch.equal(hq[0], h[0]), "satisfied witness: the six-transform quotient must equal the witness map"
+    assert not torch.equal(hq[1], h[1]) and not torch.equal(hq[2], h[2])
     path = tmp_path / "c.r1cs"
     export(circuit, logn, path)
     ni, nw, nc, mats = read_r1cs(path)
@@ -77,6 +84,9 @@ def test_witness_map_equals_oracle(engine, oracle, tmp_path, circuit, logn):
         (az, bz, cz), want = oracle_h(oracle, mats, ni, z)
         got = from_montgomery(h[k].cpu().numpy().view(np.uint64))
         assert got == T.limbs_to_ints(want), "signature %d" % k
+        # ... and the quotient entry point: hi of a(X) b(X), whatever the witness (for k = 0 that is `want` again)
+        want_hi = oracle.qap_product_high_half(az, bz, ni, z)
+        assert from_montgomery(hq[k].cpu().numpy().view(np.uint64)) == T.limbs_to_ints(want_hi), "quotient, signature %d" % k
         if k == 0:
             assert got[-1] == 0                                          # deg h <= n - 2 for a satisfied system
 

@@ -50,10 +50,12 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     ms_all = timed(lambda: eng.qap_witness_map_dev(r, batch, wit, inst, h, ws, batch * per, bad, s0))
+    ms_q = timed(lambda: eng.qap_quotient_dev(r, batch, wit, inst, h, ws, batch * per, bad, s0))
     ms_mv = timed(lambda: eng.r1cs_eval_dev(r, batch, wit, inst, bad, abc, s0))
     assert int(bad.abs().sum()) == 0
     print("Falcon-%d, %d signatures per call, domain 2^%d" % (1 << logn, batch, int(q.log_domain_size)))
     print("  witness map      %9.3f ms/call  %8.1f us/signature  %9.1f signatures/s" % (ms_all, 1e3 * ms_all / batch, batch / ms_all * 1e3))
+    print("  six-transform quotient (h of a satisfied system) %9.3f ms/call  %8.1f us/signature  %9.1f signatures/s" % (ms_q, 1e3 * ms_q / batch, batch / ms_q * 1e3))
     print("  of which A z, B z, C z (frw_r1cs_eval_dev alone) %9.3f ms/call  %8.1f us/signature" % (ms_mv, 1e3 * ms_mv / batch))
     mul = 7 * (n // 2) * int(q.log_domain_size) + 5 * n
     print("  transforms: %.1f M Montgomery products per signature -> %.1f G products/s" % (mul / 1e6, mul * batch / ((ms_all - ms_mv) * 1e-3) / 1e9))
