@@ -198,3 +198,28 @@ def test_host_entry_point_equals_device_entry_point(engine):
         assert np.array_equal(dh.cpu().numpy().view(np.uint64), h)
     finally:
         engine.r1cs_free(r)
+
+
+def test_argument_checks(engine):
+    """FRW_E_INVALID_ARG for a workspace smaller than one signature's and for null buffers; an empty batch is a no-op."""
+    import ctypes as C
+    import torch
+    import falcon_r1cs_amd as frw
+    lib = frw.load_library()
+    r = engine.r1cs_load(0, 9)
+    try:
+        q = engine.qap_info(r)
+        per = int(q.workspace_bytes_per_signature)
+        dev = torch.device("cuda:0")
+        buf = torch.zeros(1024, dtype=torch.int64, device=dev)
+        P = C.c_void_p(buf.data_ptr())
+        for fn in (lib.frw_qap_witness_map_dev, lib.frw_qap_quotient_dev):
+            assert fn(r, 0, None, None, None, None, None, 0, None) == 0                     # empty batch
+            assert fn(r, 1, P, P, P, None, P, per - 1, None) == -1                         # workspace too small
+            assert fn(r, 1, None, P, P, None, P, per, None) == -1                          # null witness
+            assert fn(None, 1, P, P, P, None, P, per, None) == -1                          # no matrices
+        assert lib.frw_qap_witness_map(r, 0, None, None, None, None) == 0
+        assert lib.frw_qap_witness_map(r, 1, None, None, None, None) == -1
+        assert lib.frw_qap_info(r, None) == -1
+    finally:
+        engine.r1cs_free(r)
