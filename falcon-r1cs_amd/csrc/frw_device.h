@@ -104,7 +104,7 @@ struct R1csDev {
     uint32_t k_rrp[9];          // R R' mod p (R = 2^256, R' = 2^261) as an integer, 29-bit limbs
 };
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
-                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st);
+                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st, void *scratch = nullptr);
 // Tables of the QAP witness map's domain (frw_qap.hip), built by frw_r1cs_load.  Every entry is a field element times
 // R' = 2^261 (frw_fr29.h): the per-index factors packed in 8 x 32 bits (they are < p), the 64-th roots in nine limbs.
 struct QapDev {

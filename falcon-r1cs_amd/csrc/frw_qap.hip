@@ -433,7 +433,7 @@ hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batc
         uint32_t *abc = (uint32_t *)workspace;
         uint32_t *work = abc + cnt * 3 * (size_t)r.num_constraints * 8;
         const uint64_t *wit = witness + lo * (size_t)r.num_witness * 4, *inst = instance + lo * (size_t)r.num_instance * 4;
-        hipError_t e = launch_r1cs_check(r, cnt, wit, inst, num_unsatisfied ? num_unsatisfied + lo : nullptr, (uint64_t *)abc, st);
+        hipError_t e = launch_r1cs_check(r, cnt, wit, inst, num_unsatisfied ? num_unsatisfied + lo : nullptr, (uint64_t *)abc, st, work);   // the working arrays are idle during the products: they lend the scratch
         if (e != hipSuccess) return e;
         NttPass p{};
         p.abc = abc;
@@ -473,7 +473,7 @@ hipError_t launch_qap_quotient(const R1csDev &r, const QapDev &q, size_t batch, 
         uint32_t *work = abc + cnt * 3 * (size_t)r.num_constraints * 8;           // two arrays per signature
         const uint64_t *wit = witness + lo * (size_t)r.num_witness * 4, *inst = instance + lo * (size_t)r.num_instance * 4;
         uint32_t *hh = (uint32_t *)(h + lo * n * 4);
-        hipError_t e = launch_r1cs_check(r, cnt, wit, inst, num_unsatisfied ? num_unsatisfied + lo : nullptr, (uint64_t *)abc, st);
+        hipError_t e = launch_r1cs_check(r, cnt, wit, inst, num_unsatisfied ? num_unsatisfied + lo : nullptr, (uint64_t *)abc, st, work);   // the working arrays are idle during the products: they lend the scratch
         if (e != hipSuccess) return e;
         NttPass p{};
         p.abc = abc;

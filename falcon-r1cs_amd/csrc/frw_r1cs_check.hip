@@ -311,8 +311,11 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, s
     }
 }
 
+// `scratch` (optional, at least batch x num_long_vars x 4 bytes): where the small values of the long rows' variables go
+// when the caller has room for them (the QAP entry points lend part of their workspace); otherwise a stream-ordered
+// allocation is made for the duration of the call.
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
-                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st)
+                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st, void *caller_scratch)
 {
     if (batch == 0) return hipSuccess;
     if (batch > 65535) return hipErrorInvalidValue;
@@ -326,7 +329,10 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
     // stream-ordered scratch: the small values of the long rows' variables, and (check only) the long rows' products
     uint32_t *zs = nullptr, *long_out = nullptr;
     bool scratch = true;
-    if (r.num_long) {
+    const bool lent = caller_scratch != nullptr && abc != nullptr;
+    if (r.num_long && lent) {
+        zs = (uint32_t *)caller_scratch;
+    } else if (r.num_long) {
         scratch = hipMallocAsync((void **)&zs, batch * (size_t)r.num_long_vars * sizeof(uint32_t), st) == hipSuccess && zs;
         if (scratch && !abc) scratch = hipMallocAsync((void **)&long_out, batch * (size_t)r.num_long * 32, st) == hipSuccess && long_out;
         if (!scratch) (void)hipGetLastError();
@@ -348,7 +354,7 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
         hipLaunchKernelGGL(r1cs_check_kernel, egrid, dim3(BLOCK), 0, st, r, batch, wit, inst, num_unsatisfied);
     }
     const hipError_t e = hipGetLastError();
-    if (zs) (void)hipFreeAsync(zs, st);
+    if (zs && !lent) (void)hipFreeAsync(zs, st);
     if (long_out) (void)hipFreeAsync(long_out, st);
     return e;
 }
