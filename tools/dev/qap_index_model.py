@@ -1,6 +1,8 @@
-"""Python model of frw_qap.hip's index arithmetic (tiles, bit-reversed first pass, twiddle exponents, fused element-wise
-steps) with exact integers, checked against oracle/qap.py on a small domain.  Run on the CPU before touching the kernel's
-indexing:  python tools/dev/qap_index_model.py [L=12]"""
+"""Python model of the tile geometry of frw_qap.hip (which working indices a tile holds per pass, the bit-reversed first
+pass that reads the products in constraint order, where the fused element-wise steps sit) with exact integers, checked
+against oracle/qap.py on a small domain.  The butterflies here still take one twiddle per stage from the full table
+(the kernel's predecessor); the four-step form the kernel uses now -- 64-th roots inside a pass, one per-index factor
+after it -- is modelled in qap_fourstep_model.py and qap_radix8_model.py.   python tools/dev/qap_index_model.py [L=12]"""
 import os
 import random
 import sys
