@@ -60,8 +60,11 @@ __device__ __forceinline__ F29 row_dot29(const R1csMatrixDev &m, uint32_t row, c
 
 // STORE: write A z, B z, C z to abc (and read the long rows' products from there).  !STORE: check only -- nothing is
 // written; the long rows' products are read from `long_out` ([signature][long row], r.long_slot maps (matrix, row) to it).
+#ifndef FRW_EVAL_WAVES
+#define FRW_EVAL_WAVES 4
+#endif
 template <bool STORE>
-__global__ __launch_bounds__(BLOCK) void r1cs_eval_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
+__global__ __launch_bounds__(BLOCK, FRW_EVAL_WAVES) void r1cs_eval_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
                                                           const uint32_t *__restrict__ instance,
                                                           unsigned int *__restrict__ num_unsatisfied,
                                                           uint32_t *__restrict__ abc, const uint32_t *__restrict__ long_out)
