@@ -6,7 +6,8 @@
 
 A step = one pass of the hot path (falcon-r1cs/src/circuits/falcon_ntt.rs:26-123 of the reference) over one batch
 of synthetic signatures per GPU: BASELINE.json configs[2], "Falcon-1024 batch=65536 sigs, full verify-with-ntt
-witness" (N = 8: configs[3], 1 M signatures over the node = 131,072 per GPU).  65,536 witnesses are 329 GB, more than
+witness" -- the SAME 65,536 signatures per GPU per step for every N, so that N = 1, 2, 4, 8 are one weak-scaling series
+(N = 8: two steps are BASELINE configs[3]'s 1 M signatures over the node).  65,536 witnesses are 329 GB, more than
 one GPU's 288 GB, so a step streams the batch through one reused HBM witness buffer in launches of `--chunk`
 signatures; inputs are resident in HBM before the timed region and outputs stay in HBM (the boundary a GPU prover or a
 peer would consume them from).  Multi-GPU: signatures shard by index, every rank processes its own batch (weak scaling),
@@ -487,7 +488,7 @@ def emit(obj):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
-def gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d_wit, d_st, stream):
+def gather_leg(args, plan, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d_wit, d_st, stream):
     """Second curve (north_star / BASELINE configs[3]): generate + all-gather of the per-signature witness vectors for a
     FULL step, every chunk.  MI355X-first form: each rank generates its chunk in FRW_ENC_COMPACT (0.51 MB per signature
     instead of 5.08 MB), one all_gather_into_tensor (RCCL over xGMI) moves the compact chunks, and every receiver
@@ -497,10 +498,10 @@ def gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d
     every GPU, so this curve is bounded by HBM write bandwidth at ~1/world of `value` per GPU -- not by xGMI."""
     CL = frw.compact_layout(logn)
     d_sig, d_pk, d_hm = d_in
-    # signatures per rank per collective: 4,096 (2.1 GB of compact witnesses per rank, world x 2.1 GB gathered, twice for
+    # signatures per rank per collective: 4,096 (0.46 GB of compact witnesses per rank, world x that gathered, twice for
     # the double buffer) unless asked otherwise; the expansion target must fit the benchmark's witness buffer
-    gc = max(1, min(args.allgather_chunk or 4096, chunk // world))
-    nk = batch // gc
+    # (sharding.step_plan: the same arithmetic the CPU tests evaluate for world = 8)
+    gc, nk = plan["gather_chunk_per_rank"], plan["gather_chunks"]
     loc = [torch.empty((gc, CL.bytes_per_signature), dtype=torch.uint8, device=dev) for _ in range(2)]
     gathered = [torch.empty((world, gc, CL.bytes_per_signature), dtype=torch.uint8, device=dev) for _ in range(2)]
     exp_wit = d_wit[:world * gc]
@@ -539,19 +540,18 @@ def gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d
     eng.digest_dev(exp_wit, L.num_witness * 4, world * gc, dig, stream.cuda_stream)
     torch.cuda.synchronize()
     a = (nk - 1) * gc
-    own_dig = torch.zeros(gc, dtype=torch.int64, device=dev)
-    own_inst = torch.empty((gc, L.num_instance, 4), dtype=torch.int64, device=dev)
-    # the direct launch goes into the part of the witness buffer the expansion does not occupy when there is room
-    # (world * gc <= chunk - gc), else into a buffer of its own
-    own_wit = d_wit[world * gc:(world + 1) * gc] if (world + 1) * gc <= d_wit.shape[0] else \
-        torch.empty((gc, L.num_witness, 4), dtype=torch.int64, device=dev)
-    eng.witness_ntt_verify_dev(logn, gc, d_sig[a:a + gc], d_pk[a:a + gc], d_hm[a:a + gc], own_wit, own_inst, st,
+    oc = plan["own_shard_signatures_checked"]             # all gc when the witness buffer has room next to the expansion
+    own_dig = torch.zeros(oc, dtype=torch.int64, device=dev)
+    own_inst = torch.empty((oc, L.num_instance, 4), dtype=torch.int64, device=dev)
+    own_wit = d_wit[world * gc:world * gc + oc] if plan["own_shard_checked_in_place"] else \
+        torch.empty((oc, L.num_witness, 4), dtype=torch.int64, device=dev)
+    eng.witness_ntt_verify_dev(logn, oc, d_sig[a:a + oc], d_pk[a:a + oc], d_hm[a:a + oc], own_wit, own_inst, st,
                                frw.ENC_MONTGOMERY, stream.cuda_stream)
-    eng.digest_dev(own_wit, L.num_witness * 4, gc, own_dig, stream.cuda_stream)
+    eng.digest_dev(own_wit, L.num_witness * 4, oc, own_dig, stream.cuda_stream)
     torch.cuda.synchronize()
-    own_ok = bool(torch.equal(own_dig, dig[rank * gc:(rank + 1) * gc])) and \
-        bool(torch.equal(own_inst, exp_inst[rank * gc:(rank + 1) * gc]))
-    all_dig = sharding.gather_per_signature(dig.to(cdev), world * world * gc, rank, world) if world > 1 else dig.to(cdev)
+    own_ok = bool(torch.equal(own_dig, dig[rank * gc:rank * gc + oc])) and \
+        bool(torch.equal(own_inst, exp_inst[rank * gc:rank * gc + oc]))
+    all_dig = sharding.gather_per_signature(dig.to(cdev), plan["all_digests_gathered"], rank, world) if world > 1 else dig.to(cdev)
     same = all(bool(torch.equal(all_dig[r * world * gc:(r + 1) * world * gc], all_dig[:world * gc])) for r in range(world))
     del own_wit
     return {"signatures_per_s_node": round(world * nk * gc / t, 1), "seconds": round(t, 4),
@@ -562,18 +562,18 @@ def gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d
             "expanded_bytes_written_GBs_per_gpu": round(world * nk * gc * 32 * (L.num_witness + L.num_instance) / t / 1e9, 1),
             "collective": "all_gather_into_tensor (RCCL)" if nccl else "gloo rehearsal (staged through the host)",
             "overlap": "expand(k-1) and generate(k+1) run while chunk k is gathered (double buffer)",
-            "expanded_own_shard_equals_direct_output": own_ok, "expanded_digests_identical_on_all_ranks": same}
+            "expanded_own_shard_equals_direct_output": own_ok, "own_shard_signatures_compared": oc,
+            "expanded_digests_identical_on_all_ranks": same}
 
 
-def regenerate_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d_wit, d_inst, stream):
+def regenerate_leg(args, plan, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_in, d_wit, d_inst, stream):
     """Third curve, the recompute-instead-of-communicate form of 'every GPU holds every witness': all-gather the 6 KB
     INPUTS of a chunk and let every GPU run the witness kernel over all `world` shards itself.  The fabric carries
     0.1 % of the bytes; each GPU writes world x 5 MB per signature of its shard size, so like the compact curve this is
     bounded by one GPU's HBM write rate for the whole node -- with the generator's rate instead of the expander's."""
     d_sig, d_pk, d_hm = d_in
     n = L.n
-    gc = max(1, min(args.allgather_chunk or 4096, chunk // world))
-    nk = batch // gc
+    gc, nk = plan["gather_chunk_per_rank"], plan["gather_chunks"]
     loc = [torch.empty((3, gc, n), dtype=torch.int16, device=dev) for _ in range(2)]
     gathered = [torch.empty((world, 3, gc, n), dtype=torch.int16, device=dev) for _ in range(2)]
     st = torch.empty(world * gc, dtype=torch.int32, device=dev)
@@ -617,10 +617,10 @@ def regenerate_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, d_i
             "all_statuses_ok": ok}
 
 
-def arkworks_gather_probe(args, eng, dev, cdev, world, rank, logn, L, d_in, d_wit, d_inst, d_st, stream, chunk):
+def arkworks_gather_probe(args, plan, eng, dev, cdev, world, rank, logn, L, d_in, d_wit, d_inst, d_st, stream, chunk):
     """Bounded probe of the naive form (32-byte elements over the wire), for the xGMI ceiling it runs into."""
     d_sig, d_pk, d_hm = d_in
-    gc, iters = min(512, chunk // 2), 6
+    gc, iters = plan["probe_chunk_per_rank"], 6
     loc = [d_wit[:gc], d_wit[gc:2 * gc]]
     gathered = torch.empty((world,) + tuple(loc[0].shape), dtype=torch.int64, device=dev)
     works = [None, None]
@@ -653,8 +653,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logn", type=int, default=10, choices=[9, 10])
     ap.add_argument("--batch", type=int, default=0,
-                    help="signatures per GPU per step (default: 65,536 = BASELINE configs[2]; with --gpus 8: 131,072 = "
-                         "configs[3], 1 M signatures over the node)")
+                    help="signatures per GPU per step (default: 65,536 = BASELINE configs[2], for every N: one weak-scaling "
+                         "series; at N = 8 two steps are configs[3]'s 1 M signatures over the node)")
+    ap.add_argument("--plan", action="store_true",
+                    help="touch no GPU: print, for N = 1, 2, 4, 8 (or --gpus N alone if given), every rank's global index "
+                         "range, launches, gather chunking and HBM bytes of the run these arguments describe, assert that "
+                         "each fits 0.9 x 288 GB, and exit")
     ap.add_argument("--chunk", type=int, default=0,
                     help="signatures per kernel launch = size of the reused HBM witness buffer.  Default: 32,768 Falcon-1024 "
                          "witnesses = 164 GB of the 288 GB (a step = two launches): sized for the HBM, and measured -- the "
@@ -691,6 +695,8 @@ def main():
                     help="after the run, write this rank's per-signature (global index, status, witness digest) of one "
                          "extra, untimed pass to PATH.rank<r>.npy (multi-rank consistency tests)")
     args = ap.parse_args()
+    if args.plan:
+        return print_plans(args, ap.get_default("gpus") != args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -730,23 +736,27 @@ def main():
             args.batch = 256
         return bench_qap(args, world, rank, dev)
     logn = args.logn
-    batch = args.batch or (131072 if world == 8 else 65536)
     dual = args.circuit == "dual"
     L = frw.layout_dual(logn) if dual else frw.layout(logn)
+    # the whole shape of the run -- index range, launches, gather chunking, HBM bytes -- comes from one piece of plain
+    # arithmetic that the CPU tests evaluate for world = 8 as well (falcon-r1cs_amd/sharding.py::step_plan)
+    plan = make_plan(args, world, rank)
+    assert plan["fits"], "this run plans %.1f GB of HBM per GPU (limit %.1f GB): reduce --chunk" % (
+        plan["hbm_plan_bytes"] / 1e9, plan["hbm_limit_bytes"] / 1e9)
+    batch, chunk = plan["batch_per_gpu"], plan["chunk"]
     eng = frw.WitnessEngine(dev_index)
-    chunk = min(args.chunk or (32768 if logn == 10 else 65536), batch)
     launch = eng.witness_dual_ntt_verify_dev if dual else eng.witness_ntt_verify_dev
     threads = max(1, (os.cpu_count() or 1) // world)
 
     # ---- inputs resident in HBM -------------------------------------------------------------
-    lo, hi = sharding.shard_range(batch * world, rank, world)      # this rank's global signature indices
+    lo, hi = plan["global_lo"], plan["global_hi"]                  # this rank's global signature indices
     sig, pk, hm = synth(logn, hi - lo, lo, threads)
     d_sig, d_pk, d_hm = (torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm))
     d_wit = torch.empty((chunk, L.num_witness, 4), dtype=torch.int64, device=dev)
     d_inst = torch.empty((chunk, L.num_instance, 4), dtype=torch.int64, device=dev)
     d_st = torch.full((batch,), -1, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
-    nchunks = (batch + chunk - 1) // chunk
+    nchunks = plan["launches_per_step"]
     n = L.n
 
     def step(events=None):
@@ -865,12 +875,12 @@ def main():
         def legs():
             torch.cuda.set_device(dev_index)
             try:
-                box["r"] = gather_leg(args, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit,
+                box["r"] = gather_leg(args, plan, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit,
                                       d_st, stream)
                 box["r"]["allgather_inputs_and_regenerate"] = regenerate_leg(
-                    args, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit, d_inst, stream)
+                    args, plan, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit, d_inst, stream)
                 box["r"]["naive_32_byte_elements_probe"] = arkworks_gather_probe(
-                    args, eng, dev, cdev, world, rank, logn, L, (d_sig, d_pk, d_hm), d_wit, d_inst, d_st, stream, chunk)
+                    args, plan, eng, dev, cdev, world, rank, logn, L, (d_sig, d_pk, d_hm), d_wit, d_inst, d_st, stream, chunk)
             except Exception as ex:      # the primary metric must not depend on these legs
                 box["e"] = repr(ex)[:300]
         th = threading.Thread(target=legs, daemon=True)
@@ -901,8 +911,8 @@ def main():
     traffic = None if dual else measured_traffic(logn, chunk)
     if rank == 0:
         value = world * batch * args.steps / elapsed
-        cfg_name = "BASELINE configs[3]: %d signatures sharded over %d GPUs" % (batch * world, world) if world == 8 \
-            else "BASELINE configs[2]"
+        cfg_name = "BASELINE configs[2] on every GPU" + (
+            "; two steps = BASELINE configs[3], 1 M signatures sharded over 8 GPUs" if world == 8 and batch == 65536 else "")
         result = {
             "metric": "falcon%d_verify_with_%sntt_r1cs_witnesses_per_sec" % (n, "dual_" if dual else ""), "value": round(value, 1),
             "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -916,7 +926,10 @@ def main():
                        "seed": hex(SEED), "sharding": "by signature index, no data-path collective",
                        "signatures_failing_range_checks": n_bad,
                        "ranks_seen": ranks_seen, "device_index_per_rank": [int(x) for x in devs.tolist()],
-                       "backend": (args.backend if use_pg else None)},
+                       "backend": (args.backend if use_pg else None),
+                       "hbm_plan_bytes": plan["hbm_plan_bytes"], "hbm_plan_limit_bytes": plan["hbm_limit_bytes"],
+                       "hbm_peak_allocated_bytes": int(torch.cuda.max_memory_allocated(dev)),
+                       "global_index_range_rank0": [plan["global_lo"], plan["global_hi"]]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic[0] if traffic else None,
@@ -951,12 +964,72 @@ def main():
             result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, slot_sig[slots], lambda i: digest_of[int(i)])
         emit(result)
     if use_pg:
-        if legs_hung or world > 1:
-            # no further rendezvous with the peers: a rank whose legs timed out must not wait, and the others must not
-            # wait for it
-            sys.stderr.flush()
-            os._exit(0)
-        dist.destroy_process_group()
+        leave(legs_hung, bool(gather_info and "error" in gather_info), rank)
+
+
+def leave(legs_hung, legs_failed, rank, teardown_timeout=10.0):
+    """End of a run with a process group.  A gather leg that hung (a collective never completed) or raised is a FAILED run:
+    the primary line has been printed, and the process exits non-zero so that no harness records it as healthy.  Otherwise
+    the group is torn down -- under a timer, because a teardown that waits for a peer must not outlive the run -- and only
+    a teardown that does not return falls back to os._exit, saying so on stderr.  Nothing here re-executes anything."""
+    import threading
+    sys.stdout.flush()
+    if legs_hung:
+        # peers may be stuck inside the same collective: no further rendezvous, leave at once
+        sys.stderr.write("bench.py rank %d: a gather leg did not complete within its deadline -> exit 3\n" % rank)
+        sys.stderr.flush()
+        os._exit(3)
+    done = {}
+
+    def teardown():
+        try:
+            dist.destroy_process_group()
+            done["ok"] = True
+        except Exception as ex:                      # noqa: BLE001 -- reported below
+            done["error"] = repr(ex)[:300]
+    th = threading.Thread(target=teardown, daemon=True)
+    th.start()
+    th.join(teardown_timeout)
+    rc = 3 if legs_failed else 0
+    if th.is_alive() or "error" in done:
+        sys.stderr.write("bench.py rank %d: destroy_process_group %s\n" % (
+            rank, "did not return within %.0f s" % teardown_timeout if th.is_alive() else "raised " + done["error"]))
+        sys.stderr.flush()
+        os._exit(rc or 4)
+    if rc:
+        sys.stderr.write("bench.py rank %d: a gather leg raised -> exit %d\n" % (rank, rc))
+        sys.stderr.flush()
+        sys.exit(rc)
+
+
+def make_plan(args, world, rank):
+    dual = args.circuit == "dual"
+    L = frw.layout_dual(args.logn) if dual else frw.layout(args.logn)
+    CL = frw.compact_layout(args.logn)
+    batch = args.batch or 65536
+    chunk = min(args.chunk or (32768 if args.logn == 10 else 65536), batch)
+    legs = (world > 1 or args.force_pg) and not args.no_allgather and not dual
+    return sharding.step_plan(world, rank, batch, chunk, args.allgather_chunk, L.n, L.num_witness, L.num_instance,
+                              int(CL.bytes_per_signature), with_gather_legs=legs)
+
+
+def print_plans(args, only_this_world):
+    """--plan: no GPU, no process group.  One JSON object on stdout; AssertionError (non-zero exit) if a plan does not fit."""
+    out = {}
+    for world in ([args.gpus] if only_this_world else [1, 2, 4, 8]):
+        plans = [make_plan(args, world, r) for r in range(world)]
+        sharding.check_plans(plans)
+        p0 = plans[0]
+        out["gpus_%d" % world] = {
+            "signatures_per_step_all_gpus": p0["signatures_per_step_all_gpus"], "batch_per_gpu": p0["batch_per_gpu"],
+            "chunk": p0["chunk"], "launches_per_step": p0["launches_per_step"],
+            "global_index_range_per_rank": [[p["global_lo"], p["global_hi"]] for p in plans],
+            "gather": {k: p0[k] for k in ("gather_chunk_per_rank", "gather_chunks", "gathered_signatures_per_collective",
+                                          "own_shard_checked_in_place", "all_digests_gathered") if k in p0},
+            "hbm_plan_bytes_per_rank": p0["hbm_plan_bytes"], "hbm_plan_GB_per_rank": round(p0["hbm_plan_bytes"] / 1e9, 2),
+            "hbm_limit_bytes": p0["hbm_limit_bytes"], "fits": p0["fits"],
+            "buffers_GB": {k: round(v / 1e9, 3) for k, v in p0["buffers"].items()}}
+    emit(out)
 
 
 if __name__ == "__main__":

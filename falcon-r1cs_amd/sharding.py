@@ -75,3 +75,86 @@ def all_gather_chunks(local, gathered, async_op=False):
     for r, h in enumerate(host):
         gb[r * n:(r + 1) * n].copy_(h)
     return None
+
+
+# ---- the shape of one benchmark / production step on `world` GPUs, as plain arithmetic ---------------------------------
+# bench.py allocates from this plan and nothing else, and the CPU tests evaluate it for world = 1, 2, 4, 8: the rank
+# arithmetic of an 8-GPU run is executed (and its HBM budget asserted) before the first 8-GPU node ever sees it.
+
+HBM_BYTES_PER_GPU = 288 * 10**9          # MI355X: 288 GB of HBM3E (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PLAN_FRACTION = 0.9                  # a plan may claim at most this much of it
+
+
+def step_plan(world, rank, batch_per_gpu, chunk, allgather_chunk, n, num_witness, num_instance, compact_bytes,
+              with_gather_legs=True):
+    """Everything bench.py derives from (world, rank, per-GPU batch, launch size): this rank's global index range, the
+    launches of a step, the chunking of the gather legs and the bytes of every HBM buffer the run allocates.
+
+    Independent signatures (falcon_ntt.rs:143-151) => rank r owns global indices [r * batch_per_gpu, (r+1) * batch_per_gpu)
+    (``shard_range`` of an evenly divisible total).  All sizes in bytes; ``hbm_plan_bytes`` is their sum."""
+    if world < 1 or not 0 <= rank < world or batch_per_gpu < 1 or chunk < 1:
+        raise ValueError("step_plan: bad arguments")
+    chunk = min(chunk, batch_per_gpu)
+    lo, hi = shard_range(batch_per_gpu * world, rank, world)
+    nchunks = (batch_per_gpu + chunk - 1) // chunk
+    wit_row, inst_row = 32 * num_witness, 32 * num_instance
+    buffers = {
+        "inputs (sig, pk, hm as u16)": 3 * 2 * n * batch_per_gpu,
+        "witness buffer (one launch, reused)": chunk * wit_row,
+        "instance buffer (one launch, reused)": chunk * inst_row,
+        "status words": 4 * batch_per_gpu,
+        "digests of the checked launch": 8 * chunk + 4 * chunk,
+    }
+    plan = {"world": world, "rank": rank, "global_lo": lo, "global_hi": hi, "batch_per_gpu": batch_per_gpu,
+            "signatures_per_step_all_gpus": batch_per_gpu * world, "chunk": chunk, "launches_per_step": nchunks}
+    if with_gather_legs and world >= 1:
+        # signatures per rank per collective; the expansion of all `world` shards must fit the witness buffer
+        gc = max(1, min(allgather_chunk or 4096, chunk // world))
+        nk = batch_per_gpu // gc
+        own_in_place = (world + 1) * gc <= chunk           # room for the direct launch next to the expansion?
+        own_checked = gc if own_in_place else min(gc, 1024)  # else a buffer of its own: the first 1,024 of the shard
+        probe_gc = max(1, min(512, chunk // 2, 2048 // world))
+        plan.update({"gather_chunk_per_rank": gc, "gather_chunks": nk, "gather_signatures_per_rank": nk * gc,
+                     "gathered_signatures_per_collective": world * gc, "own_shard_checked_in_place": own_in_place,
+                     "own_shard_signatures_checked": own_checked,
+                     "all_digests_gathered": world * world * gc, "probe_chunk_per_rank": probe_gc})
+        if world * gc > chunk:
+            raise ValueError("step_plan: %d ranks x %d signatures do not fit a witness buffer of %d" % (world, gc, chunk))
+        buffers.update({
+            "compact chunks, local (double buffer)": 2 * gc * compact_bytes,
+            "compact chunks, gathered (double buffer)": 2 * world * gc * compact_bytes,
+            "instances of the expanded chunk": world * gc * inst_row,
+            "direct launch of the own shard (parity of the gather)": (0 if own_in_place else own_checked * wit_row)
+                                                                     + own_checked * inst_row,
+            "digests of the expanded chunk": 8 * (world * gc + gc),
+            "input chunks, local + gathered (regenerate leg, double buffer)": 2 * (1 + world) * 3 * 2 * n * gc,
+            "status of the regenerated chunk": 4 * world * gc,
+            "naive probe: gathered 32-byte witnesses": world * probe_gc * wit_row,
+        })
+    plan["buffers"] = buffers
+    plan["hbm_plan_bytes"] = int(sum(buffers.values()))
+    plan["hbm_limit_bytes"] = int(HBM_PLAN_FRACTION * HBM_BYTES_PER_GPU)
+    plan["fits"] = plan["hbm_plan_bytes"] <= plan["hbm_limit_bytes"]
+    return plan
+
+
+def check_plans(plans):
+    """Cross-rank invariants of the plans of one world (raises AssertionError with the reason): the shards tile the global
+    index range in rank order, every rank has the same shape, the gather legs cover whole steps, and the plan fits HBM."""
+    world = plans[0]["world"]
+    assert len(plans) == world and [p["rank"] for p in plans] == list(range(world)), "one plan per rank, in rank order"
+    assert plans[0]["global_lo"] == 0 and plans[-1]["global_hi"] == plans[0]["signatures_per_step_all_gpus"]
+    for a, b in zip(plans, plans[1:]):
+        assert a["global_hi"] == b["global_lo"], "shards must be contiguous"
+    for p in plans:
+        assert p["global_hi"] - p["global_lo"] == p["batch_per_gpu"], "every rank owns exactly batch_per_gpu signatures"
+        assert p["launches_per_step"] * p["chunk"] >= p["batch_per_gpu"] > (p["launches_per_step"] - 1) * p["chunk"]
+        for k in ("chunk", "launches_per_step", "hbm_plan_bytes") + (("gather_chunk_per_rank", "gather_chunks")
+                                                                      if "gather_chunks" in p else ()):
+            assert p[k] == plans[0][k], "rank %d differs from rank 0 in %s" % (p["rank"], k)
+        if "gather_chunks" in p:
+            assert p["gather_chunks"] >= 1 and p["gathered_signatures_per_collective"] <= p["chunk"]
+            assert p["all_digests_gathered"] == world * p["gathered_signatures_per_collective"]
+        assert p["fits"], "rank %d plans %.1f GB of HBM, limit %.1f GB" % (p["rank"], p["hbm_plan_bytes"] / 1e9,
+                                                                            p["hbm_limit_bytes"] / 1e9)
+    return True

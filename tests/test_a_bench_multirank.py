@@ -1,4 +1,6 @@
-"""N > 1 path of bench.py on real hardware, as far as one GPU allows: two ranks (gloo process group) sharing the card.
+"""N > 1 path of bench.py on real hardware, as far as one GPU allows: two and four ranks (gloo process group) sharing the
+card.  (Eight cannot: the pool allows at most 6 processes on a card; the world-8 plan runs on CPU tensors in
+tests/test_sharding_gloo.py.)
 
 Runs first in the -m gpu suite (file name), i.e. before this process has touched the GPU itself: everything happens in
 child processes.  The two ranks shard the global signature range exactly as RCCL ranks would (falcon-r1cs_amd/sharding.py),
@@ -27,23 +29,52 @@ def _run(cmd, timeout=600):
 
 
 @pytest.mark.gpu
-def test_two_ranks_reproduce_the_one_rank_run(tmp_path):
-    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+def test_two_and_four_ranks_reproduce_the_one_rank_run(tmp_path):
+    one = str(tmp_path / "one")
     j1 = _run([sys.executable, "bench.py", "--gpus", "1", "--batch", "512", "--chunk", "256", "--dump-digests", one] + COMMON)
-    j2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29617", "bench.py", "--gpus", "2", "--backend", "gloo", "--batch", "256", "--chunk", "128",
-               "--dump-digests", two] + COMMON)
     a = np.load(one + ".rank0.npy")
-    b = np.concatenate([np.load(two + ".rank0.npy"), np.load(two + ".rank1.npy")], axis=1)
-    assert a.shape == b.shape == (3, 512)
-    assert np.array_equal(a[0], np.arange(512)) and np.array_equal(a, b)          # indices, statuses, digests
-    assert not a[1].any()
-    assert j2["n_gpus"] == 2 and j2["config"]["ranks_seen"] == 2 and j2["config"]["signatures_per_step_all_gpus"] == 512
-    assert j2["r1cs_check"]["witnesses_checked"] == 2 * 128 and j2["r1cs_check"]["unsatisfied"] == 0
-    g = j2["scaling_curves"]["generate_plus_allgather"]
-    assert "error" not in g, g
-    assert g["expanded_own_shard_equals_direct_output"] and g["expanded_digests_identical_on_all_ranks"]
-    assert g["signatures_per_rank"] == 256
-    assert g["allgather_inputs_and_regenerate"]["all_statuses_ok"] and g["naive_32_byte_elements_probe"]["signatures_per_s_node"] > 0
+    assert a.shape == (3, 512) and np.array_equal(a[0], np.arange(512)) and not a[1].any()
     assert j1["launch_shape_checked"]["signatures"] == 256 and j1["r1cs_check"]["witnesses_checked"] == 256
     assert j1["launch_shape_checked"]["from_the_last_timed_launch"] == 256
+    assert j1["config"]["hbm_plan_bytes"] <= j1["config"]["hbm_plan_limit_bytes"]
+    for world, port in ((2, 29617), (4, 29641)):
+        per = 512 // world
+        out = str(tmp_path / ("w%d" % world))
+        jw = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(world), "--backend", "gloo",
+                   "--batch", str(per), "--chunk", str(per // 2), "--dump-digests", out]
+                  # world 2: own shard checked inside the witness buffer (the default N = 2, 4 shape); world 4: in a buffer
+                  # of its own (the default N = 8 shape)
+                  + (["--allgather-chunk", "32"] if world == 2 else []) + COMMON)
+        b = np.concatenate([np.load("%s.rank%d.npy" % (out, r)) for r in range(world)], axis=1)
+        assert np.array_equal(a, b), "world %d: indices / statuses / digests differ from the one-rank run" % world
+        assert jw["n_gpus"] == world and jw["config"]["ranks_seen"] == world
+        assert jw["config"]["signatures_per_step_all_gpus"] == 512 and jw["config"]["batch_per_gpu"] == per
+        assert jw["r1cs_check"]["witnesses_checked"] == world * (per // 2) and jw["r1cs_check"]["unsatisfied"] == 0
+        g = jw["scaling_curves"]["generate_plus_allgather"]
+        assert "error" not in g, g
+        assert g["expanded_own_shard_equals_direct_output"] and g["expanded_digests_identical_on_all_ranks"]
+        assert g["signatures_per_rank"] == per and g["chunk_per_rank"] == (32 if world == 2 else (per // 2) // world)
+        assert g["own_shard_signatures_compared"] == g["chunk_per_rank"]
+        assert g["allgather_inputs_and_regenerate"]["all_statuses_ok"]
+        assert g["naive_32_byte_elements_probe"]["signatures_per_s_node"] > 0
+
+
+def _leave(code, timeout=120):
+    """bench.leave() in a child with a one-rank gloo group (no GPU involved): returns the exit code."""
+    prog = ("import os, sys, torch.distributed as dist; sys.path.insert(0, %r); import bench; "
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29655', RANK='0', WORLD_SIZE='1'); "
+            "dist.init_process_group('gloo'); %s" % (ROOT, code))
+    return subprocess.run([sys.executable, "-c", prog], cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+def test_failed_or_hung_gather_legs_exit_non_zero():
+    """a collective that never completed, or a leg that raised, must not be recorded as a healthy run."""
+    ok = _leave("bench.leave(False, False, 0)")
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    failed = _leave("bench.leave(False, True, 0)")
+    assert failed.returncode == 3 and "gather leg raised" in failed.stderr
+    hung = _leave("bench.leave(True, False, 0)")
+    assert hung.returncode == 3 and "did not complete" in hung.stderr
+    stuck = _leave("dist.destroy_process_group = lambda: __import__('time').sleep(60); bench.leave(False, False, 0, 1.0)")
+    assert stuck.returncode == 4 and "did not return" in stuck.stderr

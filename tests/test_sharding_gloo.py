@@ -1,7 +1,14 @@
-"""The N > 1 path on CPU: world_size-2 gloo process group exercising the same sharding / reduction helpers
-bench.py uses over RCCL (falcon-r1cs_amd/sharding.py)."""
+"""The N > 1 path on CPU: gloo process groups of 2 and of 8 ranks exercising the same sharding / reduction helpers and
+the same step plan bench.py uses over RCCL (falcon-r1cs_amd/sharding.py).  Eight ranks cannot share one MI355X on the
+pool (at most 6 processes may use the card), so the world-8 arithmetic -- index ranges, gather chunking, the digest
+exchange of the gather leg, the HBM budget -- is executed here, on CPU tensors, with the plan the real run allocates from."""
+import json
 import os
 import socket
+import subprocess
+import sys
+
+import pytest
 
 import torch
 import torch.distributed as dist
@@ -42,22 +49,92 @@ def _worker(rank, world, port, total, q):
     ok = (g_status.tolist() == [i % 3 for i in range(total)]
           and g_digest.tolist() == [i * 2654435761 for i in range(total)]
           and slow == float(world) and n == total and chunks_ok)
+    # the gather leg of bench.py in miniature, driven by the plan the real run allocates from: every rank "generates" gc
+    # compact records per chunk (record = its global signature index), the chunk is all-gathered, "expanded" (digest =
+    # index * K) and the expanded digests are exchanged over plan["all_digests_gathered"] slots to prove that every rank
+    # holds the same thing and that rank r's own shard sits at [r * gc, (r + 1) * gc)
+    plan = sharding.step_plan(world, rank, 64, 64, 0, 512, 1000, 100, 128)
+    gc, nk = plan["gather_chunk_per_rank"], plan["gather_chunks"]
+    own_lo = plan["global_lo"]
+    last = None
+    for k in range(nk):
+        loc = torch.arange(own_lo + k * gc, own_lo + (k + 1) * gc, dtype=torch.int64)
+        gathered = torch.empty((world, gc), dtype=torch.int64)
+        sharding.all_gather_chunks(loc, gathered)
+        last = gathered.reshape(-1) * 2654435761
+    all_dig = sharding.gather_per_signature(last, plan["all_digests_gathered"], rank, world)
+    wg = world * gc
+    same = all(bool(torch.equal(all_dig[r * wg:(r + 1) * wg], all_dig[:wg])) for r in range(world))
+    want = [(r * 64 + (nk - 1) * gc + j) * 2654435761 for r in range(world) for j in range(gc)]
+    ok = ok and same and last.tolist() == want and nk * gc == 64 and \
+        last[rank * gc:(rank + 1) * gc].tolist() == [(own_lo + (nk - 1) * gc + j) * 2654435761 for j in range(gc)]
     q.put((rank, ok))
     dist.destroy_process_group()
 
 
-def test_gather_and_reduce_world2_gloo():
+@pytest.mark.parametrize("world,total", [(2, 37), (8, 8 * 13 + 5)])          # ragged shards in both
+def test_gather_and_reduce_gloo(world, total):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    world, total = 2, 37                       # ragged: 19 + 18
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = sorted(q.get(timeout=120) for _ in range(world))
+    results = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(60)
-    assert results == [(0, True), (1, True)]
+    assert results == [(r, True) for r in range(world)]
+
+
+def _layout_numbers(logn):
+    import falcon_r1cs_amd as frw
+    L, CL = frw.layout(logn), frw.compact_layout(logn)
+    return L.n, L.num_witness, L.num_instance, int(CL.bytes_per_signature)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_default_step_plan_is_one_weak_scaling_series_and_fits_hbm(world):
+    """The run the driver launches (bench.py --gpus N, defaults): 65,536 Falcon-1024 signatures per GPU for EVERY N, shards
+    tile the global range, the gather legs cover a whole step, and every rank's buffers fit 0.9 x 288 GB."""
+    nums = _layout_numbers(10)
+    plans = [sharding.step_plan(world, r, 65536, 32768, 0, *nums, with_gather_legs=world > 1) for r in range(world)]
+    assert sharding.check_plans(plans)
+    p = plans[-1]
+    assert p["batch_per_gpu"] == 65536 and p["signatures_per_step_all_gpus"] == 65536 * world
+    assert (p["global_lo"], p["global_hi"]) == (65536 * (world - 1), 65536 * world)
+    assert p["launches_per_step"] == 2 and p["buffers"]["witness buffer (one launch, reused)"] == 32768 * 156724 * 32
+    if world > 1:
+        gc = min(4096, 32768 // world)
+        assert p["gather_chunk_per_rank"] == gc and p["gather_chunks"] * gc == 65536
+        assert p["gathered_signatures_per_collective"] == world * gc <= 32768
+        assert p["all_digests_gathered"] == world * world * gc
+        assert p["own_shard_checked_in_place"] == ((world + 1) * gc <= 32768)
+    assert p["hbm_plan_bytes"] < 0.9 * 288e9
+    if world == 8:                             # the one nobody can rehearse on hardware here: spell its numbers out
+        assert p["gather_chunk_per_rank"] == 4096 and not p["own_shard_checked_in_place"]
+        assert p["own_shard_signatures_checked"] == 1024 and p["probe_chunk_per_rank"] == 256
+        assert 180e9 < p["hbm_plan_bytes"] < 200e9
+
+
+def test_a_plan_that_does_not_fit_is_refused():
+    nums = _layout_numbers(10)
+    plans = [sharding.step_plan(1, 0, 65536, 65536, 0, *nums)]              # 329 GB witness buffer
+    assert not plans[0]["fits"]
+    with pytest.raises(AssertionError):
+        sharding.check_plans(plans)
+
+
+def test_bench_plan_cli_runs_without_a_gpu():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "bench.py", "--plan"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert sorted(j) == ["gpus_1", "gpus_2", "gpus_4", "gpus_8"]
+    assert all(v["fits"] and v["batch_per_gpu"] == 65536 for v in j.values())
+    assert j["gpus_8"]["global_index_range_per_rank"][7] == [458752, 524288]
+    bad = subprocess.run([sys.executable, "bench.py", "--plan", "--chunk", "65536"], cwd=root, capture_output=True, text=True,
+                         timeout=300)
+    assert bad.returncode != 0 and "plans" in bad.stderr
