@@ -11,13 +11,14 @@
 #include <vector>
 
 #include "../../include/frw.h"
+#include "frw_arena.h"
 #include "frw_device.h"
 
 struct frw_ctx {
     int device;
     int num_cu;
     frw::Tables *d_tables;
-    hipStream_t host_compute, host_copy;                            // streams of the host-buffer entry points
+    frw::HostArena arena;            // streams, events, device and page-locked memory of the host-buffer entry points
 };
 
 namespace {
@@ -77,6 +78,10 @@ bool bad_common(const frw_ctx *ctx, int logn, int encoding)
 }
 
 }  // namespace
+
+namespace frw {
+int record_hip_error(hipError_t e, const char *what) { return hip_fail(e, what); }
+}  // namespace frw
 
 extern "C" {
 
@@ -138,13 +143,11 @@ int frw_ctx_create(int device, frw_ctx **out)
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
     ctx->d_tables = nullptr;
-    ctx->host_compute = ctx->host_copy = nullptr;
     frw::Tables host;
     build_tables(host);
     hipError_t e = hipMalloc((void **)&ctx->d_tables, sizeof(frw::Tables));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tables, &host, sizeof host, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->host_compute, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->host_copy, hipStreamNonBlocking);
+    if (e == hipSuccess) e = ctx->arena.init();
     if (e != hipSuccess) {
         frw_ctx_destroy(ctx);
         return hip_fail(e, "context setup");
@@ -161,9 +164,25 @@ void frw_ctx_destroy(frw_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
-    if (ctx->host_compute) (void)hipStreamDestroy(ctx->host_compute);
-    if (ctx->host_copy) (void)hipStreamDestroy(ctx->host_copy);
+    ctx->arena.destroy();
     delete ctx;
+}
+
+int frw_diag_host_allocations(frw_ctx *ctx, uint64_t *count)
+{
+    if (!ctx || !count) return FRW_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->arena.mu);
+    *count = ctx->arena.allocations;
+    return FRW_OK;
+}
+
+int frw_ctx_trim(frw_ctx *ctx)
+{
+    if (!ctx) return FRW_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->arena.mu);
+    FRW_HIP(hipSetDevice(ctx->device));
+    ctx->arena.trim();
+    return FRW_OK;
 }
 
 int frw_witness_ntt_verify_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_sig, const uint16_t *d_pk,
@@ -194,24 +213,14 @@ int frw_ntt_modq_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_pol
 }
 
 namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
-};
-}  // namespace
-
-namespace {
-struct Event {
-    hipEvent_t e = nullptr;
-    ~Event() { if (e) (void)hipEventDestroy(e); }
-    hipError_t create() { return hipEventCreateWithFlags(&e, hipEventDisableTiming); }
-};
-
-// Host-buffer driver shared by the two circuits.  Two device buffer sets and two streams: while the copy stream
-// drains chunk k (5 MB per signature over PCIe), the compute stream already fills chunk k+1.  With caller buffers
-// from frw_host_alloc (pinned) every copy is a true asynchronous DMA; with pageable memory the runtime stages the
-// copies itself and the overlap degrades gracefully, the results are the same.
+// Host-buffer driver shared by the two circuits.  Working memory comes from the context's arena (grow-only: a call after
+// the first allocates nothing).  Inputs travel through the arena's page-locked buffer, so the three polynomials of a
+// chunk are ONE host-to-device copy whatever memory the caller holds them in.  A batch that fits one chunk -- the
+// reference's own call pattern is one signature per generate_constraints -- runs on one stream: copy in, kernel, copies
+// out, one synchronisation.  Longer batches use two device slots and two streams: while the copy stream drains chunk k
+// (5 MB per signature over PCIe), the compute stream already fills chunk k+1.  With output buffers from frw_host_alloc
+// (pinned) every copy out is a true asynchronous DMA; with pageable memory the runtime stages the copies itself and the
+// overlap degrades gracefully, the results are the same.
 int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t *sig, const uint16_t *pk,
                  const uint16_t *hm, int encoding, uint64_t *witness, uint64_t *instance, int32_t *status, int strict)
 {
@@ -219,57 +228,63 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
     if (compact ? bad_common(ctx, logn, FRW_ENC_MONTGOMERY) : bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
     if (!sig || !pk || !hm || !witness || (!instance && !compact) || !status) return FRW_E_INVALID_ARG;
+    frw::HostArena &A = ctx->arena;
+    std::lock_guard<std::mutex> lock(A.mu);
     FRW_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << logn;
     const size_t nb = logn == 9 ? 50 : 52;
     const size_t wbytes = compact ? frw::compact_layout(logn).bytes : (dual ? 186 * n + 4 + nb : 153 * n + nb) * 32;
-    const size_t ibytes = compact ? 16 : (2 * n + 1) * 32;
+    const size_t ibytes = compact ? 0 : (2 * n + 1) * 32;
     const size_t chunk = std::min<size_t>(batch, compact ? 2048 : 256);      // 2 x (<= 1.6 GB) of device witness
-    DevBuf d_in[2][3], d_wit[2], d_inst[2], d_st[2];
-    struct { hipStream_t s; } compute{ctx->host_compute}, copy{ctx->host_copy};
-    Event done[2], drained[2];
     const int nbuf = batch > chunk ? 2 : 1;
+    const size_t in_bytes = 3 * chunk * n * 2;                              // sig | pk | hm of one chunk, contiguous
+    struct Slot { uint16_t *in; char *wit, *inst; int32_t *st; } slot[2];
     for (int b = 0; b < nbuf; b++) {
-        for (auto &x : d_in[b]) FRW_HIP(x.alloc(chunk * n * 2));
-        FRW_HIP(d_wit[b].alloc(chunk * wbytes));
-        FRW_HIP(d_inst[b].alloc(chunk * ibytes));
-        FRW_HIP(d_st[b].alloc(chunk * sizeof(int32_t)));
-        FRW_HIP(done[b].create());
-        FRW_HIP(drained[b].create());
+        frw::Carve size(nullptr);
+        size.take(in_bytes); size.take(chunk * wbytes); size.take(chunk * ibytes + 16); size.take(chunk * sizeof(int32_t));
+        FRW_HIP(A.reserve_device(b, size.off));
+        frw::Carve c(A.d_slot[b]);
+        slot[b].in = c.take<uint16_t>(in_bytes);
+        slot[b].wit = c.take<char>(chunk * wbytes);
+        slot[b].inst = c.take<char>(chunk * ibytes + 16);
+        slot[b].st = c.take<int32_t>(chunk * sizeof(int32_t));
     }
+    FRW_HIP(A.reserve_pinned((size_t)nbuf * in_bytes));
     const uint16_t *src[3] = {sig, pk, hm};
     size_t k = 0;
     for (size_t lo = 0; lo < batch; lo += chunk, k++) {
         const size_t cnt = std::min(chunk, batch - lo);
         const int b = (int)(k & 1);
-        if (k >= 2) FRW_HIP(hipStreamWaitEvent(compute.s, drained[b].e, 0));      // buffer b has been copied out
-        for (int j = 0; j < 3; j++)
-            FRW_HIP(hipMemcpyAsync(d_in[b][j].p, src[j] + lo * n, cnt * n * 2, hipMemcpyHostToDevice, compute.s));
+        // slot b was last used by chunk k - 2: its copies out have finished before its memory is written again (the
+        // host waits too: it is about to overwrite the page-locked inputs that chunk's H2D copy read)
+        if (k >= 2) FRW_HIP(hipEventSynchronize(A.drained[b]));
+        uint16_t *stage = (uint16_t *)((char *)A.h_pin + (size_t)b * in_bytes);
+        for (int j = 0; j < 3; j++) memcpy(stage + (size_t)j * cnt * n, src[j] + lo * n, cnt * n * 2);
+        FRW_HIP(hipMemcpyAsync(slot[b].in, stage, 3 * cnt * n * 2, hipMemcpyHostToDevice, A.compute));
+        const uint16_t *d_sig = slot[b].in, *d_pk = d_sig + cnt * n, *d_hm = d_pk + cnt * n;
         if (dual)
-            FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, cnt,
-                                                        (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
-                                                        (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
-                                                        (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
+            FRW_HIP(frw::launch_witness_dual_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, cnt, d_sig, d_pk, d_hm,
+                                                        (uint64_t *)slot[b].wit, (uint64_t *)slot[b].inst, slot[b].st, A.compute));
         else if (compact)
-            FRW_HIP(frw::launch_witness_ntt_verify_compact(ctx->d_tables, ctx->num_cu, logn, cnt,
-                                                           (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
-                                                           (const uint16_t *)d_in[b][2].p, d_wit[b].p, (int32_t *)d_st[b].p,
-                                                           compute.s));
+            FRW_HIP(frw::launch_witness_ntt_verify_compact(ctx->d_tables, ctx->num_cu, logn, cnt, d_sig, d_pk, d_hm, slot[b].wit,
+                                                           slot[b].st, A.compute));
         else
-            FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, cnt,
-                                                   (const uint16_t *)d_in[b][0].p, (const uint16_t *)d_in[b][1].p,
-                                                   (const uint16_t *)d_in[b][2].p, (uint64_t *)d_wit[b].p,
-                                                   (uint64_t *)d_inst[b].p, (int32_t *)d_st[b].p, compute.s));
-        FRW_HIP(hipEventRecord(done[b].e, compute.s));
-        FRW_HIP(hipStreamWaitEvent(copy.s, done[b].e, 0));
-        FRW_HIP(hipMemcpyAsync(status + lo, d_st[b].p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, copy.s));
-        FRW_HIP(hipMemcpyAsync((char *)witness + lo * wbytes, d_wit[b].p, cnt * wbytes, hipMemcpyDeviceToHost, copy.s));
+            FRW_HIP(frw::launch_witness_ntt_verify(ctx->d_tables, ctx->num_cu, logn, encoding, cnt, d_sig, d_pk, d_hm,
+                                                   (uint64_t *)slot[b].wit, (uint64_t *)slot[b].inst, slot[b].st, A.compute));
+        hipStream_t out = A.compute;
+        if (nbuf == 2) {
+            FRW_HIP(hipEventRecord(A.done[b], A.compute));
+            FRW_HIP(hipStreamWaitEvent(A.copy, A.done[b], 0));
+            out = A.copy;
+        }
+        FRW_HIP(hipMemcpyAsync((char *)witness + lo * wbytes, slot[b].wit, cnt * wbytes, hipMemcpyDeviceToHost, out));
         if (!compact)
-            FRW_HIP(hipMemcpyAsync((char *)instance + lo * ibytes, d_inst[b].p, cnt * ibytes, hipMemcpyDeviceToHost, copy.s));
-        FRW_HIP(hipEventRecord(drained[b].e, copy.s));
+            FRW_HIP(hipMemcpyAsync((char *)instance + lo * ibytes, slot[b].inst, cnt * ibytes, hipMemcpyDeviceToHost, out));
+        FRW_HIP(hipMemcpyAsync(status + lo, slot[b].st, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, out));
+        if (nbuf == 2) FRW_HIP(hipEventRecord(A.drained[b], A.copy));
     }
-    FRW_HIP(hipStreamSynchronize(compute.s));
-    FRW_HIP(hipStreamSynchronize(copy.s));
+    FRW_HIP(hipStreamSynchronize(A.compute));
+    if (nbuf == 2) FRW_HIP(hipStreamSynchronize(A.copy));
     bool any_bad = false;
     for (size_t i = 0; i < batch; i++) any_bad |= status[i] != FRW_ST_OK;
     return strict && any_bad ? FRW_E_RANGE : FRW_OK;
@@ -479,39 +494,49 @@ int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int
     if (bad_common(ctx, logn, encoding)) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
     if (!poly || !witness || !ntt_out || !status) return FRW_E_INVALID_ARG;
+    frw::HostArena &A = ctx->arena;
+    std::lock_guard<std::mutex> lock(A.mu);
     FRW_HIP(hipSetDevice(ctx->device));
-    // same two-buffer, two-stream pipeline as witness_host: the D2H of chunk k overlaps the kernel of chunk k+1
+    // same pipeline as witness_host: arena memory, one stream for a batch that fits a chunk, else the D2H of chunk k
+    // overlaps the kernel of chunk k+1
     const size_t n = (size_t)1 << logn, wbytes = 29 * n * 32;
     const size_t chunk = std::min<size_t>(batch, 2048);
-    DevBuf d_in[2], d_wit[2], d_out[2], d_st[2];
-    Event done[2], drained[2];
-    hipStream_t compute = ctx->host_compute, copy = ctx->host_copy;
     const int nbuf = batch > chunk ? 2 : 1;
+    struct Slot { uint16_t *in, *out; char *wit; int32_t *st; } slot[2];
     for (int b = 0; b < nbuf; b++) {
-        FRW_HIP(d_in[b].alloc(chunk * n * 2));
-        FRW_HIP(d_wit[b].alloc(chunk * wbytes));
-        FRW_HIP(d_out[b].alloc(chunk * n * 2));
-        FRW_HIP(d_st[b].alloc(chunk * sizeof(int32_t)));
-        FRW_HIP(done[b].create());
-        FRW_HIP(drained[b].create());
+        frw::Carve size(nullptr);
+        size.take(chunk * n * 2); size.take(chunk * n * 2); size.take(chunk * wbytes); size.take(chunk * sizeof(int32_t));
+        FRW_HIP(A.reserve_device(b, size.off));
+        frw::Carve c(A.d_slot[b]);
+        slot[b].in = c.take<uint16_t>(chunk * n * 2);
+        slot[b].out = c.take<uint16_t>(chunk * n * 2);
+        slot[b].wit = c.take<char>(chunk * wbytes);
+        slot[b].st = c.take<int32_t>(chunk * sizeof(int32_t));
     }
+    FRW_HIP(A.reserve_pinned((size_t)nbuf * chunk * n * 2));
     size_t k = 0;
     for (size_t lo = 0; lo < batch; lo += chunk, k++) {
         const size_t cnt = std::min(chunk, batch - lo);
         const int b = (int)(k & 1);
-        if (k >= 2) FRW_HIP(hipStreamWaitEvent(compute, drained[b].e, 0));
-        FRW_HIP(hipMemcpyAsync(d_in[b].p, poly + lo * n, cnt * n * 2, hipMemcpyHostToDevice, compute));
-        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, ctx->num_cu, logn, encoding, cnt, (const uint16_t *)d_in[b].p,
-                                     (uint64_t *)d_wit[b].p, (uint16_t *)d_out[b].p, (int32_t *)d_st[b].p, compute));
-        FRW_HIP(hipEventRecord(done[b].e, compute));
-        FRW_HIP(hipStreamWaitEvent(copy, done[b].e, 0));
-        FRW_HIP(hipMemcpyAsync(status + lo, d_st[b].p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, copy));
-        FRW_HIP(hipMemcpyAsync((char *)witness + lo * wbytes, d_wit[b].p, cnt * wbytes, hipMemcpyDeviceToHost, copy));
-        FRW_HIP(hipMemcpyAsync(ntt_out + lo * n, d_out[b].p, cnt * n * 2, hipMemcpyDeviceToHost, copy));
-        FRW_HIP(hipEventRecord(drained[b].e, copy));
+        if (k >= 2) FRW_HIP(hipEventSynchronize(A.drained[b]));
+        uint16_t *stage = (uint16_t *)((char *)A.h_pin + (size_t)b * chunk * n * 2);
+        memcpy(stage, poly + lo * n, cnt * n * 2);
+        FRW_HIP(hipMemcpyAsync(slot[b].in, stage, cnt * n * 2, hipMemcpyHostToDevice, A.compute));
+        FRW_HIP(frw::launch_ntt_modq(ctx->d_tables, ctx->num_cu, logn, encoding, cnt, slot[b].in, (uint64_t *)slot[b].wit,
+                                     slot[b].out, slot[b].st, A.compute));
+        hipStream_t out = A.compute;
+        if (nbuf == 2) {
+            FRW_HIP(hipEventRecord(A.done[b], A.compute));
+            FRW_HIP(hipStreamWaitEvent(A.copy, A.done[b], 0));
+            out = A.copy;
+        }
+        FRW_HIP(hipMemcpyAsync((char *)witness + lo * wbytes, slot[b].wit, cnt * wbytes, hipMemcpyDeviceToHost, out));
+        FRW_HIP(hipMemcpyAsync(ntt_out + lo * n, slot[b].out, cnt * n * 2, hipMemcpyDeviceToHost, out));
+        FRW_HIP(hipMemcpyAsync(status + lo, slot[b].st, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, out));
+        if (nbuf == 2) FRW_HIP(hipEventRecord(A.drained[b], A.copy));
     }
-    FRW_HIP(hipStreamSynchronize(compute));
-    FRW_HIP(hipStreamSynchronize(copy));
+    FRW_HIP(hipStreamSynchronize(A.compute));
+    if (nbuf == 2) FRW_HIP(hipStreamSynchronize(A.copy));
     return FRW_OK;
 }
 
@@ -558,39 +583,52 @@ int frw_prepare_inputs(frw_ctx *ctx, int logn, size_t batch, const uint8_t *pk_b
     if (!msgs && msg_off[batch] != msg_off[0]) return FRW_E_INVALID_ARG;
     for (size_t i = 0; i < batch; i++)
         if (msg_off[i + 1] < msg_off[i]) return FRW_E_INVALID_ARG;        // offsets must be non-decreasing
+    frw::HostArena &A = ctx->arena;
+    std::lock_guard<std::mutex> lock(A.mu);
     FRW_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << logn, pk_len = FRW_PK_LEN(logn);
     const size_t msg_bytes = (size_t)(msg_off[batch] - msg_off[0]);
-    DevBuf d_pkb, d_sigb, d_msgs, d_off, d_sig, d_pk, d_hm, d_nonce, d_st1, d_st2;
-    FRW_HIP(d_pkb.alloc(batch * pk_len));
-    FRW_HIP(d_sigb.alloc(batch * sig_len));
-    FRW_HIP(d_msgs.alloc(msg_bytes ? msg_bytes : 1));
-    FRW_HIP(d_off.alloc((batch + 1) * sizeof(uint64_t)));
-    FRW_HIP(d_sig.alloc(batch * n * 2));
-    FRW_HIP(d_pk.alloc(batch * n * 2));
-    FRW_HIP(d_hm.alloc(batch * n * 2));
-    FRW_HIP(d_nonce.alloc(batch * FRW_NONCE_LEN));
-    FRW_HIP(d_st1.alloc(batch * sizeof(int32_t)));
-    FRW_HIP(d_st2.alloc(batch * sizeof(int32_t)));
-    std::vector<uint64_t> off(batch + 1);
+    // one device slot, carved; the encoded inputs travel in ONE copy through the page-locked buffer, the results and both
+    // status vectors come back in ONE copy
+    frw::Carve hs(nullptr);                                             // layout of the staged inputs == their device layout
+    const size_t o_pkb = hs.off; hs.take(batch * pk_len);
+    const size_t o_sigb = hs.off; hs.take(batch * sig_len);
+    const size_t o_msgs = hs.off; hs.take(msg_bytes ? msg_bytes : 1);
+    const size_t o_off = hs.off; hs.take((batch + 1) * sizeof(uint64_t));
+    const size_t in_total = hs.off;
+    frw::Carve os(nullptr);                                             // layout of the results
+    const size_t o_sig = os.off; os.take(batch * n * 2);
+    const size_t o_pk = os.off; os.take(batch * n * 2);
+    const size_t o_hm = os.off; os.take(batch * n * 2);
+    const size_t o_st1 = os.off; os.take(batch * sizeof(int32_t));
+    const size_t o_st2 = os.off; os.take(batch * sizeof(int32_t));
+    const size_t out_total = os.off;
+    const size_t nonce_bytes = (batch * FRW_NONCE_LEN + 255) & ~(size_t)255;
+    FRW_HIP(A.reserve_device(0, in_total + out_total + nonce_bytes));
+    FRW_HIP(A.reserve_pinned(std::max(in_total, out_total)));
+    char *d_in = (char *)A.d_slot[0], *d_out = d_in + in_total, *d_nonce = d_out + out_total, *h = (char *)A.h_pin;
+    memcpy(h + o_pkb, pk_bytes, batch * pk_len);
+    memcpy(h + o_sigb, sig_bytes, batch * sig_len);
+    if (msg_bytes) memcpy(h + o_msgs, msgs + msg_off[0], msg_bytes);
+    uint64_t *off = (uint64_t *)(h + o_off);
     for (size_t i = 0; i <= batch; i++) off[i] = msg_off[i] - msg_off[0];
-    FRW_HIP(hipMemcpy(d_pkb.p, pk_bytes, batch * pk_len, hipMemcpyHostToDevice));
-    FRW_HIP(hipMemcpy(d_sigb.p, sig_bytes, batch * sig_len, hipMemcpyHostToDevice));
-    if (msg_bytes) FRW_HIP(hipMemcpy(d_msgs.p, msgs + msg_off[0], msg_bytes, hipMemcpyHostToDevice));
-    FRW_HIP(hipMemcpy(d_off.p, off.data(), (batch + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    FRW_HIP(hipMemset(d_nonce.p, 0, batch * FRW_NONCE_LEN));
-    FRW_HIP(frw::launch_decode_public_keys(logn, batch, (const uint8_t *)d_pkb.p, (uint16_t *)d_pk.p, (int32_t *)d_st1.p, nullptr));
-    FRW_HIP(frw::launch_decode_signatures(logn, batch, (const uint8_t *)d_sigb.p, sig_len, (uint16_t *)d_sig.p,
-                                          (uint8_t *)d_nonce.p, (int32_t *)d_st2.p, nullptr));
-    FRW_HIP(frw::launch_hash_to_point(logn, batch, (const uint8_t *)d_nonce.p, (const uint8_t *)d_msgs.p,
-                                      (const uint64_t *)d_off.p, (uint16_t *)d_hm.p, nullptr));
-    std::vector<int32_t> st2(batch);
-    FRW_HIP(hipMemcpy(status, d_st1.p, batch * sizeof(int32_t), hipMemcpyDeviceToHost));
-    FRW_HIP(hipMemcpy(st2.data(), d_st2.p, batch * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < batch; i++) if (st2[i] != FRW_ST_OK) status[i] = st2[i];
-    FRW_HIP(hipMemcpy(sig, d_sig.p, batch * n * 2, hipMemcpyDeviceToHost));
-    FRW_HIP(hipMemcpy(pk, d_pk.p, batch * n * 2, hipMemcpyDeviceToHost));
-    FRW_HIP(hipMemcpy(hm, d_hm.p, batch * n * 2, hipMemcpyDeviceToHost));
+    hipStream_t st = A.compute;
+    FRW_HIP(hipMemcpyAsync(d_in, h, in_total, hipMemcpyHostToDevice, st));
+    FRW_HIP(hipMemsetAsync(d_nonce, 0, batch * FRW_NONCE_LEN, st));
+    FRW_HIP(frw::launch_decode_public_keys(logn, batch, (const uint8_t *)(d_in + o_pkb), (uint16_t *)(d_out + o_pk),
+                                           (int32_t *)(d_out + o_st1), st));
+    FRW_HIP(frw::launch_decode_signatures(logn, batch, (const uint8_t *)(d_in + o_sigb), sig_len, (uint16_t *)(d_out + o_sig),
+                                          (uint8_t *)d_nonce, (int32_t *)(d_out + o_st2), st));
+    FRW_HIP(frw::launch_hash_to_point(logn, batch, (const uint8_t *)d_nonce, (const uint8_t *)(d_in + o_msgs),
+                                      (const uint64_t *)(d_in + o_off), (uint16_t *)(d_out + o_hm), st));
+    FRW_HIP(hipStreamSynchronize(st));                                   // the staged inputs have been read
+    FRW_HIP(hipMemcpyAsync(h, d_out, out_total, hipMemcpyDeviceToHost, st));
+    FRW_HIP(hipStreamSynchronize(st));
+    memcpy(sig, h + o_sig, batch * n * 2);
+    memcpy(pk, h + o_pk, batch * n * 2);
+    memcpy(hm, h + o_hm, batch * n * 2);
+    const int32_t *st1 = (const int32_t *)(h + o_st1), *st2 = (const int32_t *)(h + o_st2);
+    for (size_t i = 0; i < batch; i++) status[i] = st2[i] != FRW_ST_OK ? st2[i] : st1[i];
     return FRW_OK;
 }
 
@@ -617,22 +655,26 @@ int frw_gadget(frw_ctx *ctx, int kind, size_t count, const void *a, const uint64
     if (bad_common(ctx, 10, encoding) || frw_gadget_block_len(kind) < 0) return FRW_E_INVALID_ARG;
     if (count == 0) return FRW_OK;
     if (!a || !out || (kind == FRW_G_ADD_MOD && !b)) return FRW_E_INVALID_ARG;
+    frw::HostArena &A = ctx->arena;
+    std::lock_guard<std::mutex> lock(A.mu);
     FRW_HIP(hipSetDevice(ctx->device));
-    const size_t in_bytes = count * (kind == FRW_G_MOD_Q ? 20 : 8);
+    const size_t in_bytes = count * (kind == FRW_G_MOD_Q ? 20 : 8), b_bytes = kind == FRW_G_ADD_MOD ? count * 8 : 0;
     const size_t out_bytes = count * (size_t)frw_gadget_block_len(kind) * 32;
-    DevBuf d_a, d_b, d_out, d_st;
-    FRW_HIP(d_a.alloc(in_bytes));
-    FRW_HIP(d_out.alloc(out_bytes));
-    FRW_HIP(d_st.alloc(count * sizeof(int32_t)));
-    FRW_HIP(hipMemcpy(d_a.p, a, in_bytes, hipMemcpyHostToDevice));
-    if (kind == FRW_G_ADD_MOD) {
-        FRW_HIP(d_b.alloc(count * 8));
-        FRW_HIP(hipMemcpy(d_b.p, b, count * 8, hipMemcpyHostToDevice));
-    }
-    FRW_HIP(frw::launch_gadget(kind, encoding, count, d_a.p, (const uint64_t *)d_b.p, (uint64_t *)d_out.p,
-                               (int32_t *)d_st.p, nullptr));
-    FRW_HIP(hipMemcpy(out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
-    if (status) FRW_HIP(hipMemcpy(status, d_st.p, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    frw::Carve size(nullptr);
+    size.take(in_bytes); size.take(b_bytes); size.take(out_bytes); size.take(count * sizeof(int32_t));
+    FRW_HIP(A.reserve_device(0, size.off));
+    frw::Carve c(A.d_slot[0]);
+    void *d_a = c.take(in_bytes);
+    uint64_t *d_b = c.take<uint64_t>(b_bytes);
+    uint64_t *d_out = c.take<uint64_t>(out_bytes);
+    int32_t *d_st = c.take<int32_t>(count * sizeof(int32_t));
+    hipStream_t st = A.compute;
+    FRW_HIP(hipMemcpyAsync(d_a, a, in_bytes, hipMemcpyHostToDevice, st));
+    if (b_bytes) FRW_HIP(hipMemcpyAsync(d_b, b, b_bytes, hipMemcpyHostToDevice, st));
+    FRW_HIP(frw::launch_gadget(kind, encoding, count, d_a, b_bytes ? d_b : nullptr, d_out, d_st, st));
+    FRW_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    if (status) FRW_HIP(hipMemcpyAsync(status, d_st, count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FRW_HIP(hipStreamSynchronize(st));
     return FRW_OK;
 }
 

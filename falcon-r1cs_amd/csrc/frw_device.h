@@ -49,6 +49,8 @@ constexpr CompactLayout compact_layout(int logn)
     return c;
 }
 
+// records the message frw_last_error() returns (thread-local) and maps the HIP error to FRW_E_HIP / FRW_E_OUT_OF_MEMORY
+int record_hip_error(hipError_t e, const char *what);
 void init_launch_config();
 hipError_t launch_witness_ntt_verify_compact(const Tables *tab, int num_cu, int logn, size_t batch,
                                              const uint16_t *sig, const uint16_t *pk, const uint16_t *hm, void *compact,
@@ -103,6 +105,7 @@ struct R1csDev {
     const uint32_t *long_cidx;  // [chunks][64] index into long_vars
     uint32_t k_rrp[9];          // R R' mod p (R = 2^256, R' = 2^261) as an integer, 29-bit limbs
 };
+size_t r1cs_check_scratch_bytes(const R1csDev &r, size_t batch, bool with_abc);
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
                              uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st, void *scratch = nullptr);
 // Tables of the QAP witness map's domain (frw_qap.hip), built by frw_r1cs_load.  Every entry is a field element times

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/frw.h"
+#include "frw_arena.h"
 #include "frw_device.h"
 #include "host/frw_host.hpp"
 
@@ -35,6 +36,7 @@ struct frw_r1cs {
     frw::R1csDev dev;
     frw::QapDev qap;
     std::vector<void *> allocs;
+    mutable frw::HostArena arena;     // working memory of frw_qap_witness_map (host buffers in, host buffers out)
 };
 
 namespace {
@@ -160,6 +162,7 @@ extern "C" void frw_r1cs_free(frw_r1cs *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     for (void *p : r->allocs) (void)hipFree(p);
+    r->arena.destroy();
     delete r;
 }
 
@@ -175,6 +178,7 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
         const frw::host::ConstraintMatrices m = build_matrices(circuit, logn);
         r = new frw_r1cs;
         r->device = device;
+        if (r->arena.init() != hipSuccess) throw std::runtime_error("stream / event creation");
         r->dev.num_instance = (uint32_t)m.num_instance_variables;
         r->dev.num_witness = (uint32_t)m.num_witness_variables;
         r->dev.num_constraints = (uint32_t)m.num_constraints;
@@ -281,20 +285,45 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
     }
 }
 
+namespace {
+int r1cs_eval(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+              uint32_t *d_num_unsatisfied, uint64_t *d_abc, void *d_scratch, void *stream)
+{
+    hipError_t e = hipSetDevice(r->device);
+    if (e != hipSuccess) return frw::record_hip_error(e, "hipSetDevice");
+    for (size_t lo = 0; lo < batch; lo += 32768) {
+        const size_t cnt = std::min<size_t>(32768, batch - lo);
+        e = frw::launch_r1cs_check(r->dev, cnt, d_witness + lo * (size_t)r->dev.num_witness * 4,
+                                   d_instance + lo * (size_t)r->dev.num_instance * 4, d_num_unsatisfied + lo,
+                                   d_abc ? d_abc + lo * (size_t)3 * r->dev.num_constraints * 4 : nullptr,
+                                   (hipStream_t)stream, d_scratch);     // the chunks run one after the other: one scratch
+        if (e != hipSuccess) return frw::record_hip_error(e, "frw_r1cs_eval_dev");
+    }
+    return FRW_OK;
+}
+}  // namespace
+
 extern "C" int frw_r1cs_eval_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
                                  uint32_t *d_num_unsatisfied, uint64_t *d_abc, void *stream)
 {
     if (!r || (batch && (!d_witness || !d_instance || !d_num_unsatisfied))) return FRW_E_INVALID_ARG;
-    if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
-    for (size_t lo = 0; lo < batch; lo += 32768) {
-        const size_t cnt = std::min<size_t>(32768, batch - lo);
-        if (frw::launch_r1cs_check(r->dev, cnt, d_witness + lo * (size_t)r->dev.num_witness * 4,
-                                   d_instance + lo * (size_t)r->dev.num_instance * 4, d_num_unsatisfied + lo,
-                                   d_abc ? d_abc + lo * (size_t)3 * r->dev.num_constraints * 4 : nullptr,
-                                   (hipStream_t)stream) != hipSuccess)
-            return FRW_E_HIP;
-    }
-    return FRW_OK;
+    return r1cs_eval(r, batch, d_witness, d_instance, d_num_unsatisfied, d_abc, nullptr, stream);
+}
+
+extern "C" size_t frw_r1cs_eval_scratch_bytes(const frw_r1cs *r, size_t batch, int with_products)
+{
+    if (!r) return 0;
+    return frw::r1cs_check_scratch_bytes(r->dev, std::min<size_t>(batch, 32768), with_products != 0);
+}
+
+extern "C" int frw_r1cs_eval_scratch_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                                         uint32_t *d_num_unsatisfied, uint64_t *d_abc, void *d_scratch, size_t scratch_bytes,
+                                         void *stream)
+{
+    if (!r || (batch && (!d_witness || !d_instance || !d_num_unsatisfied))) return FRW_E_INVALID_ARG;
+    const size_t need = frw_r1cs_eval_scratch_bytes(r, batch, d_abc != nullptr);
+    if (batch && need && (!d_scratch || scratch_bytes < need || ((uintptr_t)d_scratch & 15))) return FRW_E_INVALID_ARG;
+    return r1cs_eval(r, batch, d_witness, d_instance, d_num_unsatisfied, d_abc, need ? d_scratch : nullptr, stream);
 }
 
 extern "C" int frw_qap_info(const frw_r1cs *r, frw_qap_info_t *out)
@@ -315,9 +344,11 @@ extern "C" int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const ui
     if (!r || (batch && (!d_witness || !d_instance || !d_h || !d_workspace))) return FRW_E_INVALID_ARG;
     if (r->qap.log_n != 17 && r->qap.log_n != 18) return FRW_E_INVALID_ARG;   // the pass schedule covers the Falcon circuits' domains
     if (batch && workspace_bytes < frw::qap_workspace_bytes_per_signature(r->dev, r->qap)) return FRW_E_INVALID_ARG;
-    if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
-    return frw::launch_qap_witness_map(r->dev, r->qap, batch, d_witness, d_instance, d_h, d_num_unsatisfied, d_workspace,
-                                       workspace_bytes, (hipStream_t)stream) == hipSuccess ? FRW_OK : FRW_E_HIP;
+    hipError_t e = hipSetDevice(r->device);
+    if (e == hipSuccess)
+        e = frw::launch_qap_witness_map(r->dev, r->qap, batch, d_witness, d_instance, d_h, d_num_unsatisfied, d_workspace,
+                                        workspace_bytes, (hipStream_t)stream);
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_qap_witness_map_dev");
 }
 
 extern "C" int frw_qap_quotient_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
@@ -327,9 +358,11 @@ extern "C" int frw_qap_quotient_dev(const frw_r1cs *r, size_t batch, const uint6
     if (!r || (batch && (!d_witness || !d_instance || !d_h || !d_workspace))) return FRW_E_INVALID_ARG;
     if (r->qap.log_n != 17 && r->qap.log_n != 18) return FRW_E_INVALID_ARG;
     if (batch && workspace_bytes < frw::qap_workspace_bytes_per_signature(r->dev, r->qap)) return FRW_E_INVALID_ARG;
-    if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
-    return frw::launch_qap_quotient(r->dev, r->qap, batch, d_witness, d_instance, d_h, d_num_unsatisfied, d_workspace,
-                                    workspace_bytes, (hipStream_t)stream) == hipSuccess ? FRW_OK : FRW_E_HIP;
+    hipError_t e = hipSetDevice(r->device);
+    if (e == hipSuccess)
+        e = frw::launch_qap_quotient(r->dev, r->qap, batch, d_witness, d_instance, d_h, d_num_unsatisfied, d_workspace,
+                                     workspace_bytes, (hipStream_t)stream);
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_qap_quotient_dev");
 }
 
 // Host buffers in, host buffers out: the same map for a caller that holds `Vec<Fr>`s (arkworks' witness_assignment /
@@ -340,33 +373,44 @@ extern "C" int frw_qap_witness_map(const frw_r1cs *r, size_t batch, const uint64
     if (!r || (batch && (!witness || !instance || !h))) return FRW_E_INVALID_ARG;
     if (r->qap.log_n != 17 && r->qap.log_n != 18) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
-    if (hipSetDevice(r->device) != hipSuccess) return FRW_E_HIP;
+    frw::HostArena &A = r->arena;
+    std::lock_guard<std::mutex> lock(A.mu);
+    hipError_t e = hipSetDevice(r->device);
+    if (e != hipSuccess) return frw::record_hip_error(e, "hipSetDevice");
     const size_t n = (size_t)1 << r->qap.log_n, W = r->dev.num_witness, I = r->dev.num_instance;
     const size_t chunk = std::min<size_t>(batch, 64), per = frw::qap_workspace_bytes_per_signature(r->dev, r->qap);
-    void *d_wit = nullptr, *d_inst = nullptr, *d_h = nullptr, *d_ws = nullptr, *d_bad = nullptr;
-    hipStream_t st = nullptr;
-    int rc = FRW_OK;
-    if (hipStreamCreate(&st) != hipSuccess) return FRW_E_HIP;
-    if (hipMalloc(&d_wit, chunk * W * 32) != hipSuccess || hipMalloc(&d_inst, chunk * I * 32) != hipSuccess ||
-        hipMalloc(&d_h, chunk * n * 32) != hipSuccess || hipMalloc(&d_ws, chunk * per) != hipSuccess ||
-        hipMalloc(&d_bad, chunk * sizeof(uint32_t)) != hipSuccess)
-        rc = FRW_E_OUT_OF_MEMORY;
-    for (size_t lo = 0; rc == FRW_OK && lo < batch; lo += chunk) {
+    // one arena slot, carved (grow-only: a second call of the same size allocates nothing)
+    frw::Carve size(nullptr);
+    size.take(chunk * W * 32); size.take(chunk * I * 32); size.take(chunk * n * 32); size.take(chunk * per);
+    size.take(chunk * sizeof(uint32_t));
+    if ((e = A.reserve_device(0, size.off)) != hipSuccess) return frw::record_hip_error(e, "frw_qap_witness_map: device memory");
+    frw::Carve c(A.d_slot[0]);
+    uint64_t *d_wit = c.take<uint64_t>(chunk * W * 32), *d_inst = c.take<uint64_t>(chunk * I * 32);
+    uint64_t *d_h = c.take<uint64_t>(chunk * n * 32);
+    void *d_ws = c.take(chunk * per);
+    uint32_t *d_bad = c.take<uint32_t>(chunk * sizeof(uint32_t));
+    hipStream_t st = A.compute;
+    for (size_t lo = 0; lo < batch; lo += chunk) {
         const size_t cnt = std::min(chunk, batch - lo);
-        bool ok = hipMemcpyAsync(d_wit, witness + lo * W * 4, cnt * W * 32, hipMemcpyHostToDevice, st) == hipSuccess &&
-                  hipMemcpyAsync(d_inst, instance + lo * I * 4, cnt * I * 32, hipMemcpyHostToDevice, st) == hipSuccess;
-        ok = ok && frw::launch_qap_witness_map(r->dev, r->qap, cnt, (const uint64_t *)d_wit, (const uint64_t *)d_inst, (uint64_t *)d_h,
-                                               (uint32_t *)d_bad, d_ws, chunk * per, st) == hipSuccess;
-        ok = ok && hipMemcpyAsync(h + lo * n * 4, d_h, cnt * n * 32, hipMemcpyDeviceToHost, st) == hipSuccess;
-        if (ok && num_unsatisfied)
-            ok = hipMemcpyAsync(num_unsatisfied + lo, d_bad, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess;
-        ok = ok && hipStreamSynchronize(st) == hipSuccess;
-        if (!ok) rc = FRW_E_HIP;
+        if ((e = hipMemcpyAsync(d_wit, witness + lo * W * 4, cnt * W * 32, hipMemcpyHostToDevice, st)) == hipSuccess)
+            e = hipMemcpyAsync(d_inst, instance + lo * I * 4, cnt * I * 32, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess)
+            e = frw::launch_qap_witness_map(r->dev, r->qap, cnt, d_wit, d_inst, d_h, d_bad, d_ws, chunk * per, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h + lo * n * 4, d_h, cnt * n * 32, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && num_unsatisfied)
+            e = hipMemcpyAsync(num_unsatisfied + lo, d_bad, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return frw::record_hip_error(e, "frw_qap_witness_map");
     }
-    for (void *p : {d_wit, d_inst, d_h, d_ws, d_bad})
-        if (p) (void)hipFree(p);
-    (void)hipStreamDestroy(st);
-    return rc;
+    return FRW_OK;
+}
+
+extern "C" int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count)
+{
+    if (!r || !count) return FRW_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(r->arena.mu);
+    *count = r->arena.allocations;
+    return FRW_OK;
 }
 
 extern "C" int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,

@@ -314,9 +314,18 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, s
     }
 }
 
-// `scratch` (optional, at least batch x num_long_vars x 4 bytes): where the small values of the long rows' variables go
-// when the caller has room for them (the QAP entry points lend part of their workspace); otherwise a stream-ordered
-// allocation is made for the duration of the call.
+// Scratch of the evaluation: the small values of the long rows' variables (batch x num_long_vars x 4 bytes) and, when
+// the products are not kept (abc == nullptr), the long rows' results (batch x num_long x 32 bytes).
+size_t r1cs_check_scratch_bytes(const R1csDev &r, size_t batch, bool with_abc)
+{
+    if (!r.num_long) return 0;
+    const size_t zs = (batch * (size_t)r.num_long_vars * sizeof(uint32_t) + 255) & ~(size_t)255;
+    return zs + (with_abc ? 0 : batch * (size_t)r.num_long * 32);
+}
+
+// `caller_scratch` (optional, at least r1cs_check_scratch_bytes): the QAP entry points lend part of their workspace, and
+// frw_r1cs_eval_scratch_dev passes the caller's buffer -- then nothing is allocated and the call is capture-safe.  Without
+// it a stream-ordered allocation is made for the duration of the call (and the slow kernels run should that fail).
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
                              uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st, void *caller_scratch)
 {
@@ -332,9 +341,10 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
     // stream-ordered scratch: the small values of the long rows' variables, and (check only) the long rows' products
     uint32_t *zs = nullptr, *long_out = nullptr;
     bool scratch = true;
-    const bool lent = caller_scratch != nullptr && abc != nullptr;
+    const bool lent = caller_scratch != nullptr;
     if (r.num_long && lent) {
         zs = (uint32_t *)caller_scratch;
+        if (!abc) long_out = (uint32_t *)((char *)caller_scratch + r1cs_check_scratch_bytes(r, batch, true));
     } else if (r.num_long) {
         scratch = hipMallocAsync((void **)&zs, batch * (size_t)r.num_long_vars * sizeof(uint32_t), st) == hipSuccess && zs;
         if (scratch && !abc) scratch = hipMallocAsync((void **)&long_out, batch * (size_t)r.num_long * 32, st) == hipSuccess && long_out;
@@ -358,7 +368,7 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
     }
     const hipError_t e = hipGetLastError();
     if (zs && !lent) (void)hipFreeAsync(zs, st);
-    if (long_out) (void)hipFreeAsync(long_out, st);
+    if (long_out && !lent) (void)hipFreeAsync(long_out, st);
     return e;
 }
 

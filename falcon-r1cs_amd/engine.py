@@ -106,6 +106,16 @@ class WitnessEngine:
 
     __del__ = close
 
+    def host_allocations(self):
+        """Device / page-locked allocations the host-buffer entry points of this context have made so far."""
+        n = C.c_uint64()
+        check(self._lib.frw_diag_host_allocations(self._ctx, C.byref(n)), "frw_diag_host_allocations")
+        return int(n.value)
+
+    def trim(self):
+        """Gives the working memory of the host-buffer entry points back to the device (the next call allocates again)."""
+        check(self._lib.frw_ctx_trim(self._ctx), "frw_ctx_trim")
+
     def pinned_empty(self, shape, dtype):
         """numpy array over page-locked host memory (frw_host_alloc); freed when the array is collected."""
         dtype = np.dtype(dtype)

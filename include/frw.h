@@ -121,10 +121,15 @@ int frw_ntt_modq_dev(frw_ctx *ctx, int logn, size_t batch, const uint16_t *d_pol
                      uint64_t *d_witness, uint16_t *d_ntt_out, int32_t *d_status, void *stream);
 
 /* ---- hot path, host buffers ----------------------------------------------------------------
- * Same results through pageable host memory: H2D of the inputs, the kernels, D2H of the outputs,
- * chunked so that any batch fits the device.  strict != 0 mirrors the reference's non-test
- * build: returns FRW_E_RANGE if any status != FRW_ST_OK (outputs of those signatures must not
- * be used).  strict == 0 mirrors its cfg(test) build (see FRW_ST_NORM_BOUND above).
+ * Same results through host memory (pageable, or page-locked from frw_host_alloc: faster): H2D of the inputs, the
+ * kernels, D2H of the outputs, chunked so that any batch fits the device.  This is the call the reference's own
+ * consumers make -- one signature per generate_constraints (examples/constraint_counts.rs:61-63, pok_sig.rs:24-32) --
+ * so it is built for batch = 1 as much as for 10^5: device buffers, a page-locked staging buffer, streams and events
+ * belong to the context and only grow (a call after the first allocates nothing; frw_diag_host_allocations counts,
+ * frw_ctx_trim gives the memory back), and a batch that fits one chunk is one copy in, one launch, the copies out and
+ * one synchronisation.  Calls on one context are serialised (a mutex); use one context per host thread for concurrency.
+ * strict != 0 mirrors the reference's non-test build: returns FRW_E_RANGE if any status != FRW_ST_OK (outputs of those
+ * signatures must not be used).  strict == 0 mirrors its cfg(test) build (see FRW_ST_NORM_BOUND above).
  * encoding FRW_ENC_COMPACT: `witness` receives batch x bytes_per_signature compact bytes, `instance` may be NULL. */
 int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
                            const uint16_t *sig, const uint16_t *pk, const uint16_t *hm,
@@ -133,6 +138,10 @@ int frw_witness_ntt_verify(frw_ctx *ctx, int logn, size_t batch,
 
 int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int encoding,
                  uint64_t *witness, uint16_t *ntt_out, int32_t *status);
+/* number of device / page-locked allocations the host-buffer entry points of this context have made so far (it stops
+ * growing once the largest batch shape has been seen), and release of everything they hold */
+int frw_diag_host_allocations(frw_ctx *ctx, uint64_t *count);
+int frw_ctx_trim(frw_ctx *ctx);
 
 /* ---- compact encoding (no counterpart in the reference; for GPU-side consumers, the multi-GPU gather and PCIe) ----
  * 140 N + nb of the W witness elements of falcon_ntt.rs:58-122 are booleans, and all but 2 N of the others are integers
@@ -243,12 +252,16 @@ int frw_r1cs_eval_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness
  *                       signatures as fit.
  * Returns FRW_E_INVALID_ARG for a null pointer, a workspace smaller than one signature's, or a domain other than 2^17 /
  * 2^18 (the transform schedule is built for the four Falcon circuits).  Stream-ordered: everything is enqueued on
- * `stream`; the sparse products take a stream-ordered scratch allocation (hipMallocAsync) for the duration of the call. */
+ * `stream` and NOTHING is allocated -- the sparse products borrow the working arrays, idle at that point, as their
+ * scratch -- so a call may be captured in a HIP graph.  A HIP failure is recorded for frw_last_error().
+ * Precondition: every witness / instance element is canonical Montgomery form (limbs < p), which is what arkworks and
+ * the witness entry points produce; the 29-bit evaluation path does not reduce its inputs, so an element >= p gives an
+ * h that is wrong without an error code. */
 typedef struct {
     int32_t log_domain_size;
     uint64_t domain_size;                      /* n */
     uint64_t num_constraints, num_instance;    /* C, I */
-    uint64_t workspace_bytes_per_signature;    /* 3 C x 32 (A z, B z, C z) + 3 x 36 n (working arrays) */
+    uint64_t workspace_bytes_per_signature;    /* 3 C x 32 (A z, B z, C z) + 3 x 32 n (working arrays) */
 } frw_qap_info_t;
 int frw_qap_info(const frw_r1cs *r, frw_qap_info_t *out);
 int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
@@ -265,9 +278,11 @@ int frw_qap_quotient_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witn
                          void *stream);
 /* Host buffers: witness uint64_t[batch][W][4], instance uint64_t[batch][I][4] (the constant one first) -- the bytes of
  * arkworks' witness_assignment / instance_assignment -- to h uint64_t[batch][n][4]; num_unsatisfied may be NULL.
- * Synchronous; device buffers are allocated and freed inside (64 signatures in flight). */
+ * Synchronous; 64 signatures in flight; the device buffers belong to the handle and only grow (a second call of the
+ * same shape allocates nothing: frw_r1cs_diag_host_allocations).  Same canonical-limbs precondition as above. */
 int frw_qap_witness_map(const frw_r1cs *r, size_t batch, const uint64_t *witness, const uint64_t *instance,
                         uint64_t *h, uint32_t *num_unsatisfied);
+int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
 
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),

@@ -101,6 +101,8 @@ extern "C" {
                                   status: *mut i32, strict: c_int) -> c_int;
     pub fn frw_ntt_modq(ctx: *mut frw_ctx, logn: c_int, batch: usize, poly: *const u16, encoding: c_int,
                         witness: *mut u64, ntt_out: *mut u16, status: *mut i32) -> c_int;
+    pub fn frw_diag_host_allocations(ctx: *mut frw_ctx, count: *mut u64) -> c_int;
+    pub fn frw_ctx_trim(ctx: *mut frw_ctx) -> c_int;
     pub fn frw_compact_layout(logn: c_int, out: *mut frw_compact_layout_t) -> c_int;
     pub fn frw_witness_ntt_verify_compact_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_sig: *const u16,
                                               d_pk: *const u16, d_hm: *const u16, d_compact: *mut c_void,
@@ -132,6 +134,7 @@ extern "C" {
                                 stream: *mut c_void) -> c_int;
     pub fn frw_qap_witness_map(r: *const frw_r1cs, batch: usize, witness: *const u64, instance: *const u64, h: *mut u64,
                                num_unsatisfied: *mut u32) -> c_int;
+    pub fn frw_r1cs_diag_host_allocations(r: *const frw_r1cs, count: *mut u64) -> c_int;
     pub fn frw_hash_to_point_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_nonces: *const u8, d_msgs: *const u8,
                                  d_msg_off: *const u64, d_hm: *mut u16, stream: *mut c_void) -> c_int;
     pub fn frw_decode_public_keys_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_pk_bytes: *const u8,

@@ -871,3 +871,42 @@ def test_expand_dev_equals_expand_host_on_random_compact_buffers(engine, logn):
     torch.cuda.synchronize()
     assert np.array_equal(wit.cpu().numpy().view(np.uint64), hw)
     assert np.array_equal(inst.cpu().numpy().view(np.uint64), hi)
+
+
+@pytest.mark.gpu
+def test_one_signature_per_call_like_the_reference_and_no_allocation_after_the_first(oracle):
+    """The reference's consumers call generate_constraints once per signature (examples/constraint_counts.rs:61-63,
+    pok_sig.rs:24-32): the host-buffer entry point with batch = 1, again and again, interleaved with other shapes (a
+    long two-slot batch, the dual circuit, ntt_circuit alone, the compact form).  Every call == the oracle; the context's
+    working memory grows while new shapes arrive and then never again."""
+    import falcon_r1cs_amd as frw
+    eng = frw.WitnessEngine(0)                     # a context of its own: the counter starts at zero
+    assert eng.host_allocations() == 0
+    sig, pk, hm = frw.synth_triples(10, 300, seed=4242)
+    want = oracle.witness_ntt_verify(10, sig, pk, hm, 1)
+
+    def one_round():
+        for i in (0, 1, 299):
+            w, ins, st = eng.witness_ntt_verify(10, sig[i:i + 1], pk[i:i + 1], hm[i:i + 1])
+            assert np.array_equal(w[0], want[0][i]) and np.array_equal(ins[0], want[1][i]) and st[0] == 0
+        w, ins, st = eng.witness_ntt_verify(10, sig, pk, hm)                 # 300 > 256: two slots, two streams
+        assert np.array_equal(w, want[0]) and np.array_equal(ins, want[1]) and not st.any()
+        comp, st = eng.witness_ntt_verify_compact(10, sig[:3], pk[:3], hm[:3])
+        w2, i2 = eng.expand_host(10, comp)
+        assert np.array_equal(w2, want[0][:3]) and np.array_equal(i2, want[1][:3])
+        wd, _, st = eng.witness_dual_ntt_verify(9, sig[:2, :512], pk[:2, :512], hm[:2, :512], strict=False)
+        od = oracle.witness_dual_ntt_verify(9, sig[:2, :512], pk[:2, :512], hm[:2, :512], 1)
+        assert np.array_equal(wd, od[0]) and np.array_equal(st, od[2])
+        wn, on, st = eng.ntt_modq(9, sig[:5, :512])
+        ow, oo = oracle.ntt_modq(9, sig[:5, :512], 1)[:2]
+        assert np.array_equal(wn, ow) and np.array_equal(on, oo)
+    one_round()
+    grown = eng.host_allocations()
+    assert 1 <= grown <= 8
+    for _ in range(3):
+        one_round()
+    assert eng.host_allocations() == grown, "a host-buffer call allocated after every shape had been seen"
+    eng.trim()
+    w, ins, st = eng.witness_ntt_verify(10, sig[:1], pk[:1], hm[:1])         # usable after a trim
+    assert np.array_equal(w[0], want[0][0]) and eng.host_allocations() > grown
+    eng.close()
