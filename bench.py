@@ -813,6 +813,10 @@ def main():
         for name, cnt in (("full_size_launch", chunk), ("remainder_launch", last_cnt if last_cnt != chunk else 0)):
             if cnt:
                 sh = eng.launch_shape(logn, cnt)
+                want = frw.MI355X_BENCH_LAUNCH_SHAPES.get((logn, cnt))
+                if want is not None and sh["cus"] == 256:
+                    # the shape tests/test_gpu_parity.py::test_benchmark_launch_shape_is_checked covers, not a look-alike
+                    assert (sh["grid"], sh["split_signatures"]) == want, (sh, want)
                 checked[name] = {"signatures": cnt, "grid": sh["grid"], "resident_workgroups_per_cu": sh["resident_per_cu"],
                                  "rounds": round(cnt / max(1, sh["grid"]), 2), "split_signatures": sh["split_signatures"]}
     r1cs = None

@@ -38,7 +38,7 @@ class CompactLayoutStruct(C.Structure):
                 ("small_off", C.c_uint64), ("num_small", C.c_uint64), ("t_off", C.c_uint64), ("num_t", C.c_uint64),
                 ("bits_off", C.c_uint64),
                 ("num_bit_words", C.c_uint64), ("bit_seg_off", C.c_uint64 * 6), ("instance_off", C.c_uint64),
-                ("num_instance_values", C.c_uint64)]
+                ("num_instance_values", C.c_uint64), ("status_off", C.c_uint64)]
 
 
 class QapInfoStruct(C.Structure):
@@ -81,6 +81,9 @@ PROTOTYPES = {
     "frw_r1cs_free": (None, [C.c_void_p]),
     "frw_r1cs_check_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_r1cs_eval_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_r1cs_eval_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int]),
+    "frw_r1cs_eval_scratch_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_size_t, C.c_void_p]),
     "frw_qap_info": (C.c_int, [C.c_void_p, C.POINTER(QapInfoStruct)]),
     "frw_qap_witness_map": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_qap_quotient_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

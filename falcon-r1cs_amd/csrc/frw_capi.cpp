@@ -336,6 +336,7 @@ int frw_compact_layout(int logn, frw_compact_layout_t *out)
     out->bit_seg_off[5] = 4 * seg + 32 * n;
     out->instance_off = c.instance_off;
     out->num_instance_values = c.num_instance;
+    out->status_off = c.status_off;
     return FRW_OK;
 }
 
@@ -423,6 +424,11 @@ int frw_expand_host(int logn, size_t batch, const void *compact, uint64_t *witne
         const uint32_t *ins = (const uint32_t *)(base + c.instance_off);
         size_t bit = 0;
         uint64_t *w = witness + s * W * 4, *in = instance + s * I * 4;
+        if (*(const uint32_t *)(base + c.status_off) == (uint32_t)FRW_ST_COEFF_RANGE) {   // rejected: zeros, as the direct path
+            memset(w, 0, W * 32);
+            memset(in, 0, I * 32);
+            continue;
+        }
         auto value = [&](int count) {
             for (int i = 0; i < count; i++, w += 4) {
                 const uint64_t x[3] = {*small++, 0, 0};

@@ -27,11 +27,14 @@ struct Tables {
 // uint32_t (witness order: sig, v, then the b of S3, the b of S4, [prod, t, c] of S5, [r, sq] of S6), the 2 N quotients t
 // of the two ntt_circuits as 5 x uint32_t little-endian limbs (S3's, then S4's) -- the 140 N + nb boolean elements as a bit
 // array (witness order: S2, the boolean parts of S3, S4, S5, S6, then S7 in two words), and the 2 N instance values as
-// uint32_t (without the leading one).  110 KB instead of 5.08 MB per Falcon-1024 signature; frw_expand_dev rebuilds the
-// arkworks buffers (Montgomery form) from it.
+// uint32_t (without the leading one), then one status word (FRW_ST_*: a receiver of a gathered chunk has no other way to
+// learn that a signature was rejected) and zero padding up to the 128-byte stride.  110 KB instead of 5.08 MB per
+// Falcon-1024 signature; frw_expand_dev rebuilds the arkworks buffers (Montgomery form) from it.  Every byte of a record
+// is written by the producer (the padding as zeros): the wire format is deterministic.
 struct CompactLayout {
     size_t num_small, t_off, num_t, bits_off, bit_words, instance_off, num_instance, bytes;
     size_t seg_words;      // bit words of one enforce_less_than_q segment (27 N / 32)
+    size_t status_off;     // the status word, right after the instance values
 };
 constexpr CompactLayout compact_layout(int logn)
 {
@@ -45,7 +48,8 @@ constexpr CompactLayout compact_layout(int logn)
     c.bit_words = 4 * c.seg_words + n + 2;
     c.instance_off = c.bits_off + (c.bit_words * 4 + 15) / 16 * 16;
     c.num_instance = 2 * n;
-    c.bytes = (c.instance_off + c.num_instance * 4 + 127) / 128 * 128;
+    c.status_off = c.instance_off + c.num_instance * 4;
+    c.bytes = (c.status_off + 4 + 127) / 128 * 128;
     return c;
 }
 

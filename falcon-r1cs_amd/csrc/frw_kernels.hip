@@ -8,9 +8,9 @@
 // (sig, pk, hm); this file evaluates it for a batch, one workgroup (4 wavefronts) per signature.
 //
 // Shape of the work: 6 KB of input becomes 5.0 MB of output per Falcon-1024 signature, 91 % of it
-// field elements that are 0 or 1.  The kernel is an HBM write stream (measured in round 2: 0.98-1.01 of a
-// compute-free write stream on the same device, 6.5-6.7 TB/s = 0.81-0.84 of the 8 TB/s spec, HBM traffic =
-// 1.0002 x the algorithmic bytes); the integer work (mod-q NTTs, the un-reduced 160-bit butterfly ladder, short
+// field elements that are 0 or 1.  The kernel is an HBM write stream (measured in round 2, driver's box: 1.00 of a
+// compute-free write stream on the same device, 6.85 TB/s = 0.86 of the 8 TB/s spec -- 0.79-0.86 over the boxes of the
+// pool --, HBM traffic = 1.0005 x the algorithmic bytes); the integer work (mod-q NTTs, the un-reduced 160-bit butterfly ladder, short
 // divisions, Montgomery conversions, the tile writer's 3 vector instructions per store) lives in LDS/registers
 // and overlaps with the stores of the other resident wavefronts.  No MFMA: nothing here is GEMM-shaped.
 //
@@ -734,9 +734,15 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         lds_barrier();
         if (sm.bad) {                                    // uniform across the workgroup
             if (tid == 0 && does(2)) g_status[s] = ST_COEFF_RANGE;
-            if (does(0)) {
-                if constexpr (COMPACT) zero_fill((v4u *)cbase, CL.bytes / 16, tid);
-                else { zero_fill(wit, W * 2, tid); zero_fill(inst, I * 2, tid); }
+            if constexpr (COMPACT) {
+                // all zeros, except that the record says why: the status word travels with it (item 0 clears the data, item
+                // 2 owns the tail, as for an accepted signature -- two workgroups may be at work on a split signature)
+                static_assert(CL.status_off % 16 == 0 && (CL.bytes - CL.status_off) % 4 == 0, "compact tail");
+                if (does(0)) zero_fill((v4u *)cbase, CL.status_off / 16, tid);
+                if (does(2) && tid < (int)((CL.bytes - CL.status_off) / 4))
+                    ((uint32_t *)(cbase + CL.status_off))[tid] = tid == 0 ? (uint32_t)ST_COEFF_RANGE : 0u;
+            } else if (does(0)) {
+                zero_fill(wit, W * 2, tid); zero_fill(inst, I * 2, tid);
             }
             lds_barrier();
             continue;
@@ -842,8 +848,15 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
         if (wave == 0 && does(2)) {
             const unsigned long long norm = sm.norm;
             const unsigned long long nm = LOGN == 9 ? norm_mask_512(norm) : norm_mask_1024(norm);
+            const int32_t verdict = norm >= (LOGN == 9 ? 34034726ull : 70265242ull) ? ST_NORM_BOUND : ST_OK;
             if constexpr (COMPACT) {
-                if (lane < 2) cb[4 * CL.seg_words + N + lane] = (uint32_t)(nm >> (32 * lane));
+                // the two words of S7, then zeros up to the instance values; the status word and zeros up to the stride:
+                // no byte of a record is left as it was found
+                constexpr int GAP = (int)((CL.instance_off - CL.bits_off) / 4 - CL.bit_words);
+                constexpr int TAIL = (int)((CL.bytes - CL.status_off) / 4);
+                static_assert(2 + GAP <= WAVE && TAIL <= WAVE, "compact padding is written by one wave");
+                if (lane < 2 + GAP) cb[4 * CL.seg_words + N + lane] = lane < 2 ? (uint32_t)(nm >> (32 * lane)) : 0u;
+                if (lane < TAIL) ((uint32_t *)(cbase + CL.status_off))[lane] = lane == 0 ? (uint32_t)verdict : 0u;
             } else {
             constexpr uint32_t R[8] = FRW_R32;
             const int half = lane & 1;
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(BLOCK) void witness_ntt_verify_kernel(
                 o[c] = (nm >> pos) & 1ull ? one : mk4(0, 0, 0, 0);
             }
             }
-            if (lane == 0) g_status[s] = norm >= (LOGN == 9 ? 34034726ull : 70265242ull) ? ST_NORM_BOUND : ST_OK;
+            if (lane == 0) g_status[s] = verdict;
         }
 
         // ---- 4./5. ladders: S3 = mod_q blocks of NTT(sig), S4 = of NTT(v)                   :88-91
@@ -1189,6 +1202,13 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(size_t batch, const unsig
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(wit, (uint32_t)(W * 32));
         const __amdgpu_buffer_rsrc_t ri = make_rsrc(inst, (uint32_t)(I * 32));
         uint32_t e8[8];
+        // a rejected signature (FRW_ST_COEFF_RANGE in the record's status word) expands to what the direct kernel leaves for
+        // it: zeros in the witness AND the instance vector (no leading one) -- workgroup-uniform
+        if (*(const uint32_t *)(cbase + CL.status_off) == (uint32_t)ST_COEFF_RANGE) {
+            zero_fill(wit, W * 2, tid);
+            zero_fill(inst, I * 2, tid);
+            continue;
+        }
         // Every loop below keeps the loads of its NEXT tile in flight while the current tile is emitted (58 stores): under
         // a saturated write stream an HBM read takes long enough that four waves per SIMD do not hide it otherwise
         // (measured: +5 % from over-subscribing the grid before this was done, tools/ab_variants.py --workload expand).

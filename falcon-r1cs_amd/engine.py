@@ -60,6 +60,14 @@ class CompactLayout:
     bit_seg_off: tuple
     instance_off: int
     num_instance_values: int
+    status_off: int
+
+
+# Launch shapes of the two launches bench.py times on an MI355X (256 CUs, 3 resident workgroups per CU, 4x
+# over-subscription): (logn, signatures per launch) -> (grid, signatures beyond the last full round, cut into five work
+# items each).  bench.py asserts its timed launches against this table and tests/test_gpu_parity.py asserts the table
+# against the library, so the benchmark, its test and their descriptions cannot drift apart again.
+MI355X_BENCH_LAUNCH_SHAPES = {(10, 32768): (3072, 2048), (9, 8192): (2048, 0)}
 
 
 def compact_layout(logn) -> CompactLayout:
@@ -68,7 +76,7 @@ def compact_layout(logn) -> CompactLayout:
     s = CompactLayoutStruct()
     check(load_library().frw_compact_layout(int(logn), C.byref(s)), "frw_compact_layout")
     return CompactLayout(s.logn, s.n, s.bytes_per_signature, s.small_off, s.num_small, s.t_off, s.num_t, s.bits_off, s.num_bit_words,
-                         tuple(s.bit_seg_off), s.instance_off, s.num_instance_values)
+                         tuple(s.bit_seg_off), s.instance_off, s.num_instance_values, s.status_off)
 
 
 def synth_triples(logn, batch, seed=0x46414C434F4E, first_index=0):
@@ -324,6 +332,16 @@ class WitnessEngine:
         check(self._lib.frw_r1cs_eval_dev(handle, batch, self._ptr(d_wit), self._ptr(d_inst),
                                           self._ptr(d_num_unsatisfied), self._ptr(d_abc), C.c_void_p(stream)),
               "frw_r1cs_eval_dev")
+
+    def r1cs_eval_scratch_bytes(self, handle, batch, with_products):
+        return int(self._lib.frw_r1cs_eval_scratch_bytes(handle, batch, 1 if with_products else 0))
+
+    def r1cs_eval_scratch_dev(self, handle, batch, d_wit, d_inst, d_num_unsatisfied, d_abc, d_scratch, scratch_bytes, stream=0):
+        """frw_r1cs_eval_dev / frw_r1cs_check_dev (d_abc=None) with the caller's scratch: allocates nothing, capture-safe."""
+        check(self._lib.frw_r1cs_eval_scratch_dev(handle, batch, self._ptr(d_wit), self._ptr(d_inst), self._ptr(d_num_unsatisfied),
+                                                  self._ptr(d_abc) if d_abc is not None else None,
+                                                  self._ptr(d_scratch) if d_scratch is not None else None, scratch_bytes,
+                                                  C.c_void_p(stream)), "frw_r1cs_eval_scratch_dev")
 
     def qap_info(self, handle):
         """Domain of the QAP witness map for the loaded matrices: (log n, n, C, I, workspace bytes per signature)."""

@@ -156,10 +156,14 @@ int frw_ctx_trim(frw_ctx *ctx);
  *                               blocks of the S3, S4, S5 segments (27 N each), the 16 booleans of every l2-norm element
  *                               (32 N), and the norm-bound block (50 | 52 bits, in two words of their own)
  *   instance  2 N x uint32_t    pk_ntt, hm_ntt (the leading constant one is implied)
+ *   status    uint32_t          FRW_ST_* of this signature, then zeros up to the stride: a record tells its receiver (the
+ *                               other end of an all-gather, say) that the signature was rejected
  * = 112,256 bytes per Falcon-1024 signature instead of 5,080,736.  frw_expand_dev / frw_expand_host rebuild, bit for bit,
  * the buffers frw_witness_ntt_verify_dev(..., FRW_ENC_MONTGOMERY, ...) writes (x -> x * 2^256 mod p for the values, 0 / the
  * Montgomery form of 1 for the booleans); a Rust host can equally build its Vec<Fr> with Fr::from(u64) / from limbs.
- * A signature with FRW_ST_COEFF_RANGE is all zeros. */
+ * A signature with FRW_ST_COEFF_RANGE is all zeros but for its status word, and expands to what the direct entry point
+ * leaves for it: zeros in the witness and in the instance vector (no leading one).  The producer writes every byte of a
+ * record (padding as zeros), so equal inputs give equal bytes. */
 #define FRW_ENC_COMPACT     2
 typedef struct frw_compact_layout {
     int32_t logn, n;
@@ -169,6 +173,7 @@ typedef struct frw_compact_layout {
     uint64_t bits_off, num_bit_words; /* byte offset and number of uint32_t words of the bit array */
     uint64_t bit_seg_off[6];          /* first bit of S2, S3, S4, S5, S6, S7 booleans inside the bit array */
     uint64_t instance_off, num_instance_values;
+    uint64_t status_off;              /* byte offset of the status word (= instance_off + 4 x num_instance_values) */
 } frw_compact_layout_t;
 int frw_compact_layout(int logn, frw_compact_layout_t *out);
 /* d_compact: batch x bytes_per_signature bytes, 16-byte aligned.  Same statuses as frw_witness_ntt_verify_dev. */
@@ -233,9 +238,18 @@ int frw_r1cs_check_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witnes
                        uint32_t *d_num_unsatisfied, void *stream);
 /* Same pass, additionally writing the three matrix-vector products a prover's QAP witness map starts from (what
  * ark-groth16 computes on the CPU right after generate_constraints, examples/pok_sig.rs:32):
- * d_abc = uint64_t[batch][3][C][4] = A z, B z, C z per signature, Montgomery form, rows in constraint order. */
+ * d_abc = uint64_t[batch][3][C][4] = A z, B z, C z per signature, Montgomery form, rows in constraint order.
+ * frw_r1cs_check_dev and frw_r1cs_eval_dev take a stream-ordered scratch allocation (hipMallocAsync / hipFreeAsync on
+ * `stream`) per call -- they are NOT stream-capture safe -- and run slower kernels should that allocation fail.  The
+ * _scratch_ variant below is the same computation with the caller's scratch: no allocation, one fixed kernel sequence. */
 int frw_r1cs_eval_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
                       uint32_t *d_num_unsatisfied, uint64_t *d_abc, void *stream);
+/* d_scratch: at least frw_r1cs_eval_scratch_bytes(r, batch, d_abc != NULL) bytes, 16-byte aligned (may be NULL when
+ * that is 0).  d_abc may be NULL (check only). */
+size_t frw_r1cs_eval_scratch_bytes(const frw_r1cs *r, size_t batch, int with_products);
+int frw_r1cs_eval_scratch_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                              uint32_t *d_num_unsatisfied, uint64_t *d_abc, void *d_scratch, size_t scratch_bytes,
+                              void *stream);
 
 /* ---- QAP witness map (the step after the hot path in a Groth16 prover) ------------------------------------------
  * examples/pok_sig.rs:30-47 hands the circuit to Groth16::<Bls12_381>::prove; after generate_constraints the prover's

@@ -63,6 +63,7 @@ pub struct frw_compact_layout_t {
     pub bit_seg_off: [u64; 6],
     pub instance_off: u64,
     pub num_instance_values: u64,
+    pub status_off: u64,
 }
 
 #[repr(C)]
@@ -125,6 +126,10 @@ extern "C" {
                               d_num_unsatisfied: *mut u32, stream: *mut c_void) -> c_int;
     pub fn frw_r1cs_eval_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
                              d_num_unsatisfied: *mut u32, d_abc: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn frw_r1cs_eval_scratch_bytes(r: *const frw_r1cs, batch: usize, with_products: c_int) -> usize;
+    pub fn frw_r1cs_eval_scratch_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
+                                     d_num_unsatisfied: *mut u32, d_abc: *mut u64, d_scratch: *mut c_void,
+                                     scratch_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_qap_info(r: *const frw_r1cs, out: *mut frw_qap_info_t) -> c_int;
     pub fn frw_qap_witness_map_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
                                    d_h: *mut u64, d_num_unsatisfied: *mut u32, d_workspace: *mut c_void,

@@ -193,7 +193,8 @@ class CompactLayoutPy:
         self.bit_seg_off = (0, 27 * n, 54 * n, 81 * n, 108 * n, 140 * n)
         self.instance_off = self.bits_off + (4 * self.num_bit_words + 15) // 16 * 16
         self.num_instance_values = 2 * n
-        self.bytes_per_signature = (self.instance_off + 4 * self.num_instance_values + 127) // 128 * 128
+        self.status_off = self.instance_off + 4 * self.num_instance_values
+        self.bytes_per_signature = (self.status_off + 4 + 127) // 128 * 128
 
 
 P_FR = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
@@ -205,10 +206,11 @@ def _from_montgomery(limbs4):
     return x * R_INV % P_FR
 
 
-def compact_from_witness(logn, wit, inst, CL=None):
+def compact_from_witness(logn, wit, inst, CL=None, status=0):
     """FRW_ENC_COMPACT restated as a re-layout of one arkworks witness/instance pair (uint64 [W,4] / [I,4], Montgomery):
     the non-boolean elements as plain integers (11 N of them as uint32, the 2 N mod_q quotients as 5 x uint32), the boolean
-    elements as a bit array in witness order, the instance values without the leading one as uint32 (include/frw.h).
+    elements as a bit array in witness order, the instance values without the leading one as uint32, the status word
+    (include/frw.h); everything else zero.
     CL = falcon_r1cs_amd.compact_layout(logn), or None for the restated layout above.  Returns bytes."""
     CL = CL or CompactLayoutPy(logn)
     n = 1 << logn
@@ -246,4 +248,5 @@ def compact_from_witness(logn, wit, inst, CL=None):
     out[CL.bits_off: CL.bits_off + 4 * len(allw)] = allw.view(np.uint8)
     iv = np.array([_from_montgomery(inst[i]) for i in range(1, 2 * n + 1)], dtype=np.uint32)
     out[CL.instance_off: CL.instance_off + iv.nbytes] = iv.view(np.uint8)
+    out[CL.status_off: CL.status_off + 4] = np.array([status], dtype=np.uint32).view(np.uint8)
     return out.tobytes()

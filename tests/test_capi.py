@@ -108,7 +108,7 @@ def test_expand_host_inverts_the_compact_relayout(oracle):
         assert CL.bytes_per_signature % 128 == 0 and CL.num_small == 11 << logn and CL.num_t == 2 << logn
         py = T.CompactLayoutPy(logn)
         for f in ("bytes_per_signature", "small_off", "num_small", "t_off", "num_t", "bits_off", "num_bit_words",
-                  "bit_seg_off", "instance_off", "num_instance_values"):
+                  "bit_seg_off", "instance_off", "num_instance_values", "status_off"):
             assert getattr(CL, f) == getattr(py, f), f
         sig, pk, hm = frw.synth_triples(logn, 3, seed=77)
         wit, inst, st = oracle.witness_ntt_verify(logn, sig, pk, hm, 1)

@@ -651,12 +651,16 @@ def _r1cs_all_satisfied(engine, circuit, logn, wit, inst):
 
 @pytest.mark.parametrize("logn,batch", [(10, 32768), (9, 8192)])
 def test_benchmark_launch_shape_is_checked(engine, oracle, logn, batch):
-    """The launch shapes bench.py times (BASELINE configs[2]: 32,768 Falcon-1024 signatures per launch = persistent grid at
-    its residency cap, 42 full rounds of static striding + 512 signatures cut into five work items each; and the
-    Falcon-512 launch of its `secondary` block, 8,192 signatures = 10 rounds + 512 split):
+    """The launch shapes bench.py times (BASELINE configs[2]: 32,768 Falcon-1024 signatures per launch = 3,072 workgroups
+    -- 4 x the 768 resident ones -- x 10 full rounds of static striding + 2,048 signatures cut into five work items each;
+    and the Falcon-512 launch of its `secondary` block, 8,192 signatures = 2,048 workgroups x 4 rounds, no split tail;
+    frw.MI355X_BENCH_LAUNCH_SHAPES, which bench.py asserts its own launches against):
     every witness of the launch satisfies the independently emitted constraint system on the device
     (falcon_ntt.rs:159), a strided sample of 256 + the last one equals the oracle's witness by digest, all statuses OK."""
     import falcon_r1cs_amd as frw
+    shape = engine.launch_shape(logn, batch)
+    assert (shape["grid"], shape["split_signatures"]) == frw.MI355X_BENCH_LAUNCH_SHAPES[(logn, batch)]
+    assert (shape["cus"], shape["resident_per_cu"]) == (256, 3)
     sig, pk, hm = frw.synth_triples(logn, batch, seed=0xBE7C4 + logn)
     wit, inst, st, dig = _launch_and_digest(engine, logn, sig, pk, hm)
     assert int((st != 0).sum()) == 0
@@ -703,7 +707,7 @@ def test_config2_full_size_ntt_modq_all_digests(engine, oracle):
 def test_rejected_signatures_scattered_through_a_large_batch(engine, oracle, logn, dual):
     """range_proofs.rs:57-60 under load: ~30 % of a batch much larger than the persistent grid carries a coefficient >= q
     at a random place in sig, pk or hm, so every workgroup meets rejected items followed by good ones (static striding
-    at Falcon-512, the work queue at Falcon-1024).  Statuses equal the oracle's, every accepted witness and instance is
+    over whole signatures, then the split tail).  Statuses equal the oracle's, every accepted witness and instance is
     digest-equal to the oracle's, every rejected slot is zero-filled."""
     import falcon_r1cs_amd as frw
     batch = 2400 if not (dual and logn == 10) else 1536
@@ -739,8 +743,9 @@ def test_rejected_signatures_scattered_through_a_large_batch(engine, oracle, log
 @pytest.mark.parametrize("logn", [9, 10])
 def test_compact_encoding_matches_relayout_of_oracle_witness(engine, oracle, logn):
     """FRW_ENC_COMPACT straight from the kernel == the oracle's arkworks witness re-laid out on the host (values as plain
-    integers in witness order, booleans as a bit array, instance without the leading one), byte for byte; a rejected signature is
-    all zeros; and frw_expand_dev turns the compact buffer back into exactly the oracle's witness / instance bytes."""
+    integers in witness order, booleans as a bit array, instance without the leading one, status word, zero padding), byte for
+    byte; a rejected signature is all zeros but for its status word; and frw_expand_dev / frw_expand_host turn the compact buffer
+    back into exactly the bytes of the direct launch -- the oracle's witness / instance, zeros for the rejected signature."""
     import torch
     import falcon_r1cs_amd as frw
     dev = torch.device("cuda:0")
@@ -762,17 +767,32 @@ def test_compact_encoding_matches_relayout_of_oracle_witness(engine, oracle, log
     owit, oinst, ost = oracle.witness_ntt_verify(logn, sig, pk, hm, 1)
     assert st.cpu().numpy().tolist() == ost.tolist() == [0, 0, 0, 0, 2, 0, 0, 1, 0]
     got = comp.cpu().numpy()
-    used = CL.instance_off + CL.num_instance_values * 4
+    # the direct (FRW_ENC_MONTGOMERY) launch over the same batch: what an expansion must reproduce, rejected slot included
+    dwit, dinst = torch.full_like(wit, 0x77), torch.full_like(inst, 0x77)
+    dst = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    engine.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], dwit, dinst, dst, 1, s0)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, st)
     for i in range(batch):
         if ost[i] == 1:
-            assert not got[i].any()
+            # all zeros but for the status word (the record itself says "rejected"); the expansion is all zeros too --
+            # no leading one in the instance vector -- exactly like the direct output
+            assert np.frombuffer(got[i, CL.status_off:CL.status_off + 4].tobytes(), dtype=np.uint32)[0] == 1
+            rest = got[i].copy()
+            rest[CL.status_off:CL.status_off + 4] = 0
+            assert not rest.any()
+            assert not wit[i].any() and not inst[i].any()
+            assert torch.equal(wit[i], dwit[i]) and torch.equal(inst[i], dinst[i])
             continue
-        want = np.frombuffer(T.compact_from_witness(logn, owit[i], oinst[i], CL), dtype=np.uint8)
-        bits_end = CL.bits_off + 4 * CL.num_bit_words                 # then alignment padding up to instance_off
-        assert np.array_equal(got[i, :bits_end], want[:bits_end]), i
-        assert np.array_equal(got[i, CL.instance_off:used], want[CL.instance_off:used]), i
+        # the buffer was pre-filled with 0x5A: the producer writes EVERY byte of a record, padding included
+        want = np.frombuffer(T.compact_from_witness(logn, owit[i], oinst[i], CL, status=int(ost[i])), dtype=np.uint8)
+        assert np.array_equal(got[i], want), i
         assert np.array_equal(wit[i].cpu().numpy().view(np.uint64), owit[i]), i
         assert np.array_equal(inst[i].cpu().numpy().view(np.uint64), oinst[i]), i
+    assert torch.equal(wit, dwit) and torch.equal(inst, dinst)
+    # the same through host memory: frw_expand_host of the records == the direct output, rejected slot included
+    hw, hi = engine.expand_host(logn, got)
+    assert np.array_equal(hw, dwit.cpu().numpy().view(np.uint64)) and np.array_equal(hi, dinst.cpu().numpy().view(np.uint64))
 
 
 def test_expand_of_compact_equals_direct_output_full_launch(engine):
@@ -811,7 +831,7 @@ def test_expand_of_compact_equals_direct_output_full_launch(engine):
         CL, L = frw.compact_layout(logn), frw.layout(logn)
         arrs = [np.frombuffer(bytes.fromhex(fx[k]), dtype=np.uint16).reshape(1, -1) for k in ("sig", "pk", "hm")]
         d = [torch.from_numpy(a.view(np.int16).copy()).to(dev) for a in arrs]
-        comp = torch.empty((1, CL.bytes_per_signature), dtype=torch.uint8, device=dev)
+        comp = torch.full((1, CL.bytes_per_signature), 0xA5, dtype=torch.uint8, device=dev)
         st = torch.zeros(1, dtype=torch.int32, device=dev)
         wit = torch.empty((1, L.num_witness, 4), dtype=torch.int64, device=dev)
         inst = torch.empty((1, L.num_instance, 4), dtype=torch.int64, device=dev)
@@ -820,10 +840,8 @@ def test_expand_of_compact_equals_direct_output_full_launch(engine):
         torch.cuda.synchronize()
         assert hashlib.sha256(wit.cpu().numpy().tobytes()).hexdigest() == fx["witness_sha256"]["montgomery"]
         assert hashlib.sha256(inst.cpu().numpy().tobytes()).hexdigest() == fx["instance_sha256"]["montgomery"]
-        # the compact bytes themselves (padding zeroed: the kernel does not write it)
+        # the compact bytes themselves, as the kernel wrote them (every byte of a record is written)
         got = comp[0].cpu().numpy().copy()
-        got[CL.bits_off + 4 * CL.num_bit_words: CL.instance_off] = 0
-        got[CL.instance_off + 4 * CL.num_instance_values:] = 0
         assert len(got) == fx["compact_bytes"] and hashlib.sha256(got.tobytes()).hexdigest() == fx["compact_sha256"]
 
 
@@ -910,3 +928,53 @@ def test_one_signature_per_call_like_the_reference_and_no_allocation_after_the_f
     w, ins, st = eng.witness_ntt_verify(10, sig[:1], pk[:1], hm[:1])         # usable after a trim
     assert np.array_equal(w[0], want[0][0]) and eng.host_allocations() > grown
     eng.close()
+
+
+@pytest.mark.gpu
+def test_r1cs_eval_with_caller_scratch_equals_the_allocating_entry_points_and_is_capturable(engine):
+    """frw_r1cs_eval_scratch_dev: the same counts and the same A z, B z, C z as frw_r1cs_check_dev / frw_r1cs_eval_dev, from
+    the caller's scratch -- nothing allocated, so the call can sit inside a captured HIP graph and be replayed."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    logn, batch = 9, 96
+    L = frw.layout(logn)
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=909)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.empty(batch, dtype=torch.int32, device=dev)
+    engine.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, 0)
+    wit[5, 2 * L.n + 3, 0] += 1                                   # one violated signature
+    wit[77, L.seg_off[3], 0] += 1
+    h = engine.r1cs_load(0, logn)
+    try:
+        want_bad = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        want_abc = torch.zeros((batch, 3, L.num_constraints, 4), dtype=torch.int64, device=dev)
+        engine.r1cs_eval_dev(h, batch, wit, inst, want_bad, want_abc, 0)
+        torch.cuda.synchronize()
+        assert set(torch.nonzero(want_bad).flatten().tolist()) == {5, 77}
+        for with_abc in (False, True):
+            need = engine.r1cs_eval_scratch_bytes(h, batch, with_abc)
+            assert need > 0
+            scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+            bad = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+            abc = torch.zeros_like(want_abc) if with_abc else None
+            with pytest.raises(frw.FrwError):
+                engine.r1cs_eval_scratch_dev(h, batch, wit, inst, bad, abc, scratch, need - 1, 0)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                engine.r1cs_eval_scratch_dev(h, batch, wit, inst, bad, abc, scratch, need, side.cuda_stream)   # warm-up
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                engine.r1cs_eval_scratch_dev(h, batch, wit, inst, bad, abc, scratch, need, side.cuda_stream)
+            bad.fill_(-1)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(bad, want_bad)
+            if with_abc:
+                assert torch.equal(abc, want_abc)
+    finally:
+        engine.r1cs_free(h)
