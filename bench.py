@@ -307,6 +307,34 @@ def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps, logn=None, cpu_triple=
     return out
 
 
+def time_host_call(eng, logn, reps=200):
+    """The call the reference's consumers make: ONE signature per generate_constraints (examples/constraint_counts.rs:61-63,
+    pok_sig.rs:24-32), host buffers in and out (frw_witness_ntt_verify, batch = 1).  Median wall time per call, PCIe
+    included; the context's working memory must not grow while it runs."""
+    import ctypes as C
+    import statistics
+    L, CL = frw.layout(logn), frw.compact_layout(logn)
+    sig, pk, hm = frw.synth_triples(logn, 1, SEED, 1 << 42)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib, ctx = eng._lib, eng._ctx
+    wit, inst = eng.pinned_empty((1, L.num_witness, 4), np.uint64), eng.pinned_empty((1, L.num_instance, 4), np.uint64)
+    comp, st = eng.pinned_empty((1, CL.bytes_per_signature), np.uint8), eng.pinned_empty((1,), np.int32)
+    out = {"workload": "frw_witness_ntt_verify, batch = 1, Falcon-%d, host buffers (page-locked outputs), strict" % L.n}
+    for name, call in (("arkworks_layout", lambda: lib.frw_witness_ntt_verify(ctx, logn, 1, P(sig), P(pk), P(hm), 1, P(wit), P(inst), P(st), 1)),
+                       ("compact", lambda: lib.frw_witness_ntt_verify(ctx, logn, 1, P(sig), P(pk), P(hm), 2, P(comp), None, P(st), 1))):
+        for _ in range(5):
+            assert call() == 0
+        a0, ts = eng.host_allocations(), []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            call()
+            ts.append(time.perf_counter() - t0)
+        assert eng.host_allocations() == a0, "the host-buffer entry point allocated after its first call"
+        out[name] = {"median_us_per_call": round(statistics.median(ts) * 1e6, 1), "best_us_per_call": round(min(ts) * 1e6, 1),
+                     "calls_timed": reps, "allocations_during_the_timed_calls": 0}
+    return out
+
+
 def time_aggregate(eng, dev, total, reps, threads):
     """BASELINE configs[4] shape on one GPU: one aggregate statement of `total` signatures, Falcon-512 and Falcon-1024
     mixed (parameter set drawn from the seed), = one engine launch per parameter set (the reference's
@@ -959,6 +987,7 @@ def main():
                 "compact_encoding_falcon%d" % n: time_compact(eng, dev, logn, chunk, 4, 1, (d_sig, d_pk, d_hm), d_wit)}
             if qap_result is not None:
                 result["secondary"]["qap_witness_map_falcon%d" % n] = qap_result
+            result["secondary"]["host_call_one_signature_falcon%d" % n] = time_host_call(eng, logn)
             if not args.no_aggregate:
                 result["secondary"]["aggregate_1024_mixed"] = time_aggregate(eng, dev, 1024, 50, threads)
                 result["secondary"]["input_preparation_falcon%d" % n] = time_prepare(eng, dev, logn, 65536, 5, 1)
