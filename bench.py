@@ -258,6 +258,41 @@ def qap_cpu_port(logn, triple, gpu_h0):
                     "signature compared with it element for element (%d coefficients)" % len(want)}
 
 
+def qap_products_per_map(log_n):
+    """Field products one witness map executes in its transform passes (frw_qap.hip, counted from the pass schedule): a
+    six-stage pass does 17 twiddle products per 8 elements (a five-stage one 13) and, unless it stores plainly, 8 products by
+    the per-index factor; seven transforms of three passes (3 + 3 + 1 arrays), plus a(X) b(X) - c(X) once per index."""
+    n = 1 << log_n
+    t3 = 17 if log_n - 12 == 6 else 13
+    with_factor = lambda tw: (tw + 8) / 8.0
+    ifft = with_factor(17) + with_factor(17) + with_factor(t3)
+    fft = with_factor(t3) + with_factor(17) + 17 / 8.0                 # its last pass stores without a factor
+    return int(n * (3 * ifft + 3 * fft + (1 + ifft)))
+
+
+# instructions of one f29_mul as hipcc compiles it for gfx950 (tests/test_isa_hazards.py re-derives them from the assembly)
+F29_MUL_MAD64, F29_MUL_OTHER = 153, 77
+
+
+def qap_roofline(eng, log_n, maps_per_s, kernel):
+    """VALU-issue roofline of the transform passes: peak = what the chip could do if it issued nothing but the instructions
+    of the field products, priced with the issue rates measured in this process (frw_diag_valu_rates)."""
+    r = eng.valu_rates()
+    per_wave_product_us = F29_MUL_MAD64 / r["v_mad_u64_u32"] + F29_MUL_OTHER / r["v_add_u32"]
+    peak = r["simds"] * 64 / per_wave_product_us / 1e3                 # G products/s
+    achieved = qap_products_per_map(log_n) * maps_per_s / 1e9
+    return {"bound": "valu_issue", "unit": "G field products/s", "achieved": round(achieved, 1), "peak": round(peak, 1),
+            "frac": round(achieved / peak, 4), "kernel": kernel,
+            "peak_is": "%d SIMDs x 64 lanes / (%d v_mad_u64_u32 at %.1f + %d other at %.1f wave-instructions/SIMD/us), rates "
+                       "measured in this process" % (r["simds"], F29_MUL_MAD64, r["v_mad_u64_u32"], F29_MUL_OTHER, r["v_add_u32"]),
+            "products_per_map": qap_products_per_map(log_n),
+            "multiplier_loop_G_products_per_s": round(r["f29_mul_products_per_s"] / 1e9, 1),
+            "frac_of_multiplier_loop": round(achieved / (r["f29_mul_products_per_s"] / 1e9), 4),
+            "note": "achieved counts the transform passes' products over the WHOLE map's time (sparse products included, ~11 % "
+                    "of it); the multiplier loop is f29_mul alone at four waves per SIMD, no loads, no butterflies: what the "
+                    "same instruction stream sustains when nothing else is issued"}
+
+
 def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps, logn=None, cpu_triple=None):
     """The step after the hot path in a Groth16 prover (SURVEY 8-f row 4): ark-groth16's R1CStoQAP::witness_map -- A z, B z,
     C z, three inverse + three coset-forward + one coset-inverse transform over the 2^17 / 2^18 domain -- for `nsig` of the
@@ -292,12 +327,13 @@ def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps, logn=None, cpu_triple=
     torch.cuda.synchronize()
     ms6 = e0.elapsed_time(e1) / reps
     assert torch.equal(h6, h), "six-transform quotient differs from the witness map on satisfied witnesses"
-    products = 7 * (n // 2) * int(q.log_domain_size) + 5 * n
+    products = qap_products_per_map(int(q.log_domain_size))
     out = {"workload": "R1CS->QAP witness map (h = (A B - C) / Z, domain 2^%d) of %d resident witnesses per call" %
                        (int(q.log_domain_size), nsig),
            "ms_per_call": round(ms, 3), "signatures_per_s": round(nsig / (ms * 1e-3), 1), "calls_timed": reps,
            "field_products_per_signature_transforms": products,
            "bytes_out_per_signature": n * 32, "checked": "no unsatisfied rows; top coefficient of every h is zero",
+           "roofline": qap_roofline(eng, int(q.log_domain_size), nsig / (ms * 1e-3), "ntt_pass_kernel<...> (21 launches per map)"),
            "six_transform_quotient": {"ms_per_call": round(ms6, 3), "signatures_per_s": round(nsig / (ms6 * 1e-3), 1),
                                       "what": "frw_qap_quotient_dev: h as the high half of a(X) b(X), six transforms, C z not "
                                               "transformed; bit-identical to the witness map on these (satisfied) witnesses"}}
@@ -484,15 +520,14 @@ def bench_qap(args, world, rank, dev):
     ms = e0.elapsed_time(e1) / args.steps
     assert int(bad.abs().sum()) == 0 and int(h[:, -1].abs().sum()) == 0
     eng.r1cs_free(handle)
-    products = 7 * (n // 2) * int(q.log_domain_size) + 5 * n
     emit({"metric": "falcon%d_qap_witness_maps_per_sec" % (1 << logn), "value": round(batch * world * args.steps / elapsed, 1),
           "unit": "signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (BLS12-381 Fr in 29-bit limbs)",
           "data": "synthetic",
           "config": {"workload": "R1CS->QAP witness map of resident witnesses (ark-groth16 witness_map), domain 2^%d" %
                                  int(q.log_domain_size), "logn": logn, "batch_per_gpu": batch, "signatures_in_flight": chunk},
-          "field_products_per_s": round(products * batch * world * args.steps / elapsed / 1e9, 1),
-          "field_products_unit": "G Montgomery products/s (transforms only counted)",
+          "roofline": qap_roofline(eng, int(q.log_domain_size), batch * args.steps / (ms * 1e-3 * args.steps),
+                                   "ntt_pass_kernel<...> (21 launches per map)"),
           "checked": "no unsatisfied rows; top coefficient of every h is zero"})
 
 
@@ -861,7 +896,7 @@ def main():
         tc = time.perf_counter() - tc
         if world == 1 and not args.no_secondary and not dual:
             s0 = int(slot_sig[0])
-            qap_result = time_qap(eng, h, dev, d_wit, d_inst, min(64, held), 3, logn,
+            qap_result = time_qap(eng, h, dev, d_wit, d_inst, min(64, held), 20, logn,
                                   None if args.no_cpu_baseline else (sig[s0:s0 + 1], pk[s0:s0 + 1], hm[s0:s0 + 1]))
         eng.r1cs_free(h)
         n_unsat = sharding.sum_over_ranks(int((badrows != 0).sum().item()), cdev)

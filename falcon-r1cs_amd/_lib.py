@@ -64,6 +64,7 @@ PROTOTYPES = {
                                C.c_void_p]),
     "frw_diag_host_allocations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "frw_ctx_trim": (C.c_int, [C.c_void_p]),
+    "frw_diag_valu_rates": (C.c_int, [C.c_void_p, C.POINTER(C.c_double * 4)]),
     "frw_r1cs_diag_host_allocations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "frw_compact_layout": (C.c_int, [C.c_int, C.POINTER(CompactLayoutStruct)]),
     "frw_witness_ntt_verify_compact_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,

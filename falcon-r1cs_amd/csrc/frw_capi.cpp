@@ -701,6 +701,17 @@ int frw_diag_write_stream_dev(frw_ctx *ctx, void *d_buf, size_t bytes, size_t sl
     return FRW_OK;
 }
 
+int frw_diag_valu_rates(frw_ctx *ctx, double out[4])
+{
+    if (!ctx || !out) return FRW_E_INVALID_ARG;
+    frw::HostArena &A = ctx->arena;
+    std::lock_guard<std::mutex> lock(A.mu);
+    FRW_HIP(hipSetDevice(ctx->device));
+    FRW_HIP(A.reserve_device(0, (size_t)ctx->num_cu * 8192));
+    FRW_HIP(frw::diag_valu_rates(ctx->num_cu, A.d_slot[0], out, A.compute));
+    return FRW_OK;
+}
+
 int frw_host_alloc(frw_ctx *ctx, size_t bytes, void **ptr)
 {
     if (!ctx || !ptr) return FRW_E_INVALID_ARG;

@@ -129,6 +129,7 @@ struct QapDev {
     uint32_t sixteen_over_n[9];   // 16 / n, x R' in nine limbs
 };
 size_t qap_workspace_bytes_per_signature(const R1csDev &r, const QapDev &q);
+hipError_t diag_valu_rates(int num_cu, void *scratch, double out[4], hipStream_t st);
 hipError_t launch_qap_quotient(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,
                                const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,
                                size_t workspace_bytes, hipStream_t st);

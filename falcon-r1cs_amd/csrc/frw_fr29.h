@@ -39,7 +39,7 @@ constexpr uint32_t twice_p_word(int k)
 constexpr uint32_t P2_32_[8] = {twice_p_word(0), twice_p_word(1), twice_p_word(2), twice_p_word(3),
                                 twice_p_word(4), twice_p_word(5), twice_p_word(6), twice_p_word(7)};
 constexpr uint32_t p2_29(int i) { return limb29_of(P2_32_, i); }
-// the limbs of K p (K <= 16: K p < 2^259) as a constant table (a constexpr FUNCTION of the loop index is not folded in
+// the limbs of K p (K <= 32: K p < 2^260) as a constant table (a constexpr FUNCTION of the loop index is not folded in
 // device code: it was evaluated at run time through scratch memory)
 struct Limbs29 { uint32_t l[NL29]; };
 constexpr Limbs29 make_kp29(uint32_t K)
@@ -60,11 +60,12 @@ constexpr Limbs29 make_kp29(uint32_t K)
     }
     return r;
 }
-constexpr Limbs29 KP29_1 = make_kp29(1), KP29_2 = make_kp29(2), KP29_4 = make_kp29(4), KP29_8 = make_kp29(8);
+constexpr Limbs29 KP29_1 = make_kp29(1), KP29_2 = make_kp29(2), KP29_4 = make_kp29(4), KP29_8 = make_kp29(8),
+                  KP29_16 = make_kp29(16), KP29_32 = make_kp29(32);
 template <uint32_t K> constexpr const Limbs29 &kp29_table()
 {
-    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "table missing");
-    return K == 1 ? KP29_1 : K == 2 ? KP29_2 : K == 4 ? KP29_4 : KP29_8;
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8 || K == 16 || K == 32, "table missing");
+    return K == 1 ? KP29_1 : K == 2 ? KP29_2 : K == 4 ? KP29_4 : K == 8 ? KP29_8 : K == 16 ? KP29_16 : KP29_32;
 }
 static_assert(KP29_2.l[0] == p2_29(0) && KP29_2.l[8] == p2_29(8) && KP29_1.l[3] == p29(3), "K p limbs");
 static_assert(p29(0) == 1u, "p = 1 mod 2^29: the Montgomery factor -p^-1 mod 2^29 is 2^29 - 1");
@@ -163,6 +164,20 @@ __device__ __forceinline__ F29 f29_reduce_4p(const F29 &a)
     F29 d;
 #pragma unroll
     for (int i = 0; i < NL29; i++) d.l[i] = a.l[i] - p2_29(i);
+    const int neg = f29_normalise_signed(d);
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < NL29; i++) r.l[i] = neg ? a.l[i] : d.l[i];
+    return r;
+}
+
+// a < 2 K p  ->  a or a - K p, < K p
+template <uint32_t K>
+__device__ __forceinline__ F29 f29_cond_sub_kp(const F29 &a)
+{
+    F29 d;
+#pragma unroll
+    for (int i = 0; i < NL29; i++) d.l[i] = a.l[i] - kp29_table<K>().l[i];
     const int neg = f29_normalise_signed(d);
     F29 r;
 #pragma unroll

@@ -16,9 +16,11 @@
 // Every transform is three passes over HBM (6 + 6 + (L - 12) butterfly stages) in four-step form: a pass is a set of
 // plain 2^T-point transforms that need the 64-th roots of unity only, followed by ONE multiplication per element by a
 // per-index factor read alongside the data (the twist towards the next pass, or the scale factor of the witness map).
-// A workgroup of 128 threads takes a tile of 2^T rows x 2^(10-T) adjacent elements; a thread holds 8 elements in
-// registers and does three stages on them (radix 8), the tile is exchanged once through LDS, three (or two) more stages,
-// the multiplication, and out.  A/B timing of the first version (one LDS round trip and one gathered twiddle per stage)
+// A workgroup of ONE wavefront takes a tile of 2^T rows x 2^(9-T) adjacent elements; a thread holds 8 elements in
+// registers and does three stages on them (radix 8), the tile is exchanged once through LDS -- in two halves, so that
+// a wavefront needs 9 KB of it and registers, not LDS, decide how many wavefronts a SIMD holds (three; with the
+// 128-thread workgroups and 37 KB tiles of round 2 it was two, and they met at four barriers per pass) --, three (or
+// two) more stages, the multiplication, and out.  A/B timing of the first version (one LDS round trip and one gathered twiddle per stage)
 // showed the passes waiting for LDS and for the gathers, not for the multiplier (profiles/r02_qap_v2_ab.txt).
 // tools/dev/qap_fourstep_model.py and qap_radix8_model.py are exact-integer models of the index and twiddle arithmetic.
 //
@@ -33,9 +35,9 @@
 
 namespace frw {
 
-constexpr int QAP_TILE = 1024;          // elements per tile
-constexpr int QAP_THREADS = 128;        // 8 elements per thread
-constexpr int QAP_LDS_PLANE = QAP_TILE + 16;      // memory-order tiles are stored 65 apart per column (see below)
+constexpr int QAP_TILE = 512;           // elements per tile
+constexpr int QAP_THREADS = 64;         // one wavefront, 8 elements per thread
+constexpr int QAP_HALF = QAP_TILE / 2;  // elements in LDS at a time (one 32-bit word per element and limb plane)
 
 enum { PASS_FIRST = 0, PASS_DIT_SH0 = 1, PASS_DIT = 2, PASS_DIF = 3, PASS_DIF_SH0 = 4 };
 enum { LOAD_PLAIN = 0, LOAD_AB_MINUS_C = 1, LOAD_AB = 2, LOAD_PRODUCTS_AB = 3 };
@@ -112,15 +114,41 @@ __device__ __forceinline__ void dif_mul(F29 &u, F29 &v, const F29 &w)
     const F29 s = f29_reduce_4p(f29_add(u, v));
     v = QAP_MUL(f29_sub_kp<2>(u, v), w);
     u = s;
+    __builtin_amdgcn_sched_barrier(0);       // one butterfly's temporaries at a time (see round_high)
+}
+
+// The same butterflies without the conditional subtractions (PASS_DIF with a factor at the end): sums and differences
+// are left to grow -- inputs < B p give u + v < 2 B p and u - v + B p < 2 B p -- and only the products bring the values
+// back under 2 p: three stages take < 2 p to < 16 p, one conditional subtraction of 8 p between the rounds, three more
+// stages to < 64 p (2^261 = 70.4 p), and the per-index factor at the end of the pass (a product) returns < 2 p.  A
+// decimation-in-frequency pass spent a third of its vector instructions on those subtractions (two per butterfly).
+template <uint32_t B>
+__device__ __forceinline__ void dif_one_lazy(F29 &u, F29 &v)
+{
+    const F29 s = f29_add(u, v);
+    v = f29_sub_kp<B>(u, v);
+    u = s;
+}
+template <uint32_t B>
+__device__ __forceinline__ void dif_mul_lazy(F29 &u, F29 &v, const F29 &w)
+{
+    const F29 s = f29_add(u, v);
+    v = QAP_MUL(f29_sub_kp<B>(u, v), w);
+    u = s;
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // Stages 1..3 of a 2^T-point transform on the 8 elements x[e] = row 8 g + e: the twiddle of stage t for the pair whose
 // lower row is r is (2^t-th root)^(r mod 2^(t-1)), i.e. a 64-th root with exponent (e mod 2^(t-1)) 2^(6-t) -- the same
 // three constants (w8, w16, w24) for every thread.
-template <bool DIF>
+template <bool DIF, bool LAZY = false>
 __device__ __forceinline__ void round_low(F29 (&x)[8], const F29 &w8, const F29 &w16, const F29 &w24)
 {
-    if (!DIF) {
+    if (DIF && LAZY) {                                     // inputs < 8 p
+        dif_one_lazy<8>(x[0], x[4]); dif_mul_lazy<8>(x[1], x[5], w8); dif_mul_lazy<8>(x[2], x[6], w16); dif_mul_lazy<8>(x[3], x[7], w24);
+        dif_one_lazy<16>(x[0], x[2]); dif_mul_lazy<16>(x[1], x[3], w16); dif_one_lazy<16>(x[4], x[6]); dif_mul_lazy<16>(x[5], x[7], w16);
+        dif_one_lazy<32>(x[0], x[1]); dif_one_lazy<32>(x[2], x[3]); dif_one_lazy<32>(x[4], x[5]); dif_one_lazy<32>(x[6], x[7]);   // -> < 64 p
+    } else if (!DIF) {
         dit_one<2>(x[0], x[1]); dit_one<2>(x[2], x[3]); dit_one<2>(x[4], x[5]); dit_one<2>(x[6], x[7]);      // -> < 4 p
         dit_one<4>(x[0], x[2]); dit_mul(x[1], x[3], w16); dit_one<4>(x[4], x[6]); dit_mul(x[5], x[7], w16);  // -> < 8 p
         dit_one<8>(x[0], x[4]); dit_mul(x[1], x[5], w8); dit_mul(x[2], x[6], w16); dit_mul(x[3], x[7], w24); // -> < 16 p
@@ -133,10 +161,25 @@ __device__ __forceinline__ void round_low(F29 (&x)[8], const F29 &w8, const F29 
 
 // Stages 4..T on the 8 elements x[e]: T == 6: row 8 e + g (three stages over e); T == 5: row 8 (e & 3) + g + 4 (e >> 2)
 // (two stages over the low two bits of e, two independent groups).  Twiddles depend on the thread (g): table look-ups.
-template <bool DIF, int T>
+template <bool DIF, int T, bool LAZY = false>
 __device__ __forceinline__ void round_high(F29 (&x)[8], const uint32_t *roots, int g)
 {
-    if (T == 6) {
+    if (DIF && LAZY) {                                     // inputs < 2 p; T == 6: -> < 16 p, T == 5: -> < 8 p
+        if (T == 6) {
+            dif_mul_lazy<2>(x[0], x[4], root_get(roots, g)); dif_mul_lazy<2>(x[1], x[5], root_get(roots, g + 8));
+            dif_mul_lazy<2>(x[2], x[6], root_get(roots, g + 16)); dif_mul_lazy<2>(x[3], x[7], root_get(roots, g + 24));
+            { const F29 w0 = root_get(roots, g << 1), w1 = root_get(roots, (g + 8) << 1);
+              dif_mul_lazy<4>(x[0], x[2], w0); dif_mul_lazy<4>(x[1], x[3], w1); dif_mul_lazy<4>(x[4], x[6], w0); dif_mul_lazy<4>(x[5], x[7], w1); }
+            { const F29 w = root_get(roots, g << 2);
+              dif_mul_lazy<8>(x[0], x[1], w); dif_mul_lazy<8>(x[2], x[3], w); dif_mul_lazy<8>(x[4], x[5], w); dif_mul_lazy<8>(x[6], x[7], w); }
+        } else {
+            const F29 wa = root_get(roots, g << 2), wb = root_get(roots, (g + 4) << 2);
+            const F29 wa0 = root_get(roots, g << 1), wa1 = root_get(roots, (g + 8) << 1);
+            const F29 wb0 = root_get(roots, (g + 4) << 1), wb1 = root_get(roots, (g + 12) << 1);
+            dif_mul_lazy<2>(x[0], x[2], wa0); dif_mul_lazy<2>(x[1], x[3], wa1); dif_mul_lazy<2>(x[4], x[6], wb0); dif_mul_lazy<2>(x[5], x[7], wb1);
+            dif_mul_lazy<4>(x[0], x[1], wa); dif_mul_lazy<4>(x[2], x[3], wa); dif_mul_lazy<4>(x[4], x[5], wb); dif_mul_lazy<4>(x[6], x[7], wb);
+        }
+    } else if (T == 6) {
         if (!DIF) {
             { const F29 w = root_get(roots, g << 2);                                         // stage 4
               dit_mul(x[0], x[1], w); dit_mul(x[2], x[3], w); dit_mul(x[4], x[5], w); dit_mul(x[6], x[7], w); }
@@ -145,10 +188,15 @@ __device__ __forceinline__ void round_high(F29 (&x)[8], const uint32_t *roots, i
             dit_mul(x[0], x[4], root_get(roots, g)); dit_mul(x[1], x[5], root_get(roots, g + 8));                  // stage 6
             dit_mul(x[2], x[6], root_get(roots, g + 16)); dit_mul(x[3], x[7], root_get(roots, g + 24));
         } else {
+            // the scheduler would fetch all seven twiddles up front (63 registers on top of the 72 of x and the 45 of a
+            // product in flight: spills at three wavefronts per SIMD); the fences keep every stage's fetches in its stage
             dif_mul(x[0], x[4], root_get(roots, g)); dif_mul(x[1], x[5], root_get(roots, g + 8));
+            __builtin_amdgcn_sched_barrier(0);
             dif_mul(x[2], x[6], root_get(roots, g + 16)); dif_mul(x[3], x[7], root_get(roots, g + 24));
+            __builtin_amdgcn_sched_barrier(0);
             { const F29 w0 = root_get(roots, g << 1), w1 = root_get(roots, (g + 8) << 1);
               dif_mul(x[0], x[2], w0); dif_mul(x[1], x[3], w1); dif_mul(x[4], x[6], w0); dif_mul(x[5], x[7], w1); }
+            __builtin_amdgcn_sched_barrier(0);
             { const F29 w = root_get(roots, g << 2);
               dif_mul(x[0], x[1], w); dif_mul(x[2], x[3], w); dif_mul(x[4], x[5], w); dif_mul(x[6], x[7], w); }
         }
@@ -167,22 +215,22 @@ __device__ __forceinline__ void round_high(F29 (&x)[8], const uint32_t *roots, i
 }
 
 // One pass = T consecutive radix-2 stages on the index bits [sh, sh + T) of the working order, then the per-index factor.
-// Tile geometry: PASS_DIT / PASS_DIF (sh > 0): rows = index bits [sh, sh + T), columns = index bits [0, 10 - T): runs of
-// 512 / 1024 bytes in memory, threads read and write their elements directly.  PASS_DIT_SH0 / PASS_DIF_SH0 (sh == 0,
-// T == 6): 1,024 consecutive elements, row = low six bits: they go through LDS on both sides (memory order <-> the rows a
+// Tile geometry: PASS_DIT / PASS_DIF (sh > 0): rows = index bits [sh, sh + T), columns = index bits [0, 9 - T): runs of
+// 256 / 512 bytes in memory, threads read and write their elements directly.  PASS_DIT_SH0 / PASS_DIF_SH0 (sh == 0,
+// T == 6): 512 consecutive elements, row = low six bits: they go through LDS on both sides (memory order <-> the rows a
 // thread holds), since a thread's eight rows would be adjacent in memory on one of them.  PASS_FIRST: the sh == 0 pass of
 // a decimation-in-time transform whose input is still in constraint order in the products' buffers: working index =
-// bitrev(natural index), so the 64 rows are the natural-index bits [L - 6, L) reversed and the 16 columns the
-// natural-index bits [0, 4) (512-byte runs on the way in); the output is a memory-order tile of the working array.
+// bitrev(natural index), so the 64 rows are the natural-index bits [L - 6, L) reversed and the 8 columns the
+// natural-index bits [0, 3) (256-byte runs on the way in); the output is a memory-order tile of the working array.
 template <int MODE, int T, int LOAD, int STORE>
-__global__ __launch_bounds__(QAP_THREADS, 2) void ntt_pass_kernel(const NttPass p)
+__global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass p)
 {
     constexpr bool DIF = MODE == PASS_DIF || MODE == PASS_DIF_SH0;
-    constexpr bool MEMORDER = MODE == PASS_DIT_SH0 || MODE == PASS_DIF_SH0;     // tile = 1,024 consecutive elements
-    constexpr int R = 1 << T, CB = 10 - T, COLS = 1 << CB;
+    constexpr bool MEMORDER = MODE == PASS_DIT_SH0 || MODE == PASS_DIF_SH0;     // tile = 512 consecutive elements
+    constexpr int CB = 9 - T, COLS = 1 << CB;
     static_assert(T == 6 || (T == 5 && (MODE == PASS_DIT || MODE == PASS_DIF)), "five-stage passes only above bit 0");
-    __shared__ uint32_t lds[NL29 * QAP_LDS_PLANE];
-    const int tid = threadIdx.x, c = tid & (COLS - 1), g = tid >> CB;
+    __shared__ uint32_t lds[NL29 * QAP_HALF];
+    const int tid = threadIdx.x, c = tid & (COLS - 1), g = tid >> CB;           // T == 6: 8 columns x 8 g; T == 5: 16 x 4
     const uint32_t tileid = blockIdx.x;
     const size_t n = (size_t)1 << p.L;
     const uint32_t *src = p.src + (size_t)blockIdx.y * p.src_stride;
@@ -192,23 +240,17 @@ __global__ __launch_bounds__(QAP_THREADS, 2) void ntt_pass_kernel(const NttPass 
     // rows of the eight elements a thread holds in the low round (stages 1..3) and in the high round (stages 4..T)
     auto row_low = [&](int e) { return g * 8 + e; };
     auto row_high = [&](int e) { return T == 6 ? e * 8 + g : (e & 3) * 8 + g + 4 * (e >> 2); };
-    // LDS slot of (row, column): sh > 0 tiles: row-major with bit 4 flipped by bit 3 of the row (T == 6), which keeps both
-    // register patterns conflict-free; memory-order tiles: column-major, columns 65 apart
-    auto slot = [&](int row, int col) {
-        if (MEMORDER || MODE == PASS_FIRST) return col * (R + 1) + row;
-        return T == 6 ? (row * COLS + col) ^ ((row & 8) << 1) : row * COLS + col;
-    };
     // working index of (row, column)
     uint32_t lowmid = 0, high = 0;
-    if (MODE == PASS_FIRST) high = (__brev(tileid) >> (32 - (p.L - 10))) << 6;
+    if (MODE == PASS_FIRST) high = (__brev(tileid) >> (32 - (p.L - 9))) << 6;
     else if (MEMORDER) high = tileid * (uint32_t)QAP_TILE;
     else {
         lowmid = (tileid & ((1u << (p.sh - CB)) - 1u)) << CB;
         high = (tileid >> (p.sh - CB)) << (p.sh + T);
     }
     auto widx = [&](int row, int col) -> uint32_t {
-        if (MODE == PASS_FIRST) return (uint32_t)row | high | ((__brev((uint32_t)col) >> 28) << (p.L - 4));
-        if (MEMORDER) return high + (uint32_t)(col * R + row);
+        if (MODE == PASS_FIRST) return (uint32_t)row | high | ((__brev((uint32_t)col) >> 29) << (p.L - 3));
+        if (MEMORDER) return high + (uint32_t)(col * 64 + row);
         return high | ((uint32_t)row << p.sh) | lowmid | (uint32_t)col;
     };
     auto load_elem = [&](uint32_t gidx) -> F29 {
@@ -237,17 +279,61 @@ __global__ __launch_bounds__(QAP_THREADS, 2) void ntt_pass_kernel(const NttPass 
     };
     auto lds_put = [&](int s, const F29 &v) {
 #pragma unroll
-        for (int k = 0; k < NL29; k++) lds[k * QAP_LDS_PLANE + s] = v.l[k];
+        for (int k = 0; k < NL29; k++) lds[k * QAP_HALF + s] = v.l[k];
     };
     auto lds_get = [&](int s) -> F29 {
         F29 v;
 #pragma unroll
-        for (int k = 0; k < NL29; k++) v.l[k] = lds[k * QAP_LDS_PLANE + s];
+        for (int k = 0; k < NL29; k++) v.l[k] = lds[k * QAP_HALF + s];
         return v;
     };
+    // The workgroup is one wavefront: LDS traffic is ordered by waiting for the wave's own LDS operations (the compiler
+    // drops the s_barrier of a one-wave workgroup and keeps the wait).
+    auto wave_sync = [&]() { __syncthreads(); };
+
+    // ---- the exchange between the two rounds, half a tile at a time ------------------------------------------------------
+    // An 8 x 8 transpose per column between the g of a thread and the e of its registers (T == 6), or 4 x 4 transposes
+    // (T == 5); each half moves four registers of every thread.  The transpose is an involution, so low -> high
+    // (decimation in time) and high -> low (decimation in frequency) are the same code.
+    // Slot of (register j of the half, thread g, column c) and its bank (slot mod 32; a 32-lane group conflicts):
+    //   T == 6: ((8 j + g) 8 + c) with bits 3, 4 XOR-ed by j: writers (g = 0..3 or 4..7, all c) differ in g & 3, readers
+    //           (they read j' = g & 3, g' = e) differ in j'
+    //   T == 5: ((4 g + j) 16 + c) with bit 4 XOR-ed by g: writers (two g, all c) differ in g & 1, readers (they read
+    //           g' = e & 3, j' = g) in j' & 1
+    auto xslot = [&](int j, int gg) { return T == 6 ? (((8 * j + gg) * 8 + c) ^ (j << 3)) : (((4 * gg + j) * 16 + c) ^ ((gg & 1) << 4)); };
+    auto exchange = [&](F29 (&x)[8]) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (T == 6) {
+                // half h: the threads g < 4 send (and then receive into) their registers 4 h .. 4 h + 3, the threads g >= 4
+                // their registers 4 (1 - h) .. : what thread g' needs from thread e' travels in half (g' >> 2) ^ (e' >> 2),
+                // i.e. lands in the registers the receiver has just sent -- nothing is held aside
+                if ((g >> 2) == h) {
+                    static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_put(xslot(j, g), x[j]); });
+                } else {
+                    static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_put(xslot(j, g), x[4 + j]); });
+                }
+                wave_sync();
+                if ((g >> 2) == h) {
+                    static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; x[j] = lds_get(xslot(g & 3, j)); });
+                } else {
+                    static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; x[4 + j] = lds_get(xslot(g & 3, 4 + j)); });
+                }
+            } else {
+                static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_put(xslot(j, g), x[4 * h + j]); });
+                wave_sync();
+                static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; x[4 * h + j] = lds_get(xslot(g, j)); });
+            }
+            wave_sync();
+        }
+    };
+    // ---- memory order <-> register rows (sh == 0 passes, T == 6), four columns at a time --------------------------------
+    // Slot of (row, column cc of the four): cc 64 + (row ^ swz(cc)).  A 32-lane group touches it as 32 consecutive rows
+    // of one column (global order), as rows 8 g + e of four g x four columns (low round) or as rows 8 e + g (high round):
+    // swz maps the two column bits to e2 and e0 + e3, independent of {e3, e4} as of {e0, e1}: no bank is hit twice.
+    auto mslot = [&](int row, int cc) { return cc * 64 + (row ^ (((cc & 1) << 2) | ((cc >> 1) * 9))); };
 
     F29 x[8];
-    const F29 w8 = root_get(p.roots, 8), w16 = root_get(p.roots, 16), w24 = root_get(p.roots, 24);
 
     // ---- in: the eight elements of the first round -----------------------------------------------------------------------
     if (MODE == PASS_FIRST) {
@@ -257,7 +343,7 @@ __global__ __launch_bounds__(QAP_THREADS, 2) void ntt_pass_kernel(const NttPass 
         static_for<8>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
             const uint32_t ihi = __brev((uint32_t)row_low(e)) >> 26;                 // row = rev6(natural bits [L - 6, L))
-            const uint32_t i = (ihi << (p.L - 6)) | (tileid << 4) | (uint32_t)c;     // natural (constraint) index
+            const uint32_t i = (ihi << (p.L - 6)) | (tileid << 3) | (uint32_t)c;     // natural (constraint) index
             Fr8 w;
 #pragma unroll
             for (int k = 0; k < 8; k++) w.l[k] = 0;
@@ -274,40 +360,43 @@ __global__ __launch_bounds__(QAP_THREADS, 2) void ntt_pass_kernel(const NttPass 
             }
         });
     } else if (MEMORDER) {
-        // memory order -> LDS -> the rows of the first round
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int lin = tid + QAP_THREADS * k;                                   // = col * 64 + row
-            lds_put(slot(lin & 63, lin >> 6), load_elem(high + (uint32_t)lin));
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) lds_put(mslot(tid, k), load_elem(high + (uint32_t)(tid + 64 * (4 * h + k))));
+            wave_sync();
+            if ((c >> 2) == h)
+                static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = lds_get(mslot(DIF ? row_high(e) : row_low(e), c & 3)); });
+            wave_sync();
         }
-        __syncthreads();
-        static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = lds_get(slot(DIF ? row_high(e) : row_low(e), c)); });
-        __syncthreads();
     } else {
         static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = load_elem(widx(DIF ? row_high(e) : row_low(e), c)); });
     }
 
 #if !defined(FRW_QAP_NO_STAGES)
     // ---- first round, exchange, second round ---------------------------------------------------------------------------------
-    if (DIF) round_high<true, T>(x, p.roots, g);
-    else round_low<false>(x, w8, w16, w24);
-    static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; lds_put(slot(DIF ? row_high(e) : row_low(e), c), x[e]); });
-    __syncthreads();
-    static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = lds_get(slot(DIF ? row_low(e) : row_high(e), c)); });
-    if (DIF) round_low<true>(x, w8, w16, w24);
+    // (the three constants of the low round are fetched where that round is: held across the other one they cost 27
+    // registers the decimation-in-frequency passes do not have)
+    constexpr bool LAZY = MODE == PASS_DIF && STORE == STORE_FACTOR;     // see dif_mul_lazy
+    if (DIF) round_high<true, T, LAZY>(x, p.roots, g);
+    else round_low<false>(x, root_get(p.roots, 8), root_get(p.roots, 16), root_get(p.roots, 24));
+    exchange(x);
+    if (LAZY && T == 6) static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = f29_cond_sub_kp<8>(x[e]); });   // < 16 p -> < 8 p
+    if (DIF) round_low<true, LAZY>(x, root_get(p.roots, 8), root_get(p.roots, 16), root_get(p.roots, 24));
     else round_high<false, T>(x, p.roots, g);
 #endif
 
     // ---- out ---------------------------------------------------------------------------------------------------------------------
     if (MODE == PASS_FIRST || MEMORDER) {
-        // rows of the last round -> LDS -> memory order
-        __syncthreads();
-        static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; lds_put(slot(DIF ? row_low(e) : row_high(e), c), x[e]); });
-        __syncthreads();
+        // rows of the last round -> LDS -> memory order, four columns at a time
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int lin = tid + QAP_THREADS * k, row = lin & 63, col = lin >> 6;
-            store_elem(widx(row, col), lds_get(slot(row, col)));
+        for (int h = 0; h < 2; h++) {
+            if ((c >> 2) == h)
+                static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; lds_put(mslot(DIF ? row_low(e) : row_high(e), c & 3), x[e]); });
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 4; k++) store_elem(widx(tid, 4 * h + k), lds_get(mslot(tid, k)));
+            wave_sync();
         }
     } else {
         static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; store_elem(widx(DIF ? row_low(e) : row_high(e), c), x[e]); });
@@ -318,7 +407,7 @@ namespace {
 template <int MODE, int T, int LOAD, int STORE>
 hipError_t launch_pass(const NttPass &p, unsigned arrays, hipStream_t st)
 {
-    const unsigned tiles = (unsigned)(((size_t)1 << p.L) >> 10);
+    const unsigned tiles = (unsigned)(((size_t)1 << p.L) / QAP_TILE);
     hipLaunchKernelGGL((ntt_pass_kernel<MODE, T, LOAD, STORE>), dim3(tiles, arrays), dim3(QAP_THREADS), 0, st, p);
     return hipGetLastError();
 }
@@ -409,6 +498,79 @@ hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *w
                    : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR_CANONICAL>(p, arrays, st);
 }
 }  // namespace
+
+// ---- diagnostics: the VALU issue rates the transforms' roofline is priced with, measured on the device at hand ----------
+// KIND 0: v_add_u32 (full-rate class: the carry / mask instructions of a product), 1: v_mad_u64_u32 (the multiply-adds),
+// 2: f29_mul itself.  Every wave runs ITER rounds of 16 (KIND 2: 4) independent chains; four waves per SIMD.
+constexpr int DIAG_ITER = 2048;
+template <int KIND>
+__global__ __launch_bounds__(256) void valu_rate_kernel(uint64_t *out, uint32_t seed)
+{
+    uint32_t x = seed + threadIdx.x, y = seed * 3 + 1;
+    uint64_t acc = 0;
+    if (KIND == 2) {
+        F29 v[4], w;
+#pragma unroll
+        for (int k = 0; k < NL29; k++) w.l[k] = (seed * 2654435761u + k * 40503u) & M29;
+        w.l[NL29 - 1] &= 0x3fffff;                                  // < p
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < NL29; k++) v[j].l[k] = (x * (j + 3) + k) & M29;
+        for (int it = 0; it < DIAG_ITER / 8; it++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = f29_mul(v[j], w);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < NL29; k++) acc += v[j].l[k];
+    } else {
+        uint64_t a[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) a[i] = x + i;
+        for (int it = 0; it < DIAG_ITER; it++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (KIND == 0) { uint32_t t = (uint32_t)a[i]; asm volatile("v_add_u32 %0, %1, %2" : "=v"(t) : "v"(t), "v"(y)); a[i] = t; }
+                else asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y) : "vcc");
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc += a[i];
+    }
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+// out[0] = v_add_u32, out[1] = v_mad_u64_u32 in wave-instructions per SIMD per microsecond; out[2] = f29_mul products per
+// second over the chip (the multiplier loop above: no loads, no butterflies); out[3] = SIMDs.  `scratch`: num_cu x 8 KiB.
+hipError_t diag_valu_rates(int num_cu, void *scratch, double out[4], hipStream_t st)
+{
+    const int grid = num_cu * 4;                                   // 4 workgroups of 4 waves per CU = 4 waves per SIMD
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms[3] = {0, 0, 0};
+    for (int kind = 0; kind < 3 && e == hipSuccess; kind++) {
+        for (int rep = 0; rep < 2 && e == hipSuccess; rep++) {     // the second run is the timed one
+            if (rep) e = hipEventRecord(e0, st);
+            if (kind == 0) hipLaunchKernelGGL(valu_rate_kernel<0>, dim3(grid), dim3(256), 0, st, (uint64_t *)scratch, 1u + rep);
+            else if (kind == 1) hipLaunchKernelGGL(valu_rate_kernel<1>, dim3(grid), dim3(256), 0, st, (uint64_t *)scratch, 1u + rep);
+            else hipLaunchKernelGGL(valu_rate_kernel<2>, dim3(grid), dim3(256), 0, st, (uint64_t *)scratch, 1u + rep);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (rep && e == hipSuccess) e = hipEventRecord(e1, st);
+        }
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms[kind], e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return e;
+    out[0] = 4.0 * DIAG_ITER * 16 / (ms[0] * 1e3);
+    out[1] = 4.0 * DIAG_ITER * 16 / (ms[1] * 1e3);
+    out[2] = (double)grid * 256 * (DIAG_ITER / 8) * 4 / (ms[2] * 1e-3);
+    out[3] = 4.0 * num_cu;
+    return hipSuccess;
+}
 
 size_t qap_workspace_bytes_per_signature(const R1csDev &r, const QapDev &q)
 {

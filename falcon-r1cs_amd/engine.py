@@ -120,6 +120,12 @@ class WitnessEngine:
         check(self._lib.frw_diag_host_allocations(self._ctx, C.byref(n)), "frw_diag_host_allocations")
         return int(n.value)
 
+    def valu_rates(self):
+        """{v_add_u32, v_mad_u64_u32: wave-instructions / SIMD / us; f29_mul_products_per_s; simds} measured now."""
+        out = (C.c_double * 4)()
+        check(self._lib.frw_diag_valu_rates(self._ctx, C.byref(out)), "frw_diag_valu_rates")
+        return {"v_add_u32": out[0], "v_mad_u64_u32": out[1], "f29_mul_products_per_s": out[2], "simds": int(out[3])}
+
     def trim(self):
         """Gives the working memory of the host-buffer entry points back to the device (the next call allocates again)."""
         check(self._lib.frw_ctx_trim(self._ctx), "frw_ctx_trim")

@@ -379,6 +379,12 @@ int frw_diag_write_stream_dev(frw_ctx *ctx, void *d_buf, size_t bytes, size_t sl
 int frw_synth_triples(int logn, size_t batch, uint64_t seed, uint64_t first_index,
                       uint16_t *sig, uint16_t *pk, uint16_t *hm);
 
+/* Issue rates of the vector instructions a BLS12-381 Fr product is built from, measured on this device (what the QAP
+ * transforms' roofline is priced with; bench.py): out[0] = v_add_u32, out[1] = v_mad_u64_u32, both in wave-instructions
+ * per SIMD per microsecond with four waves per SIMD; out[2] = field products per second of the bare multiplier loop
+ * (frw_fr29.h f29_mul, no loads, no butterflies) over the whole chip; out[3] = number of SIMDs.  Synchronous, ~10 ms. */
+int frw_diag_valu_rates(frw_ctx *ctx, double out[4]);
+
 /* Page-locked host memory.  Output buffers of the host-buffer entry points allocated here are filled by
  * asynchronous DMA that overlaps with the kernels of the next chunk (pageable buffers work too, slower). */
 int frw_host_alloc(frw_ctx *ctx, size_t bytes, void **ptr);

@@ -104,6 +104,7 @@ extern "C" {
                         witness: *mut u64, ntt_out: *mut u16, status: *mut i32) -> c_int;
     pub fn frw_diag_host_allocations(ctx: *mut frw_ctx, count: *mut u64) -> c_int;
     pub fn frw_ctx_trim(ctx: *mut frw_ctx) -> c_int;
+    pub fn frw_diag_valu_rates(ctx: *mut frw_ctx, out: *mut f64) -> c_int;
     pub fn frw_compact_layout(logn: c_int, out: *mut frw_compact_layout_t) -> c_int;
     pub fn frw_witness_ntt_verify_compact_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_sig: *const u16,
                                               d_pk: *const u16, d_hm: *const u16, d_compact: *mut c_void,

@@ -88,6 +88,9 @@ int main()
             else if (op == "sub2") r = f29_sub_kp<2>(a, b);
             else if (op == "sub4") r = f29_sub_kp<4>(a, b);
             else if (op == "sub8") r = f29_sub_kp<8>(a, b);
+            else if (op == "sub16") r = f29_sub_kp<16>(a, b);
+            else if (op == "sub32") r = f29_sub_kp<32>(a, b);
+            else if (op == "csub8") r = f29_cond_sub_kp<8>(a);
             else if (op == "red4") r = f29_reduce_4p(a);
             else if (op == "canon") r = f29_canonical(a);
             else if (op == "packunpack") r = f29_unpack(f29_pack(a));

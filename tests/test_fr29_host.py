@@ -63,6 +63,29 @@ def test_products_and_reductions(harness):
         if op == "packunpack": assert v == args[0]
 
 
+def test_lazy_decimation_in_frequency_bounds(harness):
+    """The butterflies of the factor passes without conditional subtractions (frw_qap.hip dif_mul_lazy): differences with
+    16 p and 32 p added, the one conditional subtraction of 8 p between the rounds, and the worst case of the whole chain --
+    a sum just under 64 p entering a product with a factor just under p -- must come back below 2 p (it is 2^261 = 70.4 p
+    that allows it), exactly as an integer computation says."""
+    rng = random.Random(37)
+    ops = []
+    for _ in range(200):
+        ops += [("sub16", rng.randrange(16 * P), rng.randrange(16 * P)), ("sub32", rng.randrange(32 * P), rng.randrange(32 * P)),
+                ("csub8", rng.randrange(16 * P))]
+    ops += [("sub16", 0, 16 * P - 1), ("sub16", 16 * P - 1, 0), ("sub32", 0, 32 * P - 1), ("sub32", 32 * P - 1, 0),
+            ("csub8", 0), ("csub8", 8 * P - 1), ("csub8", 8 * P), ("csub8", 16 * P - 1)]
+    worst = [(64 * P - 1, P - 1), (64 * P - 1, 1), (63 * P + 12345, P - 2)] + [(rng.randrange(32 * P, 64 * P), rng.randrange(P)) for _ in range(200)]
+    ops += [("mul", a, b) for a, b in worst]
+    inv = pow(RP, -1, P)
+    for (op, *args), (v, norm) in zip(ops, harness(ops)):
+        assert norm, op
+        if op == "sub16": assert v == args[0] - args[1] + 16 * P
+        if op == "sub32": assert v == args[0] - args[1] + 32 * P and v < 64 * P
+        if op == "csub8": assert v == (args[0] - 8 * P if args[0] >= 8 * P else args[0]) and v < 8 * P
+        if op == "mul": assert v % P == args[0] * args[1] * inv % P and v < 2 * P and v < (1 << 256)
+
+
 def test_wide_montgomery_reduction(harness):
     """f29_redc_wide: x / 2^261 mod p for x up to 2^300 (what 64 lanes of a long row add up to), result < 2 p."""
     rng = random.Random(31)

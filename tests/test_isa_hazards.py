@@ -63,3 +63,36 @@ def test_buffer_store_data_registers_survive_two_wait_states(tmp_path):
                 slots += 1
             j += 1
     assert stores > 100          # the tile writer of every kernel instantiation is in there
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_field_product_instruction_count_is_what_the_roofline_prices(tmp_path):
+    """bench.py prices the QAP transforms' VALU-issue roofline with the instructions of ONE f29_mul (frw_fr29.h): 153
+    v_mad_u64_u32 and 77 other vector instructions.  Re-derived here from the assembly hipcc emits for a kernel that is
+    nothing but one product (loads and stores are not vector-ALU instructions), so the constant cannot go stale."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    src = tmp_path / "one_mul.hip"
+    src.write_text('#include "frw_fr29.h"\n'
+                   'using namespace frw;\n'
+                   '__global__ void one_mul(const uint32_t *a, const uint32_t *b, uint32_t *out)\n'
+                   '{\n'
+                   '    F29 x, y;\n'
+                   '    for (int k = 0; k < NL29; k++) { x.l[k] = a[threadIdx.x * NL29 + k]; y.l[k] = b[threadIdx.x * NL29 + k]; }\n'
+                   '    const F29 r = f29_mul(x, y);\n'
+                   '    for (int k = 0; k < NL29; k++) out[threadIdx.x * NL29 + k] = r.l[k];\n'
+                   '}\n')
+    asm = tmp_path / "one_mul.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                           "-I", os.path.join(ROOT, "falcon-r1cs_amd", "csrc"), "-o", str(asm), str(src)], stderr=subprocess.DEVNULL)
+    body = open(asm).read().split("one_mul")
+    text = open(asm).read()
+    start = text.index("_Z7one_mulPKjS0_Pj:")
+    code = text[start:text.index("s_endpgm", start)]
+    valu = [l.split()[0] for l in code.splitlines() if re.match(r"\s*v_", l)]
+    mads = sum(1 for op in valu if op.startswith("v_mad_u64_u32"))
+    other = len(valu) - mads
+    assert mads == bench.F29_MUL_MAD64, mads
+    # address arithmetic of the three pointers is in `other` too: allow a handful beyond the product's own
+    assert bench.F29_MUL_OTHER <= other <= bench.F29_MUL_OTHER + 16, other
