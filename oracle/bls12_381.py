@@ -1,0 +1,152 @@
+"""ORACLE (test infrastructure, never imported by the product): BLS12-381 G1 and the exponents of a Groth16 proof.
+
+What this is for: the reference's consumer of the witness is `Groth16::<Bls12_381>::prove` (examples/pok_sig.rs:30-47).
+After `generate_constraints` (the hot path) and `R1CStoQAP::witness_map` (oracle/qap.py) the prover runs multi-scalar
+multiplications over the proving key's queries -- ark-groth16 0.3.0 src/prover.rs, create_proof_with_reduction_and_matrices:
+
+    h_acc     = VariableBaseMSM::multi_scalar_mul(&pk.h_query, &h_assignment)        (2^18 - 1 points for Falcon-1024)
+    l_aux_acc = VariableBaseMSM::multi_scalar_mul(&pk.l_query, &aux_assignment)
+    g_a  = r delta_g1 + a_query[0] + MSM(a_query[1..], assignment) + alpha_g1         (calculate_coeff)
+    g1_b = s delta_g1 + b_g1_query[0] + MSM(b_g1_query[1..], assignment) + beta_g1    (g2_b alike, in G2)
+    g_c  = s g_a + r g1_b - r s delta_g1 + l_aux_acc + h_acc
+
+and the proving key comes from src/generator.rs, generate_parameters: with t outside the domain, u_i(t), v_i(t), w_i(t)
+from R1CStoQAP::instance_map_with_evaluation and zt = t^n - 1,
+
+    h_query[i] = (zt / delta) t^i G1,  i < n - 1;   a_query[i] = u_i(t) G1;   b_g1_query[i] = v_i(t) G1;
+    l_query[i] = ((beta u_i + alpha v_i + w_i)(t) / delta) G1 for the witness variables;  gamma_abc likewise with gamma
+
+PARITY UNPINNED against ark-groth16 / ark-ec / ark-bls12-381 0.3.0 (crates.io dependencies absent from /root/reference,
+no Rust toolchain): this restates their published algorithm and the curve's published parameters.  It pins itself by
+  * q, r from the BLS parametrisation (z = -0xd201000000010000): r = z^4 - z^2 + 1, q = (z - 1)^2 r / 3 + z;
+  * the published generator on y^2 = x^3 + 4 and of order r;
+  * the Groth16 verification equation in the exponent -- with the toxic waste known, every element's discrete logarithm is
+    an Fr value, e(A, B) = e(alpha, beta) e(sum x_i gamma_abc_i, gamma) e(C, delta) becomes
+    a b = alpha beta + (sum x_i abc_i) gamma + c delta  (no pairing needed) -- for proofs of small satisfied systems, and its
+    failure for a wrong witness;
+  * an MSM's expected value without any MSM: sum h_i h_query[i] = (h(t) zt / delta) G1, one scalar multiplication.
+Affine points are (x, y) tuples of Python integers, None = the point at infinity."""
+Z_BLS = -0xD201000000010000
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+Q = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+G1 = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+      0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
+FQ_R = (1 << 384) % Q            # ark-ff's Montgomery radix for Fp384
+
+
+def check_parameters():
+    assert R == Z_BLS ** 4 - Z_BLS ** 2 + 1
+    assert Q == (Z_BLS - 1) ** 2 * R // 3 + Z_BLS and (Z_BLS - 1) ** 2 * R % 3 == 0
+    assert on_curve(G1) and mul(G1, R) is None and mul(G1, 1) == G1
+
+
+def on_curve(p):
+    return p is None or (p[1] * p[1] - p[0] * p[0] * p[0] - 4) % Q == 0
+
+
+def neg(p):
+    return None if p is None else (p[0], (-p[1]) % Q)
+
+
+def add(p, q):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    if p[0] == q[0]:
+        if (p[1] + q[1]) % Q == 0:
+            return None
+        lam = 3 * p[0] * p[0] * pow(2 * p[1], -1, Q) % Q
+    else:
+        lam = (q[1] - p[1]) * pow(q[0] - p[0], -1, Q) % Q
+    x = (lam * lam - p[0] - q[0]) % Q
+    return x, (lam * (p[0] - x) - p[1]) % Q
+
+
+def mul(p, k):
+    k %= R
+    acc = None
+    while k:
+        if k & 1:
+            acc = add(acc, p)
+        p = add(p, p)
+        k >>= 1
+    return acc
+
+
+def msm_naive(bases, scalars):
+    acc = None
+    for b, k in zip(bases, scalars):
+        acc = add(acc, mul(b, k))
+    return acc
+
+
+def to_limbs(p):
+    """ark-ff bytes of an affine point: x R, y R mod q as 6 + 6 little-endian u64 limbs; infinity = zeros."""
+    if p is None:
+        return [0] * 12
+    return [(v * FQ_R % Q >> (64 * i)) & (2 ** 64 - 1) for v in p for i in range(6)]
+
+
+def from_limbs(limbs):
+    limbs = [int(v) for v in limbs]
+    if not any(limbs):
+        return None
+    inv = pow(FQ_R, -1, Q)
+    return tuple(sum(l << (64 * i) for i, l in enumerate(limbs[6 * c:6 * c + 6])) * inv % Q for c in range(2))
+
+
+# ---- Groth16 in the exponent ------------------------------------------------------------------------------------------------
+def _lagrange_at(domain_size, gen, t):
+    """EvaluationDomain::evaluate_all_lagrange_coefficients(t) for t outside the domain: L_i(t) = zt w^i / (n (t - w^i))."""
+    zt = (pow(t, domain_size, R) - 1) % R
+    ninv = pow(domain_size, -1, R)
+    out, w = [], 1
+    for _ in range(domain_size):
+        out.append(zt * w % R * ninv % R * pow((t - w) % R, -1, R) % R)
+        w = w * gen % R
+    return out, zt
+
+
+def setup_exponents(matrices, num_instance, num_witness, domain, toxic):
+    """generator.rs generate_parameters, discrete logarithms only.  matrices = (A, B, C) as lists of rows [(coeff, column)],
+    columns = instance variables (the constant one first) then witness variables; toxic = dict(alpha, beta, gamma, delta, t).
+    domain = oracle.qap.Domain(num_constraints + num_instance)."""
+    a_m, b_m, c_m = matrices
+    nc, nv = len(a_m), num_instance + num_witness
+    t, alpha, beta, gamma, delta = (toxic[k] % R for k in ("t", "alpha", "beta", "gamma", "delta"))
+    lag, zt = _lagrange_at(domain.size, domain.group_gen, t)
+    u, v, w = [0] * nv, [0] * nv, [0] * nv
+    for i in range(num_instance):                      # r1cs_to_qap.rs: a[i] = u[num_constraints + i] for the inputs
+        u[i] = lag[nc + i]
+    for row in range(nc):
+        for vec, mat in ((u, a_m), (v, b_m), (w, c_m)):
+            for coeff, col in mat[row]:
+                vec[col] = (vec[col] + lag[row] * coeff) % R
+    dinv, ginv = pow(delta, -1, R), pow(gamma, -1, R)
+    abc = [(beta * u[i] + alpha * v[i] + w[i]) % R for i in range(nv)]
+    return {"u": u, "v": v, "zt": zt, "toxic": dict(toxic),
+            "gamma_abc": [x * ginv % R for x in abc[:num_instance]],
+            "l": [x * dinv % R for x in abc[num_instance:]],
+            "h": [zt * dinv % R * pow(t, i, R) % R for i in range(domain.size - 1)]}
+
+
+def prove_exponents(pk, z, h, r, s):
+    """prover.rs create_proof_with_reduction_and_matrices, discrete logarithms of (A, B, C).  z = full assignment (the
+    constant one first), h = the witness map's coefficients."""
+    ni = len(pk["gamma_abc"])
+    tx = pk["toxic"]
+    a = (tx["alpha"] + sum(zi * ui for zi, ui in zip(z, pk["u"])) + r * tx["delta"]) % R
+    b = (tx["beta"] + sum(zi * vi for zi, vi in zip(z, pk["v"])) + s * tx["delta"]) % R
+    h_acc = sum(hi * qi for hi, qi in zip(h, pk["h"])) % R          # zip stops at n - 1 like the prover's MSM
+    l_acc = sum(zi * li for zi, li in zip(z[ni:], pk["l"])) % R
+    c = (s * a + r * b - r * s * tx["delta"] + l_acc + h_acc) % R
+    return a, b, c, h_acc
+
+
+def verify_exponents(pk, public_inputs, proof):
+    """verifier.rs verify_proof in the exponent: e(A, B) = e(alpha, beta) e(sum x_i gamma_abc_i, gamma) e(C, delta)."""
+    a, b, c = proof[:3]
+    tx = pk["toxic"]
+    acc = sum(x * g for x, g in zip([1] + list(public_inputs), pk["gamma_abc"])) % R
+    return (a * b - tx["alpha"] * tx["beta"] - acc * tx["gamma"] - c * tx["delta"]) % R == 0

@@ -40,7 +40,59 @@ class Oracle:
         lib.frw_oracle_qap_matvec.restype = None
         lib.frw_oracle_qap_witness_map.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         lib.frw_oracle_qap_product_high_half.argtypes = [C.c_void_p] * 2 + [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        lib.frw_oracle_g1_generator.argtypes = [C.c_void_p]
+        lib.frw_oracle_g1_on_curve.argtypes = [C.c_void_p]
+        lib.frw_oracle_g1_scalar_mul.argtypes = [C.c_void_p] * 3
+        lib.frw_oracle_g1_add.argtypes = [C.c_void_p] * 3
+        lib.frw_oracle_g1_fixed_base.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        lib.frw_oracle_g1_msm.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        for f in (lib.frw_oracle_g1_generator, lib.frw_oracle_g1_scalar_mul, lib.frw_oracle_g1_add, lib.frw_oracle_g1_fixed_base,
+                  lib.frw_oracle_g1_msm):
+            f.restype = None
         self.lib = lib
+
+    # ---- BLS12-381 G1 (oracle/bls12_381.c): points are uint64[12] = ark-ff's Montgomery limbs of x then y, zeros = infinity
+    def g1_generator(self):
+        out = np.zeros(12, dtype=np.uint64)
+        self.lib.frw_oracle_g1_generator(out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def g1_on_curve(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        return bool(self.lib.frw_oracle_g1_on_curve(p.ctypes.data_as(C.c_void_p)))
+
+    def g1_scalar_mul(self, base, k):
+        base = np.ascontiguousarray(base, dtype=np.uint64)
+        kk = ints_to_limbs([int(k)])
+        out = np.zeros(12, dtype=np.uint64)
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.lib.frw_oracle_g1_scalar_mul(P(base), P(kk), P(out))
+        return out
+
+    def g1_add(self, a, b):
+        a, b = (np.ascontiguousarray(x, dtype=np.uint64) for x in (a, b))
+        out = np.zeros(12, dtype=np.uint64)
+        P = lambda x: x.ctypes.data_as(C.c_void_p)
+        self.lib.frw_oracle_g1_add(P(a), P(b), P(out))
+        return out
+
+    def g1_fixed_base(self, scalars, threads=8):
+        """k_i G1 for canonical scalars uint64[count, 4] -> uint64[count, 12]."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((scalars.shape[0], 12), dtype=np.uint64)
+        P = lambda x: x.ctypes.data_as(C.c_void_p)
+        self.lib.frw_oracle_g1_fixed_base(scalars.shape[0], P(scalars), P(out), threads)
+        return out
+
+    def g1_msm(self, bases, scalars, window_bits=13, threads=8):
+        """sum k_i P_i (bucket method on the CPU): bases uint64[count, 12], canonical scalars uint64[count, 4] -> uint64[12]."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 12)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        assert bases.shape[0] == scalars.shape[0]
+        out = np.zeros(12, dtype=np.uint64)
+        P = lambda x: x.ctypes.data_as(C.c_void_p)
+        self.lib.frw_oracle_g1_msm(bases.shape[0], P(bases), P(scalars), P(out), window_bits, threads)
+        return out
 
     def qap_product_high_half(self, az, bz, num_inputs, z):
         """hi of a(X) b(X) = lo + X^n hi (what frw_qap_quotient_dev returns); uint64[., 4] canonical."""
@@ -132,7 +184,7 @@ class Oracle:
 
 def load_oracle():
     so = os.path.join(ORACLE_DIR, "libfrw_oracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("frw_oracle.c", "qap_oracle.c")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("frw_oracle.c", "qap_oracle.c", "bls12_381.c")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "libfrw_oracle.so"])
     return Oracle(so)
