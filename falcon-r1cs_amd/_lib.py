@@ -41,6 +41,11 @@ class CompactLayoutStruct(C.Structure):
                 ("num_instance_values", C.c_uint64), ("status_off", C.c_uint64)]
 
 
+class MsmInfoStruct(C.Structure):
+    _fields_ = [("num_points", C.c_uint64), ("window_bits", C.c_int32), ("num_windows", C.c_int32), ("table_bytes", C.c_uint64),
+                ("workspace_bytes_per_signature", C.c_uint64)]
+
+
 class QapInfoStruct(C.Structure):
     _fields_ = [("log_domain_size", C.c_int32), ("domain_size", C.c_uint64), ("num_constraints", C.c_uint64),
                 ("num_instance", C.c_uint64), ("workspace_bytes_per_signature", C.c_uint64)]
@@ -66,6 +71,13 @@ PROTOTYPES = {
     "frw_ctx_trim": (C.c_int, [C.c_void_p]),
     "frw_diag_valu_rates": (C.c_int, [C.c_void_p, C.POINTER(C.c_double * 4)]),
     "frw_r1cs_diag_host_allocations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "frw_msm_g1_load": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "frw_msm_free": (None, [C.c_void_p]),
+    "frw_msm_info": (C.c_int, [C.c_void_p, C.POINTER(MsmInfoStruct)]),
+    "frw_msm_g1_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                 C.c_void_p]),
+    "frw_groth16_msm_h_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
     "frw_compact_layout": (C.c_int, [C.c_int, C.POINTER(CompactLayoutStruct)]),
     "frw_witness_ntt_verify_compact_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,0 +1,324 @@
+// frw_fq29.h -- BLS12-381 Fq (the 381-bit base field of G1) on the device in fourteen 29-bit limbs, and G1 in XYZZ
+// coordinates on top of it: what the multi-scalar multiplications of a Groth16 prover compute with
+// (examples/pok_sig.rs:30-47 -> ark-groth16 0.3.0 prover.rs: VariableBaseMSM over pk.h_query, a_query, b_g1_query, l_query).
+//
+// Same design as frw_fr29.h, for the same reason: v_mad_u64_u32 is what the chip multiplies with, and with 29-bit limbs a
+// column of a 14 x 14 product (14 x 2^58) and the column of the Montgomery reduction on top of it (14 x 2^58 more) fit 64
+// bits, so a product is 2 x 196 chained multiply-adds with no carry handling in between.  14 x 29 = 406 bits for a 381-bit
+// modulus: 2^406 = 2^25 q of headroom, so sums and differences are never reduced -- a difference adds K q, K >= the bound of
+// what is subtracted -- and only the products bring values back under 2 q.
+// Montgomery radix R'' = 2^406; ark-ff's representation is x 2^384 (six 64-bit limbs), converted on the way in and out.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace frw {
+
+constexpr int NLQ = 14;
+constexpr uint32_t MQ29 = (1u << 29) - 1u;
+
+struct Fq29 { uint32_t l[NLQ]; };
+struct LimbsQ { uint32_t l[NLQ]; };
+
+// q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab, 32-bit words
+constexpr uint32_t Q32_[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                               0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+constexpr LimbsQ make_kq29(uint32_t K)
+{
+    uint32_t w[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t carry = 0;
+    for (int k = 0; k < 12; k++) {
+        const uint64_t t = (uint64_t)K * Q32_[k] + carry;
+        w[k] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    w[12] = (uint32_t)carry;
+    LimbsQ r{};
+    for (int i = 0; i < NLQ; i++) {
+        const int bit = 29 * i, k = bit >> 5, s = bit & 31;
+        const uint64_t both = (uint64_t)w[k] | ((uint64_t)w[k + 1] << 32);
+        r.l[i] = (uint32_t)(both >> s) & (i == NLQ - 1 ? 0xffffffffu : MQ29);
+    }
+    return r;
+}
+constexpr LimbsQ KQ29_1 = make_kq29(1), KQ29_4 = make_kq29(4), KQ29_16 = make_kq29(16), KQ29_64 = make_kq29(64);
+template <uint32_t K> constexpr const LimbsQ &kq29_table()
+{
+    static_assert(K == 1 || K == 4 || K == 16 || K == 64, "table missing");
+    return K == 1 ? KQ29_1 : K == 4 ? KQ29_4 : K == 16 ? KQ29_16 : KQ29_64;
+}
+static_assert(KQ29_1.l[0] == 0x1fffaaabu && KQ29_1.l[13] == 0xdu && KQ29_16.l[13] == 0xd0u, "q in 29-bit limbs");
+constexpr uint32_t QINV29 = 0x1ffcfffdu;      // -q^-1 mod 2^29
+constexpr uint32_t QPOSINV29 = 0x00030003u;   //  q^-1 mod 2^29
+static_assert(((uint64_t)KQ29_1.l[0] * QPOSINV29 & MQ29) == 1u && ((QINV29 + QPOSINV29) & MQ29) == 0u, "inverse of q mod 2^29");
+// 2^406 mod q (one), 2^428 mod q (x 2^384 -> x 2^406 by one product), 2^384 mod q (back); tests/test_fq29_host.py re-derives them
+constexpr LimbsQ FQ29_ONE = {{0x03a9fb84u, 0x0ba00690u, 0x071288f1u, 0x0f59bcc5u, 0x126cb614u, 0x0585bf36u, 0x1b85ac3du,
+                              0x1cf856fau, 0x1891ecbdu, 0x1a7eec05u, 0x155a88f0u, 0x0741ac6du, 0x1317c30fu, 0x00000009u}};
+constexpr LimbsQ FQ29_C_IN = {{0x1fddebbdu, 0x1a4f5474u, 0x0291f399u, 0x14d03b3cu, 0x0f6cad2cu, 0x1b4cabcau, 0x1592827cu,
+                               0x021c6ac7u, 0x1ec52a84u, 0x16fd5ec4u, 0x0c960da6u, 0x0fd2af6bu, 0x13263591u, 0x0000000bu}};
+constexpr LimbsQ FQ29_C_OUT = {{0x0002fffdu, 0x10480000u, 0x0300009du, 0x08001788u, 0x158baebfu, 0x0c2ba9e3u, 0x1d157d22u,
+                                0x0a6e0a4au, 0x0d77ce58u, 0x1d12b763u, 0x1701c6a5u, 0x1501c926u, 0x1f65ec3fu, 0x0000000au}};
+
+__host__ __device__ __forceinline__ Fq29 fq_const(const LimbsQ &c)
+{
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) r.l[i] = c.l[i];
+    return r;
+}
+__host__ __device__ __forceinline__ Fq29 fq_zero()
+{
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) r.l[i] = 0;
+    return r;
+}
+
+// 12 x 32-bit words (a 384-bit integer, little-endian) <-> limbs
+__host__ __device__ __forceinline__ Fq29 fq_unpack(const uint32_t *w)
+{
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) {
+        const int bit = 29 * i, k = bit >> 5, s = bit & 31;
+        const uint64_t both = (uint64_t)w[k] | (k + 1 < 12 ? (uint64_t)w[k + 1] << 32 : 0ull);
+        r.l[i] = (uint32_t)(both >> s) & MQ29;
+    }
+    return r;
+}
+// normalised limbs, value < 2^384
+__host__ __device__ __forceinline__ void fq_pack(const Fq29 &a, uint32_t *w)
+{
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const int bit = 32 * k, i = bit / 29, s = bit - 29 * i;
+        uint32_t v = a.l[i] >> s;
+        int filled = 29 - s;
+        if (filled < 32 && i + 1 < NLQ) { v |= a.l[i + 1] << filled; filled += 29; }
+        if (filled < 32 && i + 2 < NLQ) v |= a.l[i + 2] << filled;
+        w[k] = v;
+    }
+}
+
+__host__ __device__ __forceinline__ void fq_normalise(Fq29 &a)
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NLQ - 1; i++) {
+        const uint32_t x = a.l[i] + c;
+        a.l[i] = x & MQ29;
+        c = x >> 29;
+    }
+    a.l[NLQ - 1] += c;
+}
+// limbs are signed 32-bit differences, the value is >= 0 unless the return value says otherwise (top limb negative)
+__host__ __device__ __forceinline__ int fq_normalise_signed(Fq29 &a)
+{
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NLQ - 1; i++) {
+        const int32_t x = (int32_t)a.l[i] + c;
+        a.l[i] = (uint32_t)x & MQ29;
+        c = x >> 29;
+    }
+    const int32_t top = (int32_t)a.l[NLQ - 1] + c;
+    a.l[NLQ - 1] = (uint32_t)top;
+    return top < 0;
+}
+__host__ __device__ __forceinline__ Fq29 fq_add(const Fq29 &a, const Fq29 &b)
+{
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) r.l[i] = a.l[i] + b.l[i];
+    fq_normalise(r);
+    return r;
+}
+// a - b + K q  (b < K q), normalised
+template <uint32_t K>
+__host__ __device__ __forceinline__ Fq29 fq_sub(const Fq29 &a, const Fq29 &b)
+{
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) r.l[i] = a.l[i] - b.l[i] + kq29_table<K>().l[i];
+    (void)fq_normalise_signed(r);
+    return r;
+}
+// K q - b  (b < K q): the negative
+template <uint32_t K>
+__host__ __device__ __forceinline__ Fq29 fq_neg(const Fq29 &b)
+{
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) r.l[i] = kq29_table<K>().l[i] - b.l[i];
+    (void)fq_normalise_signed(r);
+    return r;
+}
+
+// Montgomery product a b / 2^406 mod q.  a: limbs < 2^31 (need not be normalised); b: normalised limbs.
+// Result: normalised, < a b / 2^406 + q  (< 2 q whenever a b < 2^406 q: any two values below 2^12 q).
+__host__ __device__ __forceinline__ Fq29 fq_mul(const Fq29 &a, const Fq29 &b)
+{
+    uint64_t col[2 * NLQ];
+#pragma unroll
+    for (int k = 0; k < 2 * NLQ - 1; k++) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = (k < NLQ ? 0 : k - (NLQ - 1)); i <= (k < NLQ ? k : NLQ - 1); i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+        col[k] = acc;
+    }
+    col[2 * NLQ - 1] = 0;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) {
+        const uint32_t m = ((uint32_t)col[i] * QINV29) & MQ29;
+#pragma unroll
+        for (int j = 0; j < NLQ; j++) col[i + j] += (uint64_t)m * KQ29_1.l[j];
+        col[i + 1] += col[i] >> 29;                                  // the low 29 bits of column i are zero now
+    }
+    Fq29 r;
+#pragma unroll
+    for (int k = NLQ; k < 2 * NLQ - 1; k++) {
+        r.l[k - NLQ] = (uint32_t)col[k] & MQ29;
+        col[k + 1] += col[k] >> 29;
+    }
+    r.l[NLQ - 1] = (uint32_t)col[2 * NLQ - 1];
+    return r;
+}
+__host__ __device__ __forceinline__ Fq29 fq_sqr(const Fq29 &a) { return fq_mul(a, a); }
+
+// a < 2 q (normalised)  ->  the canonical representative < q
+__host__ __device__ __forceinline__ Fq29 fq_canonical(const Fq29 &a)
+{
+    Fq29 d;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) d.l[i] = a.l[i] - KQ29_1.l[i];
+    const int neg = fq_normalise_signed(d);
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) r.l[i] = neg ? a.l[i] : d.l[i];
+    return r;
+}
+// any lazily reduced value (< 2^12 q) -> canonical: a product with one, then the conditional subtraction
+__host__ __device__ __forceinline__ Fq29 fq_reduce(const Fq29 &a) { return fq_canonical(fq_mul(a, fq_const(FQ29_ONE))); }
+
+// a = 0 mod q?  a < 64 q, normalised.  A multiple k q of q has k = a.l[0] q^-1 mod 2^29: anything else is ruled out by two
+// instructions, and only a candidate (one value in 2^23) pays for the exact reduction.
+__host__ __device__ __forceinline__ bool fq_is_zero(const Fq29 &a)
+{
+    if (((a.l[0] * QPOSINV29) & MQ29) >= 64u) return false;
+    const Fq29 c = fq_reduce(a);
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) any |= c.l[i];
+    return any == 0;
+}
+
+// ark-ff's x 2^384 (12 words) -> x 2^406 in limbs (< 2 q), and back to canonical words
+__host__ __device__ __forceinline__ Fq29 fq_from_ark(const uint32_t *w) { return fq_mul(fq_unpack(w), fq_const(FQ29_C_IN)); }
+__host__ __device__ __forceinline__ void fq_to_ark(const Fq29 &a, uint32_t *w) { fq_pack(fq_canonical(fq_mul(a, fq_const(FQ29_C_OUT))), w); }
+
+// a^(q - 2): the inverse (a != 0 mod q); ~380 squarings + ~230 products, for the one conversion to affine per result
+__host__ __device__ inline Fq29 fq_inv(const Fq29 &a)
+{
+    // q - 2 in 32-bit words
+    uint32_t e[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) e[k] = Q32_[k];
+    e[0] -= 2;
+    Fq29 acc = fq_const(FQ29_ONE);
+    for (int i = 380; i >= 0; i--) {
+        acc = fq_sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1u) acc = fq_mul(acc, a);
+    }
+    return acc;
+}
+
+// ---- G1: y^2 = x^3 + 4, XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2); inf = the point at infinity -----------------
+// Bounds kept by every formula below (in units of q): X < 10, Y < 6, ZZ < 2, ZZZ < 2, affine coordinates < 2.
+struct G1Affine29 { Fq29 x, y; bool inf; };
+struct G1Xyzz { Fq29 x, y, zz, zzz; bool inf; };
+
+__host__ __device__ __forceinline__ G1Xyzz g1_identity()
+{
+    G1Xyzz r;
+    r.x = r.y = r.zz = r.zzz = fq_zero();
+    r.inf = true;
+    return r;
+}
+__host__ __device__ __forceinline__ G1Xyzz g1_from_affine(const G1Affine29 &p)
+{
+    G1Xyzz r;
+    r.x = p.x; r.y = p.y; r.zz = r.zzz = fq_const(FQ29_ONE);
+    r.inf = p.inf;
+    return r;
+}
+// dbl-2008-s-1 (a = 0): 6 M + 3 S
+__host__ __device__ inline G1Xyzz g1_double(const G1Xyzz &p)
+{
+    if (p.inf) return p;
+    const Fq29 u = fq_add(p.y, p.y);                     // < 12
+    const Fq29 v = fq_sqr(u), w = fq_mul(u, v);
+    const Fq29 s = fq_mul(p.x, v);
+    const Fq29 xx = fq_sqr(p.x);
+    const Fq29 m = fq_add(fq_add(xx, xx), xx);           // < 6
+    G1Xyzz r;
+    r.x = fq_sub<4>(fq_sqr(m), fq_add(s, s));            // < 6
+    r.y = fq_sub<4>(fq_mul(m, fq_sub<16>(s, r.x)), fq_mul(w, p.y));
+    r.zz = fq_mul(v, p.zz);
+    r.zzz = fq_mul(w, p.zzz);
+    r.inf = false;
+    return r;
+}
+// madd-2008-s: 8 M + 2 S; complete (an accumulator that meets its own value doubles, its negative cancels)
+__host__ __device__ inline G1Xyzz g1_add_affine(const G1Xyzz &p, const G1Affine29 &q)
+{
+    if (q.inf) return p;
+    if (p.inf) return g1_from_affine(q);
+    const Fq29 u2 = fq_mul(q.x, p.zz), s2 = fq_mul(q.y, p.zzz);
+    const Fq29 pp_ = fq_sub<16>(u2, p.x);                // P, < 18
+    const Fq29 rr = fq_sub<16>(s2, p.y);                 // R, < 18
+    if (fq_is_zero(pp_)) {
+        if (fq_is_zero(rr)) return g1_double(g1_from_affine(q));
+        return g1_identity();
+    }
+    const Fq29 pp = fq_sqr(pp_), ppp = fq_mul(pp_, pp), qq = fq_mul(p.x, pp);
+    G1Xyzz r;
+    r.x = fq_sub<4>(fq_sub<4>(fq_sqr(rr), ppp), fq_add(qq, qq));          // < 10
+    r.y = fq_sub<4>(fq_mul(rr, fq_sub<16>(qq, r.x)), fq_mul(p.y, ppp));   // < 6
+    r.zz = fq_mul(p.zz, pp);
+    r.zzz = fq_mul(p.zzz, ppp);
+    r.inf = false;
+    return r;
+}
+// add-2008-s: 12 M + 2 S; complete
+__host__ __device__ inline G1Xyzz g1_add(const G1Xyzz &p, const G1Xyzz &q)
+{
+    if (q.inf) return p;
+    if (p.inf) return q;
+    const Fq29 u1 = fq_mul(p.x, q.zz), u2 = fq_mul(q.x, p.zz), s1 = fq_mul(p.y, q.zzz), s2 = fq_mul(q.y, p.zzz);
+    const Fq29 pp_ = fq_sub<4>(u2, u1), rr = fq_sub<4>(s2, s1);
+    if (fq_is_zero(pp_)) {
+        if (fq_is_zero(rr)) return g1_double(p);
+        return g1_identity();
+    }
+    const Fq29 pp = fq_sqr(pp_), ppp = fq_mul(pp_, pp), qq = fq_mul(u1, pp);
+    G1Xyzz r;
+    r.x = fq_sub<4>(fq_sub<4>(fq_sqr(rr), ppp), fq_add(qq, qq));
+    r.y = fq_sub<4>(fq_mul(rr, fq_sub<16>(qq, r.x)), fq_mul(s1, ppp));
+    r.zz = fq_mul(fq_mul(p.zz, q.zz), pp);
+    r.zzz = fq_mul(fq_mul(p.zzz, q.zzz), ppp);
+    r.inf = false;
+    return r;
+}
+// x = X / ZZ, y = Y / ZZZ with one inversion; (0, 0) for the point at infinity.  Coordinates < 2 q.
+__host__ __device__ inline G1Affine29 g1_to_affine(const G1Xyzz &p)
+{
+    G1Affine29 r;
+    r.inf = p.inf;
+    if (p.inf) { r.x = r.y = fq_zero(); return r; }
+    const Fq29 inv = fq_inv(fq_mul(p.zz, p.zzz));
+    r.x = fq_mul(p.x, fq_mul(inv, p.zzz));
+    r.y = fq_mul(p.y, fq_mul(inv, p.zz));
+    return r;
+}
+
+}  // namespace frw

@@ -1,0 +1,367 @@
+// frw_msm.hip -- multi-scalar multiplication over BLS12-381 G1 on the device: the step after the QAP witness map in a Groth16
+// prover.  examples/pok_sig.rs:30-47 of the reference calls Groth16::<Bls12_381>::prove; ark-groth16 0.3.0 prover.rs
+// (create_proof_with_reduction_and_matrices) then computes
+//     h_acc = VariableBaseMSM::multi_scalar_mul(&pk.h_query, &h_assignment)          2^18 - 1 points for Falcon-1024
+// (and the same over a_query / b_g1_query / l_query with the witness as scalars).  frw_qap_witness_map_dev leaves h in HBM;
+// this file consumes it there.
+//
+// MI355X-first shape.  The bases belong to the proving key: fixed per circuit, shared by every signature ever proved.  So
+// (1) frw_msm_g1_load spends 288 GB-class memory on them once: the table holds 2^(16 j) P_i for all sixteen 16-bit windows
+//     j (436 MB for 2^18 points, affine, fourteen 29-bit limbs per coordinate), which turns a 255-bit MSM over n points
+//     into ONE bucket accumulation over 16 n points with 16-bit signed digits -- no doublings, no per-window passes;
+// (2) a call handles a batch of signatures: per signature the 16 n (digit, point) pairs are counting-sorted by bucket
+//     (32,768 buckets, ~128 entries each), one thread per bucket adds its entries up in registers (XYZZ coordinates, mixed
+//     additions, 8 M + 2 S), gathering the table rows it needs; 512 threads fold the buckets (sum of (b + 1) B_b by running
+//     sums over 64-bucket chunks, small multiples, a tree through LDS), and the result leaves as one affine point in
+//     ark-ff's bytes.
+// Group addition is associative and commutative, so the result does not depend on the order the atomics of the sort
+// happened to produce: the output is the unique affine point, bit for bit what any other schedule (or the CPU) gives.
+// Field arithmetic: frw_fq29.h.  Bound: vector-ALU issue (a mixed addition is ~5,700 vector instructions), not HBM (a
+// signature reads 16 n x 112 B = 0.47 GB of table rows).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <new>
+#include "../../include/frw.h"
+#include "frw_device.h"
+#include "frw_fq29.h"
+#include "frw_fr29.h"
+
+namespace frw {
+
+constexpr int MSM_C = 16;                       // window bits
+constexpr int MSM_W = 16;                       // windows: 16 x 16 = 256 >= 255 bits
+constexpr int MSM_BUCKETS = 1 << (MSM_C - 1);   // signed digits: |d| in 1 .. 2^15
+constexpr int MSM_PT_WORDS = 2 * NLQ;           // a table row: x, y limbs (all zero = the point at infinity)
+constexpr int MSM_BK_WORDS = 4 * NLQ + 4;       // a bucket: X, Y, ZZ, ZZZ limbs + the infinity flag (padded to 16 bytes)
+constexpr int MSM_CHUNK = 64;                   // buckets per thread in the fold
+constexpr int MSM_FOLD_THREADS = MSM_BUCKETS / MSM_CHUNK;
+
+struct MsmDev {
+    uint32_t n;                 // points
+    const uint32_t *table;      // [MSM_W][n][MSM_PT_WORDS]
+};
+
+__device__ __forceinline__ G1Affine29 load_row(const uint32_t *row)
+{
+    G1Affine29 p;
+    uint32_t any = 0;
+    const uint4 *v = (const uint4 *)row;
+    uint32_t w[MSM_PT_WORDS];
+#pragma unroll
+    for (int k = 0; k < MSM_PT_WORDS / 4; k++) {
+        const uint4 t = v[k];
+        w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < NLQ; k++) { p.x.l[k] = w[k]; p.y.l[k] = w[NLQ + k]; any |= w[k] | w[NLQ + k]; }
+    p.inf = any == 0;
+    return p;
+}
+__device__ __forceinline__ void store_row(uint32_t *row, const G1Affine29 &p)
+{
+#pragma unroll
+    for (int k = 0; k < NLQ; k++) { row[k] = p.inf ? 0u : p.x.l[k]; row[NLQ + k] = p.inf ? 0u : p.y.l[k]; }
+}
+__device__ __forceinline__ void store_bucket(uint32_t *b, const G1Xyzz &p)
+{
+#pragma unroll
+    for (int k = 0; k < NLQ; k++) { b[k] = p.x.l[k]; b[NLQ + k] = p.y.l[k]; b[2 * NLQ + k] = p.zz.l[k]; b[3 * NLQ + k] = p.zzz.l[k]; }
+    b[4 * NLQ] = p.inf ? 1u : 0u;
+}
+__device__ __forceinline__ G1Xyzz load_bucket(const uint32_t *b)
+{
+    G1Xyzz p;
+#pragma unroll
+    for (int k = 0; k < NLQ; k++) { p.x.l[k] = b[k]; p.y.l[k] = b[NLQ + k]; p.zz.l[k] = b[2 * NLQ + k]; p.zzz.l[k] = b[3 * NLQ + k]; }
+    p.inf = b[4 * NLQ] != 0;
+    return p;
+}
+
+// ---- load time: table[j][i] = 2^(16 j) P_i, affine, Montgomery limbs ----------------------------------------------------------
+__global__ __launch_bounds__(64) void msm_precompute_kernel(uint32_t n, const uint32_t *__restrict__ bases /* [n][24] ark-ff */,
+                                                            uint32_t *__restrict__ table)
+{
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *w = bases + (size_t)i * 24;
+    uint32_t any = 0;
+    for (int k = 0; k < 24; k++) any |= w[k];
+    G1Affine29 p;
+    p.inf = any == 0;
+    p.x = fq_from_ark(w);
+    p.y = fq_from_ark(w + 12);
+    for (int j = 0; j < MSM_W; j++) {
+        store_row(table + ((size_t)j * n + i) * MSM_PT_WORDS, p);
+        if (j + 1 == MSM_W) break;
+        G1Xyzz d = g1_from_affine(p);
+        for (int k = 0; k < MSM_C; k++) d = g1_double(d);
+        p = g1_to_affine(d);
+    }
+}
+
+// ---- the scalars: canonical integer, sixteen signed 16-bit digits ---------------------------------------------------------------
+// d_j in [-2^15, 2^15] with sum d_j 2^(16 j) = k; the top digit takes the last carry (k < 2^255, so it stays <= 2^15)
+__device__ __forceinline__ void scalar_digits(const uint32_t *src, int montgomery, int (&d)[MSM_W])
+{
+    Fr8 w = fr_load(src);
+    if (montgomery) {
+        // ark-ff's h R (R = 2^256) -> h: one product with 2^5 in R' = 2^261 arithmetic (frw_fr29.h), then the canonical form
+        F29 c;
+#pragma unroll
+        for (int k = 0; k < NL29; k++) c.l[k] = k ? 0u : 32u;
+        w = f29_pack(f29_canonical(f29_mul(f29_unpack(w), c)));
+    }
+    int carry = 0;
+#pragma unroll
+    for (int j = 0; j < MSM_W; j++) {
+        int v = (int)((w.l[j >> 1] >> (16 * (j & 1))) & 0xffffu) + carry;
+        carry = 0;
+        if (j + 1 < MSM_W && v > MSM_BUCKETS) { v -= 1 << MSM_C; carry = 1; }
+        d[j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void msm_count_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
+                                                        int montgomery, uint32_t *__restrict__ counts)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t sig = blockIdx.y;
+    int d[MSM_W];
+    scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d);
+    uint32_t *cnt = counts + sig * MSM_BUCKETS;
+#pragma unroll
+    for (int j = 0; j < MSM_W; j++)
+        if (d[j]) atomicAdd(&cnt[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
+}
+
+// exclusive prefix sums of a signature's 32,768 counts: offsets (kept) and cursors (consumed by the scatter)
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
+                                                        uint32_t *__restrict__ cursors)
+{
+    __shared__ uint32_t part[1024];
+    const size_t sig = blockIdx.x;
+    const uint32_t *cnt = counts + sig * MSM_BUCKETS;
+    const int t = threadIdx.x;
+    constexpr int PER = MSM_BUCKETS / 1024;
+    uint32_t local[PER], s = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { local[k] = s; s += cnt[t * PER + k]; }
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const uint32_t base = part[t] - s;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        offsets[sig * MSM_BUCKETS + t * PER + k] = base + local[k];
+        cursors[sig * MSM_BUCKETS + t * PER + k] = base + local[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void msm_scatter_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
+                                                          int montgomery, uint32_t *__restrict__ cursors, uint32_t *__restrict__ entries)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t sig = blockIdx.y;
+    int d[MSM_W];
+    scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d);
+    uint32_t *cur = cursors + sig * MSM_BUCKETS;
+    uint32_t *ent = entries + sig * (size_t)MSM_W * n;
+#pragma unroll
+    for (int j = 0; j < MSM_W; j++) {
+        if (!d[j]) continue;
+        const uint32_t b = (uint32_t)(d[j] < 0 ? -d[j] : d[j]) - 1u;
+        const uint32_t pos = atomicAdd(&cur[b], 1u);
+        ent[pos] = ((uint32_t)j * n + i) | (d[j] < 0 ? 0x80000000u : 0u);
+    }
+}
+
+// one thread per (signature, bucket): the sum of the bucket's table rows, in registers
+__global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
+                                                           const uint32_t *__restrict__ entries, uint32_t *__restrict__ buckets)
+{
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    const size_t sig = blockIdx.y;
+    const uint32_t start = offsets[sig * MSM_BUCKETS + b], cnt = counts[sig * MSM_BUCKETS + b];
+    const uint32_t *ent = entries + sig * (size_t)MSM_W * m.n + start;
+    G1Xyzz acc = g1_identity();
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t e = ent[k];
+        G1Affine29 p = load_row(m.table + (size_t)(e & 0x7fffffffu) * MSM_PT_WORDS);
+        if (e >> 31) p.y = fq_neg<4>(p.y);
+        acc = g1_add_affine(acc, p);
+    }
+    store_bucket(buckets + (sig * MSM_BUCKETS + b) * (size_t)MSM_BK_WORDS, acc);
+}
+
+// sum_b (b + 1) B_b per signature: 512 threads x 64 buckets, then a tree; thread 0 converts to affine and writes ark-ff's bytes
+__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32_t *__restrict__ buckets, uint32_t *__restrict__ out /* [batch][24] */)
+{
+    __shared__ uint32_t lds[MSM_FOLD_THREADS / 2 * (4 * NLQ + 1)];       // 58 KB: the upper half of a tree level parks here
+    const size_t sig = blockIdx.x;
+    const int t = threadIdx.x;
+    const uint32_t *bk = buckets + (sig * MSM_BUCKETS + (size_t)t * MSM_CHUNK) * MSM_BK_WORDS;
+    G1Xyzz run = g1_identity(), sum = g1_identity();
+    for (int k = MSM_CHUNK - 1; k >= 0; k--) {
+        run = g1_add(run, load_bucket(bk + (size_t)k * MSM_BK_WORDS));
+        sum = g1_add(sum, run);
+    }
+    // sum = sum_k (k + 1) B_(64 t + k); the buckets' weights are 64 t + k + 1: add (64 t) run = 2^6 (t run)
+    G1Xyzz mult = g1_identity();
+    for (int bit = 8; bit >= 0; bit--) {
+        mult = g1_double(mult);
+        if ((t >> bit) & 1) mult = g1_add(mult, run);
+    }
+    for (int k = 0; k < 6; k++) mult = g1_double(mult);
+    sum = g1_add(sum, mult);
+    auto put = [&](int slot, const G1Xyzz &p) {
+        uint32_t *s = lds + slot * (4 * NLQ + 1);
+#pragma unroll
+        for (int k = 0; k < NLQ; k++) { s[k] = p.x.l[k]; s[NLQ + k] = p.y.l[k]; s[2 * NLQ + k] = p.zz.l[k]; s[3 * NLQ + k] = p.zzz.l[k]; }
+        s[4 * NLQ] = p.inf ? 1u : 0u;
+    };
+    auto get = [&](int slot) {
+        const uint32_t *s = lds + slot * (4 * NLQ + 1);
+        G1Xyzz p;
+#pragma unroll
+        for (int k = 0; k < NLQ; k++) { p.x.l[k] = s[k]; p.y.l[k] = s[NLQ + k]; p.zz.l[k] = s[2 * NLQ + k]; p.zzz.l[k] = s[3 * NLQ + k]; }
+        p.inf = s[4 * NLQ] != 0;
+        return p;
+    };
+    for (int stride = MSM_FOLD_THREADS / 2; stride >= 1; stride >>= 1) {
+        if (t >= stride && t < 2 * stride) put(t - stride, sum);
+        __syncthreads();
+        if (t < stride) sum = g1_add(sum, get(t));
+        __syncthreads();
+    }
+    if (t == 0) {
+        const G1Affine29 a = g1_to_affine(sum);
+        uint32_t *o = out + sig * 24;
+        if (a.inf) {
+            for (int k = 0; k < 24; k++) o[k] = 0;
+        } else {
+            fq_to_ark(a.x, o);
+            fq_to_ark(a.y, o + 12);
+        }
+    }
+}
+
+}  // namespace frw
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------------------------
+struct frw_msm {
+    int device;
+    frw::MsmDev dev;
+    void *table;
+};
+
+namespace {
+size_t msm_workspace_per_signature(uint32_t n)
+{
+    // counts, offsets, cursors (3 x 32,768 x 4 B), entries (16 n x 4 B), buckets (32,768 x 240 B)
+    return 3 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::MSM_BK_WORDS * 4;
+}
+}  // namespace
+
+extern "C" void frw_msm_free(frw_msm *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->table) (void)hipFree(m->table);
+    delete m;
+}
+
+extern "C" int frw_msm_g1_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
+{
+    if (!out || !bases || num_points == 0 || num_points > ((size_t)1 << 26)) return FRW_E_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return frw::record_hip_error(e, "hipSetDevice");
+    frw_msm *m = new (std::nothrow) frw_msm;
+    if (!m) return FRW_E_OUT_OF_MEMORY;
+    m->device = device;
+    m->table = nullptr;
+    m->dev.n = (uint32_t)num_points;
+    void *d_bases = nullptr;
+    const size_t table_bytes = (size_t)frw::MSM_W * num_points * frw::MSM_PT_WORDS * 4;
+    e = hipMalloc(&m->table, table_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_bases, num_points * 96);
+    if (e == hipSuccess) e = hipMemcpy(d_bases, bases, num_points * 96, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(frw::msm_precompute_kernel, dim3((unsigned)((num_points + 63) / 64)), dim3(64), 0, nullptr,
+                           (uint32_t)num_points, (const uint32_t *)d_bases, (uint32_t *)m->table);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (d_bases) (void)hipFree(d_bases);
+    if (e != hipSuccess) {
+        frw_msm_free(m);
+        return frw::record_hip_error(e, "frw_msm_g1_load");
+    }
+    m->dev.table = (const uint32_t *)m->table;
+    *out = m;
+    return FRW_OK;
+}
+
+extern "C" int frw_msm_info(const frw_msm *m, frw_msm_info_t *out)
+{
+    if (!m || !out) return FRW_E_INVALID_ARG;
+    out->num_points = m->dev.n;
+    out->window_bits = frw::MSM_C;
+    out->num_windows = frw::MSM_W;
+    out->table_bytes = (uint64_t)frw::MSM_W * m->dev.n * frw::MSM_PT_WORDS * 4;
+    out->workspace_bytes_per_signature = msm_workspace_per_signature(m->dev.n);
+    return FRW_OK;
+}
+
+extern "C" int frw_msm_g1_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery,
+                              uint64_t *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (!m || (batch && (!d_scalars || !d_out || !d_workspace)) || scalar_stride < m->dev.n) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    const uint32_t n = m->dev.n;
+    const size_t per = msm_workspace_per_signature(n);
+    size_t chunk = workspace_bytes / per;
+    if (chunk == 0 || ((uintptr_t)d_workspace & 15)) return FRW_E_INVALID_ARG;
+    if (chunk > 32768) chunk = 32768;                                  // grid.y
+    hipError_t e = hipSetDevice(m->device);
+    hipStream_t st = (hipStream_t)stream;
+    for (size_t lo = 0; e == hipSuccess && lo < batch; lo += chunk) {
+        const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
+        uint32_t *counts = (uint32_t *)d_workspace;
+        uint32_t *offsets = counts + cnt * frw::MSM_BUCKETS;
+        uint32_t *cursors = offsets + cnt * frw::MSM_BUCKETS;
+        uint32_t *entries = cursors + cnt * frw::MSM_BUCKETS;
+        uint32_t *buckets = entries + cnt * (size_t)frw::MSM_W * n;
+        const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
+        const size_t stride_words = scalar_stride * 8;
+        e = hipMemsetAsync(counts, 0, cnt * frw::MSM_BUCKETS * 4, st);
+        if (e != hipSuccess) break;
+        const dim3 pgrid((n + 255) / 256, (unsigned)cnt);
+        hipLaunchKernelGGL(frw::msm_count_kernel, pgrid, dim3(256), 0, st, n, sc, stride_words, montgomery, counts);
+        hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, cursors);
+        hipLaunchKernelGGL(frw::msm_scatter_kernel, pgrid, dim3(256), 0, st, n, sc, stride_words, montgomery, cursors, entries);
+        hipLaunchKernelGGL(frw::msm_bucket_kernel, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
+                           entries, buckets);
+        hipLaunchKernelGGL(frw::msm_fold_kernel, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, buckets,
+                           (uint32_t *)(d_out + lo * 12));
+        e = hipGetLastError();
+    }
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_g1_dev");
+}
+
+extern "C" int frw_groth16_msm_h_dev(const frw_msm *m, size_t batch, const uint64_t *d_h, size_t domain_size, uint64_t *d_out,
+                                     void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    // prover.rs: the scalars are h's coefficients 0 .. n - 2 (h_query has n - 1 points; the zip drops the last coefficient)
+    if (!m || (size_t)m->dev.n + 1 != domain_size) return FRW_E_INVALID_ARG;
+    return frw_msm_g1_dev(m, batch, d_h, domain_size, 1, d_out, d_workspace, workspace_bytes, stream);
+}

@@ -349,6 +349,31 @@ class WitnessEngine:
                                                   self._ptr(d_scratch) if d_scratch is not None else None, scratch_bytes,
                                                   C.c_void_p(stream)), "frw_r1cs_eval_scratch_dev")
 
+    # ---- multi-scalar multiplication over BLS12-381 G1 (frw_msm.hip) --------------------------------------------------
+    def msm_g1_load(self, bases):
+        """bases: uint64[n, 12] (ark-ff's bytes of n affine points, zeros = infinity) -> handle; free with msm_free."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 12)
+        h = C.c_void_p()
+        check(self._lib.frw_msm_g1_load(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_msm_g1_load")
+        return h
+
+    def msm_free(self, handle):
+        self._lib.frw_msm_free(handle)
+
+    def msm_info(self, handle):
+        from ._lib import MsmInfoStruct
+        info = MsmInfoStruct()
+        check(self._lib.frw_msm_info(handle, C.byref(info)), "frw_msm_info")
+        return info
+
+    def msm_g1_dev(self, handle, batch, d_scalars, scalar_stride, montgomery, d_out, d_workspace, workspace_bytes, stream=0):
+        check(self._lib.frw_msm_g1_dev(handle, batch, self._ptr(d_scalars), scalar_stride, 1 if montgomery else 0, self._ptr(d_out),
+                                       self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)), "frw_msm_g1_dev")
+
+    def groth16_msm_h_dev(self, handle, batch, d_h, domain_size, d_out, d_workspace, workspace_bytes, stream=0):
+        check(self._lib.frw_groth16_msm_h_dev(handle, batch, self._ptr(d_h), domain_size, self._ptr(d_out), self._ptr(d_workspace),
+                                              workspace_bytes, C.c_void_p(stream)), "frw_groth16_msm_h_dev")
+
     def qap_info(self, handle):
         """Domain of the QAP witness map for the loaded matrices: (log n, n, C, I, workspace bytes per signature)."""
         from ._lib import QapInfoStruct

@@ -298,6 +298,40 @@ int frw_qap_witness_map(const frw_r1cs *r, size_t batch, const uint64_t *witness
                         uint64_t *h, uint32_t *num_unsatisfied);
 int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
 
+/* ---- multi-scalar multiplication over BLS12-381 G1 (the step after the witness map in a Groth16 prover) --------------
+ * ark-groth16 0.3.0 prover.rs, create_proof_with_reduction_and_matrices (what examples/pok_sig.rs:30-47 runs):
+ *     h_acc = VariableBaseMSM::multi_scalar_mul(&pk.h_query, &h_assignment)
+ * and likewise over a_query / b_g1_query / l_query.  The bases are the proving key's: fixed per circuit.  frw_msm_g1_load
+ * takes them once (host memory, ark-ff's bytes: per point x then y, each 6 x uint64_t little-endian limbs of the Fq element
+ * in Montgomery form, all zero = the point at infinity) and builds a device table of 2^(16 j) P_i for the sixteen 16-bit
+ * windows j (448 bytes per point); frw_msm_g1_dev then computes sum_i k_i P_i for every signature of a batch:
+ *     d_scalars   uint64_t[batch][scalar_stride][4]; the first num_points elements of each signature's vector are used.
+ *                 montgomery != 0: ark-ff's Fr Montgomery form (what frw_qap_witness_map_dev writes); 0: canonical
+ *                 integers < r (what into_repr() gives)
+ *     d_out       uint64_t[batch][12]: the affine result in ark-ff's bytes (x, y; all zero = infinity) -- the bytes of the
+ *                 G1Affine arkworks' into_affine() would hold
+ *     d_workspace at least workspace_bytes_per_signature (frw_msm_info) bytes, 16-byte aligned; the batch is processed in
+ *                 chunks of as many signatures as fit
+ * Stream-ordered, allocates nothing.  The kernels assume the digits of the scalars spread over the 32,768 buckets (true
+ * for h, whose coefficients are uniform field elements); a vector of mostly 0 / 1 scalars (a Falcon witness) is computed
+ * correctly but slowly -- one bucket takes all the ones.
+ * frw_groth16_msm_h_dev is the call for h_acc: scalars = the first domain_size - 1 coefficients of every h as the witness
+ * map left them (stride domain_size, Montgomery form); num_points must equal domain_size - 1. */
+typedef struct frw_msm frw_msm;
+typedef struct {
+    uint64_t num_points;
+    int32_t window_bits, num_windows;          /* 16, 16 */
+    uint64_t table_bytes;                      /* 16 x num_points x 112 */
+    uint64_t workspace_bytes_per_signature;    /* sort keys (64 num_points bytes) + 32,768 buckets x 240 bytes + counters */
+} frw_msm_info_t;
+int frw_msm_g1_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out);
+void frw_msm_free(frw_msm *m);
+int frw_msm_info(const frw_msm *m, frw_msm_info_t *out);
+int frw_msm_g1_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery,
+                   uint64_t *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
+int frw_groth16_msm_h_dev(const frw_msm *m, size_t batch, const uint64_t *d_h, size_t domain_size, uint64_t *d_out,
+                          void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),
  * hm = Polynomial::from_hash_of_message(msg, sig.nonce()).  Formats are the Falcon specification's:

@@ -68,6 +68,16 @@ pub struct frw_compact_layout_t {
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
+pub struct frw_msm_info_t {
+    pub num_points: u64,
+    pub window_bits: i32,
+    pub num_windows: i32,
+    pub table_bytes: u64,
+    pub workspace_bytes_per_signature: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
 pub struct frw_qap_info_t {
     pub log_domain_size: i32,
     pub domain_size: u64,
@@ -82,6 +92,10 @@ pub struct frw_ctx {
 }
 #[repr(C)]
 pub struct frw_r1cs {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct frw_msm {
     _private: [u8; 0],
 }
 
@@ -141,6 +155,13 @@ extern "C" {
     pub fn frw_qap_witness_map(r: *const frw_r1cs, batch: usize, witness: *const u64, instance: *const u64, h: *mut u64,
                                num_unsatisfied: *mut u32) -> c_int;
     pub fn frw_r1cs_diag_host_allocations(r: *const frw_r1cs, count: *mut u64) -> c_int;
+    pub fn frw_msm_g1_load(device: c_int, num_points: usize, bases: *const u64, out: *mut *mut frw_msm) -> c_int;
+    pub fn frw_msm_free(m: *mut frw_msm);
+    pub fn frw_msm_info(m: *const frw_msm, out: *mut frw_msm_info_t) -> c_int;
+    pub fn frw_msm_g1_dev(m: *const frw_msm, batch: usize, d_scalars: *const u64, scalar_stride: usize, montgomery: c_int,
+                          d_out: *mut u64, d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn frw_groth16_msm_h_dev(m: *const frw_msm, batch: usize, d_h: *const u64, domain_size: usize, d_out: *mut u64,
+                                 d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_hash_to_point_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_nonces: *const u8, d_msgs: *const u8,
                                  d_msg_off: *const u64, d_hm: *mut u16, stream: *mut c_void) -> c_int;
     pub fn frw_decode_public_keys_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_pk_bytes: *const u8,

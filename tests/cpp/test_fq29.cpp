@@ -1,0 +1,78 @@
+// Host harness (shared library, ctypes) around the fourteen-limb Fq arithmetic and the XYZZ point formulas of the MSM
+// kernels (falcon-r1cs_amd/csrc/frw_fq29.h), compiled with g++ through tests/cpp/hip_host.  tests/test_fq29_host.py
+// drives it against Python integers and oracle/bls12_381.py.
+#include <cstdint>
+#include <cstring>
+#include "frw_fq29.h"
+
+using namespace frw;
+
+static Fq29 load(const uint32_t *w) { Fq29 r; std::memcpy(r.l, w, sizeof r.l); return r; }
+static void store(const Fq29 &a, uint32_t *w) { std::memcpy(w, a.l, sizeof a.l); }
+
+extern "C" void t_fq(int op, const uint32_t *a, const uint32_t *b, uint32_t *out)
+{
+    switch (op) {
+    case 0: store(fq_mul(load(a), load(b)), out); break;
+    case 1: store(fq_add(load(a), load(b)), out); break;
+    case 2: store(fq_sub<4>(load(a), load(b)), out); break;
+    case 3: store(fq_sub<16>(load(a), load(b)), out); break;
+    case 4: store(fq_sub<64>(load(a), load(b)), out); break;
+    case 5: store(fq_canonical(load(a)), out); break;
+    case 6: store(fq_reduce(load(a)), out); break;
+    case 7: store(fq_from_ark(a), out); break;                 // a: 12 words
+    case 8: fq_to_ark(load(a), out); break;                     // out: 12 words
+    case 9: store(fq_inv(load(a)), out); break;
+    case 10: out[0] = fq_is_zero(load(a)) ? 1u : 0u; break;
+    case 11: store(fq_neg<4>(load(a)), out); break;
+    case 12: { Fq29 t = fq_unpack(a); store(t, out); break; }   // a: 12 words
+    case 13: fq_pack(load(a), out); break;
+    }
+}
+
+static G1Affine29 load_point(const uint32_t *w)                 // 24 words, ark-ff; zeros = infinity
+{
+    G1Affine29 p;
+    uint32_t any = 0;
+    for (int i = 0; i < 24; i++) any |= w[i];
+    p.inf = any == 0;
+    p.x = fq_from_ark(w);
+    p.y = fq_from_ark(w + 12);
+    return p;
+}
+static void store_point(const G1Xyzz &p, uint32_t *w)
+{
+    const G1Affine29 a = g1_to_affine(p);
+    if (a.inf) { std::memset(w, 0, 96); return; }
+    fq_to_ark(a.x, w);
+    fq_to_ark(a.y, w + 12);
+}
+
+// op 0: p + q (mixed);  1: 2 p;  2: 2 p + 2 q through the general addition (both operands with ZZ != 1);
+// 3: ((p + q) + p) + q, mixed, from the identity;  4: (2 p + q) - q  (the affine operand negated);
+// 5: general addition of 2 p and 2 p (its doubling branch) ; 6: 2 p + (-(2 p))
+extern "C" void t_g1(int op, const uint32_t *pw, const uint32_t *qw, uint32_t *out)
+{
+    const G1Affine29 p = load_point(pw), q = load_point(qw);
+    G1Xyzz r = g1_identity();
+    switch (op) {
+    case 0: r = g1_add_affine(g1_from_affine(p), q); break;
+    case 1: r = g1_double(g1_from_affine(p)); break;
+    case 2: r = g1_add(g1_double(g1_from_affine(p)), g1_double(g1_from_affine(q))); break;
+    case 3: r = g1_add_affine(g1_add_affine(g1_add_affine(g1_add_affine(r, p), q), p), q); break;
+    case 4: {
+        G1Affine29 nq = q;
+        nq.y = fq_neg<4>(q.y);
+        r = g1_add_affine(g1_add_affine(g1_double(g1_from_affine(p)), q), nq);
+        break;
+    }
+    case 5: r = g1_add(g1_double(g1_from_affine(p)), g1_double(g1_from_affine(p))); break;
+    case 6: {
+        G1Xyzz d = g1_double(g1_from_affine(p)), n = d;
+        n.y = fq_neg<16>(d.y);
+        r = g1_add(d, n);
+        break;
+    }
+    }
+    store_point(r, out);
+}

@@ -1,0 +1,145 @@
+"""The fourteen-limb Fq arithmetic and the XYZZ point formulas of the MSM kernels (falcon-r1cs_amd/csrc/frw_fq29.h),
+compiled for the host through the test-only shim (tests/cpp/hip_host) and checked against Python integers and the G1 oracle
+(oracle/bls12_381.py): products at the lazy bounds the formulas rely on, differences with their K q offsets, the constants
+of the header, conversion from and to ark-ff's bytes, inversion, the zero test, and every branch of the point additions."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import bls12_381 as E
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+Q = E.Q
+RQ = 1 << 406
+M29 = (1 << 29) - 1
+
+
+@pytest.fixture(scope="module")
+def lib():
+    out = os.path.join(HERE, "cpp", "build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libtest_fq29.so")
+    src = os.path.join(HERE, "cpp", "test_fq29.cpp")
+    hdr = os.path.join(ROOT, "falcon-r1cs_amd", "csrc", "frw_fq29.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in (src, hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-I", os.path.join(HERE, "cpp", "hip_host"),
+                               "-I", os.path.join(ROOT, "falcon-r1cs_amd", "csrc"), "-o", so, src])
+    return C.CDLL(so)
+
+
+def limbs(v, n=14):
+    assert v >> (29 * (n - 1) + 32) == 0
+    return (C.c_uint32 * n)(*([(v >> (29 * i)) & M29 for i in range(n - 1)] + [v >> (29 * (n - 1))]))
+
+
+def words(v, n=12):
+    return (C.c_uint32 * n)(*[(v >> (32 * i)) & 0xFFFFFFFF for i in range(n)])
+
+
+def value(arr, bits=29):
+    return sum(int(x) << (bits * i) for i, x in enumerate(arr))
+
+
+def fq(lib, op, a, b=0, out_words=14):
+    out = (C.c_uint32 * 24)()
+    lib.t_fq(op, a, b if not isinstance(b, int) else limbs(b), out)
+    return out[:out_words]
+
+
+def test_constants_of_the_header():
+    src = open(os.path.join(ROOT, "falcon-r1cs_amd", "csrc", "frw_fq29.h")).read()
+    import re
+
+    def table(name):
+        body = re.search(name + r" = \{\{([^}]*)\}\}", src).group(1)
+        return value([int(x.strip().rstrip("u"), 16) for x in body.split(",")])
+    assert table("FQ29_ONE") == RQ % Q
+    assert table("FQ29_C_IN") == pow(2, 428, Q) and table("FQ29_C_OUT") == pow(2, 384, Q)
+    assert int(re.search(r"QINV29 = (0x[0-9a-f]+)u", src).group(1), 16) == (-pow(Q, -1, 1 << 29)) % (1 << 29)
+    q_words = [int(x.rstrip("u"), 16) for x in re.search(r"Q32_\[12\] = \{([^}]*)\}", src, re.S).group(1).replace("\n", " ").replace(" ", "").split(",")]
+    assert value(q_words, 32) == Q
+
+
+def test_field_operations_at_their_bounds(lib):
+    rng = random.Random(41)
+    inv = pow(RQ, -1, Q)
+    edge = [0, 1, Q - 1, Q, 2 * Q - 1]
+    for _ in range(300):
+        a = rng.choice(edge + [rng.randrange(64 * Q)] * 5)
+        b = rng.choice(edge + [rng.randrange(32 * Q)] * 5)
+        got = fq(lib, 0, limbs(a), limbs(b))
+        v = value(got)
+        assert all(x <= M29 for x in got[:13]) and v % Q == a * b * inv % Q and v < 2 * Q and v < (a * b >> 406) + Q + 1
+    # an un-normalised left operand (limbs up to 2^31 - 1): what a sum of four products' worth of limbs looks like
+    for _ in range(50):
+        la = [rng.randrange(1 << 31) for _ in range(13)] + [rng.randrange(1 << 12)]
+        a = value(la)
+        b = rng.randrange(2 * Q)
+        got = fq(lib, 0, (C.c_uint32 * 14)(*la), limbs(b))
+        assert value(got) % Q == a * b * inv % Q and all(x <= M29 for x in got[:13])
+    for _ in range(200):
+        a, b = rng.randrange(18 * Q), rng.randrange(18 * Q)
+        assert value(fq(lib, 1, limbs(a), limbs(b))) == a + b
+        assert value(fq(lib, 2, limbs(a), limbs(b % (4 * Q)))) == a - b % (4 * Q) + 4 * Q
+        assert value(fq(lib, 3, limbs(a), limbs(b % (16 * Q)))) == a - b % (16 * Q) + 16 * Q
+        assert value(fq(lib, 4, limbs(a), limbs(b))) == a - b + 64 * Q
+        assert value(fq(lib, 11, limbs(b % (4 * Q)))) == 4 * Q - b % (4 * Q)
+        assert value(fq(lib, 6, limbs(a))) == a % Q
+    for a in (0, 1, Q - 1, Q, Q + 1, 2 * Q - 1):
+        assert value(fq(lib, 5, limbs(a))) == a % Q
+    assert value(fq(lib, 2, limbs(0), limbs(4 * Q - 1))) == 1 and value(fq(lib, 3, limbs(0), limbs(16 * Q - 1))) == 1
+    # zero test: every multiple of q below 64 q is zero, neighbours and random values are not
+    for k in range(64):
+        assert fq(lib, 10, limbs(k * Q))[0] == 1
+        assert fq(lib, 10, limbs(k * Q + 1))[0] == 0 and (k == 0 or fq(lib, 10, limbs(k * Q - 1))[0] == 0)
+    assert all(fq(lib, 10, limbs(rng.randrange(1, Q)))[0] == 0 for _ in range(200))
+    # a value that passes the two-instruction filter without being a multiple of q
+    fake = 5 * Q + (1 << 29) * 12345
+    assert (fake & M29) == (5 * Q) & M29 and fq(lib, 10, limbs(fake))[0] == 0
+
+
+def test_conversions_and_inverse(lib):
+    rng = random.Random(43)
+    for x in [0, 1, Q - 1] + [rng.randrange(Q) for _ in range(40)]:
+        ark = x * E.FQ_R % Q
+        assert value(fq(lib, 12, words(ark))) == ark                              # unpack
+        assert value(fq(lib, 13, limbs(ark), out_words=12), 32) == ark            # pack
+        mont = fq(lib, 7, words(ark))
+        assert value(mont) % Q == x * RQ % Q and value(mont) < 2 * Q
+        back = fq(lib, 8, (C.c_uint32 * 14)(*mont), out_words=12)
+        assert value(back, 32) == ark
+        if x:
+            got = value(fq(lib, 9, (C.c_uint32 * 14)(*mont)))
+            assert got % Q == pow(x, -1, Q) * RQ % Q
+
+
+def _pt(p):
+    return (C.c_uint32 * 24)(*[(l >> (32 * h)) & 0xFFFFFFFF for l in E.to_limbs(p) for h in range(2)])
+
+
+def _g1(lib, op, p, q=None):
+    out = (C.c_uint32 * 24)()
+    lib.t_g1(op, _pt(p), _pt(q), out)
+    return E.from_limbs([out[2 * i] | out[2 * i + 1] << 32 for i in range(12)])
+
+
+def test_point_formulas_every_branch(lib):
+    rng = random.Random(47)
+    for _ in range(4):
+        p, q = E.mul(E.G1, rng.randrange(1, E.R)), E.mul(E.G1, rng.randrange(1, E.R))
+        assert _g1(lib, 0, p, q) == E.add(p, q)
+        assert _g1(lib, 1, p) == E.add(p, p)
+        assert _g1(lib, 2, p, q) == E.add(E.add(p, p), E.add(q, q))
+        assert _g1(lib, 3, p, q) == E.add(E.add(p, q), E.add(p, q))
+        assert _g1(lib, 4, p, q) == E.add(p, p)
+        assert _g1(lib, 5, p) == E.mul(p, 4) and _g1(lib, 6, p) is None
+        # the branches a bucket can run into: the accumulator meets its own value, its negative, the point at infinity
+        assert _g1(lib, 0, p, p) == E.add(p, p) and _g1(lib, 0, p, E.neg(p)) is None
+        assert _g1(lib, 0, p, None) == p and _g1(lib, 0, None, q) == q and _g1(lib, 0, None, None) is None
+        assert _g1(lib, 3, p, E.neg(p)) is None and _g1(lib, 3, p, None) == E.add(p, p) and _g1(lib, 3, None, q) == E.add(q, q)
+        assert _g1(lib, 2, p, E.neg(p)) is None and _g1(lib, 2, p, p) == E.mul(p, 4) and _g1(lib, 2, None, q) == E.add(q, q)
+    assert _g1(lib, 1, None) is None and _g1(lib, 5, None) is None

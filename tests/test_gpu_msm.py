@@ -1,0 +1,168 @@
+"""GPU parity of the multi-scalar multiplication over BLS12-381 G1 (frw_msm_g1_dev / frw_groth16_msm_h_dev) against the
+oracle: oracle/bls12_381.c's bucket method (pinned to Python integers by tests/test_bls12_381.py) on small and adversarial
+inputs, the MSM-free value (h(t) zt / delta) G1 for a proving key made from known toxic waste at full size, and the committed
+golden points of tests/golden/msm.json.  Bit-exact: the result is ONE affine point, in ark-ff's bytes."""
+import hashlib
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+import frw_testlib as T
+from oracle import bls12_381 as E
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+FR_R = (1 << 256) % E.R
+
+
+def _run(engine, handle, scalars, montgomery, chunk=None):
+    """scalars: uint64[batch, stride, 4] on the host -> uint64[batch, 12]."""
+    import torch
+    dev = torch.device("cuda:0")
+    info = engine.msm_info(handle)
+    batch, stride = scalars.shape[0], scalars.shape[1]
+    d_sc = torch.from_numpy(scalars.view(np.int64)).to(dev)
+    out = torch.full((batch, 12), -1, dtype=torch.int64, device=dev)
+    per = int(info.workspace_bytes_per_signature)
+    ws = torch.empty((chunk or batch) * per, dtype=torch.uint8, device=dev)
+    engine.msm_g1_dev(handle, batch, d_sc, stride, montgomery, out, ws, ws.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(np.uint64)
+
+
+def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle):
+    rng = random.Random(2026)
+    n = 300
+    ks = [rng.randrange(1, E.R) for _ in range(n)]
+    bases = oracle.g1_fixed_base(T.ints_to_limbs(ks))
+    # bases that meet each other inside a bucket: a duplicate, a negative, the point at infinity
+    bases[10] = bases[3]
+    bases[11] = np.array(E.to_limbs(E.neg(E.from_limbs(bases[4]))), dtype=np.uint64)
+    bases[12] = 0
+    vectors = [
+        [rng.randrange(E.R) for _ in range(n)],
+        [0] * n,
+        [1] * n,                                                   # every point into bucket 0 of window 0
+        [E.R - 1] * n,                                             # negative digits and carries all the way up
+        [0x0001000100010001000100010001000100010001000100010001000100010001] * n,      # one bucket, sixteen windows
+        [(1 << 255) - 19 if i % 2 else 0x8000 for i in range(n)],  # digit exactly 2^15 (kept positive); top-window carry
+        [rng.randrange(1 << 16) for _ in range(n)],
+    ]
+    vectors[0][3] = vectors[0][10]                                 # the duplicated base with the same scalar: doubling
+    vectors[0][11] = vectors[0][4]                                 # the negated base with the same scalar: cancellation
+    handle = engine.msm_g1_load(bases)
+    try:
+        info = engine.msm_info(handle)
+        assert info.num_points == n and info.window_bits == 16 and info.num_windows == 16
+        canon = np.stack([T.ints_to_limbs(v) for v in vectors])
+        mont = np.stack([T.ints_to_limbs([x * FR_R % E.R for x in v]) for v in vectors])
+        want = [oracle.g1_msm(bases, T.ints_to_limbs(v), 11).tolist() for v in vectors]
+        assert want[1] == [0] * 12                                 # all-zero scalars: the point at infinity
+        for got in (_run(engine, handle, canon, 0), _run(engine, handle, mont, 1), _run(engine, handle, mont, 1, chunk=3)):
+            assert [g.tolist() for g in got] == want
+        # a longer stride than points: only the first n scalars of each vector count (how h is laid out: n + 1 per signature)
+        padded = np.concatenate([canon, np.full((len(vectors), 5, 4), 0xFFFFFFFF, dtype=np.uint64)], axis=1)
+        assert [g.tolist() for g in _run(engine, handle, padded, 0)] == want
+    finally:
+        engine.msm_free(handle)
+
+
+def _h_query(oracle, n, toxic):
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_msm
+    scalars, _ = make_msm.h_query_scalars(n, toxic)
+    return oracle.g1_fixed_base(T.ints_to_limbs(scalars), threads=min(16, os.cpu_count() or 1)), make_msm
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_h_acc_of_gpu_witnesses_equals_the_msm_free_value(engine, oracle, logn):
+    """The prover's flow on the device, end to end: synthetic signatures -> witness (the hot path) -> witness map -> h_acc over
+    a proving key's h_query (2^17 - 1 / 2^18 - 1 points) made from known toxic waste.  Expected value per signature, with no
+    multi-scalar multiplication anywhere: (h(t) zt / delta) G1 from the GPU's own h read back as integers."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    batch = 3
+    L = frw.layout(logn)
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=777 + logn)
+    d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+    wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+    inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+    st = torch.empty(batch, dtype=torch.int32, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    engine.witness_ntt_verify_dev(logn, batch, d[0], d[1], d[2], wit, inst, st, 1, s0)
+    r = engine.r1cs_load(0, logn)
+    q = engine.qap_info(r)
+    n = int(q.domain_size)
+    ws = torch.empty(batch * int(q.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+    h = torch.empty((batch, n, 4), dtype=torch.int64, device=dev)
+    bad = torch.empty(batch, dtype=torch.int32, device=dev)
+    engine.qap_witness_map_dev(r, batch, wit, inst, h, ws, ws.numel(), bad, s0)
+    torch.cuda.synchronize()
+    engine.r1cs_free(r)
+    del ws
+    assert not bad.any()
+    toxic = {"t": 0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % E.R, "delta": 987654321987654321 + logn}
+    bases, make_msm = _h_query(oracle, n, toxic)
+    handle = engine.msm_g1_load(bases)
+    try:
+        info = engine.msm_info(handle)
+        assert info.num_points == n - 1
+        out = torch.full((batch, 12), -1, dtype=torch.int64, device=dev)
+        mws = torch.empty(2 * int(info.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)      # chunks of 2 + 1
+        engine.groth16_msm_h_dev(handle, batch, h, n, out, mws, mws.numel(), s0)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint64)
+        r_inv = pow(FR_R, -1, E.R)
+        for i in range(batch):
+            h_int = [v * r_inv % E.R for v in T.limbs_to_ints(h[i].cpu().numpy().view(np.uint64))]
+            assert got[i].tolist() == E.to_limbs(make_msm.expected_point(h_int, n, toxic)), i
+        with pytest.raises(frw.FrwError):                          # a key of another size
+            engine.groth16_msm_h_dev(handle, batch, h, n // 2, out, mws, mws.numel(), s0)
+    finally:
+        engine.msm_free(handle)
+
+
+def test_h_acc_equals_the_committed_golden_points(engine, oracle):
+    """tests/golden/msm.json (made by tests/golden/make_msm.py from the oracle alone): witness fixture -> GPU witness -> GPU
+    witness map -> GPU h_acc == the committed affine point, for both parameter sets; the bases the oracle regenerates here are
+    the ones the golden file was cross-checked with (digest)."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    gold = json.load(open(os.path.join(HERE, "golden", "msm.json")))
+    toxic = {k: int(v, 16) for k, v in gold["toxic"].items()}
+    s0 = torch.cuda.current_stream().cuda_stream
+    for case in gold["cases"]:
+        logn, n = case["logn"], case["domain_size"]
+        fx = json.load(open(os.path.join(HERE, "golden", case["witness_fixture"])))
+        L = frw.layout(logn)
+        d = [torch.from_numpy(np.frombuffer(bytes.fromhex(fx[k]), dtype=np.uint16).copy().view(np.int16)).to(dev) for k in ("sig", "pk", "hm")]
+        wit = torch.empty((1, L.num_witness, 4), dtype=torch.int64, device=dev)
+        inst = torch.empty((1, L.num_instance, 4), dtype=torch.int64, device=dev)
+        st = torch.empty(1, dtype=torch.int32, device=dev)
+        engine.witness_ntt_verify_dev(logn, 1, d[0], d[1], d[2], wit, inst, st, 1, s0)
+        r = engine.r1cs_load(0, logn)
+        q = engine.qap_info(r)
+        assert int(q.domain_size) == n
+        ws = torch.empty(int(q.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+        h = torch.empty((1, n, 4), dtype=torch.int64, device=dev)
+        engine.qap_witness_map_dev(r, 1, wit, inst, h, ws, ws.numel(), None, s0)
+        torch.cuda.synchronize()
+        engine.r1cs_free(r)
+        bases, _ = _h_query(oracle, n, toxic)
+        assert hashlib.sha256(bases.tobytes()).hexdigest() == case["bases_sha256"]
+        handle = engine.msm_g1_load(bases)
+        try:
+            info = engine.msm_info(handle)
+            out = torch.empty((1, 12), dtype=torch.int64, device=dev)
+            mws = torch.empty(int(info.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+            engine.groth16_msm_h_dev(handle, 1, h, n, out, mws, mws.numel(), s0)
+            torch.cuda.synchronize()
+            assert ["%016x" % v for v in out.cpu().numpy().view(np.uint64)[0].tolist()] == case["h_acc"], case["witness_fixture"]
+        finally:
+            engine.msm_free(handle)
