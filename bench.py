@@ -340,7 +340,85 @@ def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps, logn=None, cpu_triple=
     if cpu_triple is not None:
         out["cpu_port"] = qap_cpu_port(logn, cpu_triple, h[0].cpu().numpy().view(np.uint64))
         out["cpu_port"]["gpu_maps_per_cpu_core_map"] = round(out["signatures_per_s"] * out["cpu_port"]["seconds_per_map"], 1)
-    return out
+    del h6, ws
+    return out, h
+
+
+# instructions of one fq_mul (frw_fq29.h) as hipcc compiles it for gfx950: 392 v_mad_u64_u32 + 14 v_mul_lo_u32, 90 others
+# (tests/test_isa_hazards.py re-derives them from the assembly)
+FQ_MUL_MULTIPLY, FQ_MUL_OTHER = 406, 90
+R_FR = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+def groth16_h_query(eng, n, t=0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % R_FR, delta=987654321):
+    """A proving key's h_query from toy toxic waste, on the device: h_query[i] = (zt / delta) t^i G1 (ark-groth16 0.3.0
+    generator.rs).  Any key does for timing; a known one lets the result be checked without a second MSM."""
+    c = (pow(t, n, R_FR) - 1) * pow(delta, -1, R_FR) % R_FR
+    ks, x = [], c
+    for _ in range(n - 1):
+        ks.append(x)
+        x = x * t % R_FR
+    lim = np.frombuffer(b"".join(k.to_bytes(32, "little") for k in ks), dtype=np.uint64).reshape(-1, 4)
+    return eng.g1_fixed_base(lim), (t, c)
+
+
+def time_msm(eng, dev, d_h, reps, with_cpu):
+    """The step after the witness map in the reference's consumer (examples/pok_sig.rs:30-47 -> ark-groth16 prover.rs):
+    h_acc = VariableBaseMSM(pk.h_query, h) over BLS12-381 G1, for the h vectors the witness map left in HBM."""
+    nsig, n = d_h.shape[0], d_h.shape[1]
+    bases, (t, c) = groth16_h_query(eng, n)
+    m = eng.msm_g1_load(bases)
+    info = eng.msm_info(m)
+    ws = torch.empty(nsig * int(info.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+    out = torch.empty((nsig, 12), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+    run = lambda: eng.groth16_msm_h_dev(m, nsig, d_h, n, out, ws, ws.numel(), stream.cuda_stream)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    eng.msm_free(m)
+    per_s = nsig / (ms * 1e-3)
+    # MSM-free check of signature 0: sum h_i h_query[i] = (h(t) zt / delta) G1 -- one fixed-base multiple, on the device too
+    r_inv = pow(1 << 256, -1, R_FR)
+    h0 = d_h[0].cpu().numpy().view(np.uint64)
+    acc = 0
+    for row in h0[n - 2::-1]:
+        acc = (acc * t + int.from_bytes(row.tobytes(), "little") * r_inv) % R_FR
+    want = eng.g1_fixed_base(np.frombuffer((acc * c % R_FR).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4))[0]
+    got = out[0].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want), "h_acc differs from (h(t) zt / delta) G1"
+    rates = eng.valu_rates()
+    products = 16 * (n - 1) * 10 + 2 * 32768 * 14          # mixed additions (8 M + 2 S) into the buckets + the fold's full additions
+    peak = rates["simds"] * 64 / (FQ_MUL_MULTIPLY / rates["v_mad_u64_u32"] + FQ_MUL_OTHER / rates["v_add_u32"]) / 1e3
+    res = {"workload": "Groth16 h_acc = sum h_i h_query[i] over BLS12-381 G1, %d points, %d resident h vectors per call" % (n - 1, nsig),
+           "ms_per_call": round(ms, 3), "signatures_per_s": round(per_s, 1), "calls_timed": reps,
+           "mixed_additions_per_signature": 16 * (n - 1), "window_table_bytes": int(info.table_bytes),
+           "checked": "h_acc of one signature == (h(t) zt / delta) G1 for the known toxic waste, bit for bit (affine, ark-ff's bytes)",
+           "roofline": {"bound": "valu_issue", "unit": "G Fq products/s", "achieved": round(products * per_s / 1e9, 2),
+                        "peak": round(peak, 2), "frac": round(products * per_s / 1e9 / peak, 4),
+                        "kernel": "msm_bucket_kernel (+ count / scan / scatter / fold)", "fq_products_per_signature": products,
+                        "peak_is": "%d SIMDs x 64 lanes / (%d multiplies at %.1f + %d other at %.1f wave-instructions/SIMD/us)"
+                                   % (rates["simds"], FQ_MUL_MULTIPLY, rates["v_mad_u64_u32"], FQ_MUL_OTHER, rates["v_add_u32"])}}
+    if with_cpu:
+        oracle = load_oracle()
+        h_can = np.frombuffer(b"".join((int.from_bytes(row.tobytes(), "little") * r_inv % R_FR).to_bytes(32, "little") for row in h0[:n - 1]),
+                              dtype=np.uint64).reshape(-1, 4)
+        nproc = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        cpu = oracle.g1_msm(bases, h_can, 16, threads=nproc)
+        sec = time.perf_counter() - t0
+        assert np.array_equal(cpu, got), "GPU h_acc differs from the oracle's bucket method"
+        res["cpu_port"] = {"seconds_per_msm": round(sec, 3), "threads": min(nproc, 17), "kind": "port",
+                           "what": "oracle/bls12_381.c: bucket method, 16-bit signed windows, one thread per window (17), Jacobian "
+                                   "mixed additions, 64-bit-limb Montgomery arithmetic; same point as the GPU's, bit for bit",
+                           "gpu_msms_per_cpu_msm": round(per_s * sec, 1)}
+    return res
 
 
 def time_host_call(eng, logn, reps=200):
@@ -883,7 +961,7 @@ def main():
                 checked[name] = {"signatures": cnt, "grid": sh["grid"], "resident_workgroups_per_cu": sh["resident_per_cu"],
                                  "rounds": round(cnt / max(1, sh["grid"]), 2), "split_signatures": sh["split_signatures"]}
     r1cs = None
-    qap_result = None
+    qap_result = msm_result = None
     if not args.no_r1cs_check:
         # the reference's assert!(cs.is_satisfied()) (falcon_ntt.rs:159) for every witness in the buffer, on the device,
         # in place, against matrices emitted from the gadget definitions by the host mirror (not the kernels' closed form)
@@ -896,8 +974,10 @@ def main():
         tc = time.perf_counter() - tc
         if world == 1 and not args.no_secondary and not dual:
             s0 = int(slot_sig[0])
-            qap_result = time_qap(eng, h, dev, d_wit, d_inst, min(64, held), 20, logn,
-                                  None if args.no_cpu_baseline else (sig[s0:s0 + 1], pk[s0:s0 + 1], hm[s0:s0 + 1]))
+            qap_result, d_hvec = time_qap(eng, h, dev, d_wit, d_inst, min(64, held), 20, logn,
+                                          None if args.no_cpu_baseline else (sig[s0:s0 + 1], pk[s0:s0 + 1], hm[s0:s0 + 1]))
+            msm_result = time_msm(eng, dev, d_hvec, 5, not args.no_cpu_baseline)
+            del d_hvec
         eng.r1cs_free(h)
         n_unsat = sharding.sum_over_ranks(int((badrows != 0).sum().item()), cdev)
         assert n_unsat == 0, "%d witnesses left by the timed launches violate the constraint system" % n_unsat
@@ -1022,6 +1102,7 @@ def main():
                 "compact_encoding_falcon%d" % n: time_compact(eng, dev, logn, chunk, 4, 1, (d_sig, d_pk, d_hm), d_wit)}
             if qap_result is not None:
                 result["secondary"]["qap_witness_map_falcon%d" % n] = qap_result
+                result["secondary"]["groth16_msm_h_falcon%d" % n] = msm_result
             result["secondary"]["host_call_one_signature_falcon%d" % n] = time_host_call(eng, logn)
             if not args.no_aggregate:
                 result["secondary"]["aggregate_1024_mixed"] = time_aggregate(eng, dev, 1024, 50, threads)

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "frw_r1cs_diag_host_allocations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "frw_msm_g1_load": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
     "frw_msm_free": (None, [C.c_void_p]),
+    "frw_g1_fixed_base": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "frw_msm_info": (C.c_int, [C.c_void_p, C.POINTER(MsmInfoStruct)]),
     "frw_msm_g1_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),

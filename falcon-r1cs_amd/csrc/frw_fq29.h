@@ -232,6 +232,12 @@ __host__ __device__ inline Fq29 fq_inv(const Fq29 &a)
     return acc;
 }
 
+// the published generator of G1 (ark-bls12-381 g1.rs G1_GENERATOR_X / _Y), x 2^406; tests/test_fq29_host.py re-derives the limbs
+constexpr LimbsQ G1_GEN_X29 = {{0x0af58fd1u, 0x1662a68eu, 0x07d2c530u, 0x08993c24u, 0x1e4f4756u, 0x0c5f7ae2u, 0x0f589991u,
+                                0x00dc570eu, 0x121b54f5u, 0x05242b28u, 0x17442464u, 0x0ee8a0cdu, 0x1f591099u, 0x00000009u}};
+constexpr LimbsQ G1_GEN_Y29 = {{0x1cd65f60u, 0x1919ce91u, 0x0da44145u, 0x0810b2ccu, 0x08f38c44u, 0x00629241u, 0x0f521d8cu,
+                                0x0529cbadu, 0x0506077fu, 0x191b2712u, 0x0c587ccbu, 0x1017da2fu, 0x1c72eafau, 0x0000000bu}};
+
 // ---- G1: y^2 = x^3 + 4, XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2); inf = the point at infinity -----------------
 // Bounds kept by every formula below (in units of q): X < 10, Y < 6, ZZ < 2, ZZZ < 2, affine coordinates < 2.
 struct G1Affine29 { Fq29 x, y; bool inf; };

@@ -121,23 +121,51 @@ __device__ __forceinline__ void scalar_digits(const uint32_t *src, int montgomer
     }
 }
 
-__global__ __launch_bounds__(256) void msm_count_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
-                                                        int montgomery, uint32_t *__restrict__ counts)
+// The counting sort of a signature's 16 n (digit, point) pairs by bucket, without a global atomic: the points are cut into
+// MSM_SLICES slices, a workgroup per (signature, slice) histograms its slice in LDS (32,768 counters = 128 KB of the CU's
+// 160 KB), the histograms are turned into per-slice starting positions inside every bucket, and the same workgroups then hand
+// out positions from LDS again.  (With one global atomicAdd per pair the sort took a third of the whole call: 10^10 atomics
+// per second is what the L2 gives, and a signature has 4 x 10^6 pairs to place twice.)
+constexpr int MSM_SLICES = 32;
+__global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
+                                                        int montgomery, uint32_t *__restrict__ slice_hist /* [sig][slice][buckets] */)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ uint32_t hist[MSM_BUCKETS];
     const size_t sig = blockIdx.y;
-    int d[MSM_W];
-    scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d);
-    uint32_t *cnt = counts + sig * MSM_BUCKETS;
+    const uint32_t slice = blockIdx.x, per = (n + MSM_SLICES - 1) / MSM_SLICES;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int d[MSM_W];
+        scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d);
 #pragma unroll
-    for (int j = 0; j < MSM_W; j++)
-        if (d[j]) atomicAdd(&cnt[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
+        for (int j = 0; j < MSM_W; j++)
+            if (d[j]) atomicAdd(&hist[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = slice_hist + (sig * MSM_SLICES + slice) * MSM_BUCKETS;
+    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) out[b] = hist[b];
 }
 
-// exclusive prefix sums of a signature's 32,768 counts: offsets (kept) and cursors (consumed by the scatter)
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
-                                                        uint32_t *__restrict__ cursors)
+// per bucket: its size (counts) and, in place of every slice's count, the slice's first position inside the bucket
+__global__ __launch_bounds__(256) void msm_slice_offsets_kernel(uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ counts)
+{
+    const size_t sig = blockIdx.y;
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    uint32_t *h = slice_hist + sig * MSM_SLICES * (size_t)MSM_BUCKETS + b;
+    uint32_t run = 0;
+#pragma unroll 4
+    for (int s_ = 0; s_ < MSM_SLICES; s_++) {
+        const uint32_t c = h[(size_t)s_ * MSM_BUCKETS];
+        h[(size_t)s_ * MSM_BUCKETS] = run;
+        run += c;
+    }
+    counts[sig * MSM_BUCKETS + b] = run;
+}
+
+// exclusive prefix sums of a signature's 32,768 bucket sizes: where each bucket's entries start
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets)
 {
     __shared__ uint32_t part[1024];
     const size_t sig = blockIdx.x;
@@ -157,45 +185,84 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *__restri
     }
     const uint32_t base = part[t] - s;
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        offsets[sig * MSM_BUCKETS + t * PER + k] = base + local[k];
-        cursors[sig * MSM_BUCKETS + t * PER + k] = base + local[k];
-    }
+    for (int k = 0; k < PER; k++) offsets[sig * MSM_BUCKETS + t * PER + k] = base + local[k];
 }
 
-__global__ __launch_bounds__(256) void msm_scatter_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
-                                                          int montgomery, uint32_t *__restrict__ cursors, uint32_t *__restrict__ entries)
+__global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
+                                                           int montgomery, const uint32_t *__restrict__ offsets,
+                                                           const uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ entries)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ uint32_t cursor[MSM_BUCKETS];
     const size_t sig = blockIdx.y;
-    int d[MSM_W];
-    scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d);
-    uint32_t *cur = cursors + sig * MSM_BUCKETS;
+    const uint32_t slice = blockIdx.x, per = (n + MSM_SLICES - 1) / MSM_SLICES;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    const uint32_t *first = slice_hist + (sig * MSM_SLICES + slice) * MSM_BUCKETS, *off = offsets + sig * MSM_BUCKETS;
+    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) cursor[b] = off[b] + first[b];
+    __syncthreads();
     uint32_t *ent = entries + sig * (size_t)MSM_W * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int d[MSM_W];
+        scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d);
 #pragma unroll
-    for (int j = 0; j < MSM_W; j++) {
-        if (!d[j]) continue;
-        const uint32_t b = (uint32_t)(d[j] < 0 ? -d[j] : d[j]) - 1u;
-        const uint32_t pos = atomicAdd(&cur[b], 1u);
-        ent[pos] = ((uint32_t)j * n + i) | (d[j] < 0 ? 0x80000000u : 0u);
+        for (int j = 0; j < MSM_W; j++) {
+            if (!d[j]) continue;
+            const uint32_t b = (uint32_t)(d[j] < 0 ? -d[j] : d[j]) - 1u;
+            ent[atomicAdd(&cursor[b], 1u)] = ((uint32_t)j * n + i) | (d[j] < 0 ? 0x80000000u : 0u);
+        }
     }
 }
 
-// one thread per (signature, bucket): the sum of the bucket's table rows, in registers
-__global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
-                                                           const uint32_t *__restrict__ entries, uint32_t *__restrict__ buckets)
+// Buckets by decreasing size: `order[rank] = bucket`.  Bucket sizes are Poisson(16 n / 32,768) -- 128 +- 11 for 2^18 points --
+// and a wavefront runs as long as its longest lane: with neighbouring lanes on neighbouring sizes none of them idles
+// (unsorted, the longest of 64 is ~1.2 x the mean).  A counting sort by size, one workgroup per signature.
+constexpr int MSM_SIZE_CLASSES = 1024;         // sizes >= this share the first class
+__global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ order)
 {
-    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    __shared__ uint32_t hist[MSM_SIZE_CLASSES];
+    const size_t sig = blockIdx.x;
+    const uint32_t *cnt = counts + sig * MSM_BUCKETS;
+    const int t = threadIdx.x;
+    hist[t] = 0;
+    __syncthreads();
+    auto cls = [](uint32_t c) { return c >= (uint32_t)MSM_SIZE_CLASSES ? 0u : (uint32_t)(MSM_SIZE_CLASSES - 1) - c; };   // big first
+    for (int b = t; b < MSM_BUCKETS; b += 1024) atomicAdd(&hist[cls(cnt[b])], 1u);
+    __syncthreads();
+    // exclusive scan of the 1,024 class counts
+    const uint32_t mine = hist[t];
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = t >= off ? hist[t - off] : 0u;
+        __syncthreads();
+        hist[t] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = hist[t] - mine;
+    __syncthreads();
+    hist[t] = excl;
+    __syncthreads();
+    for (int b = t; b < MSM_BUCKETS; b += 1024) order[sig * MSM_BUCKETS + atomicAdd(&hist[cls(cnt[b])], 1u)] = (uint32_t)b;
+}
+
+// one thread per (signature, bucket): the sum of the bucket's table rows, in registers.  The row of entry k + 1 is fetched
+// while entry k is added (an addition is ~5,000 vector instructions: the gather of 112 bytes hides behind it).
+__global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
+                                                           const uint32_t *__restrict__ order, const uint32_t *__restrict__ entries,
+                                                           uint32_t *__restrict__ buckets)
+{
     const size_t sig = blockIdx.y;
+    const uint32_t b = order[sig * MSM_BUCKETS + blockIdx.x * 64 + threadIdx.x];
     const uint32_t start = offsets[sig * MSM_BUCKETS + b], cnt = counts[sig * MSM_BUCKETS + b];
     const uint32_t *ent = entries + sig * (size_t)MSM_W * m.n + start;
     G1Xyzz acc = g1_identity();
+    uint32_t e = cnt ? ent[0] : 0u;
+    G1Affine29 p = load_row(m.table + (size_t)(e & 0x7fffffffu) * MSM_PT_WORDS);
     for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t e = ent[k];
-        G1Affine29 p = load_row(m.table + (size_t)(e & 0x7fffffffu) * MSM_PT_WORDS);
+        const uint32_t e_next = k + 1 < cnt ? ent[k + 1] : e;
+        const G1Affine29 p_next = load_row(m.table + (size_t)(e_next & 0x7fffffffu) * MSM_PT_WORDS);
         if (e >> 31) p.y = fq_neg<4>(p.y);
         acc = g1_add_affine(acc, p);
+        e = e_next;
+        p = p_next;
     }
     store_bucket(buckets + (sig * MSM_BUCKETS + b) * (size_t)MSM_BK_WORDS, acc);
 }
@@ -252,6 +319,46 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32
     }
 }
 
+// ---- k G1 for many scalars: the FixedBaseMSM of ark-groth16's generator (generator.rs builds h_query, a_query, l_query this
+// way from the toxic waste).  8-bit windows of the generator: table[w][d] = d 2^(8 w) G1, then 32 mixed additions per scalar.
+constexpr int FB_WINDOWS = 32, FB_DIGITS = 256;
+__global__ __launch_bounds__(64) void fixed_base_table_kernel(uint32_t *__restrict__ table /* [32][256][MSM_PT_WORDS] */)
+{
+    const int id = blockIdx.x * 64 + threadIdx.x, w = id >> 8, d = id & 255;
+    if (w >= FB_WINDOWS) return;
+    G1Affine29 g;
+    g.x = fq_const(G1_GEN_X29);
+    g.y = fq_const(G1_GEN_Y29);
+    g.inf = false;
+    G1Xyzz acc = g1_identity();
+    for (int bit = 7; bit >= 0; bit--) {                      // d G
+        acc = g1_double(acc);
+        if ((d >> bit) & 1) acc = g1_add_affine(acc, g);
+    }
+    for (int k = 0; k < 8 * w; k++) acc = g1_double(acc);     // 2^(8 w) d G
+    store_row(table + (size_t)id * MSM_PT_WORDS, g1_to_affine(acc));
+}
+__global__ __launch_bounds__(64) void fixed_base_kernel(size_t count, const uint32_t *__restrict__ scalars /* [count][8], canonical */,
+                                                        const uint32_t *__restrict__ table, uint32_t *__restrict__ out /* [count][24] */)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    const Fr8 k = fr_load(scalars + i * 8);
+    G1Xyzz acc = g1_identity();
+    for (int w = 0; w < FB_WINDOWS; w++) {
+        const uint32_t d = (k.l[w >> 2] >> (8 * (w & 3))) & 255u;
+        if (d) acc = g1_add_affine(acc, load_row(table + ((size_t)w * FB_DIGITS + d) * MSM_PT_WORDS));
+    }
+    const G1Affine29 a = g1_to_affine(acc);
+    uint32_t *o = out + i * 24;
+    if (a.inf) {
+        for (int j = 0; j < 24; j++) o[j] = 0;
+    } else {
+        fq_to_ark(a.x, o);
+        fq_to_ark(a.y, o + 12);
+    }
+}
+
 }  // namespace frw
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------------------------
@@ -264,7 +371,9 @@ struct frw_msm {
 namespace {
 size_t msm_workspace_per_signature(uint32_t n)
 {
-    // counts, offsets, cursors (3 x 32,768 x 4 B), entries (16 n x 4 B), buckets (32,768 x 240 B)
+    // counts, offsets, order (3 x 32,768 x 4 B), entries (16 n x 4 B), buckets (32,768 x 240 B; the sort's per-slice
+    // histograms, 32 x 32,768 x 4 B, live there before the buckets are written)
+    static_assert((size_t)frw::MSM_SLICES * 4 <= (size_t)frw::MSM_BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
     return 3 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::MSM_BK_WORDS * 4;
 }
 }  // namespace
@@ -311,6 +420,30 @@ extern "C" int frw_msm_g1_load(int device, size_t num_points, const uint64_t *ba
     return FRW_OK;
 }
 
+extern "C" int frw_g1_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out)
+{
+    if (count && (!scalars || !out)) return FRW_E_INVALID_ARG;
+    if (count == 0) return FRW_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
+    hipError_t e = hipSetDevice(device);
+    void *d_table = nullptr, *d_sc = nullptr, *d_out = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&d_table, (size_t)frw::FB_WINDOWS * frw::FB_DIGITS * frw::MSM_PT_WORDS * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_sc, count * 32);
+    if (e == hipSuccess) e = hipMalloc(&d_out, count * 96);
+    if (e == hipSuccess) e = hipMemcpy(d_sc, scalars, count * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(frw::fixed_base_table_kernel, dim3(frw::FB_WINDOWS * frw::FB_DIGITS / 64), dim3(64), 0, nullptr, (uint32_t *)d_table);
+        hipLaunchKernelGGL(frw::fixed_base_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, nullptr, count,
+                           (const uint32_t *)d_sc, (const uint32_t *)d_table, (uint32_t *)d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, count * 96, hipMemcpyDeviceToHost);
+    for (void *p : {d_table, d_sc, d_out})
+        if (p) (void)hipFree(p);
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_g1_fixed_base");
+}
+
 extern "C" int frw_msm_info(const frw_msm *m, frw_msm_info_t *out)
 {
     if (!m || !out) return FRW_E_INVALID_ARG;
@@ -338,19 +471,20 @@ extern "C" int frw_msm_g1_dev(const frw_msm *m, size_t batch, const uint64_t *d_
         const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
         uint32_t *counts = (uint32_t *)d_workspace;
         uint32_t *offsets = counts + cnt * frw::MSM_BUCKETS;
-        uint32_t *cursors = offsets + cnt * frw::MSM_BUCKETS;
-        uint32_t *entries = cursors + cnt * frw::MSM_BUCKETS;
+        uint32_t *order = offsets + cnt * frw::MSM_BUCKETS;
+        uint32_t *entries = order + cnt * frw::MSM_BUCKETS;
         uint32_t *buckets = entries + cnt * (size_t)frw::MSM_W * n;
+        uint32_t *slice_hist = buckets;                                  // [cnt][32][32,768], dead before the first bucket is stored
         const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
         const size_t stride_words = scalar_stride * 8;
-        e = hipMemsetAsync(counts, 0, cnt * frw::MSM_BUCKETS * 4, st);
-        if (e != hipSuccess) break;
-        const dim3 pgrid((n + 255) / 256, (unsigned)cnt);
-        hipLaunchKernelGGL(frw::msm_count_kernel, pgrid, dim3(256), 0, st, n, sc, stride_words, montgomery, counts);
-        hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, cursors);
-        hipLaunchKernelGGL(frw::msm_scatter_kernel, pgrid, dim3(256), 0, st, n, sc, stride_words, montgomery, cursors, entries);
+        const dim3 sgrid(frw::MSM_SLICES, (unsigned)cnt);
+        hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist);
+        hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts);
+        hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
+        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, order);
+        hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
         hipLaunchKernelGGL(frw::msm_bucket_kernel, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
-                           entries, buckets);
+                           order, entries, buckets);
         hipLaunchKernelGGL(frw::msm_fold_kernel, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, buckets,
                            (uint32_t *)(d_out + lo * 12));
         e = hipGetLastError();

@@ -357,6 +357,14 @@ class WitnessEngine:
         check(self._lib.frw_msm_g1_load(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_msm_g1_load")
         return h
 
+    def g1_fixed_base(self, scalars):
+        """k_i G1 on the device: canonical scalars uint64[count, 4] -> uint64[count, 12] (ark-ff's bytes)."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((scalars.shape[0], 12), dtype=np.uint64)
+        check(self._lib.frw_g1_fixed_base(self.device, scalars.shape[0], scalars.ctypes.data_as(C.c_void_p),
+                                          out.ctypes.data_as(C.c_void_p)), "frw_g1_fixed_base")
+        return out
+
     def msm_free(self, handle):
         self._lib.frw_msm_free(handle)
 

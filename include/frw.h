@@ -317,6 +317,10 @@ int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
  * correctly but slowly -- one bucket takes all the ones.
  * frw_groth16_msm_h_dev is the call for h_acc: scalars = the first domain_size - 1 coefficients of every h as the witness
  * map left them (stride domain_size, Montgomery form); num_points must equal domain_size - 1. */
+/* k_i G1 for `count` canonical scalars (uint64_t[count][4], < r) -> uint64_t[count][12] affine points in ark-ff's bytes, host
+ * buffers: the FixedBaseMSM over the generator ark-groth16's generator.rs builds the proving key's queries with (h_query[i] =
+ * (zt / delta) t^i G1, ...) -- here so that a key can be made on the device; 8-bit windows, 32 mixed additions per scalar. */
+int frw_g1_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out);
 typedef struct frw_msm frw_msm;
 typedef struct {
     uint64_t num_points;

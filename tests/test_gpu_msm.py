@@ -166,3 +166,13 @@ def test_h_acc_equals_the_committed_golden_points(engine, oracle):
             assert ["%016x" % v for v in out.cpu().numpy().view(np.uint64)[0].tolist()] == case["h_acc"], case["witness_fixture"]
         finally:
             engine.msm_free(handle)
+
+
+def test_fixed_base_multiples_of_the_generator_equal_the_oracle(engine, oracle):
+    """frw_g1_fixed_base (the FixedBaseMSM ark-groth16's generator builds the queries with) == oracle/bls12_381.c, bit for bit."""
+    rng = random.Random(99)
+    ks = [0, 1, 2, 255, 256, E.R - 1, (1 << 255) - 1] + [rng.randrange(E.R) for _ in range(200)]
+    got = engine.g1_fixed_base(T.ints_to_limbs(ks))
+    want = oracle.g1_fixed_base(T.ints_to_limbs(ks))
+    assert np.array_equal(got, want)
+    assert got[0].tolist() == [0] * 12 and got[1].tolist() == E.to_limbs(E.G1)
