@@ -813,7 +813,8 @@ def main():
                     help="N = 1 only: skip the untimed secondary rooflines (NTT + mod_q kernel at BASELINE configs[1], "
                          "Falcon-512 full verify)")
     ap.add_argument("--no-aggregate", action="store_true",
-                    help="N = 1 only: leave the 1,024-signature mixed aggregate (BASELINE configs[4] shape) out of `secondary` "
+                    help="N = 1 only: leave the 1,024-signature mixed aggregate (BASELINE configs[4] shape) and the one-signature host "
+                         "calls out of `secondary` "
                          "(the profiling passes do: its small launches of the same kernels would blur the per-kernel averages)")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1 only: skip the second curve, 'generate + RCCL all-gather of the witness vectors'")
@@ -1103,8 +1104,8 @@ def main():
             if qap_result is not None:
                 result["secondary"]["qap_witness_map_falcon%d" % n] = qap_result
                 result["secondary"]["groth16_msm_h_falcon%d" % n] = msm_result
-            result["secondary"]["host_call_one_signature_falcon%d" % n] = time_host_call(eng, logn)
             if not args.no_aggregate:
+                result["secondary"]["host_call_one_signature_falcon%d" % n] = time_host_call(eng, logn)
                 result["secondary"]["aggregate_1024_mixed"] = time_aggregate(eng, dev, 1024, 50, threads)
                 result["secondary"]["input_preparation_falcon%d" % n] = time_prepare(eng, dev, logn, 65536, 5, 1)
         if world == 1 and not args.no_cpu_baseline and not dual:

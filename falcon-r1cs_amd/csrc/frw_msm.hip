@@ -101,7 +101,9 @@ __global__ __launch_bounds__(64) void msm_precompute_kernel(uint32_t n, const ui
 
 // ---- the scalars: canonical integer, sixteen signed 16-bit digits ---------------------------------------------------------------
 // d_j in [-2^15, 2^15] with sum d_j 2^(16 j) = k; the top digit takes the last carry (k < 2^255, so it stays <= 2^15)
-__device__ __forceinline__ void scalar_digits(const uint32_t *src, int montgomery, int (&d)[MSM_W])
+// Returns true (and no digits) for the scalar 1: a Falcon witness is 45 % ones (the boolean elements that are set), which
+// would all land in bucket 0 of window 0 -- they are summed by msm_ones_kernel instead.
+__device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomery, int (&d)[MSM_W])
 {
     Fr8 w = fr_load(src);
     if (montgomery) {
@@ -111,6 +113,7 @@ __device__ __forceinline__ void scalar_digits(const uint32_t *src, int montgomer
         for (int k = 0; k < NL29; k++) c.l[k] = k ? 0u : 32u;
         w = f29_pack(f29_canonical(f29_mul(f29_unpack(w), c)));
     }
+    if (w.l[0] == 1u && !(w.l[1] | w.l[2] | w.l[3] | w.l[4] | w.l[5] | w.l[6] | w.l[7])) return true;
     int carry = 0;
 #pragma unroll
     for (int j = 0; j < MSM_W; j++) {
@@ -119,6 +122,7 @@ __device__ __forceinline__ void scalar_digits(const uint32_t *src, int montgomer
         if (j + 1 < MSM_W && v > MSM_BUCKETS) { v -= 1 << MSM_C; carry = 1; }
         d[j] = v;
     }
+    return false;
 }
 
 // The counting sort of a signature's 16 n (digit, point) pairs by bucket, without a global atomic: the points are cut into
@@ -128,7 +132,8 @@ __device__ __forceinline__ void scalar_digits(const uint32_t *src, int montgomer
 // per second is what the L2 gives, and a signature has 4 x 10^6 pairs to place twice.)
 constexpr int MSM_SLICES = 32;
 __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
-                                                        int montgomery, uint32_t *__restrict__ slice_hist /* [sig][slice][buckets] */)
+                                                        int montgomery, uint32_t *__restrict__ slice_hist /* [sig][slice][buckets] */,
+                                                        uint32_t *__restrict__ ones_count /* [sig] */, uint32_t *__restrict__ ones_list /* [sig][n] */)
 {
     __shared__ uint32_t hist[MSM_BUCKETS];
     const size_t sig = blockIdx.y;
@@ -138,7 +143,10 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
         int d[MSM_W];
-        scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d);
+        if (scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d)) {
+            ones_list[sig * n + atomicAdd(&ones_count[sig], 1u)] = i;
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < MSM_W; j++)
             if (d[j]) atomicAdd(&hist[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uin
     uint32_t *ent = entries + sig * (size_t)MSM_W * n;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
         int d[MSM_W];
-        scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d);
+        if (scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d)) continue;
 #pragma unroll
         for (int j = 0; j < MSM_W; j++) {
             if (!d[j]) continue;
@@ -267,8 +275,23 @@ __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint3
     store_bucket(buckets + (sig * MSM_BUCKETS + b) * (size_t)MSM_BK_WORDS, acc);
 }
 
+// the points whose scalar is one, summed by the 512 threads that will fold the buckets (thread t: every 512th of the list);
+// the partial sums enter the fold with weight one
+__global__ __launch_bounds__(64, 2) void msm_ones_kernel(MsmDev m, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
+                                                         uint32_t *__restrict__ partial /* [sig][MSM_FOLD_THREADS][MSM_BK_WORDS] */)
+{
+    const size_t sig = blockIdx.y;
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x, cnt = ones_count[sig];
+    const uint32_t *list = ones_list + sig * m.n;
+    G1Xyzz acc = g1_identity();
+    for (uint32_t k = t; k < cnt; k += MSM_FOLD_THREADS)
+        acc = g1_add_affine(acc, load_row(m.table + (size_t)list[k] * MSM_PT_WORDS));      // window 0 of the table = the point itself
+    store_bucket(partial + (sig * MSM_FOLD_THREADS + t) * (size_t)MSM_BK_WORDS, acc);
+}
+
 // sum_b (b + 1) B_b per signature: 512 threads x 64 buckets, then a tree; thread 0 converts to affine and writes ark-ff's bytes
-__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32_t *__restrict__ buckets, uint32_t *__restrict__ out /* [batch][24] */)
+__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ partial,
+                                                                    uint32_t *__restrict__ out /* [batch][24] */)
 {
     __shared__ uint32_t lds[MSM_FOLD_THREADS / 2 * (4 * NLQ + 1)];       // 58 KB: the upper half of a tree level parks here
     const size_t sig = blockIdx.x;
@@ -287,6 +310,7 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32
     }
     for (int k = 0; k < 6; k++) mult = g1_double(mult);
     sum = g1_add(sum, mult);
+    sum = g1_add(sum, load_bucket(partial + (sig * MSM_FOLD_THREADS + t) * (size_t)MSM_BK_WORDS));      // the scalars that are one
     auto put = [&](int slot, const G1Xyzz &p) {
         uint32_t *s = lds + slot * (4 * NLQ + 1);
 #pragma unroll
@@ -372,9 +396,11 @@ namespace {
 size_t msm_workspace_per_signature(uint32_t n)
 {
     // counts, offsets, order (3 x 32,768 x 4 B), entries (16 n x 4 B), buckets (32,768 x 240 B; the sort's per-slice
-    // histograms, 32 x 32,768 x 4 B, live there before the buckets are written)
+    // histograms, 32 x 32,768 x 4 B, live there before the buckets are written), the list of scalars that are one (n x 4 B +
+    // a counter) and their 512 partial sums
     static_assert((size_t)frw::MSM_SLICES * 4 <= (size_t)frw::MSM_BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
-    return 3 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::MSM_BK_WORDS * 4;
+    return 3 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::MSM_BK_WORDS * 4 +
+           ((size_t)n + 4) * 4 + (size_t)frw::MSM_FOLD_THREADS * frw::MSM_BK_WORDS * 4;
 }
 }  // namespace
 
@@ -475,17 +501,24 @@ extern "C" int frw_msm_g1_dev(const frw_msm *m, size_t batch, const uint64_t *d_
         uint32_t *entries = order + cnt * frw::MSM_BUCKETS;
         uint32_t *buckets = entries + cnt * (size_t)frw::MSM_W * n;
         uint32_t *slice_hist = buckets;                                  // [cnt][32][32,768], dead before the first bucket is stored
+        uint32_t *partial = buckets + cnt * (size_t)frw::MSM_BUCKETS * frw::MSM_BK_WORDS;
+        uint32_t *ones_list = partial + cnt * (size_t)frw::MSM_FOLD_THREADS * frw::MSM_BK_WORDS;
+        uint32_t *ones_count = ones_list + cnt * (size_t)n;             // [cnt], padded to four words per signature in the budget
         const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
         const size_t stride_words = scalar_stride * 8;
         const dim3 sgrid(frw::MSM_SLICES, (unsigned)cnt);
-        hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist);
+        e = hipMemsetAsync(ones_count, 0, cnt * 4, st);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
         hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts);
         hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
         hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, order);
         hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
         hipLaunchKernelGGL(frw::msm_bucket_kernel, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
                            order, entries, buckets);
-        hipLaunchKernelGGL(frw::msm_fold_kernel, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, buckets,
+        hipLaunchKernelGGL(frw::msm_ones_kernel, dim3(frw::MSM_FOLD_THREADS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list,
+                           partial);
+        hipLaunchKernelGGL(frw::msm_fold_kernel, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, buckets, partial,
                            (uint32_t *)(d_out + lo * 12));
         e = hipGetLastError();
     }

@@ -312,9 +312,10 @@ int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
  *                 G1Affine arkworks' into_affine() would hold
  *     d_workspace at least workspace_bytes_per_signature (frw_msm_info) bytes, 16-byte aligned; the batch is processed in
  *                 chunks of as many signatures as fit
- * Stream-ordered, allocates nothing.  The kernels assume the digits of the scalars spread over the 32,768 buckets (true
- * for h, whose coefficients are uniform field elements); a vector of mostly 0 / 1 scalars (a Falcon witness) is computed
- * correctly but slowly -- one bucket takes all the ones.
+ * Stream-ordered, allocates nothing.  Scalars that are zero cost nothing and scalars that are one are summed apart from the
+ * buckets, so the witness-side sums of the prover (a_query, b_g1_query, l_query with a Falcon witness: 91 % of its elements
+ * are 0 or 1) run as fast as h_acc, whose coefficients are uniform field elements.  Any other heavy repetition of ONE digit
+ * (all scalars equal to 2, say) is computed correctly but slowly -- one bucket, one thread.
  * frw_groth16_msm_h_dev is the call for h_acc: scalars = the first domain_size - 1 coefficients of every h as the witness
  * map left them (stride domain_size, Montgomery form); num_points must equal domain_size - 1. */
 /* k_i G1 for `count` canonical scalars (uint64_t[count][4], < r) -> uint64_t[count][12] affine points in ark-ff's bytes, host

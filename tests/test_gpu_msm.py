@@ -176,3 +176,34 @@ def test_fixed_base_multiples_of_the_generator_equal_the_oracle(engine, oracle):
     want = oracle.g1_fixed_base(T.ints_to_limbs(ks))
     assert np.array_equal(got, want)
     assert got[0].tolist() == [0] * 12 and got[1].tolist() == E.to_limbs(E.G1)
+
+
+def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine, oracle):
+    """The witness-side sums of the prover (prover.rs calculate_coeff / l_aux_acc: MSM(a_query | b_g1_query | l_query,
+    assignment)): the scalars are a Falcon-512 witness -- 91 % of them 0 or 1 -- over as many bases as the circuit has
+    variables.  Ones are summed apart from the buckets; the result must be the CPU's, bit for bit, for genuine witnesses and
+    for the degenerate vectors (all ones, a single one)."""
+    import torch
+    import falcon_r1cs_amd as frw
+    logn, batch = 9, 3
+    L = frw.layout(logn)
+    sig, pk, hm = frw.synth_triples(logn, batch, seed=31337)
+    wit, inst, st = engine.witness_ntt_verify(logn, sig, pk, hm, frw.ENC_CANONICAL)
+    z = np.concatenate([inst[:, 1:], wit], axis=1)                # calculate_coeff: query[1..] x (inputs ++ aux)
+    n = z.shape[1]
+    assert n == L.num_instance - 1 + L.num_witness
+    ones = (z == np.array([1, 0, 0, 0], dtype=np.uint64)).all(axis=2).mean()
+    assert 0.3 < ones < 0.6
+    rng = random.Random(5)
+    bases = oracle.g1_fixed_base(T.ints_to_limbs([rng.randrange(1, E.R) for _ in range(n)]), threads=min(16, os.cpu_count() or 1))
+    z = np.concatenate([z, np.zeros((2, n, 4), dtype=np.uint64)])
+    z[batch, :, 0] = 1                                            # all ones
+    z[batch + 1, 12345, 0] = 1                                    # a single one
+    handle = engine.msm_g1_load(bases)
+    try:
+        got = _run(engine, handle, z, 0)
+        for i in range(z.shape[0]):
+            assert got[i].tolist() == oracle.g1_msm(bases, z[i], 13, threads=min(16, os.cpu_count() or 1)).tolist(), i
+        assert got[batch + 1].tolist() == bases[12345].tolist()
+    finally:
+        engine.msm_free(handle)
