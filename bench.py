@@ -155,10 +155,32 @@ def time_ntt_modq(eng, dev, logn, batch, launches, warm):
     assert int((st != 0).sum().item()) == 0
     bytes_per = 32 * 29 * n + 2 * n                               # 476,160 / 952,320 B per polynomial
     achieved = batch * bytes_per / (ms * 1e-3) / 1e9
+    # The same launches dealt over three streams (independent batches, each with its own output buffer): a launch this short
+    # -- 0.3 ms -- spends a tenth of its time filling and draining the chip, and on one stream the next launch waits for the
+    # last workgroup of this one; on three the ramp of launch k + 1 runs under the tail of launch k
+    # (tools/ab_short_launches.py, profiles/r03_short_launches.txt).  Reported beside `frac`, which stays the per-launch figure
+    # rocprofv3's per-kernel average can be compared with.
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    bufs = [(torch.empty_like(wit), torch.empty_like(out), torch.empty_like(st)) for _ in streams]
+    runs = [(lambda s=s_, b=b_: eng.ntt_modq_dev(logn, batch, poly, b[0], b[1], b[2], frw.ENC_MONTGOMERY, s.cuda_stream))
+            for s_, b_ in zip(streams, bufs)]
+    for r_ in runs:
+        for _ in range(warm):
+            r_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(launches):
+        runs[i % 3]()
+    torch.cuda.synchronize()
+    ms3 = (time.perf_counter() - t0) / launches * 1e3
+    assert all(int((b[2] != 0).sum().item()) == 0 for b in bufs) and all(torch.equal(b[1], out) for b in bufs)
+    achieved3 = batch * bytes_per / (ms3 * 1e-3) / 1e9
     return {"kernel": "ntt_modq_kernel<%d,1>" % logn, "workload": "falcon-%d NTT + mod_q witness kernel, batch=%d" % (n, batch),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4), "launches_timed": launches,
-            "algorithmic_bytes_per_launch": batch * bytes_per, "polynomials_per_s": round(batch * launches / wall, 1)}
+            "algorithmic_bytes_per_launch": batch * bytes_per, "polynomials_per_s": round(batch * launches / wall, 1),
+            "three_streams": {"ms_per_launch": round(ms3, 4), "achieved": round(achieved3, 1), "frac": round(achieved3 / HBM_PEAK_GBS, 4),
+                              "what": "the same %d launches dealt over three streams (wall clock over all of them)" % launches}}
 
 
 def time_verify(eng, dev, logn, batch, launches, warm, threads):
