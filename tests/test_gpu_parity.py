@@ -855,11 +855,19 @@ def test_compact_host_path_and_host_expansion(engine, oracle, logn):
     sig, pk, hm = frw.synth_triples(logn, batch, seed=0x40 + logn)
     sig[1234, 7] = T.Q
     comp, st = engine.witness_ntt_verify_compact(logn, sig, pk, hm, strict=False)
-    assert st[1234] == frw.ST_COEFF_RANGE and int((st != 0).sum()) == 1 and not comp[1234].any()
+    CL = frw.compact_layout(logn)
+    assert st[1234] == frw.ST_COEFF_RANGE and int((st != 0).sum()) == 1
+    rejected = comp[1234].copy()                                      # all zeros but for the status word it carries
+    assert rejected[CL.status_off:CL.status_off + 4].view(np.uint32)[0] == frw.ST_COEFF_RANGE
+    rejected[CL.status_off:CL.status_off + 4] = 0
+    assert not rejected.any()
+    assert not comp[:, CL.status_off:CL.status_off + 4].view(np.uint32)[np.arange(batch) != 1234].any()
     idx = [0, 1, 255, 256, 2047, 2048, 2049, 2299]
     wit, inst = engine.expand_host(logn, comp[idx])
     owit, oinst, ost = oracle.witness_ntt_verify(logn, sig[idx], pk[idx], hm[idx], 1)
     assert not ost.any() and np.array_equal(wit, owit) and np.array_equal(inst, oinst)
+    wz, iz = engine.expand_host(logn, comp[1234:1235])                # expands to zeros, instance vector included
+    assert not wz.any() and not iz.any()
     with pytest.raises(frw.FrwError):
         engine.witness_ntt_verify_compact(logn, sig, pk, hm, strict=True)
 
