@@ -41,11 +41,12 @@ constexpr LimbsQ make_kq29(uint32_t K)
     }
     return r;
 }
-constexpr LimbsQ KQ29_1 = make_kq29(1), KQ29_4 = make_kq29(4), KQ29_16 = make_kq29(16), KQ29_64 = make_kq29(64);
+constexpr LimbsQ KQ29_1 = make_kq29(1), KQ29_4 = make_kq29(4), KQ29_16 = make_kq29(16), KQ29_64 = make_kq29(64),
+                 KQ29_256 = make_kq29(256), KQ29_1024 = make_kq29(1024);
 template <uint32_t K> constexpr const LimbsQ &kq29_table()
 {
-    static_assert(K == 1 || K == 4 || K == 16 || K == 64, "table missing");
-    return K == 1 ? KQ29_1 : K == 4 ? KQ29_4 : K == 16 ? KQ29_16 : KQ29_64;
+    static_assert(K == 1 || K == 4 || K == 16 || K == 64 || K == 256 || K == 1024, "table missing");
+    return K == 1 ? KQ29_1 : K == 4 ? KQ29_4 : K == 16 ? KQ29_16 : K == 64 ? KQ29_64 : K == 256 ? KQ29_256 : KQ29_1024;
 }
 static_assert(KQ29_1.l[0] == 0x1fffaaabu && KQ29_1.l[13] == 0xdu && KQ29_16.l[13] == 0xd0u, "q in 29-bit limbs");
 constexpr uint32_t QINV29 = 0x1ffcfffdu;      // -q^-1 mod 2^29
@@ -200,11 +201,11 @@ __host__ __device__ __forceinline__ Fq29 fq_canonical(const Fq29 &a)
 // any lazily reduced value (< 2^12 q) -> canonical: a product with one, then the conditional subtraction
 __host__ __device__ __forceinline__ Fq29 fq_reduce(const Fq29 &a) { return fq_canonical(fq_mul(a, fq_const(FQ29_ONE))); }
 
-// a = 0 mod q?  a < 64 q, normalised.  A multiple k q of q has k = a.l[0] q^-1 mod 2^29: anything else is ruled out by two
-// instructions, and only a candidate (one value in 2^23) pays for the exact reduction.
+// a = 0 mod q?  a < 2048 q, normalised.  A multiple k q of q has k = a.l[0] q^-1 mod 2^29: anything else is ruled out by two
+// instructions, and only a candidate (one value in 2^18) pays for the exact reduction.
 __host__ __device__ __forceinline__ bool fq_is_zero(const Fq29 &a)
 {
-    if (((a.l[0] * QPOSINV29) & MQ29) >= 64u) return false;
+    if (((a.l[0] * QPOSINV29) & MQ29) >= 2048u) return false;
     const Fq29 c = fq_reduce(a);
     uint32_t any = 0;
 #pragma unroll
@@ -232,99 +233,198 @@ __host__ __device__ inline Fq29 fq_inv(const Fq29 &a)
     return acc;
 }
 
-// the published generator of G1 (ark-bls12-381 g1.rs G1_GENERATOR_X / _Y), x 2^406; tests/test_fq29_host.py re-derives the limbs
+// ---- Fq2 = Fq[u] / (u^2 + 1): the field of G2's coordinates ------------------------------------------------------------------------
+// Components are lazily reduced Fq values.  A product leaves c0 < 6 q, c1 < 10 q (Karatsuba: three Fq products), a square
+// c0 < 2 q, c1 < 4 q (two); operands may be anything below 2^10 q.
+struct Fq2_29 { Fq29 c0, c1; };
+__host__ __device__ __forceinline__ Fq2_29 fq2_mul(const Fq2_29 &a, const Fq2_29 &b)
+{
+    const Fq29 m0 = fq_mul(a.c0, b.c0), m1 = fq_mul(a.c1, b.c1), m2 = fq_mul(fq_add(a.c0, a.c1), fq_add(b.c0, b.c1));
+    Fq2_29 r;
+    r.c0 = fq_sub<4>(m0, m1);
+    r.c1 = fq_sub<4>(fq_sub<4>(m2, m0), m1);
+    return r;
+}
+__host__ __device__ __forceinline__ Fq2_29 fq2_sqr(const Fq2_29 &a)           // a.c1 < 1024 q
+{
+    Fq2_29 r;
+    r.c0 = fq_mul(fq_add(a.c0, a.c1), fq_sub<1024>(a.c0, a.c1));
+    const Fq29 t = fq_mul(a.c0, a.c1);
+    r.c1 = fq_add(t, t);
+    return r;
+}
+
+// ---- the two fields as policies of the point formulas below --------------------------------------------------------------------------
+// K_MUL >= the bound (in q) of one product, K_2MUL of the sum of two, K_X / K_Y of a stored X / Y coordinate: what a
+// difference adds so that it cannot go negative.
+struct FqField {
+    typedef Fq29 El;
+    static constexpr uint32_t K_MUL = 4, K_2MUL = 4, K_X = 16, K_Y = 16;
+    static constexpr int WORDS = NLQ, ARK_WORDS = 12;
+    __host__ __device__ static __forceinline__ El mul(const El &a, const El &b) { return fq_mul(a, b); }
+    __host__ __device__ static __forceinline__ El sqr(const El &a) { return fq_mul(a, a); }
+    __host__ __device__ static __forceinline__ El add(const El &a, const El &b) { return fq_add(a, b); }
+    template <uint32_t K> __host__ __device__ static __forceinline__ El sub(const El &a, const El &b) { return fq_sub<K>(a, b); }
+    template <uint32_t K> __host__ __device__ static __forceinline__ El neg(const El &a) { return fq_neg<K>(a); }
+    __host__ __device__ static __forceinline__ El zero() { return fq_zero(); }
+    __host__ __device__ static __forceinline__ El one() { return fq_const(FQ29_ONE); }
+    __host__ __device__ static __forceinline__ bool is_zero(const El &a) { return fq_is_zero(a); }
+    __host__ __device__ static inline El inv(const El &a) { return fq_inv(a); }
+    __host__ __device__ static __forceinline__ El from_ark(const uint32_t *w) { return fq_from_ark(w); }
+    __host__ __device__ static __forceinline__ void to_ark(const El &a, uint32_t *w) { fq_to_ark(a, w); }
+    __host__ __device__ static __forceinline__ void store(const El &a, uint32_t *w)
+    {
+#pragma unroll
+        for (int k = 0; k < NLQ; k++) w[k] = a.l[k];
+    }
+    __host__ __device__ static __forceinline__ El load(const uint32_t *w)
+    {
+        El a;
+#pragma unroll
+        for (int k = 0; k < NLQ; k++) a.l[k] = w[k];
+        return a;
+    }
+};
+struct Fq2Field {
+    typedef Fq2_29 El;
+    static constexpr uint32_t K_MUL = 16, K_2MUL = 64, K_X = 256, K_Y = 64;
+    static constexpr int WORDS = 2 * NLQ, ARK_WORDS = 24;
+    __host__ __device__ static __forceinline__ El mul(const El &a, const El &b) { return fq2_mul(a, b); }
+    __host__ __device__ static __forceinline__ El sqr(const El &a) { return fq2_sqr(a); }
+    __host__ __device__ static __forceinline__ El add(const El &a, const El &b) { El r; r.c0 = fq_add(a.c0, b.c0); r.c1 = fq_add(a.c1, b.c1); return r; }
+    template <uint32_t K> __host__ __device__ static __forceinline__ El sub(const El &a, const El &b)
+    {
+        El r; r.c0 = fq_sub<K>(a.c0, b.c0); r.c1 = fq_sub<K>(a.c1, b.c1); return r;
+    }
+    template <uint32_t K> __host__ __device__ static __forceinline__ El neg(const El &a) { El r; r.c0 = fq_neg<K>(a.c0); r.c1 = fq_neg<K>(a.c1); return r; }
+    __host__ __device__ static __forceinline__ El zero() { El r; r.c0 = r.c1 = fq_zero(); return r; }
+    __host__ __device__ static __forceinline__ El one() { El r; r.c0 = fq_const(FQ29_ONE); r.c1 = fq_zero(); return r; }
+    __host__ __device__ static __forceinline__ bool is_zero(const El &a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
+    __host__ __device__ static inline El inv(const El &a)                         // conj(a) / (c0^2 + c1^2)
+    {
+        const Fq29 n = fq_inv(fq_add(fq_mul(a.c0, a.c0), fq_mul(a.c1, a.c1)));
+        El r; r.c0 = fq_mul(a.c0, n); r.c1 = fq_mul(fq_neg<1024>(a.c1), n); return r;
+    }
+    __host__ __device__ static __forceinline__ El from_ark(const uint32_t *w) { El r; r.c0 = fq_from_ark(w); r.c1 = fq_from_ark(w + 12); return r; }
+    __host__ __device__ static __forceinline__ void to_ark(const El &a, uint32_t *w) { fq_to_ark(a.c0, w); fq_to_ark(a.c1, w + 12); }
+    __host__ __device__ static __forceinline__ void store(const El &a, uint32_t *w) { FqField::store(a.c0, w); FqField::store(a.c1, w + NLQ); }
+    __host__ __device__ static __forceinline__ El load(const uint32_t *w) { El r; r.c0 = FqField::load(w); r.c1 = FqField::load(w + NLQ); return r; }
+};
+
+// the published generators (ark-bls12-381 g1.rs / g2.rs), x 2^406; tests/test_fq29_host.py re-derives the limbs
 constexpr LimbsQ G1_GEN_X29 = {{0x0af58fd1u, 0x1662a68eu, 0x07d2c530u, 0x08993c24u, 0x1e4f4756u, 0x0c5f7ae2u, 0x0f589991u,
                                 0x00dc570eu, 0x121b54f5u, 0x05242b28u, 0x17442464u, 0x0ee8a0cdu, 0x1f591099u, 0x00000009u}};
 constexpr LimbsQ G1_GEN_Y29 = {{0x1cd65f60u, 0x1919ce91u, 0x0da44145u, 0x0810b2ccu, 0x08f38c44u, 0x00629241u, 0x0f521d8cu,
                                 0x0529cbadu, 0x0506077fu, 0x191b2712u, 0x0c587ccbu, 0x1017da2fu, 0x1c72eafau, 0x0000000bu}};
+constexpr LimbsQ G2_GEN_X0_29 = {{0x085d7b9eu, 0x0d352838u, 0x124c5276u, 0x1748cfe0u, 0x10081802u, 0x0bfc6540u, 0x01ac1784u,
+                                   0x11aab37fu, 0x08f338c1u, 0x19443e06u, 0x1cc29975u, 0x0a0da681u, 0x0a53e408u, 0x00000004u}};
+constexpr LimbsQ G2_GEN_X1_29 = {{0x0ba695cbu, 0x1034485fu, 0x124f6eb5u, 0x0778336bu, 0x1e170b2du, 0x12164b09u, 0x1d34eb65u,
+                                   0x10a72ef2u, 0x07b96a4eu, 0x194de314u, 0x0fd4fa4au, 0x0178f021u, 0x10455591u, 0x0000000bu}};
+constexpr LimbsQ G2_GEN_Y0_29 = {{0x1ec793b8u, 0x1780929bu, 0x0cdd65c4u, 0x126ca64fu, 0x0f9f2f6bu, 0x09485ce0u, 0x0621fd94u,
+                                   0x1e0e7efdu, 0x09ba1f86u, 0x06d0a458u, 0x1f790335u, 0x0af83757u, 0x00c11d05u, 0x0000000cu}};
+constexpr LimbsQ G2_GEN_Y1_29 = {{0x014e8093u, 0x07f6c9aau, 0x19bd3883u, 0x156ca3e1u, 0x0e34898fu, 0x0840b6feu, 0x0594f57du,
+                                   0x149969ecu, 0x12886b3eu, 0x1cbcbe34u, 0x1cae2f62u, 0x08f5e851u, 0x187a6c6cu, 0x00000003u}};
 
-// ---- G1: y^2 = x^3 + 4, XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2); inf = the point at infinity -----------------
-// Bounds kept by every formula below (in units of q): X < 10, Y < 6, ZZ < 2, ZZZ < 2, affine coordinates < 2.
-struct G1Affine29 { Fq29 x, y; bool inf; };
-struct G1Xyzz { Fq29 x, y, zz, zzz; bool inf; };
+// ---- short Weierstrass curves with a = 0 in XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2) over either field:
+// G1: y^2 = x^3 + 4 over Fq, G2: y^2 = x^3 + 4 (1 + u) over Fq2 (the formulas never see b).  inf = the point at infinity.
+// Bounds kept by every formula (units of q per component): Fq: X < 10, Y < 6, ZZ, ZZZ < 2; Fq2: X < 90, Y < 26, ZZ, ZZZ < 10.
+template <class F> struct AffineT { typename F::El x, y; bool inf; };
+template <class F> struct XyzzT { typename F::El x, y, zz, zzz; bool inf; };
 
-__host__ __device__ __forceinline__ G1Xyzz g1_identity()
+template <class F> __host__ __device__ __forceinline__ XyzzT<F> pt_identity()
 {
-    G1Xyzz r;
-    r.x = r.y = r.zz = r.zzz = fq_zero();
+    XyzzT<F> r;
+    r.x = r.y = r.zz = r.zzz = F::zero();
     r.inf = true;
     return r;
 }
-__host__ __device__ __forceinline__ G1Xyzz g1_from_affine(const G1Affine29 &p)
+template <class F> __host__ __device__ __forceinline__ XyzzT<F> pt_from_affine(const AffineT<F> &p)
 {
-    G1Xyzz r;
-    r.x = p.x; r.y = p.y; r.zz = r.zzz = fq_const(FQ29_ONE);
+    XyzzT<F> r;
+    r.x = p.x; r.y = p.y; r.zz = r.zzz = F::one();
     r.inf = p.inf;
     return r;
 }
 // dbl-2008-s-1 (a = 0): 6 M + 3 S
-__host__ __device__ inline G1Xyzz g1_double(const G1Xyzz &p)
+template <class F> __host__ __device__ inline XyzzT<F> pt_double(const XyzzT<F> &p)
 {
     if (p.inf) return p;
-    const Fq29 u = fq_add(p.y, p.y);                     // < 12
-    const Fq29 v = fq_sqr(u), w = fq_mul(u, v);
-    const Fq29 s = fq_mul(p.x, v);
-    const Fq29 xx = fq_sqr(p.x);
-    const Fq29 m = fq_add(fq_add(xx, xx), xx);           // < 6
-    G1Xyzz r;
-    r.x = fq_sub<4>(fq_sqr(m), fq_add(s, s));            // < 6
-    r.y = fq_sub<4>(fq_mul(m, fq_sub<16>(s, r.x)), fq_mul(w, p.y));
-    r.zz = fq_mul(v, p.zz);
-    r.zzz = fq_mul(w, p.zzz);
+    const auto u = F::add(p.y, p.y);
+    const auto v = F::sqr(u), w = F::mul(u, v);
+    const auto s = F::mul(p.x, v);
+    const auto xx = F::sqr(p.x);
+    const auto m = F::add(F::add(xx, xx), xx);
+    XyzzT<F> r;
+    r.x = F::template sub<F::K_2MUL>(F::sqr(m), F::add(s, s));
+    r.y = F::template sub<F::K_MUL>(F::mul(m, F::template sub<F::K_X>(s, r.x)), F::mul(w, p.y));
+    r.zz = F::mul(v, p.zz);
+    r.zzz = F::mul(w, p.zzz);
     r.inf = false;
     return r;
 }
 // madd-2008-s: 8 M + 2 S; complete (an accumulator that meets its own value doubles, its negative cancels)
-__host__ __device__ inline G1Xyzz g1_add_affine(const G1Xyzz &p, const G1Affine29 &q)
+template <class F> __host__ __device__ inline XyzzT<F> pt_add_affine(const XyzzT<F> &p, const AffineT<F> &q)
 {
     if (q.inf) return p;
-    if (p.inf) return g1_from_affine(q);
-    const Fq29 u2 = fq_mul(q.x, p.zz), s2 = fq_mul(q.y, p.zzz);
-    const Fq29 pp_ = fq_sub<16>(u2, p.x);                // P, < 18
-    const Fq29 rr = fq_sub<16>(s2, p.y);                 // R, < 18
-    if (fq_is_zero(pp_)) {
-        if (fq_is_zero(rr)) return g1_double(g1_from_affine(q));
-        return g1_identity();
+    if (p.inf) return pt_from_affine(q);
+    const auto u2 = F::mul(q.x, p.zz), s2 = F::mul(q.y, p.zzz);
+    const auto pp_ = F::template sub<F::K_X>(u2, p.x);
+    const auto rr = F::template sub<F::K_Y>(s2, p.y);
+    if (F::is_zero(pp_)) {
+        if (F::is_zero(rr)) return pt_double(pt_from_affine(q));
+        return pt_identity<F>();
     }
-    const Fq29 pp = fq_sqr(pp_), ppp = fq_mul(pp_, pp), qq = fq_mul(p.x, pp);
-    G1Xyzz r;
-    r.x = fq_sub<4>(fq_sub<4>(fq_sqr(rr), ppp), fq_add(qq, qq));          // < 10
-    r.y = fq_sub<4>(fq_mul(rr, fq_sub<16>(qq, r.x)), fq_mul(p.y, ppp));   // < 6
-    r.zz = fq_mul(p.zz, pp);
-    r.zzz = fq_mul(p.zzz, ppp);
+    const auto pp = F::sqr(pp_), ppp = F::mul(pp_, pp), qq = F::mul(p.x, pp);
+    XyzzT<F> r;
+    r.x = F::template sub<F::K_2MUL>(F::template sub<F::K_MUL>(F::sqr(rr), ppp), F::add(qq, qq));
+    r.y = F::template sub<F::K_MUL>(F::mul(rr, F::template sub<F::K_X>(qq, r.x)), F::mul(p.y, ppp));
+    r.zz = F::mul(p.zz, pp);
+    r.zzz = F::mul(p.zzz, ppp);
     r.inf = false;
     return r;
 }
 // add-2008-s: 12 M + 2 S; complete
-__host__ __device__ inline G1Xyzz g1_add(const G1Xyzz &p, const G1Xyzz &q)
+template <class F> __host__ __device__ inline XyzzT<F> pt_add(const XyzzT<F> &p, const XyzzT<F> &q)
 {
     if (q.inf) return p;
     if (p.inf) return q;
-    const Fq29 u1 = fq_mul(p.x, q.zz), u2 = fq_mul(q.x, p.zz), s1 = fq_mul(p.y, q.zzz), s2 = fq_mul(q.y, p.zzz);
-    const Fq29 pp_ = fq_sub<4>(u2, u1), rr = fq_sub<4>(s2, s1);
-    if (fq_is_zero(pp_)) {
-        if (fq_is_zero(rr)) return g1_double(p);
-        return g1_identity();
+    const auto u1 = F::mul(p.x, q.zz), u2 = F::mul(q.x, p.zz), s1 = F::mul(p.y, q.zzz), s2 = F::mul(q.y, p.zzz);
+    const auto pp_ = F::template sub<F::K_MUL>(u2, u1), rr = F::template sub<F::K_MUL>(s2, s1);
+    if (F::is_zero(pp_)) {
+        if (F::is_zero(rr)) return pt_double(p);
+        return pt_identity<F>();
     }
-    const Fq29 pp = fq_sqr(pp_), ppp = fq_mul(pp_, pp), qq = fq_mul(u1, pp);
-    G1Xyzz r;
-    r.x = fq_sub<4>(fq_sub<4>(fq_sqr(rr), ppp), fq_add(qq, qq));
-    r.y = fq_sub<4>(fq_mul(rr, fq_sub<16>(qq, r.x)), fq_mul(s1, ppp));
-    r.zz = fq_mul(fq_mul(p.zz, q.zz), pp);
-    r.zzz = fq_mul(fq_mul(p.zzz, q.zzz), ppp);
+    const auto pp = F::sqr(pp_), ppp = F::mul(pp_, pp), qq = F::mul(u1, pp);
+    XyzzT<F> r;
+    r.x = F::template sub<F::K_2MUL>(F::template sub<F::K_MUL>(F::sqr(rr), ppp), F::add(qq, qq));
+    r.y = F::template sub<F::K_MUL>(F::mul(rr, F::template sub<F::K_X>(qq, r.x)), F::mul(s1, ppp));
+    r.zz = F::mul(F::mul(p.zz, q.zz), pp);
+    r.zzz = F::mul(F::mul(p.zzz, q.zzz), ppp);
     r.inf = false;
     return r;
 }
-// x = X / ZZ, y = Y / ZZZ with one inversion; (0, 0) for the point at infinity.  Coordinates < 2 q.
-__host__ __device__ inline G1Affine29 g1_to_affine(const G1Xyzz &p)
+// x = X / ZZ, y = Y / ZZZ with one inversion; (0, 0) for the point at infinity
+template <class F> __host__ __device__ inline AffineT<F> pt_to_affine(const XyzzT<F> &p)
 {
-    G1Affine29 r;
+    AffineT<F> r;
     r.inf = p.inf;
-    if (p.inf) { r.x = r.y = fq_zero(); return r; }
-    const Fq29 inv = fq_inv(fq_mul(p.zz, p.zzz));
-    r.x = fq_mul(p.x, fq_mul(inv, p.zzz));
-    r.y = fq_mul(p.y, fq_mul(inv, p.zz));
+    if (p.inf) { r.x = r.y = F::zero(); return r; }
+    const auto inv = F::inv(F::mul(p.zz, p.zzz));
+    r.x = F::mul(p.x, F::mul(inv, p.zzz));
+    r.y = F::mul(p.y, F::mul(inv, p.zz));
     return r;
 }
+
+// G1 under its round-3 names
+typedef AffineT<FqField> G1Affine29;
+typedef XyzzT<FqField> G1Xyzz;
+typedef AffineT<Fq2Field> G2Affine29;
+typedef XyzzT<Fq2Field> G2Xyzz;
+__host__ __device__ __forceinline__ G1Xyzz g1_identity() { return pt_identity<FqField>(); }
+__host__ __device__ __forceinline__ G1Xyzz g1_from_affine(const G1Affine29 &p) { return pt_from_affine(p); }
+__host__ __device__ inline G1Xyzz g1_double(const G1Xyzz &p) { return pt_double(p); }
+__host__ __device__ inline G1Xyzz g1_add_affine(const G1Xyzz &p, const G1Affine29 &q) { return pt_add_affine(p, q); }
+__host__ __device__ inline G1Xyzz g1_add(const G1Xyzz &p, const G1Xyzz &q) { return pt_add(p, q); }
+__host__ __device__ inline G1Affine29 g1_to_affine(const G1Xyzz &p) { return pt_to_affine(p); }
 
 }  // namespace frw

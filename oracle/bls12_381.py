@@ -150,3 +150,79 @@ def verify_exponents(pk, public_inputs, proof):
     tx = pk["toxic"]
     acc = sum(x * g for x, g in zip([1] + list(public_inputs), pk["gamma_abc"])) % R
     return (a * b - tx["alpha"] * tx["beta"] - acc * tx["gamma"] - c * tx["delta"]) % R == 0
+
+
+# ---- G2: y^2 = x^3 + 4 (1 + u) over Fq2 = Fq[u] / (u^2 + 1) ----------------------------------------------------------------------
+# Needed for B of a Groth16 proof (prover.rs: g2_b = s delta_g2 + b_g2_query[0] + MSM(b_g2_query[1..], assignment) + beta_g2).
+# Fq2 elements are (c0, c1) tuples; the published generator (ark-bls12-381 g2.rs G2_GENERATOR_X / _Y; the IETF draft).
+G2 = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+       0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+      (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+       0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))
+
+
+def f2_add(a, b):
+    return (a[0] + b[0]) % Q, (a[1] + b[1]) % Q
+
+
+def f2_sub(a, b):
+    return (a[0] - b[0]) % Q, (a[1] - b[1]) % Q
+
+
+def f2_mul(a, b):
+    return (a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q
+
+
+def f2_inv(a):
+    n = pow(a[0] * a[0] + a[1] * a[1], -1, Q)
+    return a[0] * n % Q, -a[1] * n % Q
+
+
+def g2_on_curve(p):
+    return p is None or f2_sub(f2_mul(p[1], p[1]), f2_add(f2_mul(f2_mul(p[0], p[0]), p[0]), (4, 4))) == (0, 0)
+
+
+def g2_neg(p):
+    return None if p is None else (p[0], ((-p[1][0]) % Q, (-p[1][1]) % Q))
+
+
+def g2_add(p, q):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    if p[0] == q[0]:
+        if f2_add(p[1], q[1]) == (0, 0):
+            return None
+        lam = f2_mul(f2_mul((3, 0), f2_mul(p[0], p[0])), f2_inv(f2_add(p[1], p[1])))
+    else:
+        lam = f2_mul(f2_sub(q[1], p[1]), f2_inv(f2_sub(q[0], p[0])))
+    x = f2_sub(f2_sub(f2_mul(lam, lam), p[0]), q[0])
+    return x, f2_sub(f2_mul(lam, f2_sub(p[0], x)), p[1])
+
+
+def g2_mul(p, k):
+    k %= R
+    acc = None
+    while k:
+        if k & 1:
+            acc = g2_add(acc, p)
+        p = g2_add(p, p)
+        k >>= 1
+    return acc
+
+
+def g2_to_limbs(p):
+    """ark-ff bytes of a G2 affine point: x.c0, x.c1, y.c0, y.c1, each x R mod q as 6 little-endian u64 limbs; infinity = zeros."""
+    if p is None:
+        return [0] * 24
+    return [(v * FQ_R % Q >> (64 * i)) & (2 ** 64 - 1) for c in p for v in c for i in range(6)]
+
+
+def g2_from_limbs(limbs):
+    limbs = [int(v) for v in limbs]
+    if not any(limbs):
+        return None
+    inv = pow(FQ_R, -1, Q)
+    v = [sum(l << (64 * i) for i, l in enumerate(limbs[6 * c:6 * c + 6])) * inv % Q for c in range(4)]
+    return (v[0], v[1]), (v[2], v[3])

@@ -76,3 +76,72 @@ extern "C" void t_g1(int op, const uint32_t *pw, const uint32_t *qw, uint32_t *o
     }
     store_point(r, out);
 }
+
+// ---- Fq2 and G2 ------------------------------------------------------------------------------------------------------------------
+static Fq2_29 load2(const uint32_t *w) { Fq2_29 r; r.c0 = load(w); r.c1 = load(w + 14); return r; }
+static void store2(const Fq2_29 &a, uint32_t *w) { store(a.c0, w); store(a.c1, w + 14); }
+// a, b, out: 28 limbs (c0 then c1).  op 0 mul, 1 sqr, 2 inv, 3 is_zero (out[0])
+extern "C" void t_fq2(int op, const uint32_t *a, const uint32_t *b, uint32_t *out)
+{
+    switch (op) {
+    case 0: store2(fq2_mul(load2(a), load2(b)), out); break;
+    case 1: store2(fq2_sqr(load2(a)), out); break;
+    case 2: store2(Fq2Field::inv(load2(a)), out); break;
+    case 3: out[0] = Fq2Field::is_zero(load2(a)) ? 1u : 0u; break;
+    }
+}
+static G2Affine29 load_point2(const uint32_t *w)                // 48 words, ark-ff; zeros = infinity
+{
+    G2Affine29 p;
+    uint32_t any = 0;
+    for (int i = 0; i < 48; i++) any |= w[i];
+    p.inf = any == 0;
+    p.x = Fq2Field::from_ark(w);
+    p.y = Fq2Field::from_ark(w + 24);
+    return p;
+}
+static void store_point2(const G2Xyzz &p, uint32_t *w)
+{
+    const G2Affine29 a = pt_to_affine(p);
+    if (a.inf) { std::memset(w, 0, 192); return; }
+    Fq2Field::to_ark(a.x, w);
+    Fq2Field::to_ark(a.y, w + 24);
+}
+// the same seven operations as t_g1, in G2; op 7: a chain of 40 mixed additions of q onto p (bounds must hold along it)
+extern "C" void t_g2(int op, const uint32_t *pw, const uint32_t *qw, uint32_t *out)
+{
+    const G2Affine29 p = load_point2(pw), q = load_point2(qw);
+    G2Xyzz r = pt_identity<Fq2Field>();
+    switch (op) {
+    case 0: r = pt_add_affine(pt_from_affine(p), q); break;
+    case 1: r = pt_double(pt_from_affine(p)); break;
+    case 2: r = pt_add(pt_double(pt_from_affine(p)), pt_double(pt_from_affine(q))); break;
+    case 3: r = pt_add_affine(pt_add_affine(pt_add_affine(pt_add_affine(r, p), q), p), q); break;
+    case 4: {
+        G2Affine29 nq = q;
+        nq.y = Fq2Field::neg<16>(q.y);
+        r = pt_add_affine(pt_add_affine(pt_double(pt_from_affine(p)), q), nq);
+        break;
+    }
+    case 5: r = pt_add(pt_double(pt_from_affine(p)), pt_double(pt_from_affine(p))); break;
+    case 6: {
+        G2Xyzz d = pt_double(pt_from_affine(p)), n = d;
+        n.y = Fq2Field::neg<64>(d.y);
+        r = pt_add(d, n);
+        break;
+    }
+    case 7:
+        r = pt_from_affine(p);
+        for (int k = 0; k < 40; k++) r = k % 7 == 6 ? pt_double(r) : pt_add_affine(r, q);
+        break;
+    }
+    store_point2(r, out);
+}
+// op 7 for G1 as well (through t_g1 would change its table): 40 steps from p with q
+extern "C" void t_g1_chain(const uint32_t *pw, const uint32_t *qw, uint32_t *out)
+{
+    const G1Affine29 p = load_point(pw), q = load_point(qw);
+    G1Xyzz r = g1_from_affine(p);
+    for (int k = 0; k < 40; k++) r = k % 7 == 6 ? g1_double(r) : g1_add_affine(r, q);
+    store_point(r, out);
+}

@@ -144,3 +144,79 @@ def test_point_formulas_every_branch(lib):
         assert _g1(lib, 3, p, E.neg(p)) is None and _g1(lib, 3, p, None) == E.add(p, p) and _g1(lib, 3, None, q) == E.add(q, q)
         assert _g1(lib, 2, p, E.neg(p)) is None and _g1(lib, 2, p, p) == E.mul(p, 4) and _g1(lib, 2, None, q) == E.add(q, q)
     assert _g1(lib, 1, None) is None and _g1(lib, 5, None) is None
+
+
+def limbs2(v):
+    return (C.c_uint32 * 28)(*(list(limbs(v[0])) + list(limbs(v[1]))))
+
+
+def value2(arr):
+    return value(arr[:14]), value(arr[14:28])
+
+
+def test_fq2_operations_at_their_bounds(lib):
+    rng = random.Random(53)
+    inv = pow(RQ, -1, Q)
+    out = (C.c_uint32 * 28)()
+    for _ in range(200):
+        a = (rng.randrange(300 * Q), rng.randrange(300 * Q))                 # the largest operands a G2 formula multiplies
+        b = (rng.randrange(300 * Q), rng.randrange(300 * Q))
+        lib.t_fq2(0, limbs2(a), limbs2(b), out)
+        c0, c1 = value2(out)
+        want = E.f2_mul((a[0] % Q, a[1] % Q), (b[0] % Q, b[1] % Q))
+        assert (c0 % Q, c1 % Q) == (want[0] * inv % Q, want[1] * inv % Q) and c0 < 6 * Q and c1 < 10 * Q
+        lib.t_fq2(1, limbs2(a), limbs2(a), out)
+        c0, c1 = value2(out)
+        want = E.f2_mul((a[0] % Q, a[1] % Q), (a[0] % Q, a[1] % Q))
+        assert (c0 % Q, c1 % Q) == (want[0] * inv % Q, want[1] * inv % Q) and c0 < 2 * Q and c1 < 4 * Q
+    for _ in range(10):
+        x = (rng.randrange(Q), rng.randrange(Q))
+        lib.t_fq2(2, limbs2((x[0] * RQ % Q, x[1] * RQ % Q)), limbs2((0, 0)), out)
+        c0, c1 = value2(out)
+        xi = E.f2_inv(x)
+        assert (c0 % Q, c1 % Q) == (xi[0] * RQ % Q, xi[1] * RQ % Q)
+    for a, z in (((0, 0), 1), ((5 * Q, 17 * Q), 1), ((Q, 1), 0), ((1, 3 * Q), 0), ((2047 * Q, 0), 1)):
+        lib.t_fq2(3, limbs2(a), limbs2((0, 0)), out)
+        assert out[0] == z
+
+
+def _pt2(p):
+    return (C.c_uint32 * 48)(*[(l >> (32 * h)) & 0xFFFFFFFF for l in E.g2_to_limbs(p) for h in range(2)])
+
+
+def _g2(lib, op, p, q=None):
+    out = (C.c_uint32 * 48)()
+    lib.t_g2(op, _pt2(p), _pt2(q), out)
+    return E.g2_from_limbs([out[2 * i] | out[2 * i + 1] << 32 for i in range(24)])
+
+
+def test_g2_point_formulas_every_branch_and_a_long_chain(lib):
+    rng = random.Random(59)
+    assert E.g2_on_curve(E.G2) and E.g2_mul(E.G2, E.R) is None
+    for _ in range(3):
+        p, q = E.g2_mul(E.G2, rng.randrange(1, E.R)), E.g2_mul(E.G2, rng.randrange(1, E.R))
+        assert _g2(lib, 0, p, q) == E.g2_add(p, q) and _g2(lib, 1, p) == E.g2_add(p, p)
+        assert _g2(lib, 2, p, q) == E.g2_add(E.g2_add(p, p), E.g2_add(q, q))
+        assert _g2(lib, 3, p, q) == E.g2_add(E.g2_add(p, q), E.g2_add(p, q))
+        assert _g2(lib, 4, p, q) == E.g2_add(p, p)
+        assert _g2(lib, 5, p) == E.g2_mul(p, 4) and _g2(lib, 6, p) is None
+        assert _g2(lib, 0, p, p) == E.g2_add(p, p) and _g2(lib, 0, p, E.g2_neg(p)) is None
+        assert _g2(lib, 0, p, None) == p and _g2(lib, 0, None, q) == q and _g2(lib, 0, None, None) is None
+        assert _g2(lib, 2, p, E.g2_neg(p)) is None and _g2(lib, 2, p, p) == E.g2_mul(p, 4)
+        # forty formulas in a row without any reduction in between: the stated bounds (X < 90 q, Y < 26 q) are invariants
+        want = p
+        for k in range(40):
+            want = E.g2_add(want, want) if k % 7 == 6 else E.g2_add(want, q)
+        assert _g2(lib, 7, p, q) == want
+        p1, q1 = E.mul(E.G1, rng.randrange(1, E.R)), E.mul(E.G1, rng.randrange(1, E.R))
+        out = (C.c_uint32 * 24)()
+        lib.t_g1_chain(_pt(p1), _pt(q1), out)
+        want = p1
+        for k in range(40):
+            want = E.add(want, want) if k % 7 == 6 else E.add(want, q1)
+        assert E.from_limbs([out[2 * i] | out[2 * i + 1] << 32 for i in range(12)]) == want
+    src = open(os.path.join(ROOT, "falcon-r1cs_amd", "csrc", "frw_fq29.h")).read()
+    import re
+    for name, v in zip(("G2_GEN_X0_29", "G2_GEN_X1_29", "G2_GEN_Y0_29", "G2_GEN_Y1_29"), (E.G2[0][0], E.G2[0][1], E.G2[1][0], E.G2[1][1])):
+        body = re.search(name + r" = \{\{([^}]*)\}\}", src).group(1)
+        assert value([int(x.strip().rstrip("u"), 16) for x in body.replace("\n", " ").split(",")]) == v * RQ % Q
