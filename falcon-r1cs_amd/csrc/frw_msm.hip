@@ -31,71 +31,93 @@ namespace frw {
 constexpr int MSM_C = 16;                       // window bits
 constexpr int MSM_W = 16;                       // windows: 16 x 16 = 256 >= 255 bits
 constexpr int MSM_BUCKETS = 1 << (MSM_C - 1);   // signed digits: |d| in 1 .. 2^15
-constexpr int MSM_PT_WORDS = 2 * NLQ;           // a table row: x, y limbs (all zero = the point at infinity)
-constexpr int MSM_BK_WORDS = 4 * NLQ + 4;       // a bucket: X, Y, ZZ, ZZZ limbs + the infinity flag (padded to 16 bytes)
 constexpr int MSM_CHUNK = 64;                   // buckets per thread in the fold
 constexpr int MSM_FOLD_THREADS = MSM_BUCKETS / MSM_CHUNK;
+// per group (F = FqField: G1, Fq2Field: G2): a table row = x, y limbs (all zero = the point at infinity); a bucket = X, Y, ZZ,
+// ZZZ limbs + the infinity flag (padded to 16 bytes); ark-ff's bytes of an affine point
+template <class F> struct Grp {
+    static constexpr int PT_WORDS = 2 * F::WORDS, BK_WORDS = 4 * F::WORDS + 4, ARK_WORDS = 2 * F::ARK_WORDS;
+    static constexpr uint32_t K_AFFINE_Y = F::K_MUL;          // bound of a table row's y: what its negation adds
+};
 
 struct MsmDev {
     uint32_t n;                 // points
-    const uint32_t *table;      // [MSM_W][n][MSM_PT_WORDS]
+    const uint32_t *table;      // [MSM_W][n][PT_WORDS]
 };
 
-__device__ __forceinline__ G1Affine29 load_row(const uint32_t *row)
+template <class F> __device__ __forceinline__ AffineT<F> load_row(const uint32_t *row)
 {
-    G1Affine29 p;
+    constexpr int PW = Grp<F>::PT_WORDS;
+    AffineT<F> p;
     uint32_t any = 0;
     const uint4 *v = (const uint4 *)row;
-    uint32_t w[MSM_PT_WORDS];
+    uint32_t w[PW];
 #pragma unroll
-    for (int k = 0; k < MSM_PT_WORDS / 4; k++) {
+    for (int k = 0; k < PW / 4; k++) {
         const uint4 t = v[k];
         w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w;
     }
 #pragma unroll
-    for (int k = 0; k < NLQ; k++) { p.x.l[k] = w[k]; p.y.l[k] = w[NLQ + k]; any |= w[k] | w[NLQ + k]; }
+    for (int k = 0; k < PW; k++) any |= w[k];
+    p.x = F::load(w);
+    p.y = F::load(w + F::WORDS);
     p.inf = any == 0;
     return p;
 }
-__device__ __forceinline__ void store_row(uint32_t *row, const G1Affine29 &p)
+template <class F> __device__ __forceinline__ void store_row(uint32_t *row, const AffineT<F> &p)
 {
+    uint32_t w[Grp<F>::PT_WORDS];
+    F::store(p.x, w);
+    F::store(p.y, w + F::WORDS);
 #pragma unroll
-    for (int k = 0; k < NLQ; k++) { row[k] = p.inf ? 0u : p.x.l[k]; row[NLQ + k] = p.inf ? 0u : p.y.l[k]; }
+    for (int k = 0; k < Grp<F>::PT_WORDS; k++) row[k] = p.inf ? 0u : w[k];
 }
-__device__ __forceinline__ void store_bucket(uint32_t *b, const G1Xyzz &p)
+template <class F> __device__ __forceinline__ void store_bucket(uint32_t *b, const XyzzT<F> &p)
 {
-#pragma unroll
-    for (int k = 0; k < NLQ; k++) { b[k] = p.x.l[k]; b[NLQ + k] = p.y.l[k]; b[2 * NLQ + k] = p.zz.l[k]; b[3 * NLQ + k] = p.zzz.l[k]; }
-    b[4 * NLQ] = p.inf ? 1u : 0u;
+    F::store(p.x, b); F::store(p.y, b + F::WORDS); F::store(p.zz, b + 2 * F::WORDS); F::store(p.zzz, b + 3 * F::WORDS);
+    b[4 * F::WORDS] = p.inf ? 1u : 0u;
 }
-__device__ __forceinline__ G1Xyzz load_bucket(const uint32_t *b)
+template <class F> __device__ __forceinline__ XyzzT<F> load_bucket(const uint32_t *b)
 {
-    G1Xyzz p;
-#pragma unroll
-    for (int k = 0; k < NLQ; k++) { p.x.l[k] = b[k]; p.y.l[k] = b[NLQ + k]; p.zz.l[k] = b[2 * NLQ + k]; p.zzz.l[k] = b[3 * NLQ + k]; }
-    p.inf = b[4 * NLQ] != 0;
+    XyzzT<F> p;
+    p.x = F::load(b); p.y = F::load(b + F::WORDS); p.zz = F::load(b + 2 * F::WORDS); p.zzz = F::load(b + 3 * F::WORDS);
+    p.inf = b[4 * F::WORDS] != 0;
     return p;
+}
+template <class F> __device__ __forceinline__ AffineT<F> load_ark_point(const uint32_t *w)
+{
+    AffineT<F> p;
+    uint32_t any = 0;
+    for (int k = 0; k < Grp<F>::ARK_WORDS; k++) any |= w[k];
+    p.inf = any == 0;
+    p.x = F::from_ark(w);
+    p.y = F::from_ark(w + F::ARK_WORDS);
+    return p;
+}
+template <class F> __device__ __forceinline__ void store_ark_point(uint32_t *o, const AffineT<F> &a)
+{
+    if (a.inf) {
+        for (int k = 0; k < Grp<F>::ARK_WORDS; k++) o[k] = 0;
+    } else {
+        F::to_ark(a.x, o);
+        F::to_ark(a.y, o + F::ARK_WORDS);
+    }
 }
 
 // ---- load time: table[j][i] = 2^(16 j) P_i, affine, Montgomery limbs ----------------------------------------------------------
-__global__ __launch_bounds__(64) void msm_precompute_kernel(uint32_t n, const uint32_t *__restrict__ bases /* [n][24] ark-ff */,
+template <class F>
+__global__ __launch_bounds__(64) void msm_precompute_kernel(uint32_t n, const uint32_t *__restrict__ bases /* [n][ARK_WORDS] ark-ff */,
                                                             uint32_t *__restrict__ table)
 {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t *w = bases + (size_t)i * 24;
-    uint32_t any = 0;
-    for (int k = 0; k < 24; k++) any |= w[k];
-    G1Affine29 p;
-    p.inf = any == 0;
-    p.x = fq_from_ark(w);
-    p.y = fq_from_ark(w + 12);
+    AffineT<F> p = load_ark_point<F>(bases + (size_t)i * Grp<F>::ARK_WORDS);
     for (int j = 0; j < MSM_W; j++) {
-        store_row(table + ((size_t)j * n + i) * MSM_PT_WORDS, p);
+        store_row<F>(table + ((size_t)j * n + i) * Grp<F>::PT_WORDS, p);
         if (j + 1 == MSM_W) break;
-        G1Xyzz d = g1_from_affine(p);
-        for (int k = 0; k < MSM_C; k++) d = g1_double(d);
-        p = g1_to_affine(d);
+        XyzzT<F> d = pt_from_affine(p);
+        for (int k = 0; k < MSM_C; k++) d = pt_double(d);
+        p = pt_to_affine(d);
     }
 }
 
@@ -251,136 +273,134 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restr
     for (int b = t; b < MSM_BUCKETS; b += 1024) order[sig * MSM_BUCKETS + atomicAdd(&hist[cls(cnt[b])], 1u)] = (uint32_t)b;
 }
 
-// one thread per (signature, bucket): the sum of the bucket's table rows, in registers.  The row of entry k + 1 is fetched
-// while entry k is added (an addition is ~5,000 vector instructions: the gather of 112 bytes hides behind it).
+// one thread per (signature, bucket): the sum of the bucket's table rows, in registers.  G1: the row of entry k + 1 is fetched
+// while entry k is added (an addition is ~5,000 vector instructions: the gather of 112 bytes hides behind it); G2 has no
+// registers to spare for that (an accumulator alone is 112).
+template <class F, bool PREFETCH>
 __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ order, const uint32_t *__restrict__ entries,
                                                            uint32_t *__restrict__ buckets)
 {
+    constexpr int PW = Grp<F>::PT_WORDS;
     const size_t sig = blockIdx.y;
     const uint32_t b = order[sig * MSM_BUCKETS + blockIdx.x * 64 + threadIdx.x];
     const uint32_t start = offsets[sig * MSM_BUCKETS + b], cnt = counts[sig * MSM_BUCKETS + b];
     const uint32_t *ent = entries + sig * (size_t)MSM_W * m.n + start;
-    G1Xyzz acc = g1_identity();
-    uint32_t e = cnt ? ent[0] : 0u;
-    G1Affine29 p = load_row(m.table + (size_t)(e & 0x7fffffffu) * MSM_PT_WORDS);
-    for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t e_next = k + 1 < cnt ? ent[k + 1] : e;
-        const G1Affine29 p_next = load_row(m.table + (size_t)(e_next & 0x7fffffffu) * MSM_PT_WORDS);
-        if (e >> 31) p.y = fq_neg<4>(p.y);
-        acc = g1_add_affine(acc, p);
-        e = e_next;
-        p = p_next;
+    XyzzT<F> acc = pt_identity<F>();
+    if (PREFETCH) {
+        uint32_t e = cnt ? ent[0] : 0u;
+        AffineT<F> p = load_row<F>(m.table + (size_t)(e & 0x7fffffffu) * PW);
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t e_next = k + 1 < cnt ? ent[k + 1] : e;
+            const AffineT<F> p_next = load_row<F>(m.table + (size_t)(e_next & 0x7fffffffu) * PW);
+            if (e >> 31) p.y = F::template neg<Grp<F>::K_AFFINE_Y>(p.y);
+            acc = pt_add_affine(acc, p);
+            e = e_next;
+            p = p_next;
+        }
+    } else {
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t e = ent[k];
+            AffineT<F> p = load_row<F>(m.table + (size_t)(e & 0x7fffffffu) * PW);
+            if (e >> 31) p.y = F::template neg<Grp<F>::K_AFFINE_Y>(p.y);
+            acc = pt_add_affine(acc, p);
+        }
     }
-    store_bucket(buckets + (sig * MSM_BUCKETS + b) * (size_t)MSM_BK_WORDS, acc);
+    store_bucket<F>(buckets + (sig * MSM_BUCKETS + b) * (size_t)Grp<F>::BK_WORDS, acc);
 }
 
 // the points whose scalar is one, summed by the 512 threads that will fold the buckets (thread t: every 512th of the list);
 // the partial sums enter the fold with weight one
+template <class F>
 __global__ __launch_bounds__(64, 2) void msm_ones_kernel(MsmDev m, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
-                                                         uint32_t *__restrict__ partial /* [sig][MSM_FOLD_THREADS][MSM_BK_WORDS] */)
+                                                         uint32_t *__restrict__ partial /* [sig][MSM_FOLD_THREADS][BK_WORDS] */)
 {
     const size_t sig = blockIdx.y;
     const uint32_t t = blockIdx.x * 64 + threadIdx.x, cnt = ones_count[sig];
     const uint32_t *list = ones_list + sig * m.n;
-    G1Xyzz acc = g1_identity();
+    XyzzT<F> acc = pt_identity<F>();
     for (uint32_t k = t; k < cnt; k += MSM_FOLD_THREADS)
-        acc = g1_add_affine(acc, load_row(m.table + (size_t)list[k] * MSM_PT_WORDS));      // window 0 of the table = the point itself
-    store_bucket(partial + (sig * MSM_FOLD_THREADS + t) * (size_t)MSM_BK_WORDS, acc);
+        acc = pt_add_affine(acc, load_row<F>(m.table + (size_t)list[k] * Grp<F>::PT_WORDS));      // window 0 of the table = the point itself
+    store_bucket<F>(partial + (sig * MSM_FOLD_THREADS + t) * (size_t)Grp<F>::BK_WORDS, acc);
 }
 
 // sum_b (b + 1) B_b per signature: 512 threads x 64 buckets, then a tree; thread 0 converts to affine and writes ark-ff's bytes
+template <class F>
 __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ partial,
-                                                                    uint32_t *__restrict__ out /* [batch][24] */)
+                                                                    uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
 {
-    __shared__ uint32_t lds[MSM_FOLD_THREADS / 2 * (4 * NLQ + 1)];       // 58 KB: the upper half of a tree level parks here
+    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
+    __shared__ uint32_t lds[MSM_FOLD_THREADS / 2 * SLOT];            // 58 KB (G1) / 116 KB (G2): the upper half of a tree level parks here
     const size_t sig = blockIdx.x;
     const int t = threadIdx.x;
-    const uint32_t *bk = buckets + (sig * MSM_BUCKETS + (size_t)t * MSM_CHUNK) * MSM_BK_WORDS;
-    G1Xyzz run = g1_identity(), sum = g1_identity();
+    const uint32_t *bk = buckets + (sig * MSM_BUCKETS + (size_t)t * MSM_CHUNK) * BW;
+    XyzzT<F> run = pt_identity<F>(), sum = pt_identity<F>();
     for (int k = MSM_CHUNK - 1; k >= 0; k--) {
-        run = g1_add(run, load_bucket(bk + (size_t)k * MSM_BK_WORDS));
-        sum = g1_add(sum, run);
+        run = pt_add(run, load_bucket<F>(bk + (size_t)k * BW));
+        sum = pt_add(sum, run);
     }
     // sum = sum_k (k + 1) B_(64 t + k); the buckets' weights are 64 t + k + 1: add (64 t) run = 2^6 (t run)
-    G1Xyzz mult = g1_identity();
+    XyzzT<F> mult = pt_identity<F>();
     for (int bit = 8; bit >= 0; bit--) {
-        mult = g1_double(mult);
-        if ((t >> bit) & 1) mult = g1_add(mult, run);
+        mult = pt_double(mult);
+        if ((t >> bit) & 1) mult = pt_add(mult, run);
     }
-    for (int k = 0; k < 6; k++) mult = g1_double(mult);
-    sum = g1_add(sum, mult);
-    sum = g1_add(sum, load_bucket(partial + (sig * MSM_FOLD_THREADS + t) * (size_t)MSM_BK_WORDS));      // the scalars that are one
-    auto put = [&](int slot, const G1Xyzz &p) {
-        uint32_t *s = lds + slot * (4 * NLQ + 1);
-#pragma unroll
-        for (int k = 0; k < NLQ; k++) { s[k] = p.x.l[k]; s[NLQ + k] = p.y.l[k]; s[2 * NLQ + k] = p.zz.l[k]; s[3 * NLQ + k] = p.zzz.l[k]; }
-        s[4 * NLQ] = p.inf ? 1u : 0u;
-    };
-    auto get = [&](int slot) {
-        const uint32_t *s = lds + slot * (4 * NLQ + 1);
-        G1Xyzz p;
-#pragma unroll
-        for (int k = 0; k < NLQ; k++) { p.x.l[k] = s[k]; p.y.l[k] = s[NLQ + k]; p.zz.l[k] = s[2 * NLQ + k]; p.zzz.l[k] = s[3 * NLQ + k]; }
-        p.inf = s[4 * NLQ] != 0;
-        return p;
-    };
+    for (int k = 0; k < 6; k++) mult = pt_double(mult);
+    sum = pt_add(sum, mult);
+    sum = pt_add(sum, load_bucket<F>(partial + (sig * MSM_FOLD_THREADS + t) * (size_t)BW));      // the scalars that are one
     for (int stride = MSM_FOLD_THREADS / 2; stride >= 1; stride >>= 1) {
-        if (t >= stride && t < 2 * stride) put(t - stride, sum);
+        if (t >= stride && t < 2 * stride) store_bucket<F>(lds + (t - stride) * SLOT, sum);
         __syncthreads();
-        if (t < stride) sum = g1_add(sum, get(t));
+        if (t < stride) sum = pt_add(sum, load_bucket<F>(lds + t * SLOT));
         __syncthreads();
     }
-    if (t == 0) {
-        const G1Affine29 a = g1_to_affine(sum);
-        uint32_t *o = out + sig * 24;
-        if (a.inf) {
-            for (int k = 0; k < 24; k++) o[k] = 0;
-        } else {
-            fq_to_ark(a.x, o);
-            fq_to_ark(a.y, o + 12);
-        }
-    }
+    if (t == 0) store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
 }
 
-// ---- k G1 for many scalars: the FixedBaseMSM of ark-groth16's generator (generator.rs builds h_query, a_query, l_query this
-// way from the toxic waste).  8-bit windows of the generator: table[w][d] = d 2^(8 w) G1, then 32 mixed additions per scalar.
+// ---- k G for many scalars: the FixedBaseMSM of ark-groth16's generator (generator.rs builds h_query, a_query, l_query and
+// b_g2_query this way from the toxic waste).  8-bit windows of the generator: table[w][d] = d 2^(8 w) G, then 32 mixed additions.
 constexpr int FB_WINDOWS = 32, FB_DIGITS = 256;
-__global__ __launch_bounds__(64) void fixed_base_table_kernel(uint32_t *__restrict__ table /* [32][256][MSM_PT_WORDS] */)
+template <class F> __device__ __forceinline__ AffineT<F> group_generator();
+template <> __device__ __forceinline__ AffineT<FqField> group_generator<FqField>()
+{
+    AffineT<FqField> g;
+    g.x = fq_const(G1_GEN_X29); g.y = fq_const(G1_GEN_Y29); g.inf = false;
+    return g;
+}
+template <> __device__ __forceinline__ AffineT<Fq2Field> group_generator<Fq2Field>()
+{
+    AffineT<Fq2Field> g;
+    g.x.c0 = fq_const(G2_GEN_X0_29); g.x.c1 = fq_const(G2_GEN_X1_29); g.y.c0 = fq_const(G2_GEN_Y0_29); g.y.c1 = fq_const(G2_GEN_Y1_29);
+    g.inf = false;
+    return g;
+}
+template <class F>
+__global__ __launch_bounds__(64) void fixed_base_table_kernel(uint32_t *__restrict__ table /* [32][256][PT_WORDS] */)
 {
     const int id = blockIdx.x * 64 + threadIdx.x, w = id >> 8, d = id & 255;
     if (w >= FB_WINDOWS) return;
-    G1Affine29 g;
-    g.x = fq_const(G1_GEN_X29);
-    g.y = fq_const(G1_GEN_Y29);
-    g.inf = false;
-    G1Xyzz acc = g1_identity();
+    const AffineT<F> g = group_generator<F>();
+    XyzzT<F> acc = pt_identity<F>();
     for (int bit = 7; bit >= 0; bit--) {                      // d G
-        acc = g1_double(acc);
-        if ((d >> bit) & 1) acc = g1_add_affine(acc, g);
+        acc = pt_double(acc);
+        if ((d >> bit) & 1) acc = pt_add_affine(acc, g);
     }
-    for (int k = 0; k < 8 * w; k++) acc = g1_double(acc);     // 2^(8 w) d G
-    store_row(table + (size_t)id * MSM_PT_WORDS, g1_to_affine(acc));
+    for (int k = 0; k < 8 * w; k++) acc = pt_double(acc);     // 2^(8 w) d G
+    store_row<F>(table + (size_t)id * Grp<F>::PT_WORDS, pt_to_affine(acc));
 }
+template <class F>
 __global__ __launch_bounds__(64) void fixed_base_kernel(size_t count, const uint32_t *__restrict__ scalars /* [count][8], canonical */,
-                                                        const uint32_t *__restrict__ table, uint32_t *__restrict__ out /* [count][24] */)
+                                                        const uint32_t *__restrict__ table, uint32_t *__restrict__ out /* [count][ARK_WORDS] */)
 {
     const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= count) return;
     const Fr8 k = fr_load(scalars + i * 8);
-    G1Xyzz acc = g1_identity();
+    XyzzT<F> acc = pt_identity<F>();
     for (int w = 0; w < FB_WINDOWS; w++) {
         const uint32_t d = (k.l[w >> 2] >> (8 * (w & 3))) & 255u;
-        if (d) acc = g1_add_affine(acc, load_row(table + ((size_t)w * FB_DIGITS + d) * MSM_PT_WORDS));
+        if (d) acc = pt_add_affine(acc, load_row<F>(table + ((size_t)w * FB_DIGITS + d) * Grp<F>::PT_WORDS));
     }
-    const G1Affine29 a = g1_to_affine(acc);
-    uint32_t *o = out + i * 24;
-    if (a.inf) {
-        for (int j = 0; j < 24; j++) o[j] = 0;
-    } else {
-        fq_to_ark(a.x, o);
-        fq_to_ark(a.y, o + 12);
-    }
+    store_ark_point<F>(out + i * Grp<F>::ARK_WORDS, pt_to_affine(acc));
 }
 
 }  // namespace frw
@@ -388,19 +408,126 @@ __global__ __launch_bounds__(64) void fixed_base_kernel(size_t count, const uint
 // ---- C ABI ------------------------------------------------------------------------------------------------------------------------
 struct frw_msm {
     int device;
+    int group;                  // 1: G1, 2: G2
     frw::MsmDev dev;
     void *table;
 };
 
 namespace {
-size_t msm_workspace_per_signature(uint32_t n)
+using frw::FqField;
+using frw::Fq2Field;
+template <class F> size_t msm_workspace_per_signature(uint32_t n)
 {
-    // counts, offsets, order (3 x 32,768 x 4 B), entries (16 n x 4 B), buckets (32,768 x 240 B; the sort's per-slice
+    // counts, offsets, order (3 x 32,768 x 4 B), entries (16 n x 4 B), buckets (32,768 buckets; the sort's per-slice
     // histograms, 32 x 32,768 x 4 B, live there before the buckets are written), the list of scalars that are one (n x 4 B +
     // a counter) and their 512 partial sums
-    static_assert((size_t)frw::MSM_SLICES * 4 <= (size_t)frw::MSM_BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
-    return 3 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::MSM_BK_WORDS * 4 +
-           ((size_t)n + 4) * 4 + (size_t)frw::MSM_FOLD_THREADS * frw::MSM_BK_WORDS * 4;
+    static_assert((size_t)frw::MSM_SLICES * 4 <= (size_t)frw::Grp<F>::BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
+    return 3 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::Grp<F>::BK_WORDS * 4 +
+           ((size_t)n + 4) * 4 + (size_t)frw::MSM_FOLD_THREADS * frw::Grp<F>::BK_WORDS * 4;
+}
+
+template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, frw_msm **out)
+{
+    if (!out || !bases || num_points == 0 || num_points > ((size_t)1 << 26)) return FRW_E_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return frw::record_hip_error(e, "hipSetDevice");
+    frw_msm *m = new (std::nothrow) frw_msm;
+    if (!m) return FRW_E_OUT_OF_MEMORY;
+    m->device = device;
+    m->group = group;
+    m->table = nullptr;
+    m->dev.n = (uint32_t)num_points;
+    void *d_bases = nullptr;
+    const size_t table_bytes = (size_t)frw::MSM_W * num_points * frw::Grp<F>::PT_WORDS * 4, ark_bytes = (size_t)frw::Grp<F>::ARK_WORDS * 4;
+    e = hipMalloc(&m->table, table_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_bases, num_points * ark_bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_bases, bases, num_points * ark_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(frw::msm_precompute_kernel<F>, dim3((unsigned)((num_points + 63) / 64)), dim3(64), 0, nullptr,
+                           (uint32_t)num_points, (const uint32_t *)d_bases, (uint32_t *)m->table);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (d_bases) (void)hipFree(d_bases);
+    if (e != hipSuccess) {
+        frw_msm_free(m);
+        return frw::record_hip_error(e, "frw_msm_load");
+    }
+    m->dev.table = (const uint32_t *)m->table;
+    *out = m;
+    return FRW_OK;
+}
+
+template <class F> int fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out)
+{
+    if (count && (!scalars || !out)) return FRW_E_INVALID_ARG;
+    if (count == 0) return FRW_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
+    hipError_t e = hipSetDevice(device);
+    void *d_table = nullptr, *d_sc = nullptr, *d_out = nullptr;
+    const size_t ark_bytes = (size_t)frw::Grp<F>::ARK_WORDS * 4;
+    if (e == hipSuccess) e = hipMalloc(&d_table, (size_t)frw::FB_WINDOWS * frw::FB_DIGITS * frw::Grp<F>::PT_WORDS * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_sc, count * 32);
+    if (e == hipSuccess) e = hipMalloc(&d_out, count * ark_bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_sc, scalars, count * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(frw::fixed_base_table_kernel<F>, dim3(frw::FB_WINDOWS * frw::FB_DIGITS / 64), dim3(64), 0, nullptr, (uint32_t *)d_table);
+        hipLaunchKernelGGL(frw::fixed_base_kernel<F>, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, nullptr, count,
+                           (const uint32_t *)d_sc, (const uint32_t *)d_table, (uint32_t *)d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, count * ark_bytes, hipMemcpyDeviceToHost);
+    for (void *p : {d_table, d_sc, d_out})
+        if (p) (void)hipFree(p);
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_fixed_base");
+}
+
+// the whole call for one group; `d_out` rows are ARK_WORDS / 2 uint64_t
+template <class F, bool PREFETCH>
+int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery, uint64_t *d_out,
+            void *d_workspace, size_t workspace_bytes, hipStream_t st)
+{
+    const uint32_t n = m->dev.n;
+    const size_t per = msm_workspace_per_signature<F>(n);
+    size_t chunk = workspace_bytes / per;
+    if (chunk == 0 || ((uintptr_t)d_workspace & 15)) return FRW_E_INVALID_ARG;
+    if (chunk > 32768) chunk = 32768;                                  // grid.y
+    constexpr int BW = frw::Grp<F>::BK_WORDS;
+    hipError_t e = hipSetDevice(m->device);
+    for (size_t lo = 0; e == hipSuccess && lo < batch; lo += chunk) {
+        const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
+        uint32_t *counts = (uint32_t *)d_workspace;
+        uint32_t *offsets = counts + cnt * frw::MSM_BUCKETS;
+        uint32_t *order = offsets + cnt * frw::MSM_BUCKETS;
+        uint32_t *entries = order + cnt * frw::MSM_BUCKETS;
+        uint32_t *buckets = entries + cnt * (size_t)frw::MSM_W * n;
+        uint32_t *slice_hist = buckets;                                  // [cnt][32][32,768], dead before the first bucket is stored
+        uint32_t *partial = buckets + cnt * (size_t)frw::MSM_BUCKETS * BW;
+        uint32_t *ones_list = partial + cnt * (size_t)frw::MSM_FOLD_THREADS * BW;
+        uint32_t *ones_count = ones_list + cnt * (size_t)n;             // [cnt], padded to four words per signature in the budget
+        const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
+        const size_t stride_words = scalar_stride * 8;
+        const dim3 sgrid(frw::MSM_SLICES, (unsigned)cnt);
+        e = hipMemsetAsync(ones_count, 0, cnt * 4, st);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
+        hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts);
+        hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
+        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, order);
+        hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
+        hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
+                           counts, order, entries, buckets);
+        hipLaunchKernelGGL(frw::msm_ones_kernel<F>, dim3(frw::MSM_FOLD_THREADS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count,
+                           ones_list, partial);
+        hipLaunchKernelGGL(frw::msm_fold_kernel<F>, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, buckets, partial,
+                           (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
+        e = hipGetLastError();
+    }
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
 }
 }  // namespace
 
@@ -414,115 +541,46 @@ extern "C" void frw_msm_free(frw_msm *m)
 
 extern "C" int frw_msm_g1_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
 {
-    if (!out || !bases || num_points == 0 || num_points > ((size_t)1 << 26)) return FRW_E_INVALID_ARG;
-    *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return frw::record_hip_error(e, "hipSetDevice");
-    frw_msm *m = new (std::nothrow) frw_msm;
-    if (!m) return FRW_E_OUT_OF_MEMORY;
-    m->device = device;
-    m->table = nullptr;
-    m->dev.n = (uint32_t)num_points;
-    void *d_bases = nullptr;
-    const size_t table_bytes = (size_t)frw::MSM_W * num_points * frw::MSM_PT_WORDS * 4;
-    e = hipMalloc(&m->table, table_bytes);
-    if (e == hipSuccess) e = hipMalloc(&d_bases, num_points * 96);
-    if (e == hipSuccess) e = hipMemcpy(d_bases, bases, num_points * 96, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(frw::msm_precompute_kernel, dim3((unsigned)((num_points + 63) / 64)), dim3(64), 0, nullptr,
-                           (uint32_t)num_points, (const uint32_t *)d_bases, (uint32_t *)m->table);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (d_bases) (void)hipFree(d_bases);
-    if (e != hipSuccess) {
-        frw_msm_free(m);
-        return frw::record_hip_error(e, "frw_msm_g1_load");
-    }
-    m->dev.table = (const uint32_t *)m->table;
-    *out = m;
-    return FRW_OK;
+    return msm_load<FqField>(device, 1, num_points, bases, out);
 }
-
+extern "C" int frw_msm_g2_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
+{
+    return msm_load<Fq2Field>(device, 2, num_points, bases, out);
+}
 extern "C" int frw_g1_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out)
 {
-    if (count && (!scalars || !out)) return FRW_E_INVALID_ARG;
-    if (count == 0) return FRW_OK;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
-    hipError_t e = hipSetDevice(device);
-    void *d_table = nullptr, *d_sc = nullptr, *d_out = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&d_table, (size_t)frw::FB_WINDOWS * frw::FB_DIGITS * frw::MSM_PT_WORDS * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_sc, count * 32);
-    if (e == hipSuccess) e = hipMalloc(&d_out, count * 96);
-    if (e == hipSuccess) e = hipMemcpy(d_sc, scalars, count * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(frw::fixed_base_table_kernel, dim3(frw::FB_WINDOWS * frw::FB_DIGITS / 64), dim3(64), 0, nullptr, (uint32_t *)d_table);
-        hipLaunchKernelGGL(frw::fixed_base_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, nullptr, count,
-                           (const uint32_t *)d_sc, (const uint32_t *)d_table, (uint32_t *)d_out);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpy(out, d_out, count * 96, hipMemcpyDeviceToHost);
-    for (void *p : {d_table, d_sc, d_out})
-        if (p) (void)hipFree(p);
-    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_g1_fixed_base");
+    return fixed_base<FqField>(device, count, scalars, out);
+}
+extern "C" int frw_g2_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out)
+{
+    return fixed_base<Fq2Field>(device, count, scalars, out);
 }
 
 extern "C" int frw_msm_info(const frw_msm *m, frw_msm_info_t *out)
 {
     if (!m || !out) return FRW_E_INVALID_ARG;
+    const bool g2 = m->group == 2;
     out->num_points = m->dev.n;
     out->window_bits = frw::MSM_C;
     out->num_windows = frw::MSM_W;
-    out->table_bytes = (uint64_t)frw::MSM_W * m->dev.n * frw::MSM_PT_WORDS * 4;
-    out->workspace_bytes_per_signature = msm_workspace_per_signature(m->dev.n);
+    out->table_bytes = (uint64_t)frw::MSM_W * m->dev.n * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
+    out->workspace_bytes_per_signature = g2 ? msm_workspace_per_signature<Fq2Field>(m->dev.n) : msm_workspace_per_signature<FqField>(m->dev.n);
     return FRW_OK;
 }
 
 extern "C" int frw_msm_g1_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery,
                               uint64_t *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
 {
-    if (!m || (batch && (!d_scalars || !d_out || !d_workspace)) || scalar_stride < m->dev.n) return FRW_E_INVALID_ARG;
+    if (!m || m->group != 1 || (batch && (!d_scalars || !d_out || !d_workspace)) || scalar_stride < m->dev.n) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
-    const uint32_t n = m->dev.n;
-    const size_t per = msm_workspace_per_signature(n);
-    size_t chunk = workspace_bytes / per;
-    if (chunk == 0 || ((uintptr_t)d_workspace & 15)) return FRW_E_INVALID_ARG;
-    if (chunk > 32768) chunk = 32768;                                  // grid.y
-    hipError_t e = hipSetDevice(m->device);
-    hipStream_t st = (hipStream_t)stream;
-    for (size_t lo = 0; e == hipSuccess && lo < batch; lo += chunk) {
-        const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
-        uint32_t *counts = (uint32_t *)d_workspace;
-        uint32_t *offsets = counts + cnt * frw::MSM_BUCKETS;
-        uint32_t *order = offsets + cnt * frw::MSM_BUCKETS;
-        uint32_t *entries = order + cnt * frw::MSM_BUCKETS;
-        uint32_t *buckets = entries + cnt * (size_t)frw::MSM_W * n;
-        uint32_t *slice_hist = buckets;                                  // [cnt][32][32,768], dead before the first bucket is stored
-        uint32_t *partial = buckets + cnt * (size_t)frw::MSM_BUCKETS * frw::MSM_BK_WORDS;
-        uint32_t *ones_list = partial + cnt * (size_t)frw::MSM_FOLD_THREADS * frw::MSM_BK_WORDS;
-        uint32_t *ones_count = ones_list + cnt * (size_t)n;             // [cnt], padded to four words per signature in the budget
-        const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
-        const size_t stride_words = scalar_stride * 8;
-        const dim3 sgrid(frw::MSM_SLICES, (unsigned)cnt);
-        e = hipMemsetAsync(ones_count, 0, cnt * 4, st);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
-        hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts);
-        hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
-        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, order);
-        hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
-        hipLaunchKernelGGL(frw::msm_bucket_kernel, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
-                           order, entries, buckets);
-        hipLaunchKernelGGL(frw::msm_ones_kernel, dim3(frw::MSM_FOLD_THREADS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list,
-                           partial);
-        hipLaunchKernelGGL(frw::msm_fold_kernel, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, buckets, partial,
-                           (uint32_t *)(d_out + lo * 12));
-        e = hipGetLastError();
-    }
-    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_g1_dev");
+    return msm_run<FqField, true>(m, batch, d_scalars, scalar_stride, montgomery, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery,
+                              uint64_t *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (!m || m->group != 2 || (batch && (!d_scalars || !d_out || !d_workspace)) || scalar_stride < m->dev.n) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    return msm_run<Fq2Field, false>(m, batch, d_scalars, scalar_stride, montgomery, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int frw_groth16_msm_h_dev(const frw_msm *m, size_t batch, const uint64_t *d_h, size_t domain_size, uint64_t *d_out,

@@ -365,6 +365,24 @@ class WitnessEngine:
                                           out.ctypes.data_as(C.c_void_p)), "frw_g1_fixed_base")
         return out
 
+    def g2_fixed_base(self, scalars):
+        """k_i G2 on the device: canonical scalars uint64[count, 4] -> uint64[count, 24] (ark-ff's bytes)."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((scalars.shape[0], 24), dtype=np.uint64)
+        check(self._lib.frw_g2_fixed_base(self.device, scalars.shape[0], scalars.ctypes.data_as(C.c_void_p),
+                                          out.ctypes.data_as(C.c_void_p)), "frw_g2_fixed_base")
+        return out
+
+    def msm_g2_load(self, bases):
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 24)
+        h = C.c_void_p()
+        check(self._lib.frw_msm_g2_load(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_msm_g2_load")
+        return h
+
+    def msm_g2_dev(self, handle, batch, d_scalars, scalar_stride, montgomery, d_out, d_workspace, workspace_bytes, stream=0):
+        check(self._lib.frw_msm_g2_dev(handle, batch, self._ptr(d_scalars), scalar_stride, 1 if montgomery else 0, self._ptr(d_out),
+                                       self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)), "frw_msm_g2_dev")
+
     def msm_free(self, handle):
         self._lib.frw_msm_free(handle)
 

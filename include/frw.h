@@ -322,6 +322,8 @@ int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
  * buffers: the FixedBaseMSM over the generator ark-groth16's generator.rs builds the proving key's queries with (h_query[i] =
  * (zt / delta) t^i G1, ...) -- here so that a key can be made on the device; 8-bit windows, 32 mixed additions per scalar. */
 int frw_g1_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out);
+/* The same in G2 (b_g2_query[i] = v_i(t) G2): uint64_t[count][24] out -- x.c0, x.c1, y.c0, y.c1 of the Fq2 coordinates. */
+int frw_g2_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out);
 typedef struct frw_msm frw_msm;
 typedef struct {
     uint64_t num_points;
@@ -336,6 +338,13 @@ int frw_msm_g1_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, si
                    uint64_t *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
 int frw_groth16_msm_h_dev(const frw_msm *m, size_t batch, const uint64_t *d_h, size_t domain_size, uint64_t *d_out,
                           void *d_workspace, size_t workspace_bytes, void *stream);
+/* G2 (the prover's g2_b = MSM(b_g2_query, assignment) + ...): bases uint64_t[num_points][24], results uint64_t[batch][24]
+ * (x.c0, x.c1, y.c0, y.c1; ark-ff's G2Affine limbs), everything else as for G1.  A handle serves the group it was loaded for;
+ * the other group's _dev call returns FRW_E_INVALID_ARG.  Same algorithm over Fq2 (a G2 addition is three times a G1 one and
+ * the kernel spills registers: fine for the 10^5 additions a witness-side sum needs, not tuned for more). */
+int frw_msm_g2_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out);
+int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery,
+                   uint64_t *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),

@@ -207,3 +207,45 @@ def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine,
         assert got[batch + 1].tolist() == bases[12345].tolist()
     finally:
         engine.msm_free(handle)
+
+
+def test_g2_fixed_base_and_msm_equal_python_integers(engine):
+    """G2 (prover.rs: g2_b = MSM(b_g2_query, assignment) + ...): the generator's fixed-base multiples and a multi-scalar
+    multiplication against oracle/bls12_381.py's Fq2 arithmetic in Python integers -- bases as multiples k_i G2 of the
+    published generator, so that the expected sum is (sum s_i k_i) G2, one scalar multiplication; with the same degenerate
+    inputs as in G1 (a base twice, a base and its negative, infinity, zeros, ones, r - 1)."""
+    rng = random.Random(4242)
+    n = 200
+    ks = [rng.randrange(1, E.R) for _ in range(n)]
+    ks[10] = ks[3]
+    ks[11] = E.R - ks[4]
+    ks[12] = 0                                                     # the point at infinity as a base
+    bases = engine.g2_fixed_base(T.ints_to_limbs(ks))
+    for i in (0, 3, 11, 12, 57):
+        assert bases[i].tolist() == E.g2_to_limbs(E.g2_mul(E.G2, ks[i])), i
+    assert engine.g2_fixed_base(T.ints_to_limbs([1]))[0].tolist() == E.g2_to_limbs(E.G2)
+    vectors = [[rng.randrange(E.R) for _ in range(n)], [0] * n, [1] * n, [E.R - 1] * n,
+               [rng.choice([0, 1, 1, rng.randrange(1 << 14), rng.randrange(1 << 146)]) for _ in range(n)]]
+    vectors[0][3] = vectors[0][10]
+    vectors[0][11] = vectors[0][4]
+    handle = engine.msm_g2_load(bases)
+    try:
+        import torch
+        dev = torch.device("cuda:0")
+        info = engine.msm_info(handle)
+        assert info.num_points == n
+        sc = np.stack([T.ints_to_limbs(v) for v in vectors])
+        d_sc = torch.from_numpy(sc.view(np.int64)).to(dev)
+        out = torch.full((len(vectors), 24), -1, dtype=torch.int64, device=dev)
+        ws = torch.empty(2 * int(info.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+        engine.msm_g2_dev(handle, len(vectors), d_sc, n, 0, out, ws, ws.numel(), 0)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint64)
+        for i, v in enumerate(vectors):
+            want = E.g2_mul(E.G2, sum(s * k for s, k in zip(v, ks)) % E.R)
+            assert got[i].tolist() == E.g2_to_limbs(want), i
+        import falcon_r1cs_amd as frw
+        with pytest.raises(frw.FrwError):                          # a G2 table through the G1 entry point
+            engine.msm_g1_dev(handle, 1, d_sc, n, 0, out, ws, ws.numel(), 0)
+    finally:
+        engine.msm_free(handle)
