@@ -46,6 +46,13 @@ class MsmInfoStruct(C.Structure):
                 ("workspace_bytes_per_signature", C.c_uint64)]
 
 
+class Groth16PkDesc(C.Structure):
+    _fields_ = [("num_instance", C.c_uint64), ("num_witness", C.c_uint64), ("domain_size", C.c_uint64),
+                ("alpha_g1", C.c_void_p), ("beta_g1", C.c_void_p), ("delta_g1", C.c_void_p), ("beta_g2", C.c_void_p),
+                ("delta_g2", C.c_void_p), ("a_query", C.c_void_p), ("b_g1_query", C.c_void_p), ("b_g2_query", C.c_void_p),
+                ("h_query", C.c_void_p), ("l_query", C.c_void_p)]
+
+
 class QapInfoStruct(C.Structure):
     _fields_ = [("log_domain_size", C.c_int32), ("domain_size", C.c_uint64), ("num_constraints", C.c_uint64),
                 ("num_instance", C.c_uint64), ("workspace_bytes_per_signature", C.c_uint64)]
@@ -83,6 +90,11 @@ PROTOTYPES = {
                                  C.c_void_p]),
     "frw_groth16_msm_h_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
+    "frw_groth16_pk_load": (C.c_int, [C.c_int, C.POINTER(Groth16PkDesc), C.POINTER(C.c_void_p)]),
+    "frw_groth16_pk_free": (None, [C.c_void_p]),
+    "frw_groth16_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "frw_groth16_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     "frw_compact_layout": (C.c_int, [C.c_int, C.POINTER(CompactLayoutStruct)]),
     "frw_witness_ntt_verify_compact_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -20,7 +20,10 @@
 // signature reads 16 n x 112 B = 0.47 GB of table rows).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
+#include <cstring>
 #include <new>
+#include <vector>
 #include "../../include/frw.h"
 #include "frw_device.h"
 #include "frw_fq29.h"
@@ -589,4 +592,201 @@ extern "C" int frw_groth16_msm_h_dev(const frw_msm *m, size_t batch, const uint6
     // prover.rs: the scalars are h's coefficients 0 .. n - 2 (h_query has n - 1 points; the zip drops the last coefficient)
     if (!m || (size_t)m->dev.n + 1 != domain_size) return FRW_E_INVALID_ARG;
     return frw_msm_g1_dev(m, batch, d_h, domain_size, 1, d_out, d_workspace, workspace_bytes, stream);
+}
+
+// ---- a whole Groth16 proof per signature, on the device ------------------------------------------------------------------------------
+// ark-groth16 0.3.0 prover.rs, create_proof_with_reduction_and_matrices (what examples/pok_sig.rs:30-47 of the reference runs),
+// for every signature of a resident batch of witnesses:
+//     h    = witness_map(...)                                                   frw_qap_witness_map_dev
+//     g_a  = r delta_g1 + a_query[0] + MSM(a_query[1..], assignment) + alpha_g1      one sum over  a_query ++ [alpha, delta1]   with z ++ [1, r]
+//     g1_b = s delta_g1 + b_g1_query[0] + MSM(b_g1_query[1..], ...) + beta_g1        the sum over  b_g1_query ++ [beta1]        with z ++ [1]   (g1_b - s delta1)
+//     g2_b = s delta_g2 + b_g2_query[0] + MSM(b_g2_query[1..], ...) + beta_g2        one sum over  b_g2_query ++ [beta2, O, delta2]  with z ++ [1, r, s]
+//     g_c  = s g_a + r g1_b - r s delta_g1 + MSM(l_query, aux) + MSM(h_query, h)  =  L + H + s g_a + r (g1_b - s delta1)
+// z = instance_assignment ++ witness_assignment (z[0] = 1 is the scalar of query[0]); the blinding terms ride in the sums as
+// extra points, the two scalar multiplications of g_c are done by one thread per signature at the end.
+namespace frw {
+// 2^517 mod p in nine 29-bit limbs: f29_mul(x, 2^517) = x 2^256, the Montgomery form of a canonical scalar
+__device__ const uint32_t FR_TO_MONT[NL29] = {0x1e538d9eu, 0x19e99103u, 0x13b31eccu, 0x04e2d5e4u, 0x181dac62u, 0x115f1ba1u,
+                                              0x1e414fbbu, 0x11b3009cu, 0x00013fecu};
+// the tail of every signature's scalar vector: [1, r, s] in Montgomery form after the nv assignment values
+__global__ __launch_bounds__(64) void groth16_tails_kernel(size_t batch, const uint32_t *__restrict__ rs /* [batch][2][8] canonical */,
+                                                           uint32_t *__restrict__ zext, size_t stride_words, size_t nv)
+{
+    const size_t sig = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (sig >= batch) return;
+    uint32_t *dst = zext + sig * stride_words + nv * 8;
+    constexpr uint32_t one[8] = FRW_R32;
+    Fr8 o;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o.l[k] = one[k];
+    fr_store(dst, o);
+    F29 c;
+#pragma unroll
+    for (int k = 0; k < NL29; k++) c.l[k] = FR_TO_MONT[k];
+    for (int j = 0; j < 2; j++)
+        fr_store(dst + 8 * (j + 1), f29_pack(f29_canonical(f29_mul(f29_unpack(fr_load(rs + (sig * 2 + j) * 8)), c))));
+}
+// C = L + H + s A + r B1', then the proof row A (12 u64) | B (24) | C (12)
+__global__ __launch_bounds__(64) void groth16_finish_kernel(size_t batch, const uint32_t *__restrict__ rs, const uint32_t *__restrict__ a_pts,
+                                                            const uint32_t *__restrict__ b1_pts, const uint32_t *__restrict__ l_pts,
+                                                            const uint32_t *__restrict__ h_pts, const uint32_t *__restrict__ b2_pts,
+                                                            uint32_t *__restrict__ proofs /* [batch][96] */)
+{
+    const size_t sig = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (sig >= batch) return;
+    const AffineT<FqField> a = load_ark_point<FqField>(a_pts + sig * 24), b1 = load_ark_point<FqField>(b1_pts + sig * 24);
+    XyzzT<FqField> acc = pt_from_affine(load_ark_point<FqField>(l_pts + sig * 24));
+    acc = pt_add_affine(acc, load_ark_point<FqField>(h_pts + sig * 24));
+    for (int j = 0; j < 2; j++) {                                   // s A, then r B1'
+        const Fr8 k = fr_load(rs + (sig * 2 + (1 - j)) * 8);
+        const AffineT<FqField> &base = j == 0 ? a : b1;
+        XyzzT<FqField> m = pt_identity<FqField>();
+        for (int bit = 254; bit >= 0; bit--) {
+            m = pt_double(m);
+            if ((k.l[bit >> 5] >> (bit & 31)) & 1u) m = pt_add_affine(m, base);
+        }
+        acc = pt_add(acc, m);
+    }
+    uint32_t *o = proofs + sig * 96;
+    for (int k = 0; k < 24; k++) o[k] = a_pts[sig * 24 + k];
+    for (int k = 0; k < 48; k++) o[24 + k] = b2_pts[sig * 48 + k];
+    store_ark_point<FqField>(o + 72, pt_to_affine(acc));
+}
+}  // namespace frw
+
+struct frw_groth16_pk {
+    int device;
+    uint64_t num_instance, num_witness, domain_size;
+    frw_msm *h, *a, *b1, *l, *b2;
+};
+
+extern "C" void frw_groth16_pk_free(frw_groth16_pk *pk)
+{
+    if (!pk) return;
+    for (frw_msm *m : {pk->h, pk->a, pk->b1, pk->l, pk->b2}) frw_msm_free(m);
+    delete pk;
+}
+
+extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, frw_groth16_pk **out)
+{
+    if (!out || !d || !d->alpha_g1 || !d->beta_g1 || !d->delta_g1 || !d->beta_g2 || !d->delta_g2 || !d->a_query || !d->b_g1_query ||
+        !d->b_g2_query || !d->h_query || !d->l_query || d->num_instance == 0 || d->domain_size < 2)
+        return FRW_E_INVALID_ARG;
+    *out = nullptr;
+    frw_groth16_pk *pk = new (std::nothrow) frw_groth16_pk;
+    if (!pk) return FRW_E_OUT_OF_MEMORY;
+    pk->device = device;
+    pk->num_instance = d->num_instance; pk->num_witness = d->num_witness; pk->domain_size = d->domain_size;
+    pk->h = pk->a = pk->b1 = pk->l = pk->b2 = nullptr;
+    const size_t nv = (size_t)(d->num_instance + d->num_witness);
+    int rc = FRW_OK;
+    try {
+        std::vector<uint64_t> g1(12 * (nv + 2)), g2(24 * (nv + 3), 0);
+        std::memcpy(g1.data(), d->a_query, nv * 96);
+        std::memcpy(g1.data() + 12 * nv, d->alpha_g1, 96);
+        std::memcpy(g1.data() + 12 * (nv + 1), d->delta_g1, 96);
+        rc = frw_msm_g1_load(device, nv + 2, g1.data(), &pk->a);
+        if (rc == FRW_OK) {
+            std::memcpy(g1.data(), d->b_g1_query, nv * 96);
+            std::memcpy(g1.data() + 12 * nv, d->beta_g1, 96);
+            rc = frw_msm_g1_load(device, nv + 1, g1.data(), &pk->b1);
+        }
+        if (rc == FRW_OK) rc = frw_msm_g1_load(device, (size_t)d->num_witness, d->l_query, &pk->l);
+        if (rc == FRW_OK) rc = frw_msm_g1_load(device, (size_t)d->domain_size - 1, d->h_query, &pk->h);
+        if (rc == FRW_OK) {
+            std::memcpy(g2.data(), d->b_g2_query, nv * 192);
+            std::memcpy(g2.data() + 24 * nv, d->beta_g2, 192);                 // row nv + 1 stays the point at infinity (the scalar there is r)
+            std::memcpy(g2.data() + 24 * (nv + 2), d->delta_g2, 192);
+            rc = frw_msm_g2_load(device, nv + 3, g2.data(), &pk->b2);
+        }
+    } catch (const std::exception &) {
+        rc = FRW_E_OUT_OF_MEMORY;
+    }
+    if (rc != FRW_OK) {
+        frw_groth16_pk_free(pk);
+        return rc;
+    }
+    *out = pk;
+    return FRW_OK;
+}
+
+namespace {
+struct Groth16Sizes { size_t qap, h, zext, msm, pts, per; };
+Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
+{
+    Groth16Sizes s{};
+    frw_qap_info_t q;
+    frw_msm_info_t mi;
+    if (frw_qap_info(r, &q) != FRW_OK) return s;
+    const size_t nv = (size_t)(pk->num_instance + pk->num_witness);
+    s.qap = q.workspace_bytes_per_signature;
+    s.h = (size_t)pk->domain_size * 32;
+    s.zext = (nv + 3) * 32;
+    for (const frw_msm *m : {pk->h, pk->a, pk->b1, pk->l, pk->b2}) {
+        frw_msm_info(m, &mi);
+        s.msm = std::max<size_t>(s.msm, mi.workspace_bytes_per_signature);
+    }
+    s.msm = (s.msm + 255) & ~(size_t)255;
+    s.pts = 4 * 96 + 192 + 64;                                        // A, B1', L, H (G1), B (G2), r and s
+    s.per = ((s.qap + s.h + s.zext + s.msm + s.pts) + 255) & ~(size_t)255;
+    return s;
+}
+}  // namespace
+
+extern "C" size_t frw_groth16_workspace_bytes(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch_in_flight)
+{
+    if (!pk || !r) return 0;
+    return groth16_sizes(pk, r).per * batch_in_flight;
+}
+
+extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, const uint64_t *d_witness,
+                                     const uint64_t *d_instance, const uint64_t *rs, uint64_t *d_proofs, uint32_t *d_num_unsatisfied,
+                                     void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (!pk || !r1cs || (batch && (!d_witness || !d_instance || !rs || !d_proofs || !d_workspace))) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    frw_qap_info_t q;
+    if (frw_qap_info(r1cs, &q) != FRW_OK || q.domain_size != pk->domain_size || q.num_instance != pk->num_instance) return FRW_E_INVALID_ARG;
+    const Groth16Sizes sz = groth16_sizes(pk, r1cs);
+    const size_t chunk = std::min<size_t>(workspace_bytes / sz.per, 4096);
+    if (chunk == 0 || ((uintptr_t)d_workspace & 255)) return FRW_E_INVALID_ARG;
+    const size_t I = (size_t)pk->num_instance, W = (size_t)pk->num_witness, nv = I + W, n = (size_t)pk->domain_size, stride = nv + 3;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(pk->device);
+    int rc = FRW_OK;
+    for (size_t lo = 0; e == hipSuccess && rc == FRW_OK && lo < batch; lo += chunk) {
+        const size_t cnt = std::min(chunk, batch - lo);
+        char *base = (char *)d_workspace;
+        void *qap_ws = base;                          base += cnt * sz.qap;
+        uint64_t *h = (uint64_t *)base;               base += cnt * sz.h;
+        uint64_t *zext = (uint64_t *)base;            base += cnt * sz.zext;
+        void *msm_ws = base;                          base += cnt * sz.msm;
+        uint64_t *pA = (uint64_t *)base, *pB1 = pA + cnt * 12, *pL = pB1 + cnt * 12, *pH = pL + cnt * 12, *pB2 = pH + cnt * 12;
+        uint64_t *d_rs = pB2 + cnt * 24;
+        const uint64_t *wit = d_witness + lo * W * 4, *inst = d_instance + lo * I * 4;
+        // the blinding factors: a host array (the prover draws them), uploaded before anything reads them
+        e = hipMemcpyAsync(d_rs, rs + lo * 8, cnt * 64, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);                                  // `rs` may be pageable and short-lived
+        if (e != hipSuccess) break;
+        rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, st);
+        if (rc != FRW_OK) break;
+        // z ++ [1, r, s] per signature
+        e = hipMemcpy2DAsync(zext, stride * 32, inst, I * 32, I * 32, cnt, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpy2DAsync(zext + I * 4, stride * 32, wit, W * 32, W * 32, cnt, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
+                           (uint32_t *)zext, stride * 8, nv);
+        rc = frw_msm_g1_dev(pk->h, cnt, h, n, 1, pH, msm_ws, cnt * sz.msm, st);
+        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->a, cnt, zext, stride, 1, pA, msm_ws, cnt * sz.msm, st);
+        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->b1, cnt, zext, stride, 1, pB1, msm_ws, cnt * sz.msm, st);
+        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->l, cnt, zext + I * 4, stride, 1, pL, msm_ws, cnt * sz.msm, st);
+        if (rc == FRW_OK) rc = frw_msm_g2_dev(pk->b2, cnt, zext, stride, 1, pB2, msm_ws, cnt * sz.msm, st);
+        if (rc != FRW_OK) break;
+        hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
+                           (const uint32_t *)pA, (const uint32_t *)pB1, (const uint32_t *)pL, (const uint32_t *)pH, (const uint32_t *)pB2,
+                           (uint32_t *)(d_proofs + lo * 48));
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) return frw::record_hip_error(e, "frw_groth16_prove_dev");
+    return rc;
 }

@@ -400,6 +400,35 @@ class WitnessEngine:
         check(self._lib.frw_groth16_msm_h_dev(handle, batch, self._ptr(d_h), domain_size, self._ptr(d_out), self._ptr(d_workspace),
                                               workspace_bytes, C.c_void_p(stream)), "frw_groth16_msm_h_dev")
 
+    # ---- a whole Groth16 proof per signature ---------------------------------------------------------------------------
+    def groth16_pk_load(self, num_instance, num_witness, domain_size, alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query,
+                        b_g1_query, b_g2_query, h_query, l_query):
+        """The proving key's elements as uint64 arrays in ark-ff's bytes (G1 rows of 12, G2 rows of 24) -> handle."""
+        from ._lib import Groth16PkDesc
+        arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query, b_g1_query,
+                                                                   b_g2_query, h_query, l_query)]
+        nv = num_instance + num_witness
+        want = [12, 12, 12, 24, 24, nv * 12, nv * 12, nv * 24, (domain_size - 1) * 12, num_witness * 12]
+        if [a.size for a in arrs] != want:
+            raise ValueError("proving key: wrong array sizes")
+        d = Groth16PkDesc(num_instance, num_witness, domain_size, *[a.ctypes.data_as(C.c_void_p) for a in arrs])
+        h = C.c_void_p()
+        check(self._lib.frw_groth16_pk_load(self.device, C.byref(d), C.byref(h)), "frw_groth16_pk_load")
+        return h
+
+    def groth16_pk_free(self, handle):
+        self._lib.frw_groth16_pk_free(handle)
+
+    def groth16_workspace_bytes(self, pk, r1cs, in_flight):
+        return int(self._lib.frw_groth16_workspace_bytes(pk, r1cs, in_flight))
+
+    def groth16_prove_dev(self, pk, r1cs, batch, d_wit, d_inst, rs, d_proofs, d_workspace, workspace_bytes, d_num_unsatisfied=None, stream=0):
+        """rs: host uint64[batch, 2, 4] (r, s per proof, canonical); d_proofs: int64[batch, 48] = A | B | C in ark-ff's bytes."""
+        rs = np.ascontiguousarray(rs, dtype=np.uint64).reshape(batch, 2, 4)
+        check(self._lib.frw_groth16_prove_dev(pk, r1cs, batch, self._ptr(d_wit), self._ptr(d_inst), rs.ctypes.data_as(C.c_void_p),
+                                              self._ptr(d_proofs), self._ptr(d_num_unsatisfied) if d_num_unsatisfied is not None else None,
+                                              self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)), "frw_groth16_prove_dev")
+
     def qap_info(self, handle):
         """Domain of the QAP witness map for the loaded matrices: (log n, n, C, I, workspace bytes per signature)."""
         from ._lib import QapInfoStruct

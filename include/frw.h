@@ -346,6 +346,35 @@ int frw_msm_g2_load(int device, size_t num_points, const uint64_t *bases, frw_ms
 int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery,
                    uint64_t *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- a whole Groth16 proof per signature (the rest of examples/pok_sig.rs:30-47) ---------------------------------------------------
+ * ark-groth16 0.3.0 prover.rs, create_proof_with_reduction_and_matrices, for every signature of a resident batch of witnesses:
+ * the witness map, the five multi-scalar multiplications (h_query; a_query, b_g1_query, l_query, b_g2_query with the
+ * assignment), the blinding terms and the assembly of (A, B, C).  frw_groth16_pk_load takes the proving key's elements in
+ * ark-ff's bytes (host memory; G1 points 12 x uint64_t, G2 points 24) and builds the five device tables once.
+ *     rs        host, uint64_t[batch][2][4]: the blinding factors r, s of every proof, canonical integers < the group order
+ *               (create_random_proof draws them; create_proof_no_zk passes zeros)
+ *     d_proofs  uint64_t[batch][48]: A (G1Affine limbs, 12), B (G2Affine limbs, 24), C (12)
+ *     d_num_unsatisfied  optional uint32_t[batch]: constraint rows the witness violates (the proof is then worthless)
+ *     d_workspace  frw_groth16_workspace_bytes(pk, r, in_flight) bytes, 256-byte aligned; the batch runs in chunks that fit
+ * d_witness / d_instance: what the witness entry points wrote (FRW_ENC_MONTGOMERY).  Enqueued on `stream` except for the upload of
+ * `rs`, which is waited for before the call goes on (the array may be short-lived). */
+typedef struct frw_groth16_pk frw_groth16_pk;
+typedef struct {
+    uint64_t num_instance, num_witness, domain_size;      /* I (with the constant one), W, n */
+    const uint64_t *alpha_g1, *beta_g1, *delta_g1;         /* vk.alpha_g1, pk.beta_g1, pk.delta_g1 */
+    const uint64_t *beta_g2, *delta_g2;                    /* vk.beta_g2, vk.delta_g2 */
+    const uint64_t *a_query, *b_g1_query;                  /* [I + W][12] */
+    const uint64_t *b_g2_query;                            /* [I + W][24] */
+    const uint64_t *h_query;                               /* [n - 1][12] */
+    const uint64_t *l_query;                               /* [W][12] */
+} frw_groth16_pk_desc_t;
+int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *desc, frw_groth16_pk **out);
+void frw_groth16_pk_free(frw_groth16_pk *pk);
+size_t frw_groth16_workspace_bytes(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch_in_flight);
+int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch, const uint64_t *d_witness,
+                          const uint64_t *d_instance, const uint64_t *rs, uint64_t *d_proofs, uint32_t *d_num_unsatisfied,
+                          void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),
  * hm = Polynomial::from_hash_of_message(msg, sig.nonce()).  Formats are the Falcon specification's:

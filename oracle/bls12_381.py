@@ -98,13 +98,25 @@ def from_limbs(limbs):
 
 # ---- Groth16 in the exponent ------------------------------------------------------------------------------------------------
 def _lagrange_at(domain_size, gen, t):
-    """EvaluationDomain::evaluate_all_lagrange_coefficients(t) for t outside the domain: L_i(t) = zt w^i / (n (t - w^i))."""
+    """EvaluationDomain::evaluate_all_lagrange_coefficients(t) for t outside the domain: L_i(t) = zt w^i / (n (t - w^i)); the
+    n inversions by Montgomery's trick (one modular inverse)."""
     zt = (pow(t, domain_size, R) - 1) % R
     ninv = pow(domain_size, -1, R)
-    out, w = [], 1
+    ws, dens, w = [], [], 1
     for _ in range(domain_size):
-        out.append(zt * w % R * ninv % R * pow((t - w) % R, -1, R) % R)
+        ws.append(w)
+        dens.append((t - w) % R)
         w = w * gen % R
+    pre, acc = [], 1
+    for d in dens:
+        pre.append(acc)
+        acc = acc * d % R
+    inv = pow(acc, -1, R)
+    out = [0] * domain_size
+    c = zt * ninv % R
+    for i in range(domain_size - 1, -1, -1):
+        out[i] = c * ws[i] % R * (inv * pre[i] % R) % R
+        inv = inv * dens[i] % R
     return out, zt
 
 

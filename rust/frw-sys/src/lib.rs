@@ -98,6 +98,27 @@ pub struct frw_r1cs {
 pub struct frw_msm {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct frw_groth16_pk {
+    _private: [u8; 0],
+}
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct frw_groth16_pk_desc_t {
+    pub num_instance: u64,
+    pub num_witness: u64,
+    pub domain_size: u64,
+    pub alpha_g1: *const u64,
+    pub beta_g1: *const u64,
+    pub delta_g1: *const u64,
+    pub beta_g2: *const u64,
+    pub delta_g2: *const u64,
+    pub a_query: *const u64,
+    pub b_g1_query: *const u64,
+    pub b_g2_query: *const u64,
+    pub h_query: *const u64,
+    pub l_query: *const u64,
+}
 
 extern "C" {
     pub fn frw_layout(logn: c_int, out: *mut frw_layout_t) -> c_int;
@@ -166,6 +187,12 @@ extern "C" {
     pub fn frw_msm_g1_dev(m: *const frw_msm, batch: usize, d_scalars: *const u64, scalar_stride: usize, montgomery: c_int,
                           d_out: *mut u64, d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_groth16_msm_h_dev(m: *const frw_msm, batch: usize, d_h: *const u64, domain_size: usize, d_out: *mut u64,
+                                 d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn frw_groth16_pk_load(device: c_int, desc: *const frw_groth16_pk_desc_t, out: *mut *mut frw_groth16_pk) -> c_int;
+    pub fn frw_groth16_pk_free(pk: *mut frw_groth16_pk);
+    pub fn frw_groth16_workspace_bytes(pk: *const frw_groth16_pk, r: *const frw_r1cs, batch_in_flight: usize) -> usize;
+    pub fn frw_groth16_prove_dev(pk: *const frw_groth16_pk, r: *const frw_r1cs, batch: usize, d_witness: *const u64,
+                                 d_instance: *const u64, rs: *const u64, d_proofs: *mut u64, d_num_unsatisfied: *mut u32,
                                  d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_hash_to_point_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_nonces: *const u8, d_msgs: *const u8,
                                  d_msg_off: *const u64, d_hm: *mut u16, stream: *mut c_void) -> c_int;

@@ -1,0 +1,98 @@
+"""A whole Groth16 proof on the device (frw_groth16_prove_dev) for Falcon-512 and Falcon-1024 signatures, against the prover restated in the
+exponent (oracle/bls12_381.py: ark-groth16 0.3.0 generator.rs / prover.rs / verifier.rs with the toxic waste known).
+
+The proving key is made from known toxic waste: every query element is (a known Fr value) x generator, built with the engine's
+fixed-base routines (checked against the oracle in tests/test_gpu_msm.py).  Expected proof = (a G1, b G2, c G1) with (a, b, c)
+the discrete logarithms prove_exponents() gives for the same witness, h, r and s -- A and C by ONE scalar multiplication of the
+C oracle each, B by Python integers over Fq2 -- and those exponents satisfy the verification equation
+a b = alpha beta + (sum x_i gamma_abc_i) gamma + c delta, i.e. the proof the GPU wrote is one verify_proof accepts."""
+import random
+
+import numpy as np
+import pytest
+
+import frw_testlib as T
+from oracle import bls12_381 as E
+from oracle import qap
+
+pytestmark = pytest.mark.gpu
+FR_R = (1 << 256) % E.R
+
+
+def _rows(ptr, col, val):
+    """CSR with canonical limbs -> the oracle's list of rows [(coeff, column)]."""
+    vals = T.limbs_to_ints(val)
+    ptr = [int(x) for x in ptr]
+    col = col.tolist()
+    return [[(vals[k], col[k]) for k in range(ptr[r], ptr[r + 1])] for r in range(len(ptr) - 1)]
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_proofs_equal_the_prover_restated_in_the_exponent(engine, oracle, tmp_path, logn):
+    import torch
+    import falcon_r1cs_amd as frw
+    from test_r1cs_export import export, read_r1cs
+    dev = torch.device("cuda:0")
+    batch = 3
+    L = frw.layout(logn)
+    export(0, logn, tmp_path / "c.r1cs")
+    ni, nw, nc, mats = read_r1cs(tmp_path / "c.r1cs")
+    assert (ni, nw, nc) == (L.num_instance, L.num_witness, L.num_constraints)
+    d = qap.Domain(nc + ni)
+    n = d.size
+    rng = random.Random(16)
+    toxic = {k: rng.randrange(2, E.R) for k in ("alpha", "beta", "gamma", "delta", "t")}
+    pk = E.setup_exponents(tuple(_rows(*m) for m in mats), ni, nw, d, toxic)
+    lim = T.ints_to_limbs
+    g1 = lambda ks: engine.g1_fixed_base(lim(ks))
+    g2 = lambda ks: engine.g2_fixed_base(lim(ks))
+    a_query, b_g1_query, b_g2_query = g1(pk["u"]), g1(pk["v"]), g2(pk["v"])
+    h_query, l_query = g1(pk["h"]), g1(pk["l"])
+    fixed = g1([toxic["alpha"], toxic["beta"], toxic["delta"]])
+    fixed2 = g2([toxic["beta"], toxic["delta"]])
+    # spot checks of the key against the oracle (the whole arrays are products of routines tested elsewhere)
+    for arr, ks in ((a_query, pk["u"]), (l_query, pk["l"]), (h_query, pk["h"])):
+        for i in (0, 1, len(ks) // 2, len(ks) - 1):
+            assert arr[i].tolist() == oracle.g1_scalar_mul(oracle.g1_generator(), ks[i]).tolist()
+    assert b_g2_query[ni + 5].tolist() == E.g2_to_limbs(E.g2_mul(E.G2, pk["v"][ni + 5]))
+    handle = engine.groth16_pk_load(ni, nw, n, fixed[0], fixed[1], fixed[2], fixed2[0], fixed2[1], a_query, b_g1_query, b_g2_query,
+                                    h_query, l_query)
+    r1cs = engine.r1cs_load(0, logn)
+    try:
+        sig, pk_, hm = frw.synth_triples(logn, batch, seed=2718)
+        dd = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk_, hm)]
+        wit = torch.empty((batch, nw, 4), dtype=torch.int64, device=dev)
+        inst = torch.empty((batch, ni, 4), dtype=torch.int64, device=dev)
+        st = torch.empty(batch, dtype=torch.int32, device=dev)
+        s0 = torch.cuda.current_stream().cuda_stream
+        engine.witness_ntt_verify_dev(logn, batch, dd[0], dd[1], dd[2], wit, inst, st, 1, s0)
+        rs = [[rng.randrange(E.R), rng.randrange(E.R)] for _ in range(batch)]
+        rs[1] = [0, 0]                                              # create_proof_no_zk
+        ws_bytes = engine.groth16_workspace_bytes(handle, r1cs, 2)  # chunks of 2 + 1
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        proofs = torch.full((batch, 48), -1, dtype=torch.int64, device=dev)
+        bad = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        engine.groth16_prove_dev(handle, r1cs, batch, wit, inst, np.array([lim(x) for x in rs]), proofs, ws, ws_bytes, bad, s0)
+        torch.cuda.synchronize()
+        assert not bad.any()
+        got = proofs.cpu().numpy().view(np.uint64)
+        # the same h, independently: the witness map on its own
+        q = engine.qap_info(r1cs)
+        qws = torch.empty(batch * int(q.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+        h = torch.empty((batch, n, 4), dtype=torch.int64, device=dev)
+        engine.qap_witness_map_dev(r1cs, batch, wit, inst, h, qws, qws.numel(), None, s0)
+        torch.cuda.synchronize()
+        r_inv = pow(FR_R, -1, E.R)
+        gen = oracle.g1_generator()
+        for i in range(batch):
+            z = [v * r_inv % E.R for v in T.limbs_to_ints(inst[i].cpu().numpy().view(np.uint64))] + \
+                [v * r_inv % E.R for v in T.limbs_to_ints(wit[i].cpu().numpy().view(np.uint64))]
+            h_int = [v * r_inv % E.R for v in T.limbs_to_ints(h[i].cpu().numpy().view(np.uint64))]
+            a, b, c, _ = E.prove_exponents(pk, z, h_int, rs[i][0], rs[i][1])
+            assert E.verify_exponents(pk, z[1:ni], (a, b, c)), "the restated prover's own proof does not verify"
+            assert got[i, :12].tolist() == oracle.g1_scalar_mul(gen, a).tolist(), "A of signature %d" % i
+            assert got[i, 12:36].tolist() == E.g2_to_limbs(E.g2_mul(E.G2, b)), "B of signature %d" % i
+            assert got[i, 36:].tolist() == oracle.g1_scalar_mul(gen, c).tolist(), "C of signature %d" % i
+    finally:
+        engine.r1cs_free(r1cs)
+        engine.groth16_pk_free(handle)
