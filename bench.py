@@ -384,6 +384,75 @@ def groth16_h_query(eng, n, t=0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF
     return eng.g1_fixed_base(lim), (t, c)
 
 
+def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L):
+    """The whole of examples/pok_sig.rs:30-47 after setup, per signature, on the device: frw_groth16_prove_dev = witness map +
+    five multi-scalar multiplications (G1: h_query, a_query, b_g1_query, l_query; G2: b_g2_query) + blinding + assembly of
+    (A, B, C), for `nsig` of the witnesses the timed launches left in HBM.  The proving key is made here from exponents the
+    benchmark draws itself (every query element = a known Fr value x generator, frw_g1_fixed_base / frw_g2_fixed_base), so one
+    proof can be checked without any multi-scalar multiplication: A, B, C must be the generator multiples their discrete
+    logarithms say.  (A key whose exponents come from the circuit's QAP at a toxic point -- a key whose proofs VERIFY -- is what
+    tests/test_gpu_groth16.py builds with the oracle; the arithmetic timed here is the same.)"""
+    import random
+    q = eng.qap_info(handle)
+    n, ni, nw = int(q.domain_size), L.num_instance, L.num_witness
+    nv = ni + nw
+    rng = random.Random(SEED)
+    draw = lambda cnt: [rng.randrange(1, R_FR) for _ in range(cnt)]
+    lim = lambda ks: np.frombuffer(b"".join(int(k).to_bytes(32, "little") for k in ks), dtype=np.uint64).reshape(-1, 4)
+    u, v, lq, hq = draw(nv), draw(nv), draw(nw), draw(n - 1)
+    alpha, beta, delta = draw(3)
+    t0 = time.perf_counter()
+    fixed, fixed2 = eng.g1_fixed_base(lim([alpha, beta, delta])), eng.g2_fixed_base(lim([beta, delta]))
+    pk = eng.groth16_pk_load(ni, nw, n, fixed[0], fixed[1], fixed[2], fixed2[0], fixed2[1], eng.g1_fixed_base(lim(u)),
+                             eng.g1_fixed_base(lim(v)), eng.g2_fixed_base(lim(v)), eng.g1_fixed_base(lim(hq)), eng.g1_fixed_base(lim(lq)))
+    key_s = time.perf_counter() - t0
+    ws_bytes = eng.groth16_workspace_bytes(pk, handle, nsig)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    proofs = torch.empty((nsig, 48), dtype=torch.int64, device=dev)
+    bad = torch.empty(nsig, dtype=torch.int32, device=dev)
+    rs = [[rng.randrange(R_FR), rng.randrange(R_FR)] for _ in range(nsig)]
+    rs_arr = np.stack([lim(x) for x in rs])
+    stream = torch.cuda.current_stream()
+    run = lambda: eng.groth16_prove_dev(pk, handle, nsig, d_wit, d_inst, rs_arr, proofs, ws, ws_bytes, bad, stream.cuda_stream)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    assert int(bad.abs().sum()) == 0
+    # one proof, checked in the exponent: a = alpha + <z, u> + r delta;  b' = beta + <z, v>;  b = b' + s delta;
+    # c = <aux, l> + <h, hq> + s a + r b'
+    r_inv = pow(1 << 256, -1, R_FR)
+    ints = lambda t_: [int.from_bytes(row.tobytes(), "little") * r_inv % R_FR for row in t_.cpu().numpy().view(np.uint64)]
+    z = ints(d_inst[0]) + ints(d_wit[0])
+    qws = torch.empty(int(q.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+    h = torch.empty((1, n, 4), dtype=torch.int64, device=dev)
+    eng.qap_witness_map_dev(handle, 1, d_wit, d_inst, h, qws, qws.numel(), None, stream.cuda_stream)
+    torch.cuda.synchronize()
+    hv = ints(h[0])
+    r_, s_ = rs[0]
+    a = (alpha + sum(x * y for x, y in zip(z, u)) + r_ * delta) % R_FR
+    b1 = (beta + sum(x * y for x, y in zip(z, v))) % R_FR
+    c = (sum(x * y for x, y in zip(z[ni:], lq)) + sum(x * y for x, y in zip(hv, hq)) + s_ * a + r_ * b1) % R_FR
+    got = proofs[0].cpu().numpy().view(np.uint64)
+    want_g1 = eng.g1_fixed_base(lim([a, c]))
+    want_b = eng.g2_fixed_base(lim([(b1 + s_ * delta) % R_FR]))[0]
+    assert np.array_equal(got[:12], want_g1[0]) and np.array_equal(got[36:], want_g1[1]) and np.array_equal(got[12:36], want_b), \
+        "proof differs from the generator multiples its discrete logarithms give"
+    eng.groth16_pk_free(pk)
+    return {"workload": "Groth16 proofs of resident Falcon-%d witnesses (ark-groth16 create_proof: witness map + 5 MSMs + assembly), "
+                        "%d per call" % (L.n, nsig),
+            "ms_per_call": round(ms, 3), "proofs_per_s": round(nsig / (ms * 1e-3), 1), "calls_timed": reps,
+            "proving_key": {"points_g1": 2 * nv + nw + n - 1 + 3, "points_g2": nv + 2, "made_on_the_device_in_s": round(key_s, 2)},
+            "workspace_bytes_per_signature": ws_bytes // nsig,
+            "checked": "no unsatisfied rows; (A, B, C) of one proof == the generator multiples given by its discrete logarithms "
+                       "(exponents of the key known to the benchmark), bit for bit in ark-ff's bytes"}
+
+
 def time_msm(eng, dev, d_h, reps, with_cpu):
     """The step after the witness map in the reference's consumer (examples/pok_sig.rs:30-47 -> ark-groth16 prover.rs):
     h_acc = VariableBaseMSM(pk.h_query, h) over BLS12-381 G1, for the h vectors the witness map left in HBM."""
@@ -984,7 +1053,7 @@ def main():
                 checked[name] = {"signatures": cnt, "grid": sh["grid"], "resident_workgroups_per_cu": sh["resident_per_cu"],
                                  "rounds": round(cnt / max(1, sh["grid"]), 2), "split_signatures": sh["split_signatures"]}
     r1cs = None
-    qap_result = msm_result = None
+    qap_result = msm_result = groth16_result = None
     if not args.no_r1cs_check:
         # the reference's assert!(cs.is_satisfied()) (falcon_ntt.rs:159) for every witness in the buffer, on the device,
         # in place, against matrices emitted from the gadget definitions by the host mirror (not the kernels' closed form)
@@ -1001,6 +1070,7 @@ def main():
                                           None if args.no_cpu_baseline else (sig[s0:s0 + 1], pk[s0:s0 + 1], hm[s0:s0 + 1]))
             msm_result = time_msm(eng, dev, d_hvec, 5, not args.no_cpu_baseline)
             del d_hvec
+            groth16_result = time_groth16(eng, h, dev, d_wit, d_inst, min(64, held), 3, L)
         eng.r1cs_free(h)
         n_unsat = sharding.sum_over_ranks(int((badrows != 0).sum().item()), cdev)
         assert n_unsat == 0, "%d witnesses left by the timed launches violate the constraint system" % n_unsat
@@ -1126,6 +1196,7 @@ def main():
             if qap_result is not None:
                 result["secondary"]["qap_witness_map_falcon%d" % n] = qap_result
                 result["secondary"]["groth16_msm_h_falcon%d" % n] = msm_result
+                result["secondary"]["groth16_prove_falcon%d" % n] = groth16_result
             if not args.no_aggregate:
                 result["secondary"]["host_call_one_signature_falcon%d" % n] = time_host_call(eng, logn)
                 result["secondary"]["aggregate_1024_mixed"] = time_aggregate(eng, dev, 1024, 50, threads)

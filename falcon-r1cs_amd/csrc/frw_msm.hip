@@ -245,15 +245,29 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uin
     }
 }
 
-// Buckets by decreasing size: `order[rank] = bucket`.  Bucket sizes are Poisson(16 n / 32,768) -- 128 +- 11 for 2^18 points --
-// and a wavefront runs as long as its longest lane: with neighbouring lanes on neighbouring sizes none of them idles
-// (unsorted, the longest of 64 is ~1.2 x the mean).  A counting sort by size, one workgroup per signature.
+// Work items.  A bucket is added up by one thread, so a bucket far above the mean is a serial chain the whole call waits for:
+// a Falcon witness as scalars leaves 35,000 pairs in all, 775 of them in the bucket of digit +-1 (carries of the recoding),
+// and a lone wavefront needs ~18 us per addition.  Buckets are therefore cut into ITEMS of at most `split` entries, equal
+// parts of their bucket, with split = max(32, 1.5 x the mean bucket size) decided per call on the device: the 2^18-point sum
+// of h (mean 128, sigma 11) is not cut at all, the witness-side sums are cut at 32.  Items are laid out by decreasing bucket
+// size (a counting sort), so the 64 lanes of a wavefront run equally long; a bucket's items are neighbours, and
+// msm_combine_kernel adds them up.  At most 32,768 + 21,845 items whatever the scalars (sum of ceil(c_b / split)).
 constexpr int MSM_SIZE_CLASSES = 1024;         // sizes >= this share the first class
-__global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ order)
+constexpr int MSM_MAX_ITEMS = 54656;           // >= 32,768 + 32,768 / 1.5, a multiple of 64
+__device__ __forceinline__ uint32_t msm_split_of(uint32_t total)
+{
+    const uint32_t s = (uint32_t)(((uint64_t)total * 3 + 2 * MSM_BUCKETS - 1) / (2 * MSM_BUCKETS));
+    return s < 32u ? 32u : s;
+}
+__global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ item_first /* [sig][buckets] */,
+                                                         uint32_t *__restrict__ items /* [sig][MSM_MAX_ITEMS]: bucket | chunk << 15 */,
+                                                         uint32_t *__restrict__ item_count /* [sig] */)
 {
     __shared__ uint32_t hist[MSM_SIZE_CLASSES];
     const size_t sig = blockIdx.x;
     const uint32_t *cnt = counts + sig * MSM_BUCKETS;
+    uint32_t *ord = order + sig * MSM_BUCKETS;
     const int t = threadIdx.x;
     hist[t] = 0;
     __syncthreads();
@@ -273,28 +287,62 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restr
     __syncthreads();
     hist[t] = excl;
     __syncthreads();
-    for (int b = t; b < MSM_BUCKETS; b += 1024) order[sig * MSM_BUCKETS + atomicAdd(&hist[cls(cnt[b])], 1u)] = (uint32_t)b;
+    for (int b = t; b < MSM_BUCKETS; b += 1024) ord[atomicAdd(&hist[cls(cnt[b])], 1u)] = (uint32_t)b;
+    __threadfence_block();
+    __syncthreads();
+    // items: rank by rank, ceil(c / split) each (an empty bucket keeps one: its thread stores the identity)
+    const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + cnt[MSM_BUCKETS - 1], split = msm_split_of(total);
+    constexpr int PER = MSM_BUCKETS / 1024;
+    uint32_t k[PER], local = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint32_t c = cnt[ord[t * PER + j]];
+        k[j] = c <= split ? 1u : (c + split - 1) / split;
+        local += k[j];
+    }
+    hist[t] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = t >= off ? hist[t - off] : 0u;
+        __syncthreads();
+        hist[t] += v;
+        __syncthreads();
+    }
+    uint32_t pos = hist[t] - local;
+    if (t == 1023) item_count[sig] = hist[t];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint32_t b = ord[t * PER + j];
+        item_first[sig * MSM_BUCKETS + b] = pos;
+        for (uint32_t c = 0; c < k[j]; c++) items[sig * MSM_MAX_ITEMS + pos + c] = b | (c << 15);
+        pos += k[j];
+    }
 }
 
-// one thread per (signature, bucket): the sum of the bucket's table rows, in registers.  G1: the row of entry k + 1 is fetched
+// one thread per (signature, item): the sum of the item's table rows, in registers.  G1: the row of entry k + 1 is fetched
 // while entry k is added (an addition is ~5,000 vector instructions: the gather of 112 bytes hides behind it); G2 has no
 // registers to spare for that (an accumulator alone is 112).
 template <class F, bool PREFETCH>
 __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
-                                                           const uint32_t *__restrict__ order, const uint32_t *__restrict__ entries,
-                                                           uint32_t *__restrict__ buckets)
+                                                           const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
+                                                           const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items)
 {
     constexpr int PW = Grp<F>::PT_WORDS;
     const size_t sig = blockIdx.y;
-    const uint32_t b = order[sig * MSM_BUCKETS + blockIdx.x * 64 + threadIdx.x];
-    const uint32_t start = offsets[sig * MSM_BUCKETS + b], cnt = counts[sig * MSM_BUCKETS + b];
-    const uint32_t *ent = entries + sig * (size_t)MSM_W * m.n + start;
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= item_count[sig]) return;
+    const uint32_t item = items[sig * MSM_MAX_ITEMS + it], b = item & (MSM_BUCKETS - 1), chunk = item >> 15;
+    const uint32_t c = counts[sig * MSM_BUCKETS + b];
+    const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total);
+    const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
+    const uint32_t lo = (uint32_t)((uint64_t)c * chunk / k), cnt = (uint32_t)((uint64_t)c * (chunk + 1) / k) - lo;     // equal parts
+    const uint32_t *ent = entries + sig * (size_t)MSM_W * m.n + offsets[sig * MSM_BUCKETS + b] + lo;
     XyzzT<F> acc = pt_identity<F>();
     if (PREFETCH) {
         uint32_t e = cnt ? ent[0] : 0u;
         AffineT<F> p = load_row<F>(m.table + (size_t)(e & 0x7fffffffu) * PW);
-        for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t e_next = k + 1 < cnt ? ent[k + 1] : e;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t e_next = j + 1 < cnt ? ent[j + 1] : e;
             const AffineT<F> p_next = load_row<F>(m.table + (size_t)(e_next & 0x7fffffffu) * PW);
             if (e >> 31) p.y = F::template neg<Grp<F>::K_AFFINE_Y>(p.y);
             acc = pt_add_affine(acc, p);
@@ -302,14 +350,32 @@ __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint3
             p = p_next;
         }
     } else {
-        for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t e = ent[k];
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t e = ent[j];
             AffineT<F> p = load_row<F>(m.table + (size_t)(e & 0x7fffffffu) * PW);
             if (e >> 31) p.y = F::template neg<Grp<F>::K_AFFINE_Y>(p.y);
             acc = pt_add_affine(acc, p);
         }
     }
-    store_bucket<F>(buckets + (sig * MSM_BUCKETS + b) * (size_t)Grp<F>::BK_WORDS, acc);
+    store_bucket<F>(partial_items + (sig * MSM_MAX_ITEMS + it) * (size_t)Grp<F>::BK_WORDS, acc);
+}
+
+// bucket b = the sum of its items (one for almost every bucket: a copy)
+template <class F>
+__global__ __launch_bounds__(64, 2) void msm_combine_kernel(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
+                                                            const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
+                                                            uint32_t *__restrict__ buckets)
+{
+    constexpr int BW = Grp<F>::BK_WORDS;
+    const size_t sig = blockIdx.y;
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t c = counts[sig * MSM_BUCKETS + b];
+    const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total);
+    const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
+    const uint32_t *src = partial_items + (sig * MSM_MAX_ITEMS + item_first[sig * MSM_BUCKETS + b]) * (size_t)BW;
+    XyzzT<F> acc = load_bucket<F>(src);
+    for (uint32_t j = 1; j < k; j++) acc = pt_add(acc, load_bucket<F>(src + (size_t)j * BW));
+    store_bucket<F>(buckets + (sig * MSM_BUCKETS + b) * (size_t)BW, acc);
 }
 
 // the points whose scalar is one, summed by the 512 threads that will fold the buckets (thread t: every 512th of the list);
@@ -425,8 +491,10 @@ template <class F> size_t msm_workspace_per_signature(uint32_t n)
     // histograms, 32 x 32,768 x 4 B, live there before the buckets are written), the list of scalars that are one (n x 4 B +
     // a counter) and their 512 partial sums
     static_assert((size_t)frw::MSM_SLICES * 4 <= (size_t)frw::Grp<F>::BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
-    return 3 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::Grp<F>::BK_WORDS * 4 +
-           ((size_t)n + 4) * 4 + (size_t)frw::MSM_FOLD_THREADS * frw::Grp<F>::BK_WORDS * 4;
+    // + the work items: first item of every bucket, the item list, a counter, and the items' partial sums
+    return 4 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::Grp<F>::BK_WORDS * 4 +
+           ((size_t)n + 4) * 4 + (size_t)frw::MSM_FOLD_THREADS * frw::Grp<F>::BK_WORDS * 4 +
+           ((size_t)frw::MSM_MAX_ITEMS + 4) * 4 + (size_t)frw::MSM_MAX_ITEMS * frw::Grp<F>::BK_WORDS * 4;
 }
 
 template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, frw_msm **out)
@@ -512,6 +580,10 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         uint32_t *partial = buckets + cnt * (size_t)frw::MSM_BUCKETS * BW;
         uint32_t *ones_list = partial + cnt * (size_t)frw::MSM_FOLD_THREADS * BW;
         uint32_t *ones_count = ones_list + cnt * (size_t)n;             // [cnt], padded to four words per signature in the budget
+        uint32_t *item_first = ones_count + cnt * 4;
+        uint32_t *items = item_first + cnt * (size_t)frw::MSM_BUCKETS;
+        uint32_t *item_count = items + cnt * (size_t)frw::MSM_MAX_ITEMS; // [cnt], padded likewise
+        uint32_t *partial_items = item_count + cnt * 4;
         const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
         const size_t stride_words = scalar_stride * 8;
         const dim3 sgrid(frw::MSM_SLICES, (unsigned)cnt);
@@ -520,10 +592,12 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
         hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts);
         hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
-        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, order);
+        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count);
         hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
-        hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
-                           counts, order, entries, buckets);
+        hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(frw::MSM_MAX_ITEMS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
+                           counts, items, item_count, entries, partial_items);
+        hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, offsets, counts, item_first,
+                           partial_items, buckets);
         hipLaunchKernelGGL(frw::msm_ones_kernel<F>, dim3(frw::MSM_FOLD_THREADS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count,
                            ones_list, partial);
         hipLaunchKernelGGL(frw::msm_fold_kernel<F>, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, buckets, partial,
@@ -658,12 +732,22 @@ struct frw_groth16_pk {
     int device;
     uint64_t num_instance, num_witness, domain_size;
     frw_msm *h, *a, *b1, *l, *b2;
+    // the four witness-side sums run beside the sum over h_query, each on a stream of its own: their folds and the sorting
+    // of a few ten thousand pairs are latency, not throughput, and hide behind the 2^18-point sum
+    hipStream_t side[4];
+    hipEvent_t fork, join[4];
 };
 
 extern "C" void frw_groth16_pk_free(frw_groth16_pk *pk)
 {
     if (!pk) return;
     for (frw_msm *m : {pk->h, pk->a, pk->b1, pk->l, pk->b2}) frw_msm_free(m);
+    (void)hipSetDevice(pk->device);
+    for (int i = 0; i < 4; i++) {
+        if (pk->side[i]) (void)hipStreamDestroy(pk->side[i]);
+        if (pk->join[i]) (void)hipEventDestroy(pk->join[i]);
+    }
+    if (pk->fork) (void)hipEventDestroy(pk->fork);
     delete pk;
 }
 
@@ -678,8 +762,22 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
     pk->device = device;
     pk->num_instance = d->num_instance; pk->num_witness = d->num_witness; pk->domain_size = d->domain_size;
     pk->h = pk->a = pk->b1 = pk->l = pk->b2 = nullptr;
+    pk->fork = nullptr;
+    for (int i = 0; i < 4; i++) { pk->side[i] = nullptr; pk->join[i] = nullptr; }
     const size_t nv = (size_t)(d->num_instance + d->num_witness);
     int rc = FRW_OK;
+    {
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->fork, hipEventDisableTiming);
+        for (int i = 0; i < 4 && e == hipSuccess; i++) {
+            e = hipStreamCreateWithFlags(&pk->side[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->join[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            frw_groth16_pk_free(pk);
+            return frw::record_hip_error(e, "frw_groth16_pk_load");
+        }
+    }
     try {
         std::vector<uint64_t> g1(12 * (nv + 2)), g2(24 * (nv + 3), 0);
         std::memcpy(g1.data(), d->a_query, nv * 96);
@@ -711,7 +809,7 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
 }
 
 namespace {
-struct Groth16Sizes { size_t qap, h, zext, msm, pts, per; };
+struct Groth16Sizes { size_t qap, h, zext, msm[5], msm_all, pts, per; };
 Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
 {
     Groth16Sizes s{};
@@ -722,13 +820,14 @@ Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
     s.qap = q.workspace_bytes_per_signature;
     s.h = (size_t)pk->domain_size * 32;
     s.zext = (nv + 3) * 32;
-    for (const frw_msm *m : {pk->h, pk->a, pk->b1, pk->l, pk->b2}) {
+    int i = 0;
+    for (const frw_msm *m : {pk->h, pk->a, pk->b1, pk->l, pk->b2}) {                // each sum has a workspace of its own: they overlap in time
         frw_msm_info(m, &mi);
-        s.msm = std::max<size_t>(s.msm, mi.workspace_bytes_per_signature);
+        s.msm[i] = (mi.workspace_bytes_per_signature + 255) & ~(size_t)255;
+        s.msm_all += s.msm[i++];
     }
-    s.msm = (s.msm + 255) & ~(size_t)255;
     s.pts = 4 * 96 + 192 + 64;                                        // A, B1', L, H (G1), B (G2), r and s
-    s.per = ((s.qap + s.h + s.zext + s.msm + s.pts) + 255) & ~(size_t)255;
+    s.per = ((s.qap + s.h + s.zext + s.msm_all + s.pts) + 255) & ~(size_t)255;
     return s;
 }
 }  // namespace
@@ -760,7 +859,8 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         void *qap_ws = base;                          base += cnt * sz.qap;
         uint64_t *h = (uint64_t *)base;               base += cnt * sz.h;
         uint64_t *zext = (uint64_t *)base;            base += cnt * sz.zext;
-        void *msm_ws = base;                          base += cnt * sz.msm;
+        char *msm_ws[5];
+        for (int i = 0; i < 5; i++) { msm_ws[i] = base; base += cnt * sz.msm[i]; }
         uint64_t *pA = (uint64_t *)base, *pB1 = pA + cnt * 12, *pL = pB1 + cnt * 12, *pH = pL + cnt * 12, *pB2 = pH + cnt * 12;
         uint64_t *d_rs = pB2 + cnt * 24;
         const uint64_t *wit = d_witness + lo * W * 4, *inst = d_instance + lo * I * 4;
@@ -768,20 +868,28 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         e = hipMemcpyAsync(d_rs, rs + lo * 8, cnt * 64, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);                                  // `rs` may be pageable and short-lived
         if (e != hipSuccess) break;
-        rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, st);
-        if (rc != FRW_OK) break;
-        // z ++ [1, r, s] per signature
+        // z ++ [1, r, s] per signature, then the witness-side sums on their own streams ...
         e = hipMemcpy2DAsync(zext, stride * 32, inst, I * 32, I * 32, cnt, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipMemcpy2DAsync(zext + I * 4, stride * 32, wit, W * 32, W * 32, cnt, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
                            (uint32_t *)zext, stride * 8, nv);
-        rc = frw_msm_g1_dev(pk->h, cnt, h, n, 1, pH, msm_ws, cnt * sz.msm, st);
-        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->a, cnt, zext, stride, 1, pA, msm_ws, cnt * sz.msm, st);
-        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->b1, cnt, zext, stride, 1, pB1, msm_ws, cnt * sz.msm, st);
-        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->l, cnt, zext + I * 4, stride, 1, pL, msm_ws, cnt * sz.msm, st);
-        if (rc == FRW_OK) rc = frw_msm_g2_dev(pk->b2, cnt, zext, stride, 1, pB2, msm_ws, cnt * sz.msm, st);
+        e = hipEventRecord(pk->fork, st);
+        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(pk->side[i], pk->fork, 0);
+        if (e != hipSuccess) break;
+        rc = frw_msm_g2_dev(pk->b2, cnt, zext, stride, 1, pB2, msm_ws[4], cnt * sz.msm[4], pk->side[3]);      // the longest of the four first
+        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->a, cnt, zext, stride, 1, pA, msm_ws[1], cnt * sz.msm[1], pk->side[0]);
+        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->b1, cnt, zext, stride, 1, pB1, msm_ws[2], cnt * sz.msm[2], pk->side[1]);
+        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->l, cnt, zext + I * 4, stride, 1, pL, msm_ws[3], cnt * sz.msm[3], pk->side[2]);
         if (rc != FRW_OK) break;
+        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
+        if (e != hipSuccess) break;
+        // ... while this stream does the witness map and the sum over h_query
+        rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, st);
+        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->h, cnt, h, n, 1, pH, msm_ws[0], cnt * sz.msm[0], st);
+        if (rc != FRW_OK) break;
+        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st, pk->join[i], 0);
+        if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
                            (const uint32_t *)pA, (const uint32_t *)pB1, (const uint32_t *)pL, (const uint32_t *)pH, (const uint32_t *)pB2,
                            (uint32_t *)(d_proofs + lo * 48));

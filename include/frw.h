@@ -356,8 +356,9 @@ int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, si
  *     d_proofs  uint64_t[batch][48]: A (G1Affine limbs, 12), B (G2Affine limbs, 24), C (12)
  *     d_num_unsatisfied  optional uint32_t[batch]: constraint rows the witness violates (the proof is then worthless)
  *     d_workspace  frw_groth16_workspace_bytes(pk, r, in_flight) bytes, 256-byte aligned; the batch runs in chunks that fit
- * d_witness / d_instance: what the witness entry points wrote (FRW_ENC_MONTGOMERY).  Enqueued on `stream` except for the upload of
- * `rs`, which is waited for before the call goes on (the array may be short-lived). */
+ * d_witness / d_instance: what the witness entry points wrote (FRW_ENC_MONTGOMERY).  Ordered on `stream` -- the four witness-side
+ * sums run on streams of the key's own, forked from and joined back into `stream` by events, beside the witness map and the sum
+ * over h_query -- except for the upload of `rs`, which is waited for before the call goes on (the array may be short-lived). */
 typedef struct frw_groth16_pk frw_groth16_pk;
 typedef struct {
     uint64_t num_instance, num_witness, domain_size;      /* I (with the constant one), W, n */
