@@ -363,7 +363,7 @@ template <class F> __host__ __device__ inline XyzzT<F> pt_double(const XyzzT<F> 
     return r;
 }
 // madd-2008-s: 8 M + 2 S; complete (an accumulator that meets its own value doubles, its negative cancels)
-template <class F> __host__ __device__ inline XyzzT<F> pt_add_affine(const XyzzT<F> &p, const AffineT<F> &q)
+template <class F> __host__ __device__ __forceinline__ XyzzT<F> pt_add_affine(const XyzzT<F> &p, const AffineT<F> &q)
 {
     if (q.inf) return p;
     if (p.inf) return pt_from_affine(q);

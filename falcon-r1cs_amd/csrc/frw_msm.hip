@@ -34,8 +34,8 @@ namespace frw {
 constexpr int MSM_C = 16;                       // window bits
 constexpr int MSM_W = 16;                       // windows: 16 x 16 = 256 >= 255 bits
 constexpr int MSM_BUCKETS = 1 << (MSM_C - 1);   // signed digits: |d| in 1 .. 2^15
-constexpr int MSM_CHUNK = 64;                   // buckets per thread in the fold
-constexpr int MSM_FOLD_THREADS = MSM_BUCKETS / MSM_CHUNK;
+constexpr int MSM_FOLD1_THREADS = 4096;         // partial sums per signature at most (first stage: 8, 32 or 64 buckets per thread)
+constexpr int MSM_FOLD_THREADS = 512;           // second stage: one workgroup per signature
 // per group (F = FqField: G1, Fq2Field: G2): a table row = x, y limbs (all zero = the point at infinity); a bucket = X, Y, ZZ,
 // ZZZ limbs + the infinity flag (padded to 16 bytes); ark-ff's bytes of an affine point
 template <class F> struct Grp {
@@ -378,45 +378,62 @@ __global__ __launch_bounds__(64, 2) void msm_combine_kernel(const uint32_t *__re
     store_bucket<F>(buckets + (sig * MSM_BUCKETS + b) * (size_t)BW, acc);
 }
 
-// the points whose scalar is one, summed by the 512 threads that will fold the buckets (thread t: every 512th of the list);
-// the partial sums enter the fold with weight one
+// the points whose scalar is one, summed by the threads of the fold's first stage (thread t: every nthreads-th of the list); the
+// partial sums enter the fold with weight one
 template <class F>
 __global__ __launch_bounds__(64, 2) void msm_ones_kernel(MsmDev m, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
-                                                         uint32_t *__restrict__ partial /* [sig][MSM_FOLD_THREADS][BK_WORDS] */)
+                                                         uint32_t *__restrict__ partial /* [sig][MSM_FOLD1_THREADS][BK_WORDS] */)
 {
     const size_t sig = blockIdx.y;
+    const uint32_t nthreads = gridDim.x * 64;
     const uint32_t t = blockIdx.x * 64 + threadIdx.x, cnt = ones_count[sig];
     const uint32_t *list = ones_list + sig * m.n;
     XyzzT<F> acc = pt_identity<F>();
-    for (uint32_t k = t; k < cnt; k += MSM_FOLD_THREADS)
+    for (uint32_t k = t; k < cnt; k += nthreads)
         acc = pt_add_affine(acc, load_row<F>(m.table + (size_t)list[k] * Grp<F>::PT_WORDS));      // window 0 of the table = the point itself
-    store_bucket<F>(partial + (sig * MSM_FOLD_THREADS + t) * (size_t)Grp<F>::BK_WORDS, acc);
+    store_bucket<F>(partial + (sig * MSM_FOLD1_THREADS + t) * (size_t)Grp<F>::BK_WORDS, acc);
 }
 
-// sum_b (b + 1) B_b per signature: 512 threads x 64 buckets, then a tree; thread 0 converts to affine and writes ark-ff's bytes
+// sum_b (b + 1) B_b per signature, in two stages (one workgroup of 512 threads x 64 buckets each was 200 dependent point
+// operations long: 6 ms for G1, 19 for G2, whatever the batch).  Stage 1: 32,768 / CHUNK threads x CHUNK buckets: running sums,
+// the multiple CHUNK g x (sum of the chunk) by double-and-add, plus the thread's share of the scalars that are one; overwrites
+// `partial`.  CHUNK = 2^LOG_CHUNK is 8 for small batches (latency) and up to 64 for large ones (the multiples are a third of the
+// work at 8).
+template <class F, int LOG_CHUNK>
+__global__ __launch_bounds__(64, 2) void msm_fold1_kernel(const uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial)
+{
+    constexpr int BW = Grp<F>::BK_WORDS, CHUNK = 1 << LOG_CHUNK;
+    const size_t sig = blockIdx.y;
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t *bk = buckets + (sig * MSM_BUCKETS + (size_t)g * CHUNK) * BW;
+    XyzzT<F> run = pt_identity<F>(), sum = pt_identity<F>();
+    for (int k = CHUNK - 1; k >= 0; k--) {
+        run = pt_add(run, load_bucket<F>(bk + (size_t)k * BW));
+        sum = pt_add(sum, run);
+    }
+    // sum = sum_k (k + 1) B_(CHUNK g + k); the buckets' weights are CHUNK g + k + 1: add (CHUNK g) run = 2^LOG_CHUNK (g run)
+    XyzzT<F> mult = pt_identity<F>();
+    for (int bit = 14 - LOG_CHUNK; bit >= 0; bit--) {
+        mult = pt_double(mult);
+        if ((g >> bit) & 1) mult = pt_add(mult, run);
+    }
+    for (int k = 0; k < LOG_CHUNK; k++) mult = pt_double(mult);
+    sum = pt_add(sum, mult);
+    uint32_t *mine = partial + (sig * MSM_FOLD1_THREADS + g) * (size_t)BW;
+    sum = pt_add(sum, load_bucket<F>(mine));                           // the scalars that are one
+    store_bucket<F>(mine, sum);
+}
+// Stage 2: 512 threads add `each` partial sums each, a tree through LDS, one inversion, ark-ff's bytes out
 template <class F>
-__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold_kernel(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ partial,
-                                                                    uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
+__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint32_t *__restrict__ partial, int each, uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
 {
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
     __shared__ uint32_t lds[MSM_FOLD_THREADS / 2 * SLOT];            // 58 KB (G1) / 116 KB (G2): the upper half of a tree level parks here
     const size_t sig = blockIdx.x;
     const int t = threadIdx.x;
-    const uint32_t *bk = buckets + (sig * MSM_BUCKETS + (size_t)t * MSM_CHUNK) * BW;
-    XyzzT<F> run = pt_identity<F>(), sum = pt_identity<F>();
-    for (int k = MSM_CHUNK - 1; k >= 0; k--) {
-        run = pt_add(run, load_bucket<F>(bk + (size_t)k * BW));
-        sum = pt_add(sum, run);
-    }
-    // sum = sum_k (k + 1) B_(64 t + k); the buckets' weights are 64 t + k + 1: add (64 t) run = 2^6 (t run)
-    XyzzT<F> mult = pt_identity<F>();
-    for (int bit = 8; bit >= 0; bit--) {
-        mult = pt_double(mult);
-        if ((t >> bit) & 1) mult = pt_add(mult, run);
-    }
-    for (int k = 0; k < 6; k++) mult = pt_double(mult);
-    sum = pt_add(sum, mult);
-    sum = pt_add(sum, load_bucket<F>(partial + (sig * MSM_FOLD_THREADS + t) * (size_t)BW));      // the scalars that are one
+    const uint32_t *src = partial + (sig * MSM_FOLD1_THREADS + (size_t)t * each) * BW;
+    XyzzT<F> sum = load_bucket<F>(src);
+    for (int k = 1; k < each; k++) sum = pt_add(sum, load_bucket<F>(src + (size_t)k * BW));
     for (int stride = MSM_FOLD_THREADS / 2; stride >= 1; stride >>= 1) {
         if (t >= stride && t < 2 * stride) store_bucket<F>(lds + (t - stride) * SLOT, sum);
         __syncthreads();
@@ -493,7 +510,7 @@ template <class F> size_t msm_workspace_per_signature(uint32_t n)
     static_assert((size_t)frw::MSM_SLICES * 4 <= (size_t)frw::Grp<F>::BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
     // + the work items: first item of every bucket, the item list, a counter, and the items' partial sums
     return 4 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::Grp<F>::BK_WORDS * 4 +
-           ((size_t)n + 4) * 4 + (size_t)frw::MSM_FOLD_THREADS * frw::Grp<F>::BK_WORDS * 4 +
+           ((size_t)n + 4) * 4 + (size_t)frw::MSM_FOLD1_THREADS * frw::Grp<F>::BK_WORDS * 4 +
            ((size_t)frw::MSM_MAX_ITEMS + 4) * 4 + (size_t)frw::MSM_MAX_ITEMS * frw::Grp<F>::BK_WORDS * 4;
 }
 
@@ -578,7 +595,7 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         uint32_t *buckets = entries + cnt * (size_t)frw::MSM_W * n;
         uint32_t *slice_hist = buckets;                                  // [cnt][32][32,768], dead before the first bucket is stored
         uint32_t *partial = buckets + cnt * (size_t)frw::MSM_BUCKETS * BW;
-        uint32_t *ones_list = partial + cnt * (size_t)frw::MSM_FOLD_THREADS * BW;
+        uint32_t *ones_list = partial + cnt * (size_t)frw::MSM_FOLD1_THREADS * BW;
         uint32_t *ones_count = ones_list + cnt * (size_t)n;             // [cnt], padded to four words per signature in the budget
         uint32_t *item_first = ones_count + cnt * 4;
         uint32_t *items = item_first + cnt * (size_t)frw::MSM_BUCKETS;
@@ -598,10 +615,15 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
                            counts, items, item_count, entries, partial_items);
         hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, offsets, counts, item_first,
                            partial_items, buckets);
-        hipLaunchKernelGGL(frw::msm_ones_kernel<F>, dim3(frw::MSM_FOLD_THREADS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count,
-                           ones_list, partial);
-        hipLaunchKernelGGL(frw::msm_fold_kernel<F>, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, buckets, partial,
-                           (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
+        // first stage of the fold: enough threads to occupy the chip (~2^16), as few as that allows
+        const int log_chunk = cnt >= 128 ? 6 : cnt >= 32 ? 5 : 3;
+        const unsigned t1 = (unsigned)frw::MSM_BUCKETS >> log_chunk;
+        hipLaunchKernelGGL(frw::msm_ones_kernel<F>, dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list, partial);
+        if (log_chunk == 6) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 6>), dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, buckets, partial);
+        else if (log_chunk == 5) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 5>), dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, buckets, partial);
+        else hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 3>), dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, buckets, partial);
+        hipLaunchKernelGGL(frw::msm_fold2_kernel<F>, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, partial,
+                           (int)(t1 / frw::MSM_FOLD_THREADS), (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
         e = hipGetLastError();
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
@@ -700,27 +722,33 @@ __global__ __launch_bounds__(64) void groth16_tails_kernel(size_t batch, const u
     for (int j = 0; j < 2; j++)
         fr_store(dst + 8 * (j + 1), f29_pack(f29_canonical(f29_mul(f29_unpack(fr_load(rs + (sig * 2 + j) * 8)), c))));
 }
+// k P for one point per signature (s g_a and r (g1_b - s delta1) of g_c), 4-bit windows; runs on the side stream that made P
+__global__ __launch_bounds__(64) void groth16_scale_kernel(size_t batch, const uint32_t *__restrict__ rs, int which, const uint32_t *__restrict__ pts,
+                                                           uint32_t *__restrict__ out /* [batch][24] */)
+{
+    const size_t sig = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (sig >= batch) return;
+    const AffineT<FqField> base = load_ark_point<FqField>(pts + sig * 24);
+    const Fr8 k = fr_load(rs + (sig * 2 + which) * 8);
+    XyzzT<FqField> m = pt_identity<FqField>();
+    for (int bit = 254; bit >= 0; bit--) {
+        m = pt_double(m);
+        if ((k.l[bit >> 5] >> (bit & 31)) & 1u) m = pt_add_affine(m, base);
+    }
+    store_ark_point<FqField>(out + sig * 24, pt_to_affine(m));
+}
 // C = L + H + s A + r B1', then the proof row A (12 u64) | B (24) | C (12)
-__global__ __launch_bounds__(64) void groth16_finish_kernel(size_t batch, const uint32_t *__restrict__ rs, const uint32_t *__restrict__ a_pts,
-                                                            const uint32_t *__restrict__ b1_pts, const uint32_t *__restrict__ l_pts,
+__global__ __launch_bounds__(64) void groth16_finish_kernel(size_t batch, const uint32_t *__restrict__ a_pts, const uint32_t *__restrict__ sa_pts,
+                                                            const uint32_t *__restrict__ rb1_pts, const uint32_t *__restrict__ l_pts,
                                                             const uint32_t *__restrict__ h_pts, const uint32_t *__restrict__ b2_pts,
                                                             uint32_t *__restrict__ proofs /* [batch][96] */)
 {
     const size_t sig = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (sig >= batch) return;
-    const AffineT<FqField> a = load_ark_point<FqField>(a_pts + sig * 24), b1 = load_ark_point<FqField>(b1_pts + sig * 24);
     XyzzT<FqField> acc = pt_from_affine(load_ark_point<FqField>(l_pts + sig * 24));
     acc = pt_add_affine(acc, load_ark_point<FqField>(h_pts + sig * 24));
-    for (int j = 0; j < 2; j++) {                                   // s A, then r B1'
-        const Fr8 k = fr_load(rs + (sig * 2 + (1 - j)) * 8);
-        const AffineT<FqField> &base = j == 0 ? a : b1;
-        XyzzT<FqField> m = pt_identity<FqField>();
-        for (int bit = 254; bit >= 0; bit--) {
-            m = pt_double(m);
-            if ((k.l[bit >> 5] >> (bit & 31)) & 1u) m = pt_add_affine(m, base);
-        }
-        acc = pt_add(acc, m);
-    }
+    acc = pt_add_affine(acc, load_ark_point<FqField>(sa_pts + sig * 24));
+    acc = pt_add_affine(acc, load_ark_point<FqField>(rb1_pts + sig * 24));
     uint32_t *o = proofs + sig * 96;
     for (int k = 0; k < 24; k++) o[k] = a_pts[sig * 24 + k];
     for (int k = 0; k < 48; k++) o[24 + k] = b2_pts[sig * 48 + k];
@@ -826,7 +854,7 @@ Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
         s.msm[i] = (mi.workspace_bytes_per_signature + 255) & ~(size_t)255;
         s.msm_all += s.msm[i++];
     }
-    s.pts = 4 * 96 + 192 + 64;                                        // A, B1', L, H (G1), B (G2), r and s
+    s.pts = 6 * 96 + 192 + 64;                                        // A, B1', L, H, s A, r B1' (G1), B (G2), r and s
     s.per = ((s.qap + s.h + s.zext + s.msm_all + s.pts) + 255) & ~(size_t)255;
     return s;
 }
@@ -861,8 +889,8 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         uint64_t *zext = (uint64_t *)base;            base += cnt * sz.zext;
         char *msm_ws[5];
         for (int i = 0; i < 5; i++) { msm_ws[i] = base; base += cnt * sz.msm[i]; }
-        uint64_t *pA = (uint64_t *)base, *pB1 = pA + cnt * 12, *pL = pB1 + cnt * 12, *pH = pL + cnt * 12, *pB2 = pH + cnt * 12;
-        uint64_t *d_rs = pB2 + cnt * 24;
+        uint64_t *pA = (uint64_t *)base, *pB1 = pA + cnt * 12, *pL = pB1 + cnt * 12, *pH = pL + cnt * 12, *pSA = pH + cnt * 12;
+        uint64_t *pRB1 = pSA + cnt * 12, *pB2 = pRB1 + cnt * 12, *d_rs = pB2 + cnt * 24;
         const uint64_t *wit = d_witness + lo * W * 4, *inst = d_instance + lo * I * 4;
         // the blinding factors: a host array (the prover draws them), uploaded before anything reads them
         e = hipMemcpyAsync(d_rs, rs + lo * 8, cnt * 64, hipMemcpyHostToDevice, st);
@@ -882,6 +910,11 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->b1, cnt, zext, stride, 1, pB1, msm_ws[2], cnt * sz.msm[2], pk->side[1]);
         if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->l, cnt, zext + I * 4, stride, 1, pL, msm_ws[3], cnt * sz.msm[3], pk->side[2]);
         if (rc != FRW_OK) break;
+        // s g_a and r (g1_b - s delta1) as soon as their points exist, on the streams that made them
+        hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[0], cnt, (const uint32_t *)d_rs, 1,
+                           (const uint32_t *)pA, (uint32_t *)pSA);
+        hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[1], cnt, (const uint32_t *)d_rs, 0,
+                           (const uint32_t *)pB1, (uint32_t *)pRB1);
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
         if (e != hipSuccess) break;
         // ... while this stream does the witness map and the sum over h_query
@@ -890,8 +923,8 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (rc != FRW_OK) break;
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st, pk->join[i], 0);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
-                           (const uint32_t *)pA, (const uint32_t *)pB1, (const uint32_t *)pL, (const uint32_t *)pH, (const uint32_t *)pB2,
+        hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)pA,
+                           (const uint32_t *)pSA, (const uint32_t *)pRB1, (const uint32_t *)pL, (const uint32_t *)pH, (const uint32_t *)pB2,
                            (uint32_t *)(d_proofs + lo * 48));
         e = hipGetLastError();
     }
