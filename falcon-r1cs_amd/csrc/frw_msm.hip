@@ -137,6 +137,10 @@ __device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomer
 #pragma unroll
         for (int k = 0; k < NL29; k++) c.l[k] = k ? 0u : 32u;
         w = f29_pack(f29_canonical(f29_mul(f29_unpack(w), c)));
+    } else {
+        // "canonical" is the caller's promise; any 256-bit integer is brought below r here (2^256 < 4 r: two conditional
+        // subtractions), because a top digit above 2^15 would index past the buckets -- and k P = (k mod r) P anyway
+        w = f29_pack(f29_canonical(f29_reduce_4p(f29_unpack(w))));
     }
     if (w.l[0] == 1u && !(w.l[1] | w.l[2] | w.l[3] | w.l[4] | w.l[5] | w.l[6] | w.l[7])) return true;
     int carry = 0;
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(64) void groth16_scale_kernel(size_t batch, const u
     const AffineT<FqField> base = load_ark_point<FqField>(pts + sig * 24);
     const Fr8 k = fr_load(rs + (sig * 2 + which) * 8);
     XyzzT<FqField> m = pt_identity<FqField>();
-    for (int bit = 254; bit >= 0; bit--) {
+    for (int bit = 255; bit >= 0; bit--) {                          // all 256 bits: an r or s >= the group order is taken mod it
         m = pt_double(m);
         if ((k.l[bit >> 5] >> (bit & 31)) & 1u) m = pt_add_affine(m, base);
     }

@@ -307,7 +307,7 @@ int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
  * windows j (448 bytes per point); frw_msm_g1_dev then computes sum_i k_i P_i for every signature of a batch:
  *     d_scalars   uint64_t[batch][scalar_stride][4]; the first num_points elements of each signature's vector are used.
  *                 montgomery != 0: ark-ff's Fr Montgomery form (what frw_qap_witness_map_dev writes); 0: canonical
- *                 integers < r (what into_repr() gives)
+ *                 integers < r (what into_repr() gives; a 256-bit integer >= r is taken mod r, never out of bounds)
  *     d_out       uint64_t[batch][12]: the affine result in ark-ff's bytes (x, y; all zero = infinity) -- the bytes of the
  *                 G1Affine arkworks' into_affine() would hold
  *     d_workspace at least workspace_bytes_per_signature (frw_msm_info) bytes, 16-byte aligned; the batch is processed in

@@ -68,6 +68,7 @@ def test_proofs_equal_the_prover_restated_in_the_exponent(engine, oracle, tmp_pa
         engine.witness_ntt_verify_dev(logn, batch, dd[0], dd[1], dd[2], wit, inst, st, 1, s0)
         rs = [[rng.randrange(E.R), rng.randrange(E.R)] for _ in range(batch)]
         rs[1] = [0, 0]                                              # create_proof_no_zk
+        rs[2] = [E.R + 12345, (1 << 256) - 1]                       # out of contract (>= the group order): taken mod it
         ws_bytes = engine.groth16_workspace_bytes(handle, r1cs, 2)  # chunks of 2 + 1
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         proofs = torch.full((batch, 48), -1, dtype=torch.int64, device=dev)
@@ -76,6 +77,13 @@ def test_proofs_equal_the_prover_restated_in_the_exponent(engine, oracle, tmp_pa
         torch.cuda.synchronize()
         assert not bad.any()
         got = proofs.cpu().numpy().view(np.uint64)
+        # a witness that violates the system is flagged (its "proof" is still three points, worth nothing)
+        wbad = wit.clone()
+        wbad[0, L.n + 3, 0] += 1
+        engine.groth16_prove_dev(handle, r1cs, 1, wbad, inst, np.array([lim(rs[0])]), torch.empty((1, 48), dtype=torch.int64, device=dev),
+                                 ws, ws_bytes, bad, s0)
+        torch.cuda.synchronize()
+        assert int(bad[0]) > 0
         # the same h, independently: the witness map on its own
         q = engine.qap_info(r1cs)
         qws = torch.empty(batch * int(q.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
@@ -88,7 +96,7 @@ def test_proofs_equal_the_prover_restated_in_the_exponent(engine, oracle, tmp_pa
             z = [v * r_inv % E.R for v in T.limbs_to_ints(inst[i].cpu().numpy().view(np.uint64))] + \
                 [v * r_inv % E.R for v in T.limbs_to_ints(wit[i].cpu().numpy().view(np.uint64))]
             h_int = [v * r_inv % E.R for v in T.limbs_to_ints(h[i].cpu().numpy().view(np.uint64))]
-            a, b, c, _ = E.prove_exponents(pk, z, h_int, rs[i][0], rs[i][1])
+            a, b, c, _ = E.prove_exponents(pk, z, h_int, rs[i][0] % E.R, rs[i][1] % E.R)
             assert E.verify_exponents(pk, z[1:ni], (a, b, c)), "the restated prover's own proof does not verify"
             assert got[i, :12].tolist() == oracle.g1_scalar_mul(gen, a).tolist(), "A of signature %d" % i
             assert got[i, 12:36].tolist() == E.g2_to_limbs(E.g2_mul(E.G2, b)), "B of signature %d" % i
