@@ -92,6 +92,7 @@ PROTOTYPES = {
                                         C.c_void_p]),
     "frw_groth16_pk_load": (C.c_int, [C.c_int, C.POINTER(Groth16PkDesc), C.POINTER(C.c_void_p)]),
     "frw_groth16_pk_free": (None, [C.c_void_p]),
+    "frw_groth16_setup": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "frw_groth16_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "frw_groth16_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),

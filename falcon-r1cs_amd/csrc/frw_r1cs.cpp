@@ -434,3 +434,81 @@ extern "C" int frw_r1cs_export(int circuit, int logn, const char *path, uint64_t
         return FRW_E_INVALID_ARG;
     }
 }
+
+// ---- Groth16 setup: ark-groth16 0.3.0 generator.rs generate_parameters, with the toxic waste GIVEN -------------------------------
+// (circuit_specific_setup draws alpha, beta, gamma, delta and the evaluation point t from an rng -- examples/pok_sig.rs:30-31 --
+// and random generators of G1 and G2; here the caller supplies the five field elements and the published generators are used.)
+// Host: the circuit's matrices, the Lagrange coefficients at t (instance_map_with_evaluation: u_i(t), v_i(t), w_i(t), zt), the
+// scalars of every query.  Device: the queries themselves, fixed-base multiples (frw_g1_fixed_base / frw_g2_fixed_base), and the
+// loaded proving key.  vk_out: alpha_g1 (12 u64) | beta_g2 (24) | gamma_g2 (24) | delta_g2 (24) | gamma_abc_g1 [I][12].
+extern "C" int frw_groth16_setup(int device, int circuit, int logn, const uint64_t *toxic /* [5][4]: alpha, beta, gamma, delta, t; canonical */,
+                                 frw_groth16_pk **pk_out, uint64_t *vk_out)
+{
+    using namespace frw::host;
+    if (!toxic || !pk_out || (logn != 9 && logn != 10) || (circuit != FRW_CIRCUIT_NTT && circuit != FRW_CIRCUIT_DUAL_NTT)) return FRW_E_INVALID_ARG;
+    *pk_out = nullptr;
+    try {
+        const ConstraintMatrices m = build_matrices(circuit, logn);
+        const size_t ni = m.num_instance_variables, nw = m.num_witness_variables, nc = m.num_constraints, nv = ni + nw;
+        const int L = domain_log(nc + ni);
+        const size_t n = (size_t)1 << L;
+        const Fr alpha = Fr::from_canonical(toxic), beta = Fr::from_canonical(toxic + 4), gamma = Fr::from_canonical(toxic + 8),
+                 delta = Fr::from_canonical(toxic + 12), t = Fr::from_canonical(toxic + 16);
+        const uint64_t root_limbs[4] = {0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL};
+        Fr w = Fr::from_montgomery(root_limbs);
+        for (int i = L; i < 32; i++) w = w * w;
+        const Fr zt = t.pow(n) - Fr::one();
+        if (zt.is_zero() || gamma.is_zero() || delta.is_zero()) return FRW_E_INVALID_ARG;       // t must lie outside the domain
+        // L_i(t) = zt w^i / (n (t - w^i)); the n inversions by Montgomery's trick
+        std::vector<Fr> lag(n), den(n), pre(n);
+        {
+            Fr wi = Fr::one(), acc = Fr::one();
+            for (size_t i = 0; i < n; i++) { lag[i] = wi; den[i] = t - wi; pre[i] = acc; acc = acc * den[i]; wi = wi * w; }
+            Fr inv = inverse(acc);
+            const Fr c = zt * inverse(Fr::from(n));
+            for (size_t i = n; i-- > 0;) { lag[i] = c * lag[i] * (inv * pre[i]); inv = inv * den[i]; }
+        }
+        std::vector<Fr> u(nv, Fr::zero()), v(nv, Fr::zero()), ww(nv, Fr::zero());
+        for (size_t i = 0; i < ni; i++) u[i] = lag[nc + i];                                    // r1cs_to_qap.rs: the input rows
+        for (size_t r = 0; r < nc; r++) {
+            for (const auto &e : m.a[r]) u[e.second] = u[e.second] + lag[r] * e.first;
+            for (const auto &e : m.b[r]) v[e.second] = v[e.second] + lag[r] * e.first;
+            for (const auto &e : m.c[r]) ww[e.second] = ww[e.second] + lag[r] * e.first;
+        }
+        const Fr dinv = inverse(delta), ginv = inverse(gamma);
+        auto canon = [](const std::vector<Fr> &x) { std::vector<uint64_t> o(4 * x.size()); for (size_t i = 0; i < x.size(); i++) x[i].to_canonical(&o[4 * i]); return o; };
+        std::vector<Fr> lq(nw), hq(n - 1), abc(ni), fixed = {alpha, beta, delta, gamma};
+        for (size_t i = 0; i < nv; i++) {
+            const Fr x = beta * u[i] + alpha * v[i] + ww[i];
+            if (i < ni) abc[i] = x * ginv; else lq[i - ni] = x * dinv;
+        }
+        { Fr x = zt * dinv; for (size_t i = 0; i + 1 < n; i++) { hq[i] = x; x = x * t; } }
+        std::vector<uint64_t> a_q(12 * nv), b1_q(12 * nv), b2_q(24 * nv), h_q(12 * (n - 1)), l_q(12 * nw), f1(12 * 4), f2(24 * 4), abc_q(12 * ni);
+        int rc = frw_g1_fixed_base(device, nv, canon(u).data(), a_q.data());
+        const std::vector<uint64_t> vc = canon(v);
+        if (rc == FRW_OK) rc = frw_g1_fixed_base(device, nv, vc.data(), b1_q.data());
+        if (rc == FRW_OK) rc = frw_g2_fixed_base(device, nv, vc.data(), b2_q.data());
+        if (rc == FRW_OK) rc = frw_g1_fixed_base(device, n - 1, canon(hq).data(), h_q.data());
+        if (rc == FRW_OK) rc = frw_g1_fixed_base(device, nw, canon(lq).data(), l_q.data());
+        if (rc == FRW_OK) rc = frw_g1_fixed_base(device, 4, canon(fixed).data(), f1.data());
+        if (rc == FRW_OK) rc = frw_g2_fixed_base(device, 4, canon(fixed).data(), f2.data());
+        if (rc == FRW_OK && vk_out) rc = frw_g1_fixed_base(device, ni, canon(abc).data(), abc_q.data());
+        if (rc != FRW_OK) return rc;
+        frw_groth16_pk_desc_t d{};
+        d.num_instance = ni; d.num_witness = nw; d.domain_size = n;
+        d.alpha_g1 = &f1[0]; d.beta_g1 = &f1[12]; d.delta_g1 = &f1[24];
+        d.beta_g2 = &f2[24]; d.delta_g2 = &f2[48];
+        d.a_query = a_q.data(); d.b_g1_query = b1_q.data(); d.b_g2_query = b2_q.data(); d.h_query = h_q.data(); d.l_query = l_q.data();
+        rc = frw_groth16_pk_load(device, &d, pk_out);
+        if (rc == FRW_OK && vk_out) {
+            std::memcpy(vk_out, &f1[0], 96);                       // alpha_g1
+            std::memcpy(vk_out + 12, &f2[24], 192);                // beta_g2
+            std::memcpy(vk_out + 36, &f2[72], 192);                // gamma_g2
+            std::memcpy(vk_out + 60, &f2[48], 192);                // delta_g2
+            std::memcpy(vk_out + 84, abc_q.data(), ni * 96);       // gamma_abc_g1
+        }
+        return rc;
+    } catch (const std::exception &) {
+        return FRW_E_OUT_OF_MEMORY;
+    }
+}

@@ -416,6 +416,17 @@ class WitnessEngine:
         check(self._lib.frw_groth16_pk_load(self.device, C.byref(d), C.byref(h)), "frw_groth16_pk_load")
         return h
 
+    def groth16_setup(self, circuit, logn, alpha, beta, gamma, delta, t):
+        """generate_parameters with the given toxic waste (Python integers) -> (proving-key handle, verifying key dict of uint64 arrays)."""
+        tox = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in (alpha, beta, gamma, delta, t)), dtype=np.uint64).copy()
+        L = layout_dual(logn) if circuit else layout(logn)
+        vk = np.zeros(84 + 12 * L.num_instance, dtype=np.uint64)
+        h = C.c_void_p()
+        check(self._lib.frw_groth16_setup(self.device, circuit, logn, tox.ctypes.data_as(C.c_void_p), C.byref(h),
+                                          vk.ctypes.data_as(C.c_void_p)), "frw_groth16_setup")
+        return h, {"alpha_g1": vk[:12], "beta_g2": vk[12:36], "gamma_g2": vk[36:60], "delta_g2": vk[60:84],
+                   "gamma_abc_g1": vk[84:].reshape(-1, 12)}
+
     def groth16_pk_free(self, handle):
         self._lib.frw_groth16_pk_free(handle)
 

@@ -370,6 +370,15 @@ typedef struct {
     const uint64_t *l_query;                               /* [W][12] */
 } frw_groth16_pk_desc_t;
 int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *desc, frw_groth16_pk **out);
+/* ark-groth16 0.3.0 generator.rs generate_parameters for one of the Falcon circuits, with the toxic waste GIVEN:
+ * toxic = uint64_t[5][4], canonical: alpha, beta, gamma, delta and the evaluation point t (circuit_specific_setup draws them
+ * from its rng, and random generators of G1 / G2; here the published generators are used).  The QAP is evaluated at t on the
+ * host (the circuit's matrices, Lagrange coefficients), the queries are fixed-base multiples made on the device, and the proving
+ * key comes back loaded.  vk_out (optional): alpha_g1 (12) | beta_g2 (24) | gamma_g2 (24) | delta_g2 (24) | gamma_abc_g1 [I][12]
+ * uint64_t -- the verifying key's elements in ark-ff's bytes.  FRW_E_INVALID_ARG if t lies in the domain or gamma / delta is 0.
+ * A key whose toxic waste somebody knows proves nothing to anybody else; this is for tests, benchmarks and ceremonies that
+ * combine contributions. */
+int frw_groth16_setup(int device, int circuit, int logn, const uint64_t *toxic, frw_groth16_pk **pk_out, uint64_t *vk_out);
 void frw_groth16_pk_free(frw_groth16_pk *pk);
 size_t frw_groth16_workspace_bytes(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch_in_flight);
 int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch, const uint64_t *d_witness,

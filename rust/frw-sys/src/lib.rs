@@ -190,6 +190,8 @@ extern "C" {
                                  d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_groth16_pk_load(device: c_int, desc: *const frw_groth16_pk_desc_t, out: *mut *mut frw_groth16_pk) -> c_int;
     pub fn frw_groth16_pk_free(pk: *mut frw_groth16_pk);
+    pub fn frw_groth16_setup(device: c_int, circuit: c_int, logn: c_int, toxic: *const u64, pk_out: *mut *mut frw_groth16_pk,
+                             vk_out: *mut u64) -> c_int;
     pub fn frw_groth16_workspace_bytes(pk: *const frw_groth16_pk, r: *const frw_r1cs, batch_in_flight: usize) -> usize;
     pub fn frw_groth16_prove_dev(pk: *const frw_groth16_pk, r: *const frw_r1cs, batch: usize, d_witness: *const u64,
                                  d_instance: *const u64, rs: *const u64, d_proofs: *mut u64, d_num_unsatisfied: *mut u32,

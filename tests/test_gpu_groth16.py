@@ -104,3 +104,66 @@ def test_proofs_equal_the_prover_restated_in_the_exponent(engine, oracle, tmp_pa
     finally:
         engine.r1cs_free(r1cs)
         engine.groth16_pk_free(handle)
+
+
+def test_setup_on_the_product_side_makes_the_same_key(engine, oracle, tmp_path):
+    """frw_groth16_setup (generator.rs generate_parameters with the toxic waste given: QAP at t on the host, queries as
+    fixed-base multiples on the device) against oracle/bls12_381.py::setup_exponents for Falcon-512: the verifying key's
+    elements are the generator multiples the oracle's exponents give, and proofs made with the returned proving key equal the
+    prover restated in the exponent -- which could not be if any query element differed."""
+    import torch
+    import falcon_r1cs_amd as frw
+    from test_r1cs_export import export, read_r1cs
+    dev = torch.device("cuda:0")
+    logn, batch = 9, 2
+    L = frw.layout(logn)
+    export(0, logn, tmp_path / "c.r1cs")
+    ni, nw, nc, mats = read_r1cs(tmp_path / "c.r1cs")
+    d = qap.Domain(nc + ni)
+    n = d.size
+    rng = random.Random(61)
+    toxic = {k: rng.randrange(2, E.R) for k in ("alpha", "beta", "gamma", "delta", "t")}
+    pk = E.setup_exponents(tuple(_rows(*m) for m in mats), ni, nw, d, toxic)
+    handle, vk = engine.groth16_setup(0, logn, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["t"])
+    gen = oracle.g1_generator()
+    assert vk["alpha_g1"].tolist() == oracle.g1_scalar_mul(gen, toxic["alpha"]).tolist()
+    for name in ("beta", "gamma", "delta"):
+        assert vk[name + "_g2"].tolist() == E.g2_to_limbs(E.g2_mul(E.G2, toxic[name])), name
+    assert vk["gamma_abc_g1"].shape == (ni, 12)
+    for i in (0, 1, ni // 2, ni - 1):
+        assert vk["gamma_abc_g1"][i].tolist() == oracle.g1_scalar_mul(gen, pk["gamma_abc"][i]).tolist(), i
+    r1cs = engine.r1cs_load(0, logn)
+    try:
+        sig, pk_, hm = frw.synth_triples(logn, batch, seed=1618)
+        dd = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk_, hm)]
+        wit = torch.empty((batch, nw, 4), dtype=torch.int64, device=dev)
+        inst = torch.empty((batch, ni, 4), dtype=torch.int64, device=dev)
+        st = torch.empty(batch, dtype=torch.int32, device=dev)
+        s0 = torch.cuda.current_stream().cuda_stream
+        engine.witness_ntt_verify_dev(logn, batch, dd[0], dd[1], dd[2], wit, inst, st, 1, s0)
+        rs = [[rng.randrange(E.R), rng.randrange(E.R)] for _ in range(batch)]
+        ws_bytes = engine.groth16_workspace_bytes(handle, r1cs, batch)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        proofs = torch.empty((batch, 48), dtype=torch.int64, device=dev)
+        engine.groth16_prove_dev(handle, r1cs, batch, wit, inst, np.array([T.ints_to_limbs(x) for x in rs]), proofs, ws, ws_bytes, None, s0)
+        q = engine.qap_info(r1cs)
+        qws = torch.empty(batch * int(q.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+        h = torch.empty((batch, n, 4), dtype=torch.int64, device=dev)
+        engine.qap_witness_map_dev(r1cs, batch, wit, inst, h, qws, qws.numel(), None, s0)
+        torch.cuda.synchronize()
+        got = proofs.cpu().numpy().view(np.uint64)
+        r_inv = pow(FR_R, -1, E.R)
+        for i in range(batch):
+            z = [v * r_inv % E.R for v in T.limbs_to_ints(inst[i].cpu().numpy().view(np.uint64))] + \
+                [v * r_inv % E.R for v in T.limbs_to_ints(wit[i].cpu().numpy().view(np.uint64))]
+            h_int = [v * r_inv % E.R for v in T.limbs_to_ints(h[i].cpu().numpy().view(np.uint64))]
+            a, b, c, _ = E.prove_exponents(pk, z, h_int, rs[i][0], rs[i][1])
+            assert E.verify_exponents(pk, z[1:ni], (a, b, c))
+            assert got[i, :12].tolist() == oracle.g1_scalar_mul(gen, a).tolist()
+            assert got[i, 12:36].tolist() == E.g2_to_limbs(E.g2_mul(E.G2, b))
+            assert got[i, 36:].tolist() == oracle.g1_scalar_mul(gen, c).tolist()
+        with pytest.raises(frw.FrwError):                          # t inside the domain: zt = 0
+            engine.groth16_setup(0, logn, 3, 5, 7, 11, d.group_gen)
+    finally:
+        engine.r1cs_free(r1cs)
+        engine.groth16_pk_free(handle)
