@@ -238,3 +238,145 @@ def g2_from_limbs(limbs):
     inv = pow(FQ_R, -1, Q)
     v = [sum(l << (64 * i) for i, l in enumerate(limbs[6 * c:6 * c + 6])) * inv % Q for c in range(4)]
     return (v[0], v[1]), (v[2], v[3])
+
+
+# ---- the pairing: e: G1 x G2 -> Fq12, for verify_proof (ark-groth16 0.3.0 verifier.rs) -------------------------------------------------
+# Restated the plain way (no towers, no sparse lines, no cyclotomic tricks): Fq12 = Fq[w] / (w^12 - 2 w^6 + 2) -- with
+# u = w^6 - 1 this contains Fq2 = Fq[u] / (u^2 + 1) and w^6 = 1 + u is the twist's non-residue --, the ate Miller loop over
+# |z| = 0xd201000000010000 in affine coordinates on E(Fq12), and the final exponentiation as one power (q^12 - 1) / r.
+# The sign of z is ignored (the loop runs over |z|): the map is then the inverse of the ate pairing, which is as bilinear and
+# non-degenerate as the pairing itself, and every use here compares products of such values with each other.
+# Pinned by tests/test_bls12_381.py: bilinearity e(a P, b Q) = e(P, Q)^(a b), e(P, Q)^r = 1, e(P, Q) != 1.
+F12_MOD = (2, 0, 0, 0, 0, 0, -2, 0, 0, 0, 0, 0)          # w^12 = 2 w^6 - 2
+
+
+def f12_mul(a, b):
+    t = [0] * 23
+    for i, x in enumerate(a):
+        if x:
+            for j, y in enumerate(b):
+                t[i + j] += x * y
+    for k in range(22, 11, -1):                             # w^k = 2 w^(k-6) - 2 w^(k-12)
+        c = t[k]
+        if c:
+            t[k - 6] += 2 * c
+            t[k - 12] -= 2 * c
+    return tuple(v % Q for v in t[:12])
+
+
+def f12_add(a, b):
+    return tuple((x + y) % Q for x, y in zip(a, b))
+
+
+def f12_sub(a, b):
+    return tuple((x - y) % Q for x, y in zip(a, b))
+
+
+F12_ONE = (1,) + (0,) * 11
+
+
+def f12_from_fq(x):
+    return (x % Q,) + (0,) * 11
+
+
+def f12_from_fq2(a):
+    """a0 + a1 u with u = w^6 - 1."""
+    return ((a[0] - a[1]) % Q, 0, 0, 0, 0, 0, a[1] % Q, 0, 0, 0, 0, 0)
+
+
+def _poly_divmod(a, b):
+    a = list(a)
+    out = [0] * max(1, len(a) - len(b) + 1)
+    inv = pow(b[-1], -1, Q)
+    for i in range(len(a) - len(b), -1, -1):
+        c = a[i + len(b) - 1] * inv % Q
+        out[i] = c
+        if c:
+            for j, y in enumerate(b):
+                a[i + j] = (a[i + j] - c * y) % Q
+    while len(a) > 1 and a[-1] == 0:
+        a.pop()
+    return out, a
+
+
+def f12_inv(a):
+    """Extended Euclid in Fq[w] against the modulus."""
+    mod = [2, 0, 0, 0, 0, 0, Q - 2, 0, 0, 0, 0, 0, 1]
+    r0, r1 = mod, list(a)
+    while len(r1) > 1 and r1[-1] == 0:
+        r1.pop()
+    s0, s1 = [0], [1]
+    while any(r1) and len(r1) > 1:
+        qq, rem = _poly_divmod(r0, r1)
+        prod = [0] * (len(qq) + len(s1) - 1)
+        for i, x in enumerate(qq):
+            for j, y in enumerate(s1):
+                prod[i + j] = (prod[i + j] + x * y) % Q
+        s2 = [((s0[i] if i < len(s0) else 0) - (prod[i] if i < len(prod) else 0)) % Q for i in range(max(len(s0), len(prod)))]
+        r0, r1, s0, s1 = r1, rem, s1, s2
+    inv = pow(r1[0], -1, Q)
+    return tuple((s1[i] * inv % Q if i < len(s1) else 0) for i in range(12))
+
+
+def f12_pow(a, e):
+    acc = F12_ONE
+    while e:
+        if e & 1:
+            acc = f12_mul(acc, a)
+        a = f12_mul(a, a)
+        e >>= 1
+    return acc
+
+
+_W2_INV = f12_inv((0, 0, 1) + (0,) * 9)
+_W3_INV = f12_inv((0, 0, 0, 1) + (0,) * 8)
+
+
+def _untwist(q):
+    """E'(Fq2) -> E(Fq12): (x, y) -> (x / w^2, y / w^3): then Y^2 - X^3 = (y^2 - x^3) / w^6 = 4 (1 + u) / (1 + u) = 4."""
+    return f12_mul(f12_from_fq2(q[0]), _W2_INV), f12_mul(f12_from_fq2(q[1]), _W3_INV)
+
+
+def _line(a, b, p):
+    """The line through a and b (the tangent if a = b) on E(Fq12), evaluated at p; and a + b."""
+    if a[0] != b[0]:
+        lam = f12_mul(f12_sub(b[1], a[1]), f12_inv(f12_sub(b[0], a[0])))
+    else:
+        lam = f12_mul(f12_mul(f12_from_fq(3), f12_mul(a[0], a[0])), f12_inv(f12_add(a[1], a[1])))
+    val = f12_sub(f12_sub(p[1], a[1]), f12_mul(lam, f12_sub(p[0], a[0])))
+    x3 = f12_sub(f12_sub(f12_mul(lam, lam), a[0]), b[0])
+    return val, (x3, f12_sub(f12_mul(lam, f12_sub(a[0], x3)), a[1]))
+
+
+def miller_loop(p, q):
+    """f_{|z|, Q}(P) for P in G1 and Q in G2 (affine tuples; either None -> 1)."""
+    if p is None or q is None:
+        return F12_ONE
+    pp = (f12_from_fq(p[0]), f12_from_fq(p[1]))
+    qq = _untwist(q)
+    t, f = qq, F12_ONE
+    for bit in bin(-Z_BLS)[3:]:
+        val, t = _line(t, t, pp)
+        f = f12_mul(f12_mul(f, f), val)
+        if bit == "1":
+            val, t = _line(t, qq, pp)
+            f = f12_mul(f, val)
+    return f
+
+
+FINAL_EXPONENT = (Q ** 12 - 1) // R
+
+
+def pairing(p, q):
+    return f12_pow(miller_loop(p, q), FINAL_EXPONENT)
+
+
+def verify_proof(vk, public_inputs, proof):
+    """ark-groth16 0.3.0 verifier.rs verify_proof: e(A, B) = e(alpha_g1, beta_g2) e(sum x_i gamma_abc_g1[i], gamma_g2) e(C, delta_g2)
+    (prepared as one product of Miller loops and one final exponentiation: e(A, B) e(-acc, gamma) e(-C, delta) == e(alpha, beta)).
+    vk: dict of affine points alpha_g1, beta_g2, gamma_g2, delta_g2 and the list gamma_abc_g1; proof = (A, B, C) affine."""
+    acc = vk["gamma_abc_g1"][0]
+    for x, g in zip(public_inputs, vk["gamma_abc_g1"][1:]):
+        acc = add(acc, mul(g, x))
+    f = f12_mul(f12_mul(miller_loop(proof[0], proof[1]), miller_loop(neg(acc), vk["gamma_g2"])), miller_loop(neg(proof[2]), vk["delta_g2"]))
+    return f12_pow(f, FINAL_EXPONENT) == pairing(vk["alpha_g1"], vk["beta_g2"])

@@ -107,3 +107,30 @@ def test_h_query_msm_has_an_msm_free_value(oracle):
     assert E.msm_naive([E.from_limbs(b) for b in bases], h[:d.size - 1]) == expected
     assert oracle.g1_msm(bases, T.ints_to_limbs(h[:d.size - 1]), 5).tolist() == E.to_limbs(expected)
     assert E.prove_exponents(pk, z, h, 0, 0)[3] == h_at_t * pk["zt"] % E.R * pow(toxic["delta"], -1, E.R) % E.R
+
+
+def test_pairing_is_bilinear_and_verifies_a_real_proof():
+    """The plain restatement of the pairing (Fq12 as Fq[w] / (w^12 - 2 w^6 + 2), affine ate Miller loop, one big final power):
+    bilinear, of order r, non-degenerate -- and with it ark-groth16's verify_proof on ACTUAL points: the proof of the toy system
+    made by the restated prover (exponents -> points) verifies, another statement and a tampered C do not."""
+    rng = random.Random(12)
+    e1 = E.pairing(E.G1, E.G2)
+    assert e1 != E.F12_ONE and E.f12_pow(e1, E.R) == E.F12_ONE
+    a, b = rng.randrange(1, E.R), rng.randrange(1, E.R)
+    assert E.pairing(E.mul(E.G1, a), E.g2_mul(E.G2, b)) == E.f12_pow(e1, a * b % E.R)
+    assert E.pairing(E.add(E.mul(E.G1, a), E.G1), E.G2) == E.f12_mul(E.f12_pow(e1, a), e1)         # additive in the first argument
+    assert E.pairing(None, E.G2) == E.F12_ONE and E.pairing(E.G1, None) == E.F12_ONE
+    x = tuple(rng.randrange(E.Q) for _ in range(12))
+    assert E.f12_mul(x, E.f12_inv(x)) == E.F12_ONE
+    mats, ni, nw, z = _toy_system()
+    d = Q.Domain(len(mats[0]) + ni)
+    toxic = {k: rng.randrange(2, E.R) for k in ("alpha", "beta", "gamma", "delta", "t")}
+    pk = E.setup_exponents(mats, ni, nw, d, toxic)
+    h = Q.witness_map(mats, ni, z)
+    pa, pb, pc, _ = E.prove_exponents(pk, z, h, rng.randrange(E.R), rng.randrange(E.R))
+    vk = {"alpha_g1": E.mul(E.G1, toxic["alpha"]), "beta_g2": E.g2_mul(E.G2, toxic["beta"]), "gamma_g2": E.g2_mul(E.G2, toxic["gamma"]),
+          "delta_g2": E.g2_mul(E.G2, toxic["delta"]), "gamma_abc_g1": [E.mul(E.G1, g) for g in pk["gamma_abc"]]}
+    proof = (E.mul(E.G1, pa), E.g2_mul(E.G2, pb), E.mul(E.G1, pc))
+    assert E.verify_proof(vk, z[1:ni], proof)
+    assert not E.verify_proof(vk, [36, 70], proof)
+    assert not E.verify_proof(vk, z[1:ni], (proof[0], proof[1], E.add(proof[2], E.G1)))

@@ -162,6 +162,19 @@ def test_setup_on_the_product_side_makes_the_same_key(engine, oracle, tmp_path):
             assert got[i, :12].tolist() == oracle.g1_scalar_mul(gen, a).tolist()
             assert got[i, 12:36].tolist() == E.g2_to_limbs(E.g2_mul(E.G2, b))
             assert got[i, 36:].tolist() == oracle.g1_scalar_mul(gen, c).tolist()
+        # ... and the flow of examples/pok_sig.rs:30-47 end to end, with nothing known in the exponent: the key from
+        # frw_groth16_setup, the proof from frw_groth16_prove_dev, and ark-groth16's verify_proof restated with a real pairing
+        # (oracle/bls12_381.py): e(A, B) = e(alpha, beta) e(sum x_i gamma_abc_i, gamma) e(C, delta)
+        vk_pts = {"alpha_g1": E.from_limbs(vk["alpha_g1"]), "beta_g2": E.g2_from_limbs(vk["beta_g2"]),
+                  "gamma_g2": E.g2_from_limbs(vk["gamma_g2"]), "delta_g2": E.g2_from_limbs(vk["delta_g2"]),
+                  "gamma_abc_g1": [E.from_limbs(row) for row in vk["gamma_abc_g1"]]}
+        z0 = [v * r_inv % E.R for v in T.limbs_to_ints(inst[0].cpu().numpy().view(np.uint64))]
+        proof0 = (E.from_limbs(got[0, :12]), E.g2_from_limbs(got[0, 12:36]), E.from_limbs(got[0, 36:]))
+        assert all(E.on_curve(p_) for p_ in (proof0[0], proof0[2])) and E.g2_on_curve(proof0[1])
+        assert E.verify_proof(vk_pts, z0[1:], proof0), "verify_proof rejects the device's proof"
+        wrong = list(z0[1:])
+        wrong[7] = (wrong[7] + 1) % E.R
+        assert not E.verify_proof(vk_pts, wrong, proof0)
         with pytest.raises(frw.FrwError):                          # t inside the domain: zt = 0
             engine.groth16_setup(0, logn, 3, 5, 7, 11, d.group_gen)
     finally:
