@@ -42,3 +42,27 @@ def test_example_satisfied_on_engine(example_bin):
         out = subprocess.run([example_bin, str(logn)], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and out.stdout.count("satisfied") >= 2 and "NOT satisfied" not in out.stdout, out.stdout
         assert "HIP engine" in out.stdout
+
+
+@pytest.mark.gpu
+def test_pok_sig_example_produces_a_proof_the_oracle_verifier_accepts():
+    """examples/pok_sig.py = the reference's examples/pok_sig.rs on the engine, for a genuine Falcon-512 signature: encoded
+    (pk, msg, sig) -> decoders + SHAKE256 -> witness -> setup -> proof, all on the device; ark-groth16's verify_proof, restated
+    with a real pairing in oracle/bls12_381.py, accepts it for the printed public inputs and rejects it for others."""
+    import json
+    import sys
+    from oracle import bls12_381 as E
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "pok_sig.py"), os.path.join(ROOT, "tests", "golden", "falcon_signed.json"),
+                          "--case", "0", "--seed", "7", "--json"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    ints = lambda hx: [int(v, 16) for v in hx]
+    vk = {"alpha_g1": E.from_limbs(ints(j["vk"]["alpha_g1"])), "beta_g2": E.g2_from_limbs(ints(j["vk"]["beta_g2"])),
+          "gamma_g2": E.g2_from_limbs(ints(j["vk"]["gamma_g2"])), "delta_g2": E.g2_from_limbs(ints(j["vk"]["delta_g2"])),
+          "gamma_abc_g1": [E.from_limbs(ints(r)) for r in j["vk"]["gamma_abc_g1"]]}
+    proof = (E.from_limbs(ints(j["proof"]["a"])), E.g2_from_limbs(ints(j["proof"]["b"])), E.from_limbs(ints(j["proof"]["c"])))
+    public = [int(x) for x in j["public_inputs"]]
+    assert len(public) == 1024 and all(x < 12289 for x in public)            # pk_ntt || hm_ntt of a Falcon-512 signature
+    assert E.verify_proof(vk, public, proof)
+    public[0] = (public[0] + 1) % 12289
+    assert not E.verify_proof(vk, public, proof)
