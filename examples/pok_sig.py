@@ -6,8 +6,8 @@
                                                                         holds triples made by the specification's algorithms)
     pok_sig.rs:24-31   build_circuit; circuit_specific_setup          -> frw_prepare_inputs; frw_groth16_setup (toxic waste from --seed)
     pok_sig.rs:32      create_random_proof                            -> frw_witness_ntt_verify_dev + frw_groth16_prove_dev
-    pok_sig.rs:34-47   public inputs pk_ntt || hm_ntt; verify_proof   -> printed; verification needs pairings, which the product does not
-                                                                        have: tests/test_examples.py verifies this output with the oracle's
+    pok_sig.rs:34-47   public inputs pk_ntt || hm_ntt; verify_proof   -> frw_groth16_verify (host pairing) on the instance buffer and the
+                                                                        proof as the device wrote them; and again for a wrong statement
 
     python examples/pok_sig.py tests/golden/falcon_signed.json [--case 0] [--seed 1] [--json]
 """
@@ -64,18 +64,28 @@ def main():
     if int(bad[0]) != 0:
         raise SystemExit("the witness violates %d constraints" % int(bad[0]))
     p = proof.cpu().numpy().view(np.uint64)[0]
+    # Groth16::verify(&vk, &public_inputs, &proof)                                             pok_sig.rs:47
+    verifier = frw.Groth16Verifier(vk)
+    inst_h = inst.cpu().numpy().view(np.uint64)
+    accepted = int(verifier.verify(inst_h, p[None])[0])
+    other = inst_h.copy()
+    other[0, 1, 0] ^= np.uint64(1)                                                           # another public key
+    accepted_other = int(verifier.verify(other, p[None])[0])
+    verifier.close()
+    if accepted != 1 or accepted_other != 0:
+        raise SystemExit("verify_proof: %d for the statement proved, %d for another one" % (accepted, accepted_other))
     # public inputs: pk_ntt || hm_ntt                                                        pok_sig.rs:38-45
     r_inv = pow(1 << 256, -1, R)
     public = [int.from_bytes(row.tobytes(), "little") * r_inv % R for row in inst[0, 1:].cpu().numpy().view(np.uint64)]
     hexl = lambda a: ["%016x" % int(v) for v in a]
     if args.json:
-        print(json.dumps({"logn": logn, "public_inputs": [str(x) for x in public], "proof": {"a": hexl(p[:12]), "b": hexl(p[12:36]), "c": hexl(p[36:])},
+        print(json.dumps({"logn": logn, "verified": accepted == 1, "public_inputs": [str(x) for x in public], "proof": {"a": hexl(p[:12]), "b": hexl(p[12:36]), "c": hexl(p[36:])},
                           "vk": {k: (hexl(v) if v.ndim == 1 else [hexl(r) for r in v]) for k, v in vk.items()}}))
     else:
         print("Falcon-%d signature on %r: Groth16 proof made on the device" % (L.n, bytes.fromhex(case["msg"])))
         print("  %d constraints, %d witnesses, %d public inputs (pk_ntt || hm_ntt)" % (L.num_constraints, L.num_witness, len(public)))
         print("  A.x = 0x%s..." % "".join(reversed(hexl(p[:6])))[:48])
-        print("  (verify_proof needs pairings: run with --json and see tests/test_examples.py)")
+        print("  verify_proof: accepted; for another public key: rejected")
     eng.r1cs_free(r1cs)
     eng.groth16_pk_free(key)
     eng.close()

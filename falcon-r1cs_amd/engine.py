@@ -88,6 +88,56 @@ def synth_triples(logn, batch, seed=0x46414C434F4E, first_index=0):
     return tuple(out)
 
 
+VERIFY_POINTS_ARE_CHECKED = 1
+
+
+class Groth16Verifier:
+    """ark-groth16's prepared verifying key + verify_proof (examples/pok_sig.rs:34-47).  Host code: no device involved.
+
+    vk: the dict WitnessEngine.groth16_setup returns, or one flat uint64 array in frw_groth16_setup's vk_out layout."""
+
+    def __init__(self, vk):
+        self._lib = load_library()
+        if isinstance(vk, dict):
+            vk = np.concatenate([np.asarray(vk[k], dtype=np.uint64).reshape(-1) for k in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1")])
+        vk = np.ascontiguousarray(vk, dtype=np.uint64).reshape(-1)
+        if vk.size < 96 or (vk.size - 84) % 12:
+            raise FrwError("verifying key: expected 84 + 12 x num_instance uint64 values")
+        self.num_instance = (vk.size - 84) // 12
+        self._h = C.c_void_p()
+        check(self._lib.frw_groth16_vk_load(vk.ctypes.data_as(C.c_void_p), self.num_instance, C.byref(self._h)), "frw_groth16_vk_load")
+
+    def verify(self, instance, proofs, encoding=ENC_MONTGOMERY, flags=0):
+        """instance: uint64[batch, num_instance, 4] as the witness entry points write it (the constant one first);
+        proofs: uint64[batch, 48].  Returns int32[batch]: 1 accepted, 0 rejected, -1 malformed."""
+        proofs = np.ascontiguousarray(proofs).view(np.uint64).reshape(-1, 48)
+        instance = np.ascontiguousarray(instance).view(np.uint64).reshape(proofs.shape[0], self.num_instance, 4)
+        out = np.zeros(proofs.shape[0], dtype=np.int32)
+        check(self._lib.frw_groth16_verify(self._h, proofs.shape[0], instance.ctypes.data_as(C.c_void_p), int(encoding),
+                                           proofs.ctypes.data_as(C.c_void_p), int(flags), out.ctypes.data_as(C.c_void_p)), "frw_groth16_verify")
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.frw_groth16_vk_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def diag_pairing(g1, g2):
+    """The verifier's pairing of one pair (ark-ff limbs: 12 and 24 uint64): uint64[12, 6], see frw.h."""
+    g1 = np.ascontiguousarray(g1, dtype=np.uint64).reshape(12)
+    g2 = np.ascontiguousarray(g2, dtype=np.uint64).reshape(24)
+    out = np.zeros((12, 6), dtype=np.uint64)
+    check(load_library().frw_diag_pairing(g1.ctypes.data_as(C.c_void_p), g2.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "frw_diag_pairing")
+    return out
+
+
 def _u16(a, n):
     a = np.ascontiguousarray(a, dtype=np.uint16)
     if a.ndim == 1:

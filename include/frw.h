@@ -385,6 +385,31 @@ int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t ba
                           const uint64_t *d_instance, const uint64_t *rs, uint64_t *d_proofs, uint32_t *d_num_unsatisfied,
                           void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Groth16 verification (examples/pok_sig.rs:34-47: Groth16::verify(&vk, &public_inputs, &proof)) --------------------------------
+ * ark-groth16 0.3.0 verifier.rs: prepare_verifying_key (e(alpha_g1, beta_g2), -gamma_g2, -delta_g2), prepare_inputs
+ * (gamma_abc_g1[0] + sum x_i gamma_abc_g1[i]) and verify_proof: e(A, B) e(inputs, -gamma_g2) e(C, -delta_g2) == e(alpha_g1, beta_g2)
+ * as one product of three Miller loops and one final exponentiation.  HOST code like the reference's (about 15 ms per proof on
+ * one core; a batch runs one proof per host thread); no device is needed.
+ *     vk          the layout frw_groth16_setup writes: alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | gamma_abc_g1[num_instance]
+ *                 (FRW_E_INVALID_ARG if a point is not on its curve, or one of the first four not in the subgroup of order r)
+ *     instance    uint64_t[batch][num_instance][4], encoding FRW_ENC_MONTGOMERY or FRW_ENC_CANONICAL: the instance vector AS THE
+ *                 WITNESS ENTRY POINTS WRITE IT, i.e. the constant one first and then ark's public inputs (pk_ntt || hm_ntt)
+ *     proofs      uint64_t[batch][48]: A | B | C as frw_groth16_prove_dev writes them
+ *     flags       FRW_VERIFY_POINTS_ARE_CHECKED: skip the subgroup checks of A, B, C (ark checks them when it deserialises a proof;
+ *                 these are raw limbs, so the check is made here unless the caller vouches for the points)
+ *     accepted    int32_t[batch]: 1 the proof verifies, 0 it does not, -1 malformed (a value >= r, instance[0] != 1, a point off
+ *                 its curve or outside the subgroup) */
+#define FRW_VERIFY_POINTS_ARE_CHECKED 1
+typedef struct frw_groth16_vk frw_groth16_vk;
+int frw_groth16_vk_load(const uint64_t *vk, size_t num_instance, frw_groth16_vk **out);
+void frw_groth16_vk_free(frw_groth16_vk *vk);
+int frw_groth16_verify(const frw_groth16_vk *vk, size_t batch, const uint64_t *instance, int encoding, const uint64_t *proofs,
+                       int flags, int32_t *accepted);
+/* diagnostics for the parity tests: the verifier's pairing of one pair (g1: 12, g2: 24 uint64_t), written as the twelve
+ * coefficients of 1, w, ..., w^11 in Fq[w] / (w^12 - 2 w^6 + 2), 6 uint64_t each in ark-ff's form.  The value is the CUBE of the
+ * reduced ate pairing (frw_pairing.h says why that is as good). */
+int frw_diag_pairing(const uint64_t *g1, const uint64_t *g2, uint64_t *out);
+
 /* ---- input preparation (what the reference does with falcon-rust before any gadget runs) ---------------------
  * falcon_ntt.rs:27-28,44: sig_poly = Polynomial::from(&sig), pk_poly = Polynomial::from(&pk),
  * hm = Polynomial::from_hash_of_message(msg, sig.nonce()).  Formats are the Falcon specification's:

@@ -103,6 +103,11 @@ pub struct frw_groth16_pk {
     _private: [u8; 0],
 }
 #[repr(C)]
+pub struct frw_groth16_vk {
+    _private: [u8; 0],
+}
+pub const FRW_VERIFY_POINTS_ARE_CHECKED: c_int = 1;
+#[repr(C)]
 #[derive(Clone, Copy, Debug)]
 pub struct frw_groth16_pk_desc_t {
     pub num_instance: u64,
@@ -196,6 +201,11 @@ extern "C" {
     pub fn frw_groth16_prove_dev(pk: *const frw_groth16_pk, r: *const frw_r1cs, batch: usize, d_witness: *const u64,
                                  d_instance: *const u64, rs: *const u64, d_proofs: *mut u64, d_num_unsatisfied: *mut u32,
                                  d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn frw_groth16_vk_load(vk: *const u64, num_instance: usize, out: *mut *mut frw_groth16_vk) -> c_int;
+    pub fn frw_groth16_vk_free(vk: *mut frw_groth16_vk);
+    pub fn frw_groth16_verify(vk: *const frw_groth16_vk, batch: usize, instance: *const u64, encoding: c_int, proofs: *const u64,
+                              flags: c_int, accepted: *mut i32) -> c_int;
+    pub fn frw_diag_pairing(g1: *const u64, g2: *const u64, out: *mut u64) -> c_int;
     pub fn frw_hash_to_point_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_nonces: *const u8, d_msgs: *const u8,
                                  d_msg_off: *const u64, d_hm: *mut u16, stream: *mut c_void) -> c_int;
     pub fn frw_decode_public_keys_dev(ctx: *mut frw_ctx, logn: c_int, batch: usize, d_pk_bytes: *const u8,

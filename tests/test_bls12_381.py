@@ -20,7 +20,7 @@ def test_published_parameters_and_generator():
     for _ in range(3):
         k = rng.randrange(E.R)
         p = E.mul(E.G1, k)
-        assert E.on_curve(p) and E.mul(p, E.R) is None
+        assert E.on_curve(p) and E.add(E.mul(p, E.R - 1), p) is None      # (mul reduces its scalar mod r)
         assert E.add(p, E.neg(p)) is None and E.add(p, p) == E.mul(E.G1, 2 * k)
 
 

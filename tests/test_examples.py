@@ -47,8 +47,10 @@ def test_example_satisfied_on_engine(example_bin):
 @pytest.mark.gpu
 def test_pok_sig_example_produces_a_proof_the_oracle_verifier_accepts():
     """examples/pok_sig.py = the reference's examples/pok_sig.rs on the engine, for a genuine Falcon-512 signature: encoded
-    (pk, msg, sig) -> decoders + SHAKE256 -> witness -> setup -> proof, all on the device; ark-groth16's verify_proof, restated
-    with a real pairing in oracle/bls12_381.py, accepts it for the printed public inputs and rejects it for others."""
+    (pk, msg, sig) -> decoders + SHAKE256 -> witness -> setup -> proof, all on the device, then the product's verifier (the
+    example exits non-zero unless it accepts the statement and rejects another).  Independently of that: ark-groth16's
+    verify_proof, restated with a real pairing in oracle/bls12_381.py, accepts the printed proof for the printed public
+    inputs and rejects it for others."""
     import json
     import sys
     from oracle import bls12_381 as E
@@ -62,6 +64,7 @@ def test_pok_sig_example_produces_a_proof_the_oracle_verifier_accepts():
           "gamma_abc_g1": [E.from_limbs(ints(r)) for r in j["vk"]["gamma_abc_g1"]]}
     proof = (E.from_limbs(ints(j["proof"]["a"])), E.g2_from_limbs(ints(j["proof"]["b"])), E.from_limbs(ints(j["proof"]["c"])))
     public = [int(x) for x in j["public_inputs"]]
+    assert j["verified"] is True
     assert len(public) == 1024 and all(x < 12289 for x in public)            # pk_ntt || hm_ntt of a Falcon-512 signature
     assert E.verify_proof(vk, public, proof)
     public[0] = (public[0] + 1) % 12289

@@ -175,6 +175,17 @@ def test_setup_on_the_product_side_makes_the_same_key(engine, oracle, tmp_path):
         wrong = list(z0[1:])
         wrong[7] = (wrong[7] + 1) % E.R
         assert not E.verify_proof(vk_pts, wrong, proof0)
+        # the product's own verifier (frw_groth16_verify: host pairing, frw_pairing.h) says the same about every proof of the
+        # batch, taking the instance buffer and the proofs exactly as the device wrote them
+        ver = frw.Groth16Verifier(vk)
+        inst_h = inst.cpu().numpy().view(np.uint64)
+        assert ver.verify(inst_h, got).tolist() == [1] * batch
+        tampered = inst_h.copy()
+        tampered[1, 8, 0] ^= np.uint64(2)
+        swapped = got[::-1].copy()                                  # proof i with statement 1 - i
+        assert ver.verify(tampered, got).tolist() == [1, 0]
+        assert ver.verify(inst_h, swapped).tolist() == [0, 0]
+        ver.close()
         with pytest.raises(frw.FrwError):                          # t inside the domain: zt = 0
             engine.groth16_setup(0, logn, 3, 5, 7, 11, d.group_gen)
     finally:
