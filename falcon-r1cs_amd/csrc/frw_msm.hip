@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <vector>
 #include "../../include/frw.h"
 #include "frw_device.h"
@@ -768,6 +769,7 @@ struct frw_groth16_pk {
     // of a few ten thousand pairs are latency, not throughput, and hide behind the 2^18-point sum
     hipStream_t side[4];
     hipEvent_t fork, join[4];
+    std::mutex enqueue;         // the side streams and events are the key's: one call at a time puts its work on them
 };
 
 extern "C" void frw_groth16_pk_free(frw_groth16_pk *pk)
@@ -883,8 +885,10 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
     if (chunk == 0 || ((uintptr_t)d_workspace & 255)) return FRW_E_INVALID_ARG;
     const size_t I = (size_t)pk->num_instance, W = (size_t)pk->num_witness, nv = I + W, n = (size_t)pk->domain_size, stride = nv + 3;
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(const_cast<frw_groth16_pk *>(pk)->enqueue);
     hipError_t e = hipSetDevice(pk->device);
     int rc = FRW_OK;
+    bool forked = false;
     for (size_t lo = 0; e == hipSuccess && rc == FRW_OK && lo < batch; lo += chunk) {
         const size_t cnt = std::min(chunk, batch - lo);
         char *base = (char *)d_workspace;
@@ -907,6 +911,7 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
                            (uint32_t *)zext, stride * 8, nv);
         e = hipEventRecord(pk->fork, st);
+        forked = true;
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(pk->side[i], pk->fork, 0);
         if (e != hipSuccess) break;
         rc = frw_msm_g2_dev(pk->b2, cnt, zext, stride, 1, pB2, msm_ws[4], cnt * sz.msm[4], pk->side[3]);      // the longest of the four first
@@ -932,6 +937,11 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
                            (uint32_t *)(d_proofs + lo * 48));
         e = hipGetLastError();
     }
-    if (e != hipSuccess) return frw::record_hip_error(e, "frw_groth16_prove_dev");
-    return rc;
+    if (e != hipSuccess || rc != FRW_OK) {
+        // a call that gave up half way may have work on the side streams that nothing joins: wait for it here, so that the
+        // caller can release the workspace when the error comes back
+        if (forked) (void)hipDeviceSynchronize();
+        return e != hipSuccess ? frw::record_hip_error(e, "frw_groth16_prove_dev") : rc;
+    }
+    return FRW_OK;
 }

@@ -186,7 +186,11 @@ extern "C" int frw_groth16_verify(const frw_groth16_vk *vk, size_t batch, const 
         if (threads <= 1) work();
         else {
             std::vector<std::thread> pool;
-            for (size_t t = 0; t < threads; t++) pool.emplace_back(work);
+            try {
+                for (size_t t = 0; t < threads; t++) pool.emplace_back(work);
+            } catch (...) {                                              // no more threads to be had: the ones there are finish the batch
+                if (pool.empty()) work();
+            }
             for (auto &t : pool) t.join();
         }
         return failed ? FRW_E_OUT_OF_MEMORY : FRW_OK;

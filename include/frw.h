@@ -358,7 +358,9 @@ int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, si
  *     d_workspace  frw_groth16_workspace_bytes(pk, r, in_flight) bytes, 256-byte aligned; the batch runs in chunks that fit
  * d_witness / d_instance: what the witness entry points wrote (FRW_ENC_MONTGOMERY).  Ordered on `stream` -- the four witness-side
  * sums run on streams of the key's own, forked from and joined back into `stream` by events, beside the witness map and the sum
- * over h_query -- except for the upload of `rs`, which is waited for before the call goes on (the array may be short-lived). */
+ * over h_query -- except for the upload of `rs`, which is waited for before the call goes on (the array may be short-lived).
+ * Calls with one key may come from several host threads: they take turns putting their work on the key's streams (each with a
+ * workspace of its own).  A call that returns an error has waited for whatever it had already started. */
 typedef struct frw_groth16_pk frw_groth16_pk;
 typedef struct {
     uint64_t num_instance, num_witness, domain_size;      /* I (with the constant one), W, n */
