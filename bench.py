@@ -366,9 +366,20 @@ def time_qap(eng, handle, dev, d_wit, d_inst, nsig, reps, logn=None, cpu_triple=
     return out, h
 
 
-# instructions of one fq_mul (frw_fq29.h) as hipcc compiles it for gfx950: 392 v_mad_u64_u32 + 14 v_mul_lo_u32, 90 others
-# (tests/test_isa_hazards.py re-derives them from the assembly)
+# instructions of one fq_mul (frw_fq29.h) as hipcc compiles it for gfx950: 392 v_mad_u64_u32 + 14 v_mul_lo_u32, 90 others;
+# of one fq_sqr (105 + 14 + 196 multiplies) and of one fq_mul_sub (a b - c d: two products, one reduction)
+# (tests/test_isa_hazards.py re-derives all three from the assembly)
 FQ_MUL_MULTIPLY, FQ_MUL_OTHER = 406, 90
+FQ_SQR_MULTIPLY, FQ_SQR_OTHER = 315, 101
+FQ_PAIR_MULTIPLY, FQ_PAIR_OTHER = 602, 135
+# the point formulas in those units (frw_fq29.h): mixed addition = 8 M + 2 S of which one M pair shares a reduction; full addition 12 M + 2 S
+MADD_OPS = {"mul": 6, "sqr": 2, "pair": 1}
+ADD_OPS = {"mul": 10, "sqr": 2, "pair": 1}
+
+
+def point_op_instructions(ops):
+    return (ops["mul"] * FQ_MUL_MULTIPLY + ops["sqr"] * FQ_SQR_MULTIPLY + ops["pair"] * FQ_PAIR_MULTIPLY,
+            ops["mul"] * FQ_MUL_OTHER + ops["sqr"] * FQ_SQR_OTHER + ops["pair"] * FQ_PAIR_OTHER)
 R_FR = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 
@@ -474,17 +485,26 @@ def time_msm(eng, dev, d_h, reps, with_cpu):
     got = out[0].cpu().numpy().view(np.uint64)
     assert np.array_equal(got, want), "h_acc differs from (h(t) zt / delta) G1"
     rates = eng.valu_rates()
-    products = 16 * (n - 1) * 10 + 2 * 32768 * 14          # mixed additions (8 M + 2 S) into the buckets + the fold's full additions
-    peak = rates["simds"] * 64 / (FQ_MUL_MULTIPLY / rates["v_mad_u64_u32"] + FQ_MUL_OTHER / rates["v_add_u32"]) / 1e3
+    # priced by the instructions of the field operations inside the point formulas, each class at its measured issue rate:
+    # mixed additions into the buckets (16 per point) + the fold's full additions (2 per bucket)
+    madds, adds = 16 * (n - 1), 2 * 32768
+    products = madds * 10 + adds * 14
+    (mm, mo), (am, ao) = point_op_instructions(MADD_OPS), point_op_instructions(ADD_OPS)
+    wave_us = (madds * mm + adds * am) / rates["v_mad_u64_u32"] + (madds * mo + adds * ao) / rates["v_add_u32"]   # one lane's work, in SIMD-microseconds per wave-instruction
+    peak_sig_per_s = rates["simds"] * 64 / wave_us * 1e6
+    peak = products * peak_sig_per_s / 1e9
     res = {"workload": "Groth16 h_acc = sum h_i h_query[i] over BLS12-381 G1, %d points, %d resident h vectors per call" % (n - 1, nsig),
            "ms_per_call": round(ms, 3), "signatures_per_s": round(per_s, 1), "calls_timed": reps,
-           "mixed_additions_per_signature": 16 * (n - 1), "window_table_bytes": int(info.table_bytes),
+           "mixed_additions_per_signature": madds, "window_table_bytes": int(info.table_bytes),
            "checked": "h_acc of one signature == (h(t) zt / delta) G1 for the known toxic waste, bit for bit (affine, ark-ff's bytes)",
            "roofline": {"bound": "valu_issue", "unit": "G Fq products/s", "achieved": round(products * per_s / 1e9, 2),
-                        "peak": round(peak, 2), "frac": round(products * per_s / 1e9 / peak, 4),
+                        "peak": round(peak, 2), "frac": round(per_s / peak_sig_per_s, 4),
                         "kernel": "msm_bucket_kernel (+ count / scan / scatter / fold)", "fq_products_per_signature": products,
-                        "peak_is": "%d SIMDs x 64 lanes / (%d multiplies at %.1f + %d other at %.1f wave-instructions/SIMD/us)"
-                                   % (rates["simds"], FQ_MUL_MULTIPLY, rates["v_mad_u64_u32"], FQ_MUL_OTHER, rates["v_add_u32"])}}
+                        "peak_is": "%d SIMDs x 64 lanes; a mixed addition = 6 products (%d multiplies + %d other instructions) + 2 squares "
+                                   "(%d + %d) + one a b - c d with a shared reduction (%d + %d), a full addition 10 + 2 + 1 of the same; "
+                                   "multiplies at %.1f, the others at %.1f wave-instructions/SIMD/us"
+                                   % (rates["simds"], FQ_MUL_MULTIPLY, FQ_MUL_OTHER, FQ_SQR_MULTIPLY, FQ_SQR_OTHER, FQ_PAIR_MULTIPLY,
+                                      FQ_PAIR_OTHER, rates["v_mad_u64_u32"], rates["v_add_u32"])}}
     if with_cpu:
         oracle = load_oracle()
         h_can = np.frombuffer(b"".join((int.from_bytes(row.tobytes(), "little") * r_inv % R_FR).to_bytes(32, "little") for row in h0[:n - 1]),

@@ -155,11 +155,14 @@ __host__ __device__ __forceinline__ Fq29 fq_neg(const Fq29 &b)
     return r;
 }
 
-// Montgomery product a b / 2^406 mod q.  a: limbs < 2^31 (need not be normalised); b: normalised limbs.
-// Result: normalised, < a b / 2^406 + q  (< 2 q whenever a b < 2^406 q: any two values below 2^12 q).
-__host__ __device__ __forceinline__ Fq29 fq_mul(const Fq29 &a, const Fq29 &b)
+// Montgomery product a b / 2^406 mod q in two halves: the 27 columns of the integer product, and their reduction.
+// Operands: normalised limbs, except that ONE operand of one product may have limbs up to 2^30 (a column is then
+// < 14 2^59, and the reduction adds < 14 2^58 to it: < 2^64).  The halves exist on their own because columns add: a b + c d
+// costs two multiplications and ONE reduction (both products of normalised operands: 2 x 14 2^58 + 14 2^58 < 2^64).
+// Result of a reduction: normalised, < (sum of the products) / 2^406 + q  (< 2 q whenever that sum is < 2^406 q: two
+// values below 2^12 q each, or two such pairs).
+__host__ __device__ __forceinline__ void fq_mul_cols(const Fq29 &a, const Fq29 &b, uint64_t (&col)[2 * NLQ])
 {
-    uint64_t col[2 * NLQ];
 #pragma unroll
     for (int k = 0; k < 2 * NLQ - 1; k++) {
         uint64_t acc = 0;
@@ -168,6 +171,25 @@ __host__ __device__ __forceinline__ Fq29 fq_mul(const Fq29 &a, const Fq29 &b)
         col[k] = acc;
     }
     col[2 * NLQ - 1] = 0;
+}
+// the columns of a^2 in 105 multiplications instead of 196: cross terms once, with the doubled operand (a: normalised)
+__host__ __device__ __forceinline__ void fq_sqr_cols(const Fq29 &a, uint64_t (&col)[2 * NLQ])
+{
+    uint32_t twice[NLQ];
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) twice[i] = a.l[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 2 * NLQ - 1; k++) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = (k < NLQ ? 0 : k - (NLQ - 1)); 2 * i < k; i++) acc += (uint64_t)twice[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
+        col[k] = acc;
+    }
+    col[2 * NLQ - 1] = 0;
+}
+__host__ __device__ __forceinline__ Fq29 fq_reduce_cols(uint64_t (&col)[2 * NLQ])
+{
 #pragma unroll
     for (int i = 0; i < NLQ; i++) {
         const uint32_t m = ((uint32_t)col[i] * QINV29) & MQ29;
@@ -184,7 +206,30 @@ __host__ __device__ __forceinline__ Fq29 fq_mul(const Fq29 &a, const Fq29 &b)
     r.l[NLQ - 1] = (uint32_t)col[2 * NLQ - 1];
     return r;
 }
-__host__ __device__ __forceinline__ Fq29 fq_sqr(const Fq29 &a) { return fq_mul(a, a); }
+__host__ __device__ __forceinline__ Fq29 fq_mul(const Fq29 &a, const Fq29 &b)
+{
+    uint64_t col[2 * NLQ];
+    fq_mul_cols(a, b, col);
+    return fq_reduce_cols(col);
+}
+__host__ __device__ __forceinline__ Fq29 fq_sqr(const Fq29 &a)
+{
+    uint64_t col[2 * NLQ];
+    fq_sqr_cols(a, col);
+    return fq_reduce_cols(col);
+}
+// a b - c d + K q d, i.e. a b - c d mod q, with one reduction (c < K q; all four normalised): what the Y coordinate of
+// every point formula ends with.  < (a b + K q d) / 2^406 + q.
+template <uint32_t K>
+__host__ __device__ __forceinline__ Fq29 fq_mul_sub(const Fq29 &a, const Fq29 &b, const Fq29 &c, const Fq29 &d)
+{
+    uint64_t col[2 * NLQ], col2[2 * NLQ];
+    fq_mul_cols(a, b, col);
+    fq_mul_cols(fq_neg<K>(c), d, col2);
+#pragma unroll
+    for (int k = 0; k < 2 * NLQ - 1; k++) col[k] += col2[k];
+    return fq_reduce_cols(col);
+}
 
 // a < 2 q (normalised)  ->  the canonical representative < q
 __host__ __device__ __forceinline__ Fq29 fq_canonical(const Fq29 &a)
@@ -262,7 +307,9 @@ struct FqField {
     static constexpr uint32_t K_MUL = 4, K_2MUL = 4, K_X = 16, K_Y = 16;
     static constexpr int WORDS = NLQ, ARK_WORDS = 12;
     __host__ __device__ static __forceinline__ El mul(const El &a, const El &b) { return fq_mul(a, b); }
-    __host__ __device__ static __forceinline__ El sqr(const El &a) { return fq_mul(a, a); }
+    __host__ __device__ static __forceinline__ El sqr(const El &a) { return fq_sqr(a); }
+    // a b - c d (c < KC q), one reduction
+    template <uint32_t KC> __host__ __device__ static __forceinline__ El mul_sub(const El &a, const El &b, const El &c, const El &d) { return fq_mul_sub<KC>(a, b, c, d); }
     __host__ __device__ static __forceinline__ El add(const El &a, const El &b) { return fq_add(a, b); }
     template <uint32_t K> __host__ __device__ static __forceinline__ El sub(const El &a, const El &b) { return fq_sub<K>(a, b); }
     template <uint32_t K> __host__ __device__ static __forceinline__ El neg(const El &a) { return fq_neg<K>(a); }
@@ -291,6 +338,10 @@ struct Fq2Field {
     static constexpr int WORDS = 2 * NLQ, ARK_WORDS = 24;
     __host__ __device__ static __forceinline__ El mul(const El &a, const El &b) { return fq2_mul(a, b); }
     __host__ __device__ static __forceinline__ El sqr(const El &a) { return fq2_sqr(a); }
+    template <uint32_t KC> __host__ __device__ static __forceinline__ El mul_sub(const El &a, const El &b, const El &c, const El &d)
+    {
+        return sub<K_MUL>(fq2_mul(a, b), fq2_mul(c, d));
+    }
     __host__ __device__ static __forceinline__ El add(const El &a, const El &b) { El r; r.c0 = fq_add(a.c0, b.c0); r.c1 = fq_add(a.c1, b.c1); return r; }
     template <uint32_t K> __host__ __device__ static __forceinline__ El sub(const El &a, const El &b)
     {
@@ -356,7 +407,7 @@ template <class F> __host__ __device__ inline XyzzT<F> pt_double(const XyzzT<F> 
     const auto m = F::add(F::add(xx, xx), xx);
     XyzzT<F> r;
     r.x = F::template sub<F::K_2MUL>(F::sqr(m), F::add(s, s));
-    r.y = F::template sub<F::K_MUL>(F::mul(m, F::template sub<F::K_X>(s, r.x)), F::mul(w, p.y));
+    r.y = F::template mul_sub<F::K_MUL>(m, F::template sub<F::K_X>(s, r.x), w, p.y);
     r.zz = F::mul(v, p.zz);
     r.zzz = F::mul(w, p.zzz);
     r.inf = false;
@@ -377,7 +428,7 @@ template <class F> __host__ __device__ __forceinline__ XyzzT<F> pt_add_affine(co
     const auto pp = F::sqr(pp_), ppp = F::mul(pp_, pp), qq = F::mul(p.x, pp);
     XyzzT<F> r;
     r.x = F::template sub<F::K_2MUL>(F::template sub<F::K_MUL>(F::sqr(rr), ppp), F::add(qq, qq));
-    r.y = F::template sub<F::K_MUL>(F::mul(rr, F::template sub<F::K_X>(qq, r.x)), F::mul(p.y, ppp));
+    r.y = F::template mul_sub<F::K_Y>(rr, F::template sub<F::K_X>(qq, r.x), p.y, ppp);
     r.zz = F::mul(p.zz, pp);
     r.zzz = F::mul(p.zzz, ppp);
     r.inf = false;
@@ -397,7 +448,7 @@ template <class F> __host__ __device__ inline XyzzT<F> pt_add(const XyzzT<F> &p,
     const auto pp = F::sqr(pp_), ppp = F::mul(pp_, pp), qq = F::mul(u1, pp);
     XyzzT<F> r;
     r.x = F::template sub<F::K_2MUL>(F::template sub<F::K_MUL>(F::sqr(rr), ppp), F::add(qq, qq));
-    r.y = F::template sub<F::K_MUL>(F::mul(rr, F::template sub<F::K_X>(qq, r.x)), F::mul(s1, ppp));
+    r.y = F::template mul_sub<F::K_MUL>(rr, F::template sub<F::K_X>(qq, r.x), s1, ppp);
     r.zz = F::mul(F::mul(p.zz, q.zz), pp);
     r.zzz = F::mul(F::mul(p.zzz, q.zzz), ppp);
     r.inf = false;

@@ -27,7 +27,14 @@ extern "C" void t_fq(int op, const uint32_t *a, const uint32_t *b, uint32_t *out
     case 11: store(fq_neg<4>(load(a)), out); break;
     case 12: { Fq29 t = fq_unpack(a); store(t, out); break; }   // a: 12 words
     case 13: fq_pack(load(a), out); break;
+    case 14: store(fq_sqr(load(a)), out); break;
     }
+}
+// a b - c d with one reduction; which = 0: c < 4 q, 1: c < 16 q
+extern "C" void t_fq_mul_sub(int which, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint32_t *out)
+{
+    if (which == 0) store(fq_mul_sub<4>(load(a), load(b), load(c), load(d)), out);
+    else store(fq_mul_sub<16>(load(a), load(b), load(c), load(d)), out);
 }
 
 static G1Affine29 load_point(const uint32_t *w)                 // 24 words, ark-ff; zeros = infinity

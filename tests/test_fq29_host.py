@@ -75,11 +75,27 @@ def test_field_operations_at_their_bounds(lib):
         got = fq(lib, 0, limbs(a), limbs(b))
         v = value(got)
         assert all(x <= M29 for x in got[:13]) and v % Q == a * b * inv % Q and v < 2 * Q and v < (a * b >> 406) + Q + 1
-    # an un-normalised left operand (limbs up to 2^31 - 1): what a sum of four products' worth of limbs looks like
-    for _ in range(50):
-        la = [rng.randrange(1 << 31) for _ in range(13)] + [rng.randrange(1 << 12)]
+    # the dedicated square (105 multiplications) and a b - c d with one reduction, incl. all limbs at their maximum
+    top = [M29] * 13 + [(16 * Q) >> (29 * 13)]
+    for k in range(300):
+        a = value(top) if k == 0 else rng.choice(edge + [rng.randrange(16 * Q)] * 5)
+        got = fq(lib, 14, limbs(a))
+        v = value(got)
+        assert all(x <= M29 for x in got[:13]) and v % Q == a * a * inv % Q and v < (a * a >> 406) + Q + 1
+    out = (C.c_uint32 * 14)()
+    for k in range(300):
+        which = k & 1
+        kq = (16 if which else 4) * Q
+        a, b, d = (value(top) if k < 2 else rng.randrange(16 * Q) for _ in range(3))
+        c = kq - 1 if k < 4 else rng.randrange(kq)
+        lib.t_fq_mul_sub(which, limbs(a), limbs(b), limbs(c), limbs(d), out)
+        v = value(list(out))
+        assert all(x <= M29 for x in list(out)[:13]) and v % Q == (a * b - c * d) * inv % Q and v < ((a * b + kq * d) >> 406) + Q + 1 and v < 2 * Q
+    # an un-normalised left operand (limbs up to 2^30 - 1): the header allows it for one operand of one product
+    for k in range(50):
+        la = [(1 << 30) - 1] * 13 + [(1 << 12) - 1] if k == 0 else [rng.randrange(1 << 30) for _ in range(13)] + [rng.randrange(1 << 12)]
         a = value(la)
-        b = rng.randrange(2 * Q)
+        b = value([M29] * 13 + [(2 * Q) >> (29 * 13)]) if k == 0 else rng.randrange(2 * Q)
         got = fq(lib, 0, (C.c_uint32 * 14)(*la), limbs(b))
         assert value(got) % Q == a * b * inv % Q and all(x <= M29 for x in got[:13])
     for _ in range(200):

@@ -100,28 +100,41 @@ def test_field_product_instruction_count_is_what_the_roofline_prices(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_fq_product_instruction_count_is_what_the_msm_roofline_prices(tmp_path):
-    """The same for the 381-bit field of the multi-scalar multiplication (frw_fq29.h fq_mul): 392 v_mad_u64_u32 + 14 v_mul_lo_u32
-    and 90 other vector instructions per product."""
+    """The same for the 381-bit field of the multi-scalar multiplication (frw_fq29.h): fq_mul = 392 v_mad_u64_u32 + 14 v_mul_lo_u32
+    and 90 other vector instructions; fq_sqr and fq_mul_sub (the other two operations the point formulas are made of) likewise."""
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    src = tmp_path / "one_fq_mul.hip"
-    src.write_text('#include "frw_fq29.h"\n'
-                   'using namespace frw;\n'
-                   '__global__ void one_mul(const uint32_t *a, const uint32_t *b, uint32_t *out)\n'
-                   '{\n'
-                   '    Fq29 x, y;\n'
-                   '    for (int k = 0; k < NLQ; k++) { x.l[k] = a[threadIdx.x * NLQ + k]; y.l[k] = b[threadIdx.x * NLQ + k]; }\n'
-                   '    const Fq29 r = fq_mul(x, y);\n'
-                   '    for (int k = 0; k < NLQ; k++) out[threadIdx.x * NLQ + k] = r.l[k];\n'
-                   '}\n')
-    asm = tmp_path / "one_fq_mul.s"
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
-                           "-I", os.path.join(ROOT, "falcon-r1cs_amd", "csrc"), "-o", str(asm), str(src)], stderr=subprocess.DEVNULL)
-    text = open(asm).read()
-    start = text.index("_Z7one_mulPKjS0_Pj:")
-    code = text[start:text.index("s_endpgm", start)]
-    valu = [l.split()[0] for l in code.splitlines() if re.match(r"\s*v_", l)]
-    mult = sum(1 for op in valu if op.startswith(("v_mad_u64_u32", "v_mul_lo_u32")))
+    def count(name, body):
+        src = tmp_path / ("one_%s.hip" % name)
+        src.write_text('#include "frw_fq29.h"\n'
+                       'using namespace frw;\n'
+                       '__global__ void one_op(const uint32_t *a, const uint32_t *b, uint32_t *out)\n'
+                       '{\n'
+                       '    Fq29 x, y;\n'
+                       '    for (int k = 0; k < NLQ; k++) { x.l[k] = a[threadIdx.x * NLQ + k]; y.l[k] = b[threadIdx.x * NLQ + k]; }\n'
+                       '    %s\n'
+                       '    for (int k = 0; k < NLQ; k++) out[threadIdx.x * NLQ + k] = r.l[k];\n'
+                       '}\n' % body)
+        asm = tmp_path / ("one_%s.s" % name)
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                               "-I", os.path.join(ROOT, "falcon-r1cs_amd", "csrc"), "-o", str(asm), str(src)], stderr=subprocess.DEVNULL)
+        text = open(asm).read()
+        start = text.index("_Z6one_opPKjS0_Pj:")
+        code = text[start:text.index("s_endpgm", start)]
+        valu = [l.split()[0] for l in code.splitlines() if re.match(r"\s*v_", l)]
+        mult = sum(1 for op in valu if op.startswith(("v_mad_u64_u32", "v_mul_lo_u32")))
+        return mult, len(valu) - mult
+
+    mult, other = count("mul", "const Fq29 r = fq_mul(x, y);")
     assert mult == bench.FQ_MUL_MULTIPLY, mult
-    assert bench.FQ_MUL_OTHER <= len(valu) - mult <= bench.FQ_MUL_OTHER + 16, len(valu) - mult
+    assert bench.FQ_MUL_OTHER <= other <= bench.FQ_MUL_OTHER + 16, other
+    # the dedicated square: 105 + 14 + 196
+    mult, other = count("sqr", "const Fq29 r = fq_sqr(x);")
+    assert mult == bench.FQ_SQR_MULTIPLY == 105 + 14 + 196, mult
+    assert bench.FQ_SQR_OTHER <= other <= bench.FQ_SQR_OTHER + 16, other
+    # a b - c d with one reduction: 2 x 196 + 14 + 196
+    mult, other = count("pair", "Fq29 z, w; for (int k = 0; k < NLQ; k++) { z.l[k] = a[(threadIdx.x + 64) * NLQ + k]; "
+                                "w.l[k] = b[(threadIdx.x + 64) * NLQ + k]; } const Fq29 r = fq_mul_sub<16>(x, y, z, w);")
+    assert mult == bench.FQ_PAIR_MULTIPLY == 2 * 196 + 14 + 196, mult
+    assert bench.FQ_PAIR_OTHER <= other <= bench.FQ_PAIR_OTHER + 16, other
