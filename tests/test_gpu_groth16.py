@@ -191,3 +191,53 @@ def test_setup_on_the_product_side_makes_the_same_key(engine, oracle, tmp_path):
     finally:
         engine.r1cs_free(r1cs)
         engine.groth16_pk_free(handle)
+
+
+@pytest.mark.parametrize("circuit,logn", [(1, 9), (0, 10)])
+def test_setup_prove_verify_with_nothing_known_in_the_exponent(engine, circuit, logn):
+    """examples/pok_sig.rs:30-47 on the product alone, for the circuits the other tests leave out (the dual-NTT circuit;
+    Falcon-1024 with a key from frw_groth16_setup): circuit_specific_setup -> frw_groth16_setup, create_random_proof ->
+    frw_groth16_prove_dev, Groth16::verify -> frw_groth16_verify.  Every proof must verify for its own statement, none for its
+    neighbour's, and a proof made from a witness that violates the system (one value flipped after the witness kernel ran) must
+    be reported (num_unsatisfied) and must not verify."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    batch = 3
+    L = frw.layout_dual(logn) if circuit else frw.layout(logn)
+    rng = random.Random(700 + logn + circuit)
+    key, vk = engine.groth16_setup(circuit, logn, *(rng.randrange(2, E.R) for _ in range(5)))
+    r1cs = engine.r1cs_load(circuit, logn)
+    try:
+        sig, pk_, hm = frw.synth_triples(logn, batch, seed=2718 + circuit)
+        dd = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk_, hm)]
+        wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+        inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+        st = torch.empty(batch, dtype=torch.int32, device=dev)
+        s0 = torch.cuda.current_stream().cuda_stream
+        if circuit:
+            engine.witness_dual_ntt_verify_dev(logn, batch, dd[0], dd[1], dd[2], wit, inst, st, 1, s0)
+        else:
+            engine.witness_ntt_verify_dev(logn, batch, dd[0], dd[1], dd[2], wit, inst, st, 1, s0)
+        torch.cuda.synchronize()
+        assert int(st.abs().sum()) == 0
+        # signature 2's witness stops satisfying the system: a bit of its first range proof flipped (Montgomery 0 <-> 1)
+        w2 = wit[2, L.seg_off[2]].clone()
+        one = torch.from_numpy(np.frombuffer(((1 << 256) % E.R).to_bytes(32, "little"), dtype=np.int64).copy()).to(dev)
+        wit[2, L.seg_off[2]] = torch.where(w2.abs().sum() == 0, one, torch.zeros_like(one))
+        rs = np.array([T.ints_to_limbs([rng.randrange(E.R), rng.randrange(E.R)]) for _ in range(batch)])
+        ws_bytes = engine.groth16_workspace_bytes(key, r1cs, batch)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        proofs = torch.empty((batch, 48), dtype=torch.int64, device=dev)
+        bad = torch.zeros(batch, dtype=torch.int32, device=dev)
+        engine.groth16_prove_dev(key, r1cs, batch, wit, inst, rs, proofs, ws, ws_bytes, bad, s0)
+        torch.cuda.synchronize()
+        assert bad[:2].tolist() == [0, 0] and int(bad[2]) > 0
+        ver = frw.Groth16Verifier(vk)
+        inst_h, proofs_h = inst.cpu().numpy().view(np.uint64), proofs.cpu().numpy().view(np.uint64)
+        assert ver.verify(inst_h, proofs_h).tolist() == [1, 1, 0]
+        assert ver.verify(inst_h[[1, 0, 2]], proofs_h).tolist() == [0, 0, 0]
+        ver.close()
+    finally:
+        engine.r1cs_free(r1cs)
+        engine.groth16_pk_free(key)
