@@ -238,6 +238,15 @@ def test_setup_prove_verify_with_nothing_known_in_the_exponent(engine, circuit, 
         assert ver.verify(inst_h, proofs_h).tolist() == [1, 1, 0]
         assert ver.verify(inst_h[[1, 0, 2]], proofs_h).tolist() == [0, 0, 0]
         ver.close()
+        # a workspace for two signatures in flight: the batch runs as 2 + 1 (the key's side streams and events used twice in one
+        # call, the workspace reused) and must give the same bytes
+        ws2_bytes = engine.groth16_workspace_bytes(key, r1cs, 2)
+        ws2 = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
+        proofs2 = torch.zeros((batch, 48), dtype=torch.int64, device=dev)
+        bad2 = torch.zeros(batch, dtype=torch.int32, device=dev)
+        engine.groth16_prove_dev(key, r1cs, batch, wit, inst, rs, proofs2, ws2, ws2_bytes, bad2, s0)
+        torch.cuda.synchronize()
+        assert torch.equal(proofs2, proofs) and torch.equal(bad2, bad)
     finally:
         engine.r1cs_free(r1cs)
         engine.groth16_pk_free(key)
