@@ -727,18 +727,30 @@ __global__ __launch_bounds__(64) void groth16_tails_kernel(size_t batch, const u
     for (int j = 0; j < 2; j++)
         fr_store(dst + 8 * (j + 1), f29_pack(f29_canonical(f29_mul(f29_unpack(fr_load(rs + (sig * 2 + j) * 8)), c))));
 }
-// k P for one point per signature (s g_a and r (g1_b - s delta1) of g_c), 4-bit windows; runs on the side stream that made P
-__global__ __launch_bounds__(64) void groth16_scale_kernel(size_t batch, const uint32_t *__restrict__ rs, int which, const uint32_t *__restrict__ pts,
-                                                           uint32_t *__restrict__ out /* [batch][24] */)
+// k P for one point per signature (s g_a and r (g1_b - s delta1) of g_c); runs on the side stream that made P.  One thread
+// per signature and a point that exists only now: the chain of doublings is the latency of a proof made alone, so the scalar
+// comes split by the endomorphism (k = k0 + lambda k1, done on the host where r and s arrive: glv_split) and the two 128-bit
+// halves share their doublings (P, phi(P) and P + phi(P): 128 doublings and ~96 additions instead of 256 and ~128).
+__global__ __launch_bounds__(64) void groth16_scale_kernel(size_t batch, const uint32_t *__restrict__ split /* [batch][2][8]: k0 | k1, 128 bits each */,
+                                                           int which, const uint32_t *__restrict__ pts, uint32_t *__restrict__ out /* [batch][24] */)
 {
     const size_t sig = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (sig >= batch) return;
     const AffineT<FqField> base = load_ark_point<FqField>(pts + sig * 24);
-    const Fr8 k = fr_load(rs + (sig * 2 + which) * 8);
+    AffineT<FqField> endo = base;
+    endo.x = fq_mul(base.x, fq_const(G1_ENDO_BETA29));
+    const XyzzT<FqField> both = pt_add_affine(pt_from_affine(base), endo);     // (1 + lambda) P: never the identity for P != O
+    const uint32_t *k = split + (sig * 2 + which) * 8;
+    uint32_t k0[4], k1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { k0[i] = k[i]; k1[i] = k[4 + i]; }
     XyzzT<FqField> m = pt_identity<FqField>();
-    for (int bit = 255; bit >= 0; bit--) {                          // all 256 bits: an r or s >= the group order is taken mod it
+    for (int bit = 127; bit >= 0; bit--) {
         m = pt_double(m);
-        if ((k.l[bit >> 5] >> (bit & 31)) & 1u) m = pt_add_affine(m, base);
+        const uint32_t sel = ((k0[bit >> 5] >> (bit & 31)) & 1u) | (((k1[bit >> 5] >> (bit & 31)) & 1u) << 1);
+        if (sel == 1) m = pt_add_affine(m, base);
+        else if (sel == 2) m = pt_add_affine(m, endo);
+        else if (sel == 3) m = pt_add(m, both);
     }
     store_ark_point<FqField>(out + sig * 24, pt_to_affine(m));
 }
@@ -843,6 +855,32 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
 }
 
 namespace {
+// k (any 256-bit value; taken mod the group order r) = k0 + lambda k1, lambda = z^2 - 1 = 0xac45a4010001a40200000000ffffffff,
+// r = lambda^2 + lambda + 1: k0 = k mod lambda, k1 = k div lambda <= lambda + 1 < 2^128.  out: k0 (2 words) | k1 (2 words).
+void glv_split(const uint64_t k_in[4], uint64_t out[4])
+{
+    typedef unsigned __int128 u128;
+    static const uint64_t R[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    const u128 lambda = ((u128)0xac45a4010001a402ULL << 64) | 0x00000000ffffffffULL;
+    uint64_t k[4] = {k_in[0], k_in[1], k_in[2], k_in[3]};
+    for (int round = 0; round < 3; round++) {                       // 2^256 < 3 r: at most two subtractions
+        bool ge = true;
+        for (int i = 3; i >= 0; i--)
+            if (k[i] != R[i]) { ge = k[i] > R[i]; break; }
+        if (!ge) break;
+        u128 borrow = 0;
+        for (int i = 0; i < 4; i++) { const u128 d = (u128)k[i] - R[i] - borrow; k[i] = (uint64_t)d; borrow = (d >> 64) & 1; }
+    }
+    u128 rem = 0, quo = 0;
+    for (int bit = 255; bit >= 0; bit--) {                          // schoolbook, one bit at a time: two scalars per proof
+        const bool top = (rem >> 127) & 1;
+        rem = (rem << 1) | ((k[bit >> 6] >> (bit & 63)) & 1);
+        quo <<= 1;                                                  // k < r: the quotient's bits above 127 are zero
+        if (top || rem >= lambda) { rem -= lambda; quo |= 1; }
+    }
+    out[0] = (uint64_t)rem; out[1] = (uint64_t)(rem >> 64);
+    out[2] = (uint64_t)quo; out[3] = (uint64_t)(quo >> 64);
+}
 struct Groth16Sizes { size_t qap, h, zext, msm[5], msm_all, pts, per; };
 Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
 {
@@ -860,7 +898,7 @@ Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
         s.msm[i] = (mi.workspace_bytes_per_signature + 255) & ~(size_t)255;
         s.msm_all += s.msm[i++];
     }
-    s.pts = 6 * 96 + 192 + 64;                                        // A, B1', L, H, s A, r B1' (G1), B (G2), r and s
+    s.pts = 6 * 96 + 192 + 64 + 64;                                   // A, B1', L, H, s A, r B1' (G1), B (G2), r and s, and their split halves
     s.per = ((s.qap + s.h + s.zext + s.msm_all + s.pts) + 255) & ~(size_t)255;
     return s;
 }
@@ -898,11 +936,14 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         char *msm_ws[5];
         for (int i = 0; i < 5; i++) { msm_ws[i] = base; base += cnt * sz.msm[i]; }
         uint64_t *pA = (uint64_t *)base, *pB1 = pA + cnt * 12, *pL = pB1 + cnt * 12, *pH = pL + cnt * 12, *pSA = pH + cnt * 12;
-        uint64_t *pRB1 = pSA + cnt * 12, *pB2 = pRB1 + cnt * 12, *d_rs = pB2 + cnt * 24;
+        uint64_t *pRB1 = pSA + cnt * 12, *pB2 = pRB1 + cnt * 12, *d_rs = pB2 + cnt * 24, *d_split = d_rs + cnt * 8;
         const uint64_t *wit = d_witness + lo * W * 4, *inst = d_instance + lo * I * 4;
         // the blinding factors: a host array (the prover draws them), uploaded before anything reads them
         e = hipMemcpyAsync(d_rs, rs + lo * 8, cnt * 64, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);                                  // `rs` may be pageable and short-lived
+        std::vector<uint64_t> halves(cnt * 8);
+        for (size_t i = 0; i < cnt * 2; i++) glv_split(rs + (lo * 2 + i) * 4, &halves[i * 4]);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_split, halves.data(), cnt * 64, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);                                  // `rs` may be pageable and short-lived; `halves` is
         if (e != hipSuccess) break;
         // z ++ [1, r, s] per signature, then the witness-side sums on their own streams ...
         e = hipMemcpy2DAsync(zext, stride * 32, inst, I * 32, I * 32, cnt, hipMemcpyDeviceToDevice, st);
@@ -920,9 +961,9 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->l, cnt, zext + I * 4, stride, 1, pL, msm_ws[3], cnt * sz.msm[3], pk->side[2]);
         if (rc != FRW_OK) break;
         // s g_a and r (g1_b - s delta1) as soon as their points exist, on the streams that made them
-        hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[0], cnt, (const uint32_t *)d_rs, 1,
+        hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[0], cnt, (const uint32_t *)d_split, 1,
                            (const uint32_t *)pA, (uint32_t *)pSA);
-        hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[1], cnt, (const uint32_t *)d_rs, 0,
+        hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[1], cnt, (const uint32_t *)d_split, 0,
                            (const uint32_t *)pB1, (uint32_t *)pRB1);
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
         if (e != hipSuccess) break;

@@ -60,6 +60,11 @@ def test_constants_of_the_header():
     assert table("FQ29_ONE") == RQ % Q
     assert table("FQ29_C_IN") == pow(2, 428, Q) and table("FQ29_C_OUT") == pow(2, 384, Q)
     assert (table("G1_GEN_X29"), table("G1_GEN_Y29")) == (E.G1[0] * RQ % Q, E.G1[1] * RQ % Q)
+    # the endomorphism constant: a primitive cube root of unity, and the one that belongs to lambda = z^2 - 1
+    beta = table("G1_ENDO_BETA29") * pow(RQ, -1, Q) % Q
+    lam = E.Z_BLS ** 2 - 1
+    assert beta != 1 and pow(beta, 3, Q) == 1 and E.R == lam * lam + lam + 1 and lam.bit_length() == 128
+    assert E.mul(E.G1, lam) == (beta * E.G1[0] % Q, E.G1[1])
     assert int(re.search(r"QINV29 = (0x[0-9a-f]+)u", src).group(1), 16) == (-pow(Q, -1, 1 << 29)) % (1 << 29)
     q_words = [int(x.rstrip("u"), 16) for x in re.search(r"Q32_\[12\] = \{([^}]*)\}", src, re.S).group(1).replace("\n", " ").replace(" ", "").split(",")]
     assert value(q_words, 32) == Q

@@ -67,6 +67,8 @@ def test_proofs_equal_the_prover_restated_in_the_exponent(engine, oracle, tmp_pa
         s0 = torch.cuda.current_stream().cuda_stream
         engine.witness_ntt_verify_dev(logn, batch, dd[0], dd[1], dd[2], wit, inst, st, 1, s0)
         rs = [[rng.randrange(E.R), rng.randrange(E.R)] for _ in range(batch)]
+        lam = E.Z_BLS ** 2 - 1                                      # the endomorphism's eigenvalue: the scalars are split by it
+        rs[0] = [E.R - 1, lam]                                      # k1 at its maximum (r - 1 = lambda (lambda + 1)); k0 = 0, k1 = 1
         rs[1] = [0, 0]                                              # create_proof_no_zk
         rs[2] = [E.R + 12345, (1 << 256) - 1]                       # out of contract (>= the group order): taken mod it
         ws_bytes = engine.groth16_workspace_bytes(handle, r1cs, 2)  # chunks of 2 + 1
@@ -142,6 +144,7 @@ def test_setup_on_the_product_side_makes_the_same_key(engine, oracle, tmp_path):
         s0 = torch.cuda.current_stream().cuda_stream
         engine.witness_ntt_verify_dev(logn, batch, dd[0], dd[1], dd[2], wit, inst, st, 1, s0)
         rs = [[rng.randrange(E.R), rng.randrange(E.R)] for _ in range(batch)]
+        rs[1] = [E.Z_BLS ** 2 - 2, 1]                               # lambda - 1: all of it in the low half; and one
         ws_bytes = engine.groth16_workspace_bytes(handle, r1cs, batch)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         proofs = torch.empty((batch, 48), dtype=torch.int64, device=dev)
