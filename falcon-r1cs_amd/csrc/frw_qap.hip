@@ -87,32 +87,54 @@ __device__ __forceinline__ F29 root_get(const uint32_t *roots, int idx)
     return r;
 }
 
+// the butterflies' additions and subtractions; -DFRW_QAP_AB_NO_NORMALISE (tools/ab_qap.py) drops their carry propagation --
+// results are then wrong; the timing is the ceiling of what any lazier limb representation could gain
+#if defined(FRW_QAP_AB_NO_NORMALISE)
+__device__ __forceinline__ F29 bf_add(const F29 &a, const F29 &b)
+{
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < NL29; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+template <uint32_t K> __device__ __forceinline__ F29 bf_sub(const F29 &a, const F29 &b)
+{
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < NL29; i++) r.l[i] = a.l[i] - b.l[i] + kp29_table<K>().l[i];
+    return r;
+}
+#else
+__device__ __forceinline__ F29 bf_add(const F29 &a, const F29 &b) { return f29_add(a, b); }
+template <uint32_t K> __device__ __forceinline__ F29 bf_sub(const F29 &a, const F29 &b) { return f29_sub_kp<K>(a, b); }
+#endif
+
 // decimation in time: (u, v) -> (u + w v, u - w v).  KV = bound of v in units of p when there is no product (w == 1).
 template <uint32_t KV>
 __device__ __forceinline__ void dit_one(F29 &u, F29 &v)
 {
-    const F29 s = f29_add(u, v);
-    v = f29_sub_kp<KV>(u, v);
+    const F29 s = bf_add(u, v);
+    v = bf_sub<KV>(u, v);
     u = s;
 }
 __device__ __forceinline__ void dit_mul(F29 &u, F29 &v, const F29 &w)
 {
     v = QAP_MUL(v, w);                    // < 2 p
-    const F29 s = f29_add(u, v);
-    v = f29_sub_kp<2>(u, v);
+    const F29 s = bf_add(u, v);
+    v = bf_sub<2>(u, v);
     u = s;
 }
 // decimation in frequency: (u, v) -> (u + v, (u - v) w), everything < 2 p
 __device__ __forceinline__ void dif_one(F29 &u, F29 &v)
 {
-    const F29 s = f29_reduce_4p(f29_add(u, v));
-    v = f29_reduce_4p(f29_sub_kp<2>(u, v));
+    const F29 s = f29_reduce_4p(bf_add(u, v));
+    v = f29_reduce_4p(bf_sub<2>(u, v));
     u = s;
 }
 __device__ __forceinline__ void dif_mul(F29 &u, F29 &v, const F29 &w)
 {
-    const F29 s = f29_reduce_4p(f29_add(u, v));
-    v = QAP_MUL(f29_sub_kp<2>(u, v), w);
+    const F29 s = f29_reduce_4p(bf_add(u, v));
+    v = QAP_MUL(bf_sub<2>(u, v), w);
     u = s;
     __builtin_amdgcn_sched_barrier(0);       // one butterfly's temporaries at a time (see round_high)
 }
@@ -125,15 +147,15 @@ __device__ __forceinline__ void dif_mul(F29 &u, F29 &v, const F29 &w)
 template <uint32_t B>
 __device__ __forceinline__ void dif_one_lazy(F29 &u, F29 &v)
 {
-    const F29 s = f29_add(u, v);
-    v = f29_sub_kp<B>(u, v);
+    const F29 s = bf_add(u, v);
+    v = bf_sub<B>(u, v);
     u = s;
 }
 template <uint32_t B>
 __device__ __forceinline__ void dif_mul_lazy(F29 &u, F29 &v, const F29 &w)
 {
-    const F29 s = f29_add(u, v);
-    v = QAP_MUL(f29_sub_kp<B>(u, v), w);
+    const F29 s = bf_add(u, v);
+    v = QAP_MUL(bf_sub<B>(u, v), w);
     u = s;
     __builtin_amdgcn_sched_barrier(0);
 }

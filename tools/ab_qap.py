@@ -2,7 +2,7 @@
 """Interleaved A/B timing of build variants of the QAP witness map in ONE process.
 
     python tools/ab_qap.py NAME=FLAGS [NAME=FLAGS ...] [--logn 10] [--batch 32] [--rounds 5]
-    e.g. python tools/ab_qap.py plain= notw=-DFRW_QAP_NO_TW nomul=-DFRW_QAP_NO_MUL copy=-DFRW_QAP_NO_STAGES
+    e.g. python tools/ab_qap.py plain= nomul=-DFRW_QAP_NO_MUL copy=-DFRW_QAP_NO_STAGES nocarry=-DFRW_QAP_AB_NO_NORMALISE
 
 Each variant is compiled to its own shared object under gpurun_out/variants/, loaded with ctypes next to the others;
 frw_qap_witness_map_dev and frw_r1cs_eval_dev (the sparse products alone) are timed with HIP events, round-robin."""
@@ -22,7 +22,7 @@ import falcon_r1cs_amd as frw  # noqa: E402
 from falcon_r1cs_amd._lib import QapInfoStruct  # noqa: E402
 
 CSRC = os.path.join(ROOT, "falcon-r1cs_amd", "csrc")
-SRC = ("frw_kernels.hip", "frw_prepare.hip", "frw_r1cs_check.hip", "frw_qap.hip", "frw_capi.cpp", "frw_synth.cpp", "frw_r1cs.cpp")
+SRC = ("frw_kernels.hip", "frw_prepare.hip", "frw_r1cs_check.hip", "frw_qap.hip", "frw_msm.hip", "frw_capi.cpp", "frw_synth.cpp", "frw_r1cs.cpp", "frw_verify.cpp")
 
 
 def build(name, flags, logn):
