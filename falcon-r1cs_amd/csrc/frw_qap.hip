@@ -39,7 +39,7 @@ constexpr int QAP_TILE = 512;           // elements per tile
 constexpr int QAP_THREADS = 64;         // one wavefront, 8 elements per thread
 constexpr int QAP_HALF = QAP_TILE / 2;  // elements in LDS at a time (one 32-bit word per element and limb plane)
 
-enum { PASS_FIRST = 0, PASS_DIT_SH0 = 1, PASS_DIT = 2, PASS_DIF = 3, PASS_DIF_SH0 = 4 };
+enum { PASS_FIRST = 0, PASS_DIT_SH0 = 1, PASS_DIT = 2, PASS_DIF = 3, PASS_DIF_SH0 = 4, PASS_DIT_DIF = 5 };
 enum { LOAD_PLAIN = 0, LOAD_AB_MINUS_C = 1, LOAD_AB = 2, LOAD_PRODUCTS_AB = 3 };
 enum { STORE_PLAIN = 0, STORE_FACTOR = 1, STORE_FACTOR_A = 2, STORE_FACTOR_CANONICAL = 3, STORE_CONST_ADD_CANONICAL = 4 };
 
@@ -50,6 +50,7 @@ struct NttPass {
     const uint32_t *factor;     // STORE_FACTOR*: [n][8], the multiplier of each working index as x R' packed
     const uint32_t *factor_a;   // STORE_FACTOR_A: the table for arrays 0, 3, 6, ... instead
     const uint32_t *roots;      // 64-th roots of unity ^k, k < 32, x R' in nine limbs, 12 words apart
+    const uint32_t *roots2, *factor2;   // PASS_DIT_DIF: roots and per-index factor of the decimation-in-frequency half
     // PASS_FIRST sources
     const uint32_t *abc;        // [signatures][3][C][8] u32
     const uint32_t *instance;   // [signatures][I][8] u32
@@ -248,9 +249,11 @@ template <int MODE, int T, int LOAD, int STORE>
 __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass p)
 {
     constexpr bool DIF = MODE == PASS_DIF || MODE == PASS_DIF_SH0;
+    constexpr bool FUSED = MODE == PASS_DIT_DIF;                                 // in as PASS_DIT, out as PASS_DIF
     constexpr bool MEMORDER = MODE == PASS_DIT_SH0 || MODE == PASS_DIF_SH0;     // tile = 512 consecutive elements
     constexpr int CB = 9 - T, COLS = 1 << CB;
-    static_assert(T == 6 || (T == 5 && (MODE == PASS_DIT || MODE == PASS_DIF)), "five-stage passes only above bit 0");
+    static_assert(T == 6 || (T == 5 && (MODE == PASS_DIT || MODE == PASS_DIF || MODE == PASS_DIT_DIF)), "five-stage passes only above bit 0");
+    static_assert(!FUSED || (LOAD == LOAD_PLAIN && (STORE == STORE_FACTOR || STORE == STORE_FACTOR_A)), "the fused pass: plain in, factor between and after");
     __shared__ uint32_t lds[NL29 * QAP_HALF];
     const int tid = threadIdx.x, c = tid & (COLS - 1), g = tid >> CB;           // T == 6: 8 columns x 8 g; T == 5: 16 x 4
     const uint32_t tileid = blockIdx.x;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
             v = f29_reduce_4p(f29_add(QAP_MUL(v, cf), f29_unpack(fr_load(dst + (size_t)gidx * 8))));
             v = f29_canonical(v);
         } else if (STORE != STORE_PLAIN) {
-            v = QAP_MUL(v, f29_unpack(fr_load(factor + (size_t)gidx * 8)));                            // < 2 p
+            v = QAP_MUL(v, f29_unpack(fr_load((FUSED ? p.factor2 : factor) + (size_t)gidx * 8)));      // < 2 p
         }
         if (STORE == STORE_FACTOR_CANONICAL) v = f29_canonical(v);
         fr_store(dst + (size_t)gidx * 8, f29_pack(v));
@@ -400,12 +403,29 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
     // (the three constants of the low round are fetched where that round is: held across the other one they cost 27
     // registers the decimation-in-frequency passes do not have)
     constexpr bool LAZY = MODE == PASS_DIF && STORE == STORE_FACTOR;     // see dif_mul_lazy
+    if (FUSED) {
+        // The last pass of an inverse transform and the first pass of the forward transform that follows it work on the same
+        // index bits, i.e. on the same tile, and the first leaves a thread the rows (8 e + g) the second starts from: the
+        // element-wise factor between them is applied in registers and the array makes one trip through memory instead of two.
+        round_low<false>(x, root_get(p.roots, 8), root_get(p.roots, 16), root_get(p.roots, 24));
+        exchange(x);
+        round_high<false, T>(x, p.roots, g);                                                                          // < 22 p
+        static_for<8>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            x[e] = QAP_MUL(x[e], f29_unpack(fr_load(factor + (size_t)widx(row_high(e), c) * 8)));                     // < 2 p
+        });
+        round_high<true, T, true>(x, p.roots2, g);
+        exchange(x);
+        if (T == 6) static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = f29_cond_sub_kp<8>(x[e]); });
+        round_low<true, true>(x, root_get(p.roots2, 8), root_get(p.roots2, 16), root_get(p.roots2, 24));             // < 64 p; the factor at the store: < 2 p
+    } else {
     if (DIF) round_high<true, T, LAZY>(x, p.roots, g);
     else round_low<false>(x, root_get(p.roots, 8), root_get(p.roots, 16), root_get(p.roots, 24));
     exchange(x);
     if (LAZY && T == 6) static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; x[e] = f29_cond_sub_kp<8>(x[e]); });   // < 16 p -> < 8 p
     if (DIF) round_low<true, LAZY>(x, root_get(p.roots, 8), root_get(p.roots, 16), root_get(p.roots, 24));
     else round_high<false, T>(x, p.roots, g);
+    }
 #endif
 
     // ---- out ---------------------------------------------------------------------------------------------------------------------
@@ -421,7 +441,7 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
             wave_sync();
         }
     } else {
-        static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; store_elem(widx(DIF ? row_low(e) : row_high(e), c), x[e]); });
+        static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; store_elem(widx(DIF || FUSED ? row_low(e) : row_high(e), c), x[e]); });
     }
 }
 
@@ -452,10 +472,12 @@ hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *w
     if (kind == XF_FFT) {
         p.roots = q.roots_fwd;
         p.src = work; p.dst = work; p.src_stride = p.dst_stride = work_stride;
+#if defined(FRW_QAP_NO_FUSE)
         p.sh = 12; p.factor = q.twist_fwd[1];
         e = T3 == 6 ? launch_pass<PASS_DIF, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
                     : launch_pass<PASS_DIF, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
         if (e != hipSuccess) return e;
+#endif                                                       // (otherwise the inverse transform before it has done this pass: PASS_DIT_DIF)
         p.sh = 6; p.factor = q.twist_fwd[0];
         if ((e = launch_pass<PASS_DIF, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
         p.sh = 0; p.factor = nullptr;
@@ -471,8 +493,14 @@ hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *w
         p.sh = 6; p.factor = q.twist_inv[1];
         if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
         p.sh = 12; p.factor = q.scale_psi_in;
+#if defined(FRW_QAP_NO_FUSE)
         return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
                        : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
+#else
+        p.roots2 = q.roots_fwd; p.factor2 = q.twist_fwd[1];     // ... and the first pass of the XF_FFT that follows
+        return T3 == 6 ? launch_pass<PASS_DIT_DIF, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
+                       : launch_pass<PASS_DIT_DIF, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
+#endif
     }
     if (kind == XF_IFFT_AB_TO_H) {
         // a b on the coset psi H from the two arrays of each signature, in place on the first; -16 psi^-k / n into h
@@ -506,8 +534,14 @@ hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *w
         p.sh = 6; p.factor = q.twist_inv[1];
         if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
         p.sh = 12; p.factor = q.scale_in; p.factor_a = q.scale_in_a;
+#if defined(FRW_QAP_NO_FUSE)
         return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st)
                        : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st);
+#else
+        p.roots2 = q.roots_fwd; p.factor2 = q.twist_fwd[1];     // ... and the first pass of the XF_FFT that follows
+        return T3 == 6 ? launch_pass<PASS_DIT_DIF, 6, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st)
+                       : launch_pass<PASS_DIT_DIF, 5, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st);
+#endif
     }
     // a b - c from the three arrays of each signature, in place on the first of them; the last pass writes h
     p.src = work; p.src_stride = 3 * work_stride; p.dst = work; p.dst_stride = 3 * work_stride;
