@@ -437,7 +437,7 @@ def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn):
     verify_s = time.perf_counter() - t0
     assert accepted.tolist() == [1] * nsig, "frw_groth16_verify rejects a proof the device made: %s" % accepted.tolist()
     other = inst_h.copy()
-    other[:, 1 + (np.arange(nsig) % (ni - 1)), 0] ^= np.uint64(1)             # one public input of every statement
+    other[np.arange(nsig), 1 + (np.arange(nsig) % (ni - 1)), 0] ^= np.uint64(1)     # one public input of every statement
     assert verifier.verify(other, proofs_h).tolist() == [0] * nsig, "a proof verifies for a statement it was not made for"
     verifier.close()
     return {"workload": "Groth16 proofs of resident Falcon-%d witnesses (ark-groth16 create_proof: witness map + 5 MSMs + assembly), "

@@ -940,7 +940,13 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         const uint64_t *wit = d_witness + lo * W * 4, *inst = d_instance + lo * I * 4;
         // the blinding factors: a host array (the prover draws them), uploaded before anything reads them
         e = hipMemcpyAsync(d_rs, rs + lo * 8, cnt * 64, hipMemcpyHostToDevice, st);
-        std::vector<uint64_t> halves(cnt * 8);
+        std::vector<uint64_t> halves;
+        try {
+            halves.resize(cnt * 8);
+        } catch (const std::exception &) {
+            rc = FRW_E_OUT_OF_MEMORY;
+            break;
+        }
         for (size_t i = 0; i < cnt * 2; i++) glv_split(rs + (lo * 2 + i) * 4, &halves[i * 4]);
         if (e == hipSuccess) e = hipMemcpyAsync(d_split, halves.data(), cnt * 64, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);                                  // `rs` may be pageable and short-lived; `halves` is
