@@ -378,7 +378,7 @@ constexpr LimbsQ G2_GEN_Y1_29 = {{0x014e8093u, 0x07f6c9aau, 0x19bd3883u, 0x156ca
 
 // G1's endomorphism phi(x, y) = (beta x, y) = lambda (x, y) with lambda = z^2 - 1 (128 bits; the group order is
 // lambda^2 + lambda + 1): beta is the cube root of unity in Fq that goes with THIS lambda (the other root goes with lambda^2),
-// x 2^406; tests/test_fq29_host.py re-derives it and checks phi(G) = lambda G with the G1 oracle.  A scalar k < r splits as
+// x 2^406; tests/test_fq29_host.py re-derives it and checks phi(G) = lambda G in Python integers.  A scalar k < r splits as
 // k = k0 + lambda k1 by plain division, k0 < lambda, k1 <= lambda + 1: two 128-bit halves, half the doublings of k P.
 constexpr LimbsQ G1_ENDO_BETA29 = {{0x1195dfebu, 0x1b04e484u, 0x06026044u, 0x086070a2u, 0x1fd68858u, 0x137e9670u, 0x06871e67u,
                                     0x1e736664u, 0x083b24f6u, 0x08a70373u, 0x02a012fdu, 0x0112f94bu, 0x18a2733cu, 0x00000003u}};
