@@ -83,6 +83,8 @@ PROTOTYPES = {
     "frw_g1_fixed_base": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "frw_g2_fixed_base": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "frw_msm_g2_load": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "frw_msm_g1_load_narrow": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "frw_msm_g2_load_narrow": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
     "frw_msm_g2_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),
     "frw_msm_info": (C.c_int, [C.c_void_p, C.POINTER(MsmInfoStruct)]),

@@ -111,16 +111,17 @@ template <class F> __device__ __forceinline__ void store_ark_point(uint32_t *o, 
 // ---- load time: table[j][i] = 2^(16 j) P_i, affine, Montgomery limbs ----------------------------------------------------------
 template <class F>
 __global__ __launch_bounds__(64) void msm_precompute_kernel(uint32_t n, const uint32_t *__restrict__ bases /* [n][ARK_WORDS] ark-ff */,
-                                                            uint32_t *__restrict__ table)
+                                                            uint32_t *__restrict__ table, int window_bits /* 16 or 8 */)
 {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
+    const int windows = 256 / window_bits;
     AffineT<F> p = load_ark_point<F>(bases + (size_t)i * Grp<F>::ARK_WORDS);
-    for (int j = 0; j < MSM_W; j++) {
+    for (int j = 0; j < windows; j++) {
         store_row<F>(table + ((size_t)j * n + i) * Grp<F>::PT_WORDS, p);
-        if (j + 1 == MSM_W) break;
+        if (j + 1 == windows) break;
         XyzzT<F> d = pt_from_affine(p);
-        for (int k = 0; k < MSM_C; k++) d = pt_double(d);
+        for (int k = 0; k < window_bits; k++) d = pt_double(d);
         p = pt_to_affine(d);
     }
 }
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(64) void msm_precompute_kernel(uint32_t n, const ui
 // d_j in [-2^15, 2^15] with sum d_j 2^(16 j) = k; the top digit takes the last carry (k < 2^255, so it stays <= 2^15)
 // Returns true (and no digits) for the scalar 1: a Falcon witness is 45 % ones (the boolean elements that are set), which
 // would all land in bucket 0 of window 0 -- they are summed by msm_ones_kernel instead.
-__device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomery, int (&d)[MSM_W])
+// the scalar as a canonical integer below r
+__device__ __forceinline__ Fr8 scalar_canonical(const uint32_t *src, int montgomery)
 {
     Fr8 w = fr_load(src);
     if (montgomery) {
@@ -143,6 +145,11 @@ __device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomer
         // subtractions), because a top digit above 2^15 would index past the buckets -- and k P = (k mod r) P anyway
         w = f29_pack(f29_canonical(f29_reduce_4p(f29_unpack(w))));
     }
+    return w;
+}
+__device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomery, int (&d)[MSM_W])
+{
+    const Fr8 w = scalar_canonical(src, montgomery);
     if (w.l[0] == 1u && !(w.l[1] | w.l[2] | w.l[3] | w.l[4] | w.l[5] | w.l[6] | w.l[7])) return true;
     int carry = 0;
 #pragma unroll
@@ -448,6 +455,216 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
     if (t == 0) store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
 }
 
+// ---- narrow windows: the witness-side sums ---------------------------------------------------------------------------------------
+// The sums over a_query, b_g1_query, b_g2_query and l_query take a WITNESS as scalars: 46 % zeros, 45 % ones, and of the rest
+// all but two thousand values are below 2^16 (Falcon-1024: 13 N values that are not boolean, 2 N of them ~146 bits).  Through
+// the 16-bit pipeline above such a sum is 35,000 additions into 32,768 buckets -- and then 65,536 full additions to fold mostly
+// empty buckets, ten kernels of one wavefront per SIMD each: a third of a whole proof's time for a thirtieth of its
+// arithmetic.  With 8-bit windows (32 of them: a table twice as long) the same scalars are 70,000 additions into 128 buckets
+// per signature, cut into ~2,048 equal work items, and the fold is one workgroup: a suffix scan and a tree over 128 points.
+constexpr int NMSM_C = 8, NMSM_W = 32, NMSM_BUCKETS = 128, NMSM_SLICES = 16;
+constexpr int NMSM_TARGET_ITEMS = 2048, NMSM_MAX_ITEMS = 2304;       // items <= buckets + total / split <= 128 + 2,048
+constexpr int NMSM_ONES_MAX = 4096, NMSM_FINISH_THREADS = 256;        // ones: 256 .. 4,096 partial sums per signature, by the batch (latency against work)
+__device__ __forceinline__ bool scalar_digits8(const uint32_t *src, int montgomery, int (&d)[NMSM_W])
+{
+    const Fr8 w = scalar_canonical(src, montgomery);
+    if (w.l[0] == 1u && !(w.l[1] | w.l[2] | w.l[3] | w.l[4] | w.l[5] | w.l[6] | w.l[7])) return true;
+    int carry = 0;
+#pragma unroll
+    for (int j = 0; j < NMSM_W; j++) {
+        int v = (int)((w.l[j >> 2] >> (8 * (j & 3))) & 0xffu) + carry;        // the top byte of a value below r is <= 0x73: no carry out
+        carry = 0;
+        if (j + 1 < NMSM_W && v > NMSM_BUCKETS) { v -= 1 << NMSM_C; carry = 1; }
+        d[j] = v;
+    }
+    return false;
+}
+__device__ __forceinline__ uint32_t nmsm_split_of(uint32_t total)
+{
+    const uint32_t s = (total + NMSM_TARGET_ITEMS - 1) / NMSM_TARGET_ITEMS;
+    return s < 32u ? 32u : s;
+}
+__global__ __launch_bounds__(1024) void nmsm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words, int montgomery,
+                                                         uint32_t *__restrict__ slice_hist /* [sig][slice][128] */,
+                                                         uint32_t *__restrict__ ones_count /* [sig] */, uint32_t *__restrict__ ones_list /* [sig][n] */)
+{
+    __shared__ uint32_t hist[NMSM_BUCKETS];
+    const size_t sig = blockIdx.y;
+    const uint32_t slice = blockIdx.x, per = (n + NMSM_SLICES - 1) / NMSM_SLICES;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    if (threadIdx.x < NMSM_BUCKETS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int d[NMSM_W];
+        if (scalar_digits8(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d)) {
+            ones_list[sig * n + atomicAdd(&ones_count[sig], 1u)] = i;
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < NMSM_W; j++)
+            if (d[j]) atomicAdd(&hist[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < NMSM_BUCKETS) slice_hist[(sig * NMSM_SLICES + slice) * NMSM_BUCKETS + threadIdx.x] = hist[threadIdx.x];
+}
+// one workgroup of 128 threads per signature: bucket sizes and starts, every slice's first position inside its buckets, the
+// work items (bucket | part << 8: equal parts of at most `split` entries)
+__global__ __launch_bounds__(NMSM_BUCKETS) void nmsm_plan_kernel(uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
+                                                                 uint32_t *__restrict__ item_first, uint32_t *__restrict__ items /* [sig][NMSM_MAX_ITEMS] */,
+                                                                 uint32_t *__restrict__ item_count /* [sig] */)
+{
+    __shared__ uint32_t scan[NMSM_BUCKETS];
+    const size_t sig = blockIdx.x;
+    const int b = threadIdx.x;
+    uint32_t *h = slice_hist + sig * NMSM_SLICES * (size_t)NMSM_BUCKETS + b;
+    uint32_t c = 0;
+    for (int s_ = 0; s_ < NMSM_SLICES; s_++) {
+        const uint32_t v = h[(size_t)s_ * NMSM_BUCKETS];
+        h[(size_t)s_ * NMSM_BUCKETS] = c;
+        c += v;
+    }
+    auto inclusive_scan = [&](uint32_t mine) {
+        scan[b] = mine;
+        __syncthreads();
+        for (int off = 1; off < NMSM_BUCKETS; off <<= 1) {
+            const uint32_t v = b >= off ? scan[b - off] : 0u;
+            __syncthreads();
+            scan[b] += v;
+            __syncthreads();
+        }
+        const uint32_t r = scan[b];
+        __syncthreads();
+        return r;
+    };
+    const uint32_t incl = inclusive_scan(c);
+    scan[b] = incl;
+    __syncthreads();
+    const uint32_t total = scan[NMSM_BUCKETS - 1], split = nmsm_split_of(total);
+    __syncthreads();
+    counts[sig * NMSM_BUCKETS + b] = c;
+    offsets[sig * NMSM_BUCKETS + b] = incl - c;
+    const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
+    const uint32_t kincl = inclusive_scan(k), first = kincl - k;
+    item_first[sig * NMSM_BUCKETS + b] = first;
+    if (b == NMSM_BUCKETS - 1) item_count[sig] = kincl;
+    for (uint32_t part = 0; part < k; part++) items[sig * NMSM_MAX_ITEMS + first + part] = (uint32_t)b | (part << 8);
+}
+__global__ __launch_bounds__(1024) void nmsm_scatter_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words, int montgomery,
+                                                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ slice_hist,
+                                                            uint32_t *__restrict__ entries /* [sig][32 n] */)
+{
+    __shared__ uint32_t cursor[NMSM_BUCKETS];
+    const size_t sig = blockIdx.y;
+    const uint32_t slice = blockIdx.x, per = (n + NMSM_SLICES - 1) / NMSM_SLICES;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    if (threadIdx.x < NMSM_BUCKETS)
+        cursor[threadIdx.x] = offsets[sig * NMSM_BUCKETS + threadIdx.x] + slice_hist[(sig * NMSM_SLICES + slice) * NMSM_BUCKETS + threadIdx.x];
+    __syncthreads();
+    uint32_t *ent = entries + sig * (size_t)NMSM_W * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int d[NMSM_W];
+        if (scalar_digits8(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d)) continue;
+#pragma unroll
+        for (int j = 0; j < NMSM_W; j++) {
+            if (!d[j]) continue;
+            const uint32_t b = (uint32_t)(d[j] < 0 ? -d[j] : d[j]) - 1u;
+            ent[atomicAdd(&cursor[b], 1u)] = ((uint32_t)j * n + i) | (d[j] < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+// one thread per (signature, item): the sum of the item's table rows
+template <class F, bool PREFETCH>
+__global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
+                                                            const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
+                                                            const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items)
+{
+    constexpr int PW = Grp<F>::PT_WORDS;
+    const size_t sig = blockIdx.y;
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= item_count[sig]) return;
+    const uint32_t item = items[sig * NMSM_MAX_ITEMS + it], b = item & (NMSM_BUCKETS - 1), part = item >> 8;
+    const uint32_t c = counts[sig * NMSM_BUCKETS + b];
+    const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total);
+    const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
+    const uint32_t lo = (uint32_t)((uint64_t)c * part / k), cnt = (uint32_t)((uint64_t)c * (part + 1) / k) - lo;     // equal parts
+    const uint32_t *ent = entries + sig * (size_t)NMSM_W * m.n + offsets[sig * NMSM_BUCKETS + b] + lo;
+    XyzzT<F> acc = pt_identity<F>();
+    if (PREFETCH) {
+        uint32_t e = cnt ? ent[0] : 0u;
+        AffineT<F> p = load_row<F>(m.table + (size_t)(e & 0x7fffffffu) * PW);
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t e_next = j + 1 < cnt ? ent[j + 1] : e;
+            const AffineT<F> p_next = load_row<F>(m.table + (size_t)(e_next & 0x7fffffffu) * PW);
+            if (e >> 31) p.y = F::template neg<Grp<F>::K_AFFINE_Y>(p.y);
+            acc = pt_add_affine(acc, p);
+            e = e_next;
+            p = p_next;
+        }
+    } else {
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t e = ent[j];
+            AffineT<F> p = load_row<F>(m.table + (size_t)(e & 0x7fffffffu) * PW);
+            if (e >> 31) p.y = F::template neg<Grp<F>::K_AFFINE_Y>(p.y);
+            acc = pt_add_affine(acc, p);
+        }
+    }
+    store_bucket<F>(partial_items + (sig * NMSM_MAX_ITEMS + it) * (size_t)Grp<F>::BK_WORDS, acc);
+}
+// the points whose scalar is one: `gridDim.x * 64` partial sums per signature (thread t: every such-th of the list)
+template <class F>
+__global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
+                                                          uint32_t *__restrict__ partial_ones /* [sig][NMSM_ONES_MAX][BK_WORDS] */)
+{
+    const size_t sig = blockIdx.y;
+    const uint32_t nthreads = gridDim.x * 64, t = blockIdx.x * 64 + threadIdx.x, cnt = ones_count[sig];
+    const uint32_t *list = ones_list + sig * m.n;
+    XyzzT<F> acc = pt_identity<F>();
+    for (uint32_t k = t; k < cnt; k += nthreads)
+        acc = pt_add_affine(acc, load_row<F>(m.table + (size_t)list[k] * Grp<F>::PT_WORDS));      // window 0 of the table = the point itself
+    store_bucket<F>(partial_ones + (sig * NMSM_ONES_MAX + t) * (size_t)Grp<F>::BK_WORDS, acc);
+}
+// one workgroup per signature: threads 0..127 add up the items of their bucket and turn the 128 bucket sums into suffix sums
+// T_b = B_b + B_(b+1) + ... (sum_b (b + 1) B_b = sum_b T_b) by a scan through LDS; threads 128..255 each take `ones_each` of
+// the ones' partial sums; then one tree over all 256 values, one inversion, ark-ff's bytes out
+template <class F>
+__global__ __launch_bounds__(NMSM_FINISH_THREADS) void nmsm_finish_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+                                                                          const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
+                                                                          const uint32_t *__restrict__ partial_ones, int ones_each,
+                                                                          uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
+{
+    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
+    __shared__ uint32_t lds[NMSM_BUCKETS * SLOT];                     // 29 KB (G1) / 58 KB (G2)
+    const size_t sig = blockIdx.x;
+    const int t = threadIdx.x;
+    XyzzT<F> sum;
+    if (t < NMSM_BUCKETS) {
+        const uint32_t c = counts[sig * NMSM_BUCKETS + t];
+        const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total);
+        const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
+        const uint32_t *src = partial_items + (sig * NMSM_MAX_ITEMS + item_first[sig * NMSM_BUCKETS + t]) * (size_t)BW;
+        sum = load_bucket<F>(src);
+        for (uint32_t j = 1; j < k; j++) sum = pt_add(sum, load_bucket<F>(src + (size_t)j * BW));
+    } else {
+        const uint32_t *src = partial_ones + (sig * NMSM_ONES_MAX + (size_t)ones_each * (t - NMSM_BUCKETS)) * BW;
+        sum = load_bucket<F>(src);
+        for (int j = 1; j < ones_each; j++) sum = pt_add(sum, load_bucket<F>(src + (size_t)j * BW));
+    }
+    // suffix sums of the buckets: after the step with offset `off`, thread b holds B_b + ... + B_(b + 2 off - 1)
+    for (int off = 1; off < NMSM_BUCKETS; off <<= 1) {
+        if (t < NMSM_BUCKETS) store_bucket<F>(lds + t * SLOT, sum);
+        __syncthreads();
+        if (t + off < NMSM_BUCKETS) sum = pt_add(sum, load_bucket<F>(lds + (t + off) * SLOT));
+        __syncthreads();
+    }
+    for (int stride = NMSM_FINISH_THREADS / 2; stride >= 1; stride >>= 1) {
+        if (t >= stride && t < 2 * stride) store_bucket<F>(lds + (t - stride) * SLOT, sum);
+        __syncthreads();
+        if (t < stride) sum = pt_add(sum, load_bucket<F>(lds + t * SLOT));
+        __syncthreads();
+    }
+    if (t == 0) store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
+}
+
 // ---- k G for many scalars: the FixedBaseMSM of ark-groth16's generator (generator.rs builds h_query, a_query, l_query and
 // b_g2_query this way from the toxic waste).  8-bit windows of the generator: table[w][d] = d 2^(8 w) G, then 32 mixed additions.
 constexpr int FB_WINDOWS = 32, FB_DIGITS = 256;
@@ -500,6 +717,7 @@ __global__ __launch_bounds__(64) void fixed_base_kernel(size_t count, const uint
 struct frw_msm {
     int device;
     int group;                  // 1: G1, 2: G2
+    int window_bits;            // 16: the dense pipeline (32,768 buckets), 8: the narrow one (128 buckets)
     frw::MsmDev dev;
     void *table;
 };
@@ -519,9 +737,17 @@ template <class F> size_t msm_workspace_per_signature(uint32_t n)
            ((size_t)frw::MSM_MAX_ITEMS + 4) * 4 + (size_t)frw::MSM_MAX_ITEMS * frw::Grp<F>::BK_WORDS * 4;
 }
 
-template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, frw_msm **out)
+template <class F> size_t nmsm_workspace_per_signature(uint32_t n)
 {
-    if (!out || !bases || num_points == 0 || num_points > ((size_t)1 << 26)) return FRW_E_INVALID_ARG;
+    // slice histograms, counts, offsets, first item of every bucket (all x 128), the item list + counter, the ones' list + counter,
+    // the entries (32 n x 4 B), the items' and the ones' partial sums
+    return ((size_t)frw::NMSM_SLICES + 3) * frw::NMSM_BUCKETS * 4 + ((size_t)frw::NMSM_MAX_ITEMS + 4) * 4 + ((size_t)n + 4) * 4 +
+           (size_t)frw::NMSM_W * n * 4 + ((size_t)frw::NMSM_MAX_ITEMS + frw::NMSM_ONES_MAX) * frw::Grp<F>::BK_WORDS * 4;
+}
+
+template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, int window_bits, frw_msm **out)
+{
+    if (!out || !bases || num_points == 0 || num_points > ((size_t)1 << (window_bits == 8 ? 25 : 26))) return FRW_E_INVALID_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
@@ -531,16 +757,17 @@ template <class F> int msm_load(int device, int group, size_t num_points, const 
     if (!m) return FRW_E_OUT_OF_MEMORY;
     m->device = device;
     m->group = group;
+    m->window_bits = window_bits;
     m->table = nullptr;
     m->dev.n = (uint32_t)num_points;
     void *d_bases = nullptr;
-    const size_t table_bytes = (size_t)frw::MSM_W * num_points * frw::Grp<F>::PT_WORDS * 4, ark_bytes = (size_t)frw::Grp<F>::ARK_WORDS * 4;
+    const size_t table_bytes = (size_t)(256 / window_bits) * num_points * frw::Grp<F>::PT_WORDS * 4, ark_bytes = (size_t)frw::Grp<F>::ARK_WORDS * 4;
     e = hipMalloc(&m->table, table_bytes);
     if (e == hipSuccess) e = hipMalloc(&d_bases, num_points * ark_bytes);
     if (e == hipSuccess) e = hipMemcpy(d_bases, bases, num_points * ark_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(frw::msm_precompute_kernel<F>, dim3((unsigned)((num_points + 63) / 64)), dim3(64), 0, nullptr,
-                           (uint32_t)num_points, (const uint32_t *)d_bases, (uint32_t *)m->table);
+                           (uint32_t)num_points, (const uint32_t *)d_bases, (uint32_t *)m->table, window_bits);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -633,6 +860,52 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
 }
+// the narrow pipeline for one group
+template <class F, bool PREFETCH>
+int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery, uint64_t *d_out,
+             void *d_workspace, size_t workspace_bytes, hipStream_t st)
+{
+    const uint32_t n = m->dev.n;
+    const size_t per = nmsm_workspace_per_signature<F>(n);
+    size_t chunk = workspace_bytes / per;
+    if (chunk == 0 || ((uintptr_t)d_workspace & 15)) return FRW_E_INVALID_ARG;
+    if (chunk > 32768) chunk = 32768;                                  // grid.y
+    constexpr int BW = frw::Grp<F>::BK_WORDS;
+    hipError_t e = hipSetDevice(m->device);
+    for (size_t lo = 0; e == hipSuccess && lo < batch; lo += chunk) {
+        const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
+        uint32_t *slice_hist = (uint32_t *)d_workspace;
+        uint32_t *counts = slice_hist + cnt * (size_t)frw::NMSM_SLICES * frw::NMSM_BUCKETS;
+        uint32_t *offsets = counts + cnt * frw::NMSM_BUCKETS;
+        uint32_t *item_first = offsets + cnt * frw::NMSM_BUCKETS;
+        uint32_t *items = item_first + cnt * frw::NMSM_BUCKETS;
+        uint32_t *item_count = items + cnt * (size_t)frw::NMSM_MAX_ITEMS;  // [cnt], padded to four words per signature in the budget
+        uint32_t *ones_count = item_count + cnt * 4;                        // likewise
+        uint32_t *ones_list = ones_count + cnt * 4;
+        uint32_t *entries = ones_list + cnt * (size_t)n;
+        uint32_t *partial_items = entries + cnt * (size_t)frw::NMSM_W * n;  // 16-byte aligned: every term above is a multiple of 4 words per signature but n
+        partial_items += (4 - ((uintptr_t)partial_items >> 2 & 3)) & 3;     // ... and that is what the four spare words of the list are for
+        uint32_t *partial_ones = partial_items + cnt * (size_t)frw::NMSM_MAX_ITEMS * BW;
+        const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
+        const size_t stride_words = scalar_stride * 8;
+        const dim3 sgrid(frw::NMSM_SLICES, (unsigned)cnt);
+        e = hipMemsetAsync(ones_count, 0, cnt * 4, st);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(frw::nmsm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
+        hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3((unsigned)cnt), dim3(frw::NMSM_BUCKETS), 0, st, slice_hist, counts, offsets, item_first, items, item_count);
+        hipLaunchKernelGGL(frw::nmsm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
+        // the ones' partial sums: enough threads to occupy the chip (~2^16 over the batch), between 256 and 4,096 per signature
+        int ones_threads = 256;
+        while (ones_threads < frw::NMSM_ONES_MAX && (size_t)ones_threads * cnt < 65536) ones_threads <<= 1;
+        hipLaunchKernelGGL(frw::nmsm_ones_kernel<F>, dim3((unsigned)ones_threads / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list, partial_ones);
+        hipLaunchKernelGGL((frw::nmsm_bucket_kernel<F, PREFETCH>), dim3(frw::NMSM_MAX_ITEMS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
+                           items, item_count, entries, partial_items);
+        hipLaunchKernelGGL(frw::nmsm_finish_kernel<F>, dim3((unsigned)cnt), dim3(frw::NMSM_FINISH_THREADS), 0, st, counts, offsets, item_first, partial_items,
+                           partial_ones, ones_threads / frw::NMSM_BUCKETS, (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
+        e = hipGetLastError();
+    }
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
+}
 }  // namespace
 
 extern "C" void frw_msm_free(frw_msm *m)
@@ -645,11 +918,19 @@ extern "C" void frw_msm_free(frw_msm *m)
 
 extern "C" int frw_msm_g1_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
 {
-    return msm_load<FqField>(device, 1, num_points, bases, out);
+    return msm_load<FqField>(device, 1, num_points, bases, 16, out);
+}
+extern "C" int frw_msm_g1_load_narrow(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
+{
+    return msm_load<FqField>(device, 1, num_points, bases, 8, out);
+}
+extern "C" int frw_msm_g2_load_narrow(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
+{
+    return msm_load<Fq2Field>(device, 2, num_points, bases, 8, out);
 }
 extern "C" int frw_msm_g2_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
 {
-    return msm_load<Fq2Field>(device, 2, num_points, bases, out);
+    return msm_load<Fq2Field>(device, 2, num_points, bases, 16, out);
 }
 extern "C" int frw_g1_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out)
 {
@@ -665,10 +946,12 @@ extern "C" int frw_msm_info(const frw_msm *m, frw_msm_info_t *out)
     if (!m || !out) return FRW_E_INVALID_ARG;
     const bool g2 = m->group == 2;
     out->num_points = m->dev.n;
-    out->window_bits = frw::MSM_C;
-    out->num_windows = frw::MSM_W;
-    out->table_bytes = (uint64_t)frw::MSM_W * m->dev.n * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
-    out->workspace_bytes_per_signature = g2 ? msm_workspace_per_signature<Fq2Field>(m->dev.n) : msm_workspace_per_signature<FqField>(m->dev.n);
+    const bool narrow = m->window_bits == 8;
+    out->window_bits = m->window_bits;
+    out->num_windows = 256 / m->window_bits;
+    out->table_bytes = (uint64_t)out->num_windows * m->dev.n * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
+    out->workspace_bytes_per_signature = narrow ? (g2 ? nmsm_workspace_per_signature<Fq2Field>(m->dev.n) : nmsm_workspace_per_signature<FqField>(m->dev.n))
+                                                : (g2 ? msm_workspace_per_signature<Fq2Field>(m->dev.n) : msm_workspace_per_signature<FqField>(m->dev.n));
     return FRW_OK;
 }
 
@@ -677,6 +960,7 @@ extern "C" int frw_msm_g1_dev(const frw_msm *m, size_t batch, const uint64_t *d_
 {
     if (!m || m->group != 1 || (batch && (!d_scalars || !d_out || !d_workspace)) || scalar_stride < m->dev.n) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
+    if (m->window_bits == 8) return nmsm_run<FqField, true>(m, batch, d_scalars, scalar_stride, montgomery, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
     return msm_run<FqField, true>(m, batch, d_scalars, scalar_stride, montgomery, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 extern "C" int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery,
@@ -684,6 +968,7 @@ extern "C" int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_
 {
     if (!m || m->group != 2 || (batch && (!d_scalars || !d_out || !d_workspace)) || scalar_stride < m->dev.n) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
+    if (m->window_bits == 8) return nmsm_run<Fq2Field, false>(m, batch, d_scalars, scalar_stride, montgomery, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
     return msm_run<Fq2Field, false>(m, batch, d_scalars, scalar_stride, montgomery, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -829,19 +1114,19 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
         std::memcpy(g1.data(), d->a_query, nv * 96);
         std::memcpy(g1.data() + 12 * nv, d->alpha_g1, 96);
         std::memcpy(g1.data() + 12 * (nv + 1), d->delta_g1, 96);
-        rc = frw_msm_g1_load(device, nv + 2, g1.data(), &pk->a);
+        rc = frw_msm_g1_load_narrow(device, nv + 2, g1.data(), &pk->a);       // the four witness-side sums: narrow windows
         if (rc == FRW_OK) {
             std::memcpy(g1.data(), d->b_g1_query, nv * 96);
             std::memcpy(g1.data() + 12 * nv, d->beta_g1, 96);
-            rc = frw_msm_g1_load(device, nv + 1, g1.data(), &pk->b1);
+            rc = frw_msm_g1_load_narrow(device, nv + 1, g1.data(), &pk->b1);
         }
-        if (rc == FRW_OK) rc = frw_msm_g1_load(device, (size_t)d->num_witness, d->l_query, &pk->l);
+        if (rc == FRW_OK) rc = frw_msm_g1_load_narrow(device, (size_t)d->num_witness, d->l_query, &pk->l);
         if (rc == FRW_OK) rc = frw_msm_g1_load(device, (size_t)d->domain_size - 1, d->h_query, &pk->h);
         if (rc == FRW_OK) {
             std::memcpy(g2.data(), d->b_g2_query, nv * 192);
             std::memcpy(g2.data() + 24 * nv, d->beta_g2, 192);                 // row nv + 1 stays the point at infinity (the scalar there is r)
             std::memcpy(g2.data() + 24 * (nv + 2), d->delta_g2, 192);
-            rc = frw_msm_g2_load(device, nv + 3, g2.data(), &pk->b2);
+            rc = frw_msm_g2_load_narrow(device, nv + 3, g2.data(), &pk->b2);
         }
     } catch (const std::exception &) {
         rc = FRW_E_OUT_OF_MEMORY;

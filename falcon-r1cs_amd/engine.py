@@ -400,11 +400,13 @@ class WitnessEngine:
                                                   C.c_void_p(stream)), "frw_r1cs_eval_scratch_dev")
 
     # ---- multi-scalar multiplication over BLS12-381 G1 (frw_msm.hip) --------------------------------------------------
-    def msm_g1_load(self, bases):
-        """bases: uint64[n, 12] (ark-ff's bytes of n affine points, zeros = infinity) -> handle; free with msm_free."""
+    def msm_g1_load(self, bases, narrow=False):
+        """bases: uint64[n, 12] (ark-ff's bytes of n affine points, zeros = infinity) -> handle; free with msm_free.
+        narrow: 8-bit windows (128 buckets) instead of 16-bit ones: for scalars that are mostly zero, one or small."""
         bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 12)
         h = C.c_void_p()
-        check(self._lib.frw_msm_g1_load(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_msm_g1_load")
+        fn = self._lib.frw_msm_g1_load_narrow if narrow else self._lib.frw_msm_g1_load
+        check(fn(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_msm_g1_load")
         return h
 
     def g1_fixed_base(self, scalars):
@@ -423,10 +425,11 @@ class WitnessEngine:
                                           out.ctypes.data_as(C.c_void_p)), "frw_g2_fixed_base")
         return out
 
-    def msm_g2_load(self, bases):
+    def msm_g2_load(self, bases, narrow=False):
         bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 24)
         h = C.c_void_p()
-        check(self._lib.frw_msm_g2_load(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_msm_g2_load")
+        fn = self._lib.frw_msm_g2_load_narrow if narrow else self._lib.frw_msm_g2_load
+        check(fn(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_msm_g2_load")
         return h
 
     def msm_g2_dev(self, handle, batch, d_scalars, scalar_stride, montgomery, d_out, d_workspace, workspace_bytes, stream=0):

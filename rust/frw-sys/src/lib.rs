@@ -186,6 +186,8 @@ extern "C" {
     pub fn frw_g1_fixed_base(device: c_int, count: usize, scalars: *const u64, out: *mut u64) -> c_int;
     pub fn frw_g2_fixed_base(device: c_int, count: usize, scalars: *const u64, out: *mut u64) -> c_int;
     pub fn frw_msm_g2_load(device: c_int, num_points: usize, bases: *const u64, out: *mut *mut frw_msm) -> c_int;
+    pub fn frw_msm_g1_load_narrow(device: c_int, num_points: usize, bases: *const u64, out: *mut *mut frw_msm) -> c_int;
+    pub fn frw_msm_g2_load_narrow(device: c_int, num_points: usize, bases: *const u64, out: *mut *mut frw_msm) -> c_int;
     pub fn frw_msm_g2_dev(m: *const frw_msm, batch: usize, d_scalars: *const u64, scalar_stride: usize, montgomery: c_int,
                           d_out: *mut u64, d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_msm_info(m: *const frw_msm, out: *mut frw_msm_info_t) -> c_int;

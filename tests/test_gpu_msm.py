@@ -34,7 +34,9 @@ def _run(engine, handle, scalars, montgomery, chunk=None):
     return out.cpu().numpy().view(np.uint64)
 
 
-def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle):
+@pytest.mark.parametrize("narrow", [False, True])
+def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle, narrow):
+    """Both pipelines (16-bit windows / 32,768 buckets; 8-bit windows / 128 buckets: frw_msm_g1_load_narrow)."""
     rng = random.Random(2026)
     n = 300
     ks = [rng.randrange(1, E.R) for _ in range(n)]
@@ -49,17 +51,19 @@ def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle
         [1] * n,                                                   # every point into bucket 0 of window 0
         [E.R - 1] * n,                                             # negative digits and carries all the way up
         [0x0001000100010001000100010001000100010001000100010001000100010001] * n,      # one bucket, sixteen windows
+        [0x0101010101010101010101010101010101010101010101010101010101010101] * n,      # one bucket, thirty-two windows (9,600 entries in it: cut into items)
         [(1 << 255) - 19 if i % 2 else 0x8000 for i in range(n)],  # digit exactly 2^15 (kept positive); top-window carry
+        [0x80 if i % 3 else 0x7f81 for i in range(n)],             # digit exactly 2^7 (kept positive), 0x81 -> -0x7f with a carry into 0x7f -> 0x80
         [rng.randrange(1 << 16) for _ in range(n)],
         # out of contract for "canonical" scalars, but harmless: integers >= r are taken mod r (k P = (k mod r) P), never past the buckets
         [rng.choice([E.R, E.R + 5, (1 << 256) - 1, 2 * E.R + 7, (1 << 255) + rng.randrange(1 << 200)]) for _ in range(n)],
     ]
     vectors[0][3] = vectors[0][10]                                 # the duplicated base with the same scalar: doubling
     vectors[0][11] = vectors[0][4]                                 # the negated base with the same scalar: cancellation
-    handle = engine.msm_g1_load(bases)
+    handle = engine.msm_g1_load(bases, narrow=narrow)
     try:
         info = engine.msm_info(handle)
-        assert info.num_points == n and info.window_bits == 16 and info.num_windows == 16
+        assert info.num_points == n and (info.window_bits, info.num_windows) == ((8, 32) if narrow else (16, 16))
         canon = np.stack([T.ints_to_limbs(v) for v in vectors])
         mont = np.stack([T.ints_to_limbs([x * FR_R % E.R for x in v]) for v in vectors])
         want = [oracle.g1_msm(bases, T.ints_to_limbs([x % E.R for x in v]), 11).tolist() for v in vectors]
@@ -180,7 +184,8 @@ def test_fixed_base_multiples_of_the_generator_equal_the_oracle(engine, oracle):
     assert got[0].tolist() == [0] * 12 and got[1].tolist() == E.to_limbs(E.G1)
 
 
-def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine, oracle):
+@pytest.mark.parametrize("narrow", [False, True])
+def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine, oracle, narrow):
     """The witness-side sums of the prover (prover.rs calculate_coeff / l_aux_acc: MSM(a_query | b_g1_query | l_query,
     assignment)): the scalars are a Falcon-512 witness -- 91 % of them 0 or 1 -- over as many bases as the circuit has
     variables.  Ones are summed apart from the buckets; the result must be the CPU's, bit for bit, for genuine witnesses and
@@ -201,7 +206,7 @@ def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine,
     z = np.concatenate([z, np.zeros((2, n, 4), dtype=np.uint64)])
     z[batch, :, 0] = 1                                            # all ones
     z[batch + 1, 12345, 0] = 1                                    # a single one
-    handle = engine.msm_g1_load(bases)
+    handle = engine.msm_g1_load(bases, narrow=narrow)
     try:
         got = _run(engine, handle, z, 0)
         for i in range(z.shape[0]):
@@ -211,7 +216,8 @@ def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine,
         engine.msm_free(handle)
 
 
-def test_g2_fixed_base_and_msm_equal_python_integers(engine):
+@pytest.mark.parametrize("narrow", [False, True])
+def test_g2_fixed_base_and_msm_equal_python_integers(engine, narrow):
     """G2 (prover.rs: g2_b = MSM(b_g2_query, assignment) + ...): the generator's fixed-base multiples and a multi-scalar
     multiplication against oracle/bls12_381.py's Fq2 arithmetic in Python integers -- bases as multiples k_i G2 of the
     published generator, so that the expected sum is (sum s_i k_i) G2, one scalar multiplication; with the same degenerate
@@ -230,7 +236,7 @@ def test_g2_fixed_base_and_msm_equal_python_integers(engine):
                [rng.choice([0, 1, 1, rng.randrange(1 << 14), rng.randrange(1 << 146)]) for _ in range(n)]]
     vectors[0][3] = vectors[0][10]
     vectors[0][11] = vectors[0][4]
-    handle = engine.msm_g2_load(bases)
+    handle = engine.msm_g2_load(bases, narrow=narrow)
     try:
         import torch
         dev = torch.device("cuda:0")
