@@ -464,7 +464,7 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
 // per signature, cut into ~2,048 equal work items, and the fold is one workgroup: a suffix scan and a tree over 128 points.
 constexpr int NMSM_C = 8, NMSM_W = 32, NMSM_BUCKETS = 128, NMSM_SLICES = 16;
 constexpr int NMSM_TARGET_ITEMS = 2048, NMSM_MAX_ITEMS = 2304;       // items <= buckets + total / split <= 128 + 2,048
-constexpr int NMSM_ONES_MAX = 4096, NMSM_FINISH_THREADS = 256;        // ones: 256 .. 4,096 partial sums per signature, by the batch (latency against work)
+constexpr int NMSM_ONES_MAX = 4096, NMSM_FINISH_THREADS = 384;        // ones: 256 .. 4,096 partial sums per signature, by the batch (latency against work)
 __device__ __forceinline__ bool scalar_digits8(const uint32_t *src, int montgomery, int (&d)[NMSM_W])
 {
     const Fr8 w = scalar_canonical(src, montgomery);
@@ -624,8 +624,8 @@ __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32
     store_bucket<F>(partial_ones + (sig * NMSM_ONES_MAX + t) * (size_t)Grp<F>::BK_WORDS, acc);
 }
 // one workgroup per signature: threads 0..127 add up the items of their bucket and turn the 128 bucket sums into suffix sums
-// T_b = B_b + B_(b+1) + ... (sum_b (b + 1) B_b = sum_b T_b) by a scan through LDS; threads 128..255 each take `ones_each` of
-// the ones' partial sums; then one tree over all 256 values, one inversion, ark-ff's bytes out
+// T_b = B_b + B_(b+1) + ... (sum_b (b + 1) B_b = sum_b T_b) by a scan through LDS; threads 128..383 each take `ones_each` of
+// the ones' partial sums; then one tree over all 384 values, one inversion, ark-ff's bytes out
 template <class F>
 __global__ __launch_bounds__(NMSM_FINISH_THREADS) void nmsm_finish_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
                                                                           const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
@@ -656,7 +656,11 @@ __global__ __launch_bounds__(NMSM_FINISH_THREADS) void nmsm_finish_kernel(const 
         if (t + off < NMSM_BUCKETS) sum = pt_add(sum, load_bucket<F>(lds + (t + off) * SLOT));
         __syncthreads();
     }
-    for (int stride = NMSM_FINISH_THREADS / 2; stride >= 1; stride >>= 1) {
+    if (t >= 2 * NMSM_BUCKETS) store_bucket<F>(lds + (t - 2 * NMSM_BUCKETS) * SLOT, sum);          // 384 -> 256
+    __syncthreads();
+    if (t < NMSM_BUCKETS) sum = pt_add(sum, load_bucket<F>(lds + t * SLOT));
+    __syncthreads();
+    for (int stride = NMSM_BUCKETS; stride >= 1; stride >>= 1) {
         if (t >= stride && t < 2 * stride) store_bucket<F>(lds + (t - stride) * SLOT, sum);
         __syncthreads();
         if (t < stride) sum = pt_add(sum, load_bucket<F>(lds + t * SLOT));
@@ -901,7 +905,7 @@ int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t s
         hipLaunchKernelGGL((frw::nmsm_bucket_kernel<F, PREFETCH>), dim3(frw::NMSM_MAX_ITEMS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
                            items, item_count, entries, partial_items);
         hipLaunchKernelGGL(frw::nmsm_finish_kernel<F>, dim3((unsigned)cnt), dim3(frw::NMSM_FINISH_THREADS), 0, st, counts, offsets, item_first, partial_items,
-                           partial_ones, ones_threads / frw::NMSM_BUCKETS, (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
+                           partial_ones, ones_threads / (2 * frw::NMSM_BUCKETS), (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
         e = hipGetLastError();
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
