@@ -464,7 +464,10 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
 // per signature, cut into ~2,048 equal work items, and the fold is one workgroup: a suffix scan and a tree over 128 points.
 constexpr int NMSM_C = 8, NMSM_W = 32, NMSM_BUCKETS = 128, NMSM_SLICES = 16;
 constexpr int NMSM_TARGET_ITEMS = 2048, NMSM_MAX_ITEMS = 2304;       // items <= buckets + total / split <= 128 + 2,048
-constexpr int NMSM_ONES_MAX = 4096, NMSM_FINISH_THREADS = 384;        // ones: 256 .. 4,096 partial sums per signature, by the batch (latency against work)
+constexpr int NMSM_ONES_MAX = 4096;
+// threads of the one-workgroup fold: 128 for the buckets + 256 (G1) / 128 (G2: four waves = one per SIMD, the whole register file
+// for an addition that needs 300 live registers) for the ones' partial sums
+template <class F> constexpr int nmsm_finish_threads() { return F::WORDS > NLQ ? 256 : 384; }        // ones: 256 .. 4,096 partial sums per signature, by the batch (latency against work)
 __device__ __forceinline__ bool scalar_digits8(const uint32_t *src, int montgomery, int (&d)[NMSM_W])
 {
     const Fr8 w = scalar_canonical(src, montgomery);
@@ -627,44 +630,70 @@ __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32
 // T_b = B_b + B_(b+1) + ... (sum_b (b + 1) B_b = sum_b T_b) by a scan through LDS; threads 128..383 each take `ones_each` of
 // the ones' partial sums; then one tree over all 384 values, one inversion, ark-ff's bytes out
 template <class F>
-__global__ __launch_bounds__(NMSM_FINISH_THREADS) void nmsm_finish_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+__global__ __launch_bounds__(nmsm_finish_threads<F>()) void nmsm_finish_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
                                                                           const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
                                                                           const uint32_t *__restrict__ partial_ones, int ones_each,
                                                                           uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
 {
-    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
+    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, FT = nmsm_finish_threads<F>();
     __shared__ uint32_t lds[NMSM_BUCKETS * SLOT];                     // 29 KB (G1) / 58 KB (G2)
+    __shared__ uint32_t longest;
     const size_t sig = blockIdx.x;
     const int t = threadIdx.x;
-    XyzzT<F> sum;
+    // ONE addition site in the whole kernel (a general addition in G2 is 1,500 instructions around 300 live registers: five
+    // inlined copies of it cost 2.9 KB of scratch per lane and most of the kernel's time): every step of every phase is
+    // "sum += the point at p", with p in global memory or in LDS.
+    const uint32_t *src;
+    uint32_t mine;                                                    // serial additions of this thread's own list
     if (t < NMSM_BUCKETS) {
         const uint32_t c = counts[sig * NMSM_BUCKETS + t];
         const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total);
-        const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
-        const uint32_t *src = partial_items + (sig * NMSM_MAX_ITEMS + item_first[sig * NMSM_BUCKETS + t]) * (size_t)BW;
-        sum = load_bucket<F>(src);
-        for (uint32_t j = 1; j < k; j++) sum = pt_add(sum, load_bucket<F>(src + (size_t)j * BW));
+        mine = (c <= split ? 1u : (c + split - 1) / split) - 1u;
+        src = partial_items + (sig * NMSM_MAX_ITEMS + item_first[sig * NMSM_BUCKETS + t]) * (size_t)BW;
     } else {
-        const uint32_t *src = partial_ones + (sig * NMSM_ONES_MAX + (size_t)ones_each * (t - NMSM_BUCKETS)) * BW;
-        sum = load_bucket<F>(src);
-        for (int j = 1; j < ones_each; j++) sum = pt_add(sum, load_bucket<F>(src + (size_t)j * BW));
+        mine = (uint32_t)ones_each - 1u;
+        src = partial_ones + (sig * NMSM_ONES_MAX + (size_t)ones_each * (t - NMSM_BUCKETS)) * BW;
     }
-    // suffix sums of the buckets: after the step with offset `off`, thread b holds B_b + ... + B_(b + 2 off - 1)
-    for (int off = 1; off < NMSM_BUCKETS; off <<= 1) {
-        if (t < NMSM_BUCKETS) store_bucket<F>(lds + t * SLOT, sum);
-        __syncthreads();
-        if (t + off < NMSM_BUCKETS) sum = pt_add(sum, load_bucket<F>(lds + (t + off) * SLOT));
-        __syncthreads();
-    }
-    if (t >= 2 * NMSM_BUCKETS) store_bucket<F>(lds + (t - 2 * NMSM_BUCKETS) * SLOT, sum);          // 384 -> 256
+    if (t == 0) longest = 0;
     __syncthreads();
-    if (t < NMSM_BUCKETS) sum = pt_add(sum, load_bucket<F>(lds + t * SLOT));
+    atomicMax(&longest, mine);
     __syncthreads();
-    for (int stride = NMSM_BUCKETS; stride >= 1; stride >>= 1) {
-        if (t >= stride && t < 2 * stride) store_bucket<F>(lds + (t - stride) * SLOT, sum);
-        __syncthreads();
-        if (t < stride) sum = pt_add(sum, load_bucket<F>(lds + t * SLOT));
-        __syncthreads();
+    const uint32_t serial = longest;
+    XyzzT<F> sum = load_bucket<F>(src);
+    // steps 0 .. serial - 1: the thread's own list; then 7 steps of the suffix scan over the buckets (offset 1, 2, .., 64), one
+    // step 384 -> 256 (G1), 8 steps of the tree (stride 128, 64, .., 1)
+    const uint32_t steps = serial + 7 + 1 + 8;
+    for (uint32_t step = 0; step < steps; step++) {
+        bool store_me = false, add_me = false;
+        int store_slot = 0, load_slot = 0;
+        const uint32_t *p = src;
+        if (step < serial) {
+            add_me = step < mine;
+            p = src + (size_t)(step + 1) * BW;
+        } else {
+            const uint32_t ph = step - serial;
+            if (ph < 7) {                                              // after the step with offset `off`, thread b holds B_b + ... + B_(b + 2 off - 1)
+                const int off = 1 << ph;
+                store_me = t < NMSM_BUCKETS; store_slot = t;
+                add_me = t + off < NMSM_BUCKETS; load_slot = t + off;
+            } else if (ph == 7) {                                      // 384 -> 256
+                if (FT <= 2 * NMSM_BUCKETS) continue;
+                store_me = t >= 2 * NMSM_BUCKETS; store_slot = t - 2 * NMSM_BUCKETS;
+                add_me = t < NMSM_BUCKETS; load_slot = t;
+            } else {
+                const int stride = NMSM_BUCKETS >> (ph - 8);
+                store_me = t >= stride && t < 2 * stride; store_slot = t - stride;
+                add_me = t < stride; load_slot = t;
+            }
+            if (store_me) store_bucket<F>(lds + store_slot * SLOT, sum);
+            __syncthreads();
+            p = lds + load_slot * SLOT;
+        }
+        if (add_me) {
+            // one layout for both sources: a bucket in global memory and a slot in LDS hold X, Y, ZZ, ZZZ and the flag alike
+            sum = pt_add(sum, load_bucket<F>(p));
+        }
+        if (step >= serial) __syncthreads();
     }
     if (t == 0) store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
 }
@@ -904,8 +933,9 @@ int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t s
         hipLaunchKernelGGL(frw::nmsm_ones_kernel<F>, dim3((unsigned)ones_threads / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list, partial_ones);
         hipLaunchKernelGGL((frw::nmsm_bucket_kernel<F, PREFETCH>), dim3(frw::NMSM_MAX_ITEMS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
                            items, item_count, entries, partial_items);
-        hipLaunchKernelGGL(frw::nmsm_finish_kernel<F>, dim3((unsigned)cnt), dim3(frw::NMSM_FINISH_THREADS), 0, st, counts, offsets, item_first, partial_items,
-                           partial_ones, ones_threads / (2 * frw::NMSM_BUCKETS), (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
+        constexpr int FT = frw::nmsm_finish_threads<F>();
+        hipLaunchKernelGGL(frw::nmsm_finish_kernel<F>, dim3((unsigned)cnt), dim3(FT), 0, st, counts, offsets, item_first, partial_items,
+                           partial_ones, ones_threads / (FT - frw::NMSM_BUCKETS), (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
         e = hipGetLastError();
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
