@@ -327,9 +327,10 @@ int frw_g2_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_
 typedef struct frw_msm frw_msm;
 typedef struct {
     uint64_t num_points;
-    int32_t window_bits, num_windows;          /* 16, 16 */
+    int32_t window_bits, num_windows;          /* 16, 16; a _narrow handle: 8, 32 */
     uint64_t table_bytes;                      /* 16 x num_points x 112 */
-    uint64_t workspace_bytes_per_signature;    /* sort keys (64 num_points bytes) + 32,768 buckets x 240 bytes + counters */
+    uint64_t workspace_bytes_per_signature;    /* sort keys (64 num_points bytes) + 32,768 buckets x 240 bytes + counters; a _narrow
+                                                * handle: 128 num_points bytes of keys, 2,304 + 4,096 partial sums */
 } frw_msm_info_t;
 int frw_msm_g1_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out);
 void frw_msm_free(frw_msm *m);
