@@ -626,31 +626,6 @@ __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32
         acc = pt_add_affine(acc, load_row<F>(m.table + (size_t)list[k] * Grp<F>::PT_WORDS));      // window 0 of the table = the point itself
     store_bucket<F>(partial_ones + (sig * NMSM_ONES_MAX + t) * (size_t)Grp<F>::BK_WORDS, acc);
 }
-// p + (the point stored at q), q's coordinates fetched where the formula needs them (ZZ and ZZZ twice) instead of being held:
-// in G2 the two operands of a general addition alone are 224 registers
-template <class F> __device__ __forceinline__ XyzzT<F> pt_add_stored(const XyzzT<F> &p, const uint32_t *q)
-{
-    constexpr int W = F::WORDS;
-    if (q[4 * W] != 0) return p;
-    if (p.inf) return load_bucket<F>(q);
-    const auto u1 = F::mul(p.x, F::load(q + 2 * W)), s1 = F::mul(p.y, F::load(q + 3 * W));
-    const auto u2 = F::mul(F::load(q), p.zz), s2 = F::mul(F::load(q + W), p.zzz);
-    const auto pp_ = F::template sub<F::K_MUL>(u2, u1), rr = F::template sub<F::K_MUL>(s2, s1);
-    if (F::is_zero(pp_)) {
-        if (F::is_zero(rr)) return pt_double(p);
-        return pt_identity<F>();
-    }
-    const auto pp = F::sqr(pp_), ppp = F::mul(pp_, pp), qq = F::mul(u1, pp);
-    XyzzT<F> r;
-    r.x = F::template sub<F::K_2MUL>(F::template sub<F::K_MUL>(F::sqr(rr), ppp), F::add(qq, qq));
-    r.y = F::template mul_sub<F::K_MUL>(rr, F::template sub<F::K_X>(qq, r.x), s1, ppp);
-    __builtin_amdgcn_sched_barrier(0);
-    r.zz = F::mul(F::mul(p.zz, F::load(q + 2 * W)), pp);
-    r.zzz = F::mul(F::mul(p.zzz, F::load(q + 3 * W)), ppp);
-    r.inf = false;
-    return r;
-}
-
 // one workgroup per signature: threads 0..127 add up the items of their bucket and turn the 128 bucket sums into suffix sums
 // T_b = B_b + B_(b+1) + ... (sum_b (b + 1) B_b = sum_b T_b) by a scan through LDS; threads 128..383 each take `ones_each` of
 // the ones' partial sums; then one tree over all 384 values, one inversion, ark-ff's bytes out
@@ -716,7 +691,7 @@ __global__ __launch_bounds__(nmsm_finish_threads<F>()) void nmsm_finish_kernel(c
         }
         if (add_me) {
             // one layout for both sources: a bucket in global memory and a slot in LDS hold X, Y, ZZ, ZZZ and the flag alike
-            sum = pt_add_stored<F>(sum, p);
+            sum = pt_add(sum, load_bucket<F>(p));
         }
         if (step >= serial) __syncthreads();
     }
