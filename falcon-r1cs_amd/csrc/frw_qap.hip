@@ -58,6 +58,9 @@ struct NttPass {
     int L, sh;                  // log n; lowest index bit this pass transforms
     int per_sig;                // PASS_FIRST: arrays per signature in this launch (array y = signature y / per_sig, matrix y % per_sig)
     uint32_t cfac[9];           // STORE_CONST_ADD_CANONICAL: the constant factor, x R' in nine limbs
+    // list mode (the seven-transform map for the few signatures whose witness violates the system): grid.y = arrays per
+    // signature, and a workgroup does its tile of every listed signature in turn; array index = list[k] x gridDim.y + blockIdx.y
+    const uint32_t *list, *list_count;
 };
 
 // A/B builds (tools/ab_qap.py): -DFRW_QAP_NO_MUL replaces the products by additions, -DFRW_QAP_NO_STAGES skips the
@@ -245,7 +248,7 @@ __device__ __forceinline__ void round_high(F29 (&x)[8], const uint32_t *roots, i
 // a decimation-in-time transform whose input is still in constraint order in the products' buffers: working index =
 // bitrev(natural index), so the 64 rows are the natural-index bits [L - 6, L) reversed and the 8 columns the
 // natural-index bits [0, 3) (256-byte runs on the way in); the output is a memory-order tile of the working array.
-template <int MODE, int T, int LOAD, int STORE>
+template <int MODE, int T, int LOAD, int STORE, bool LIST = false>
 __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass p)
 {
     constexpr bool DIF = MODE == PASS_DIF || MODE == PASS_DIF_SH0;
@@ -258,9 +261,12 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
     const int tid = threadIdx.x, c = tid & (COLS - 1), g = tid >> CB;           // T == 6: 8 columns x 8 g; T == 5: 16 x 4
     const uint32_t tileid = blockIdx.x;
     const size_t n = (size_t)1 << p.L;
-    const uint32_t *src = p.src + (size_t)blockIdx.y * p.src_stride;
-    uint32_t *dst = p.dst + (size_t)blockIdx.y * p.dst_stride;
-    const uint32_t *factor = STORE == STORE_FACTOR_A && blockIdx.y % 3 == 0 ? p.factor_a : p.factor;
+    const uint32_t turns = LIST ? *p.list_count : 1u;                // LIST is a template parameter: the loop costs the usual kernels nothing
+    for (uint32_t turn = 0; turn < turns; turn++) {                  // (one turn unless in list mode; the body is not indented for it)
+    const uint32_t array_y = LIST ? p.list[turn] * gridDim.y + blockIdx.y : blockIdx.y;
+    const uint32_t *src = p.src + (size_t)array_y * p.src_stride;
+    uint32_t *dst = p.dst + (size_t)array_y * p.dst_stride;
+    const uint32_t *factor = STORE == STORE_FACTOR_A && array_y % 3 == 0 ? p.factor_a : p.factor;
 
     // rows of the eight elements a thread holds in the low round (stages 1..3) and in the high round (stages 4..T)
     auto row_low = [&](int e) { return g * 8 + e; };
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
 
     // ---- in: the eight elements of the first round -----------------------------------------------------------------------
     if (MODE == PASS_FIRST) {
-        const size_t sig = blockIdx.y / p.per_sig, which = blockIdx.y % p.per_sig;
+        const size_t sig = array_y / p.per_sig, which = array_y % p.per_sig;
         const uint32_t *rows = p.abc + (sig * 3 + which) * (size_t)p.num_constraints * 8;
         const uint32_t *inst = p.instance + sig * (size_t)p.num_instance * 8;
         static_for<8>([&](auto ec) {
@@ -443,6 +449,8 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
     } else {
         static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; store_elem(widx(DIF || FUSED ? row_low(e) : row_high(e), c), x[e]); });
     }
+    if (LIST) wave_sync();                                           // the next turn reuses the LDS
+    }
 }
 
 namespace {
@@ -450,7 +458,8 @@ template <int MODE, int T, int LOAD, int STORE>
 hipError_t launch_pass(const NttPass &p, unsigned arrays, hipStream_t st)
 {
     const unsigned tiles = (unsigned)(((size_t)1 << p.L) / QAP_TILE);
-    hipLaunchKernelGGL((ntt_pass_kernel<MODE, T, LOAD, STORE>), dim3(tiles, arrays), dim3(QAP_THREADS), 0, st, p);
+    if (p.list) hipLaunchKernelGGL((ntt_pass_kernel<MODE, T, LOAD, STORE, true>), dim3(tiles, arrays), dim3(QAP_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((ntt_pass_kernel<MODE, T, LOAD, STORE>), dim3(tiles, arrays), dim3(QAP_THREADS), 0, st, p);
     return hipGetLastError();
 }
 
@@ -628,16 +637,31 @@ hipError_t diag_valu_rates(int num_cu, void *scratch, double out[4], hipStream_t
     return hipSuccess;
 }
 
-size_t qap_workspace_bytes_per_signature(const R1csDev &r, const QapDev &q)
+// the signatures of a chunk whose witness violates the system (num_unsatisfied != 0), in any order, and how many
+__global__ __launch_bounds__(256) void qap_list_kernel(const uint32_t *__restrict__ num_unsatisfied, uint32_t cnt, uint32_t *__restrict__ list,
+                                                       uint32_t *__restrict__ list_count)
 {
-    return 3 * (size_t)r.num_constraints * 32 + 3 * 32 * ((size_t)1 << q.log_n);
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256)
+        if (num_unsatisfied[i]) list[atomicAdd(list_count, 1u)] = i;
 }
 
-// workspace per signature in flight: A z, B z, C z (3 C x 32 B) + three working arrays (3 n x 32 B); the batch is cut into
-// chunks that fit
-hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,
-                                  const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,
-                                  size_t workspace_bytes, hipStream_t st)
+constexpr size_t QAP_FLAGS_BYTES = 64;                              // per signature in flight: its count of violated rows, its place in the list, the list's length
+size_t qap_workspace_bytes_per_signature(const R1csDev &r, const QapDev &q)
+{
+    return 3 * (size_t)r.num_constraints * 32 + 3 * 32 * ((size_t)1 << q.log_n) + QAP_FLAGS_BYTES;
+}
+
+// workspace per signature in flight: A z, B z, C z (3 C x 32 B) + three working arrays (3 n x 32 B) + 64 bytes of flags; the
+// batch is cut into chunks that fit.
+//   QAP_SIX     h = hi of a b (six transforms): ark-groth16's h for every witness that satisfies the system
+//   QAP_SEVEN   ark-groth16's witness_map as it is written (seven transforms), whatever the witness
+//   QAP_EXACT   QAP_SIX for the whole chunk, then QAP_SEVEN in list mode for the signatures whose witness violates the system
+//               (none, normally: 18 launches of a few hundred workgroups that read a zero and leave): ark-groth16's h for
+//               EVERY input at the price of six transforms
+namespace {
+enum { QAP_SIX, QAP_SEVEN, QAP_EXACT };
+hipError_t qap_run(int mode, const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness, const uint64_t *instance, uint64_t *h,
+                   uint32_t *num_unsatisfied, void *workspace, size_t workspace_bytes, hipStream_t st)
 {
     if (batch == 0) return hipSuccess;
     const int L = q.log_n;
@@ -650,23 +674,51 @@ hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batc
         const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
         uint32_t *abc = (uint32_t *)workspace;
         uint32_t *work = abc + cnt * 3 * (size_t)r.num_constraints * 8;
+        uint32_t *own_flags = work + cnt * 3 * n * 8, *list = own_flags + cnt, *list_count = list + cnt;
+        uint32_t *flags = num_unsatisfied ? num_unsatisfied + lo : (mode == QAP_EXACT ? own_flags : nullptr);
         const uint64_t *wit = witness + lo * (size_t)r.num_witness * 4, *inst = instance + lo * (size_t)r.num_instance * 4;
-        hipError_t e = launch_r1cs_check(r, cnt, wit, inst, num_unsatisfied ? num_unsatisfied + lo : nullptr, (uint64_t *)abc, st, work);   // the working arrays are idle during the products: they lend the scratch
+        uint32_t *hh = (uint32_t *)(h + lo * n * 4);
+        hipError_t e = launch_r1cs_check(r, cnt, wit, inst, flags, (uint64_t *)abc, st, work);   // the working arrays are idle during the products: they lend the scratch
         if (e != hipSuccess) return e;
         NttPass p{};
         p.abc = abc;
         p.instance = (const uint32_t *)inst;
         p.num_constraints = r.num_constraints;
         p.num_instance = r.num_instance;
+        if (mode != QAP_SEVEN) {
+            // a b on the domain and on the coset psi H: two arrays per signature
+            if ((e = transform(XF_IFFT_FROM_PRODUCTS_PSI, q, p, work, n * 8, nullptr, (unsigned)(2 * cnt), st)) != hipSuccess) return e;
+            if ((e = transform(XF_FFT, q, p, work, n * 8, nullptr, (unsigned)(2 * cnt), st)) != hipSuccess) return e;
+            if ((e = transform(XF_IFFT_AB_TO_H, q, p, work, n * 8, hh, (unsigned)cnt, st)) != hipSuccess) return e;
+            if ((e = transform(XF_IFFT_PRODUCTS_AB_ADD_H, q, p, work, n * 8, hh, (unsigned)cnt, st)) != hipSuccess) return e;
+            if (mode == QAP_SIX) continue;
+            if ((e = hipMemsetAsync(list_count, 0, 4, st)) != hipSuccess) return e;
+            hipLaunchKernelGGL(qap_list_kernel, dim3(1), dim3(256), 0, st, flags, (uint32_t)cnt, list, list_count);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            p.list = list;
+            p.list_count = list_count;
+        }
+        const unsigned per3 = p.list ? 3u : (unsigned)(3 * cnt), per1 = p.list ? 1u : (unsigned)cnt;
         // ifft + distribute_powers(g) (A z with an extra 2^5, which the a b product in R' = 2^261 arithmetic takes out again)
-        if ((e = transform(XF_IFFT_FROM_PRODUCTS, q, p, work, n * 8, nullptr, (unsigned)(3 * cnt), st)) != hipSuccess) return e;
+        if ((e = transform(XF_IFFT_FROM_PRODUCTS, q, p, work, n * 8, nullptr, per3, st)) != hipSuccess) return e;
         // fft: a, b, c on the coset (bit-reversed order)
-        if ((e = transform(XF_FFT, q, p, work, n * 8, nullptr, (unsigned)(3 * cnt), st)) != hipSuccess) return e;
+        if ((e = transform(XF_FFT, q, p, work, n * 8, nullptr, per3, st)) != hipSuccess) return e;
         // (a b - c) / Z on the coset, coset_ifft
-        if ((e = transform(XF_IFFT_POINTWISE_TO_H, q, p, work, n * 8, (uint32_t *)(h + lo * n * 4), (unsigned)cnt, st)) != hipSuccess)
-            return e;
+        if ((e = transform(XF_IFFT_POINTWISE_TO_H, q, p, work, n * 8, hh, per1, st)) != hipSuccess) return e;
     }
     return hipSuccess;
+}
+}  // namespace
+
+hipError_t launch_qap_witness_map(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,
+                                  const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,
+                                  size_t workspace_bytes, hipStream_t st)
+{
+#if defined(FRW_QAP_SEVEN_ALWAYS)
+    return qap_run(QAP_SEVEN, r, q, batch, witness, instance, h, num_unsatisfied, workspace, workspace_bytes, st);
+#else
+    return qap_run(QAP_EXACT, r, q, batch, witness, instance, h, num_unsatisfied, workspace, workspace_bytes, st);
+#endif
 }
 
 // The same quotient with six transforms instead of seven, for witnesses that satisfy the system (num_unsatisfied says):
@@ -678,32 +730,7 @@ hipError_t launch_qap_quotient(const R1csDev &r, const QapDev &q, size_t batch, 
                                const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,
                                size_t workspace_bytes, hipStream_t st)
 {
-    if (batch == 0) return hipSuccess;
-    const int L = q.log_n;
-    if (L != 17 && L != 18) return hipErrorInvalidValue;
-    const size_t n = (size_t)1 << L, per_sig = qap_workspace_bytes_per_signature(r, q);
-    size_t chunk = workspace_bytes / per_sig;
-    if (chunk == 0) return hipErrorInvalidValue;
-    if (chunk > 16384) chunk = 16384;
-    for (size_t lo = 0; lo < batch; lo += chunk) {
-        const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
-        uint32_t *abc = (uint32_t *)workspace;
-        uint32_t *work = abc + cnt * 3 * (size_t)r.num_constraints * 8;           // two arrays per signature
-        const uint64_t *wit = witness + lo * (size_t)r.num_witness * 4, *inst = instance + lo * (size_t)r.num_instance * 4;
-        uint32_t *hh = (uint32_t *)(h + lo * n * 4);
-        hipError_t e = launch_r1cs_check(r, cnt, wit, inst, num_unsatisfied ? num_unsatisfied + lo : nullptr, (uint64_t *)abc, st, work);   // the working arrays are idle during the products: they lend the scratch
-        if (e != hipSuccess) return e;
-        NttPass p{};
-        p.abc = abc;
-        p.instance = (const uint32_t *)inst;
-        p.num_constraints = r.num_constraints;
-        p.num_instance = r.num_instance;
-        if ((e = transform(XF_IFFT_FROM_PRODUCTS_PSI, q, p, work, n * 8, nullptr, (unsigned)(2 * cnt), st)) != hipSuccess) return e;
-        if ((e = transform(XF_FFT, q, p, work, n * 8, nullptr, (unsigned)(2 * cnt), st)) != hipSuccess) return e;
-        if ((e = transform(XF_IFFT_AB_TO_H, q, p, work, n * 8, hh, (unsigned)cnt, st)) != hipSuccess) return e;
-        if ((e = transform(XF_IFFT_PRODUCTS_AB_ADD_H, q, p, work, n * 8, hh, (unsigned)cnt, st)) != hipSuccess) return e;
-    }
-    return hipSuccess;
+    return qap_run(QAP_SIX, r, q, batch, witness, instance, h, num_unsatisfied, workspace, workspace_bytes, st);
 }
 
 }  // namespace frw

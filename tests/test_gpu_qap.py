@@ -63,7 +63,12 @@ def test_witness_map_equals_oracle(engine, oracle, tmp_path, circuit, logn):
         hq = torch.full((batch, n, 4), -1, dtype=torch.int64, device=dev)
         badq = torch.full((batch,), -1, dtype=torch.int32, device=dev)
         engine.qap_quotient_dev(h_r1cs, batch, wit, inst, hq, ws, ws_bytes, badq, s0)
+        # the witness map without the caller's array for the counts: it keeps its own (it needs them to know which signatures go
+        # through the seven-transform map after the six-transform one)
+        h_again = torch.full((batch, n, 4), -1, dtype=torch.int64, device=dev)
+        engine.qap_witness_map_dev(h_r1cs, batch, wit, inst, h_again, ws, ws_bytes, None, s0)
         torch.cuda.synchronize()
+        assert torch.equal(h_again, h)
     finally:
         engine.r1cs_free(h_r1cs)
     assert bad.tolist()[0] == 0 and bad.tolist()[1] > 0 and bad.tolist()[2] > 0

@@ -57,7 +57,7 @@ def main():
     print("  witness map      %9.3f ms/call  %8.1f us/signature  %9.1f signatures/s" % (ms_all, 1e3 * ms_all / batch, batch / ms_all * 1e3))
     print("  six-transform quotient (h of a satisfied system) %9.3f ms/call  %8.1f us/signature  %9.1f signatures/s" % (ms_q, 1e3 * ms_q / batch, batch / ms_q * 1e3))
     print("  of which A z, B z, C z (frw_r1cs_eval_dev alone) %9.3f ms/call  %8.1f us/signature" % (ms_mv, 1e3 * ms_mv / batch))
-    mul = 7 * (n // 2) * int(q.log_domain_size) + 5 * n
+    mul = 6 * (n // 2) * int(q.log_domain_size) + 5 * n            # textbook count of six radix-2 transforms (what both entry points run for these witnesses)
     print("  transforms: %.1f M Montgomery products per signature -> %.1f G products/s" % (mul / 1e6, mul * batch / ((ms_all - ms_mv) * 1e-3) / 1e9))
     eng.r1cs_free(r)
 
