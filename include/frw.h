@@ -257,8 +257,10 @@ int frw_r1cs_eval_scratch_dev(const frw_r1cs *r, size_t batch, const uint64_t *d
  *     h(X) = (A(X) B(X) - C(X)) / (X^n - 1)
  * over ark-poly's Radix2EvaluationDomain of size n = next_power_of_two(C + I) (2^17 for Falcon-512, 2^18 for
  * Falcon-1024), computed as  a = A z ++ instance values, b = B z, c = C z;  ifft, coset_fft (generator 7);
- * a o b - c;  / (7^n - 1);  coset_ifft.  frw_qap_witness_map_dev does exactly that for every signature of an HBM-resident
- * batch, from the buffers the witness entry points wrote (FRW_ENC_MONTGOMERY):
+ * a o b - c;  / (7^n - 1);  coset_ifft.  frw_qap_witness_map_dev returns exactly that h for every signature of an HBM-resident
+ * batch, whatever the witness -- by running the six-transform quotient below for all of them (the same h wherever the witness
+ * satisfies the system) and then ark-groth16's seven transforms, as written, for just the signatures whose witness does not
+ * (normally none: those launches find an empty list) -- from the buffers the witness entry points wrote (FRW_ENC_MONTGOMERY):
  *     d_h               uint64_t[batch][n][4], Montgomery form, coefficient k of h at index k (what the prover feeds,
  *                       after into_repr, to the MSM over pk.h_query; the last coefficient is zero for a satisfied system)
  *     d_num_unsatisfied optional uint32_t[batch]: constraint rows the witness violates (h is then not a quotient)
@@ -275,7 +277,7 @@ typedef struct {
     int32_t log_domain_size;
     uint64_t domain_size;                      /* n */
     uint64_t num_constraints, num_instance;    /* C, I */
-    uint64_t workspace_bytes_per_signature;    /* 3 C x 32 (A z, B z, C z) + 3 x 32 n (working arrays) */
+    uint64_t workspace_bytes_per_signature;    /* 3 C x 32 (A z, B z, C z) + 3 x 32 n (working arrays) + 64 (flags) */
 } frw_qap_info_t;
 int frw_qap_info(const frw_r1cs *r, frw_qap_info_t *out);
 int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
