@@ -464,7 +464,7 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
 // per signature, cut into ~2,048 equal work items, and the fold is one workgroup: a suffix scan and a tree over 128 points.
 constexpr int NMSM_C = 8, NMSM_W = 32, NMSM_BUCKETS = 128, NMSM_SLICES = 16;
 constexpr int NMSM_TARGET_ITEMS = 2048, NMSM_MAX_ITEMS = 2304;       // items <= buckets + total / split <= 128 + 2,048
-constexpr int NMSM_ONES_MAX = 4096;
+constexpr int NMSM_ONES_MAX = 4096, NMSM_ONES_GROUPS = NMSM_ONES_MAX / 64;   // ones: 256 .. 4,096 threads per signature, by the batch; one partial sum per 64
 // threads of the one-workgroup fold: 128 for the buckets + 256 (G1) / 128 (G2: four waves = one per SIMD, the whole register file
 // for an addition that needs 300 live registers) for the ones' partial sums
 template <class F> constexpr int nmsm_finish_threads() { return F::WORDS > NLQ ? 256 : 384; }        // ones: 256 .. 4,096 partial sums per signature, by the batch (latency against work)
@@ -613,53 +613,92 @@ __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(MsmDev m, const uint
     }
     store_bucket<F>(partial_items + (sig * NMSM_MAX_ITEMS + it) * (size_t)Grp<F>::BK_WORDS, acc);
 }
-// the points whose scalar is one: `gridDim.x * 64` partial sums per signature (thread t: every such-th of the list)
+// the points whose scalar is one: thread t of `gridDim.x * 64` per signature takes every such-th of the list, the 64 sums of a
+// workgroup are added up through LDS (six steps instead of the 64 / 128-fold serial addition they would cost the fold), and one
+// partial sum per workgroup goes out: gridDim.x <= 64 of them per signature
 template <class F>
 __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
-                                                          uint32_t *__restrict__ partial_ones /* [sig][NMSM_ONES_MAX][BK_WORDS] */)
+                                                          uint32_t *__restrict__ partial_ones /* [sig][64][BK_WORDS] */)
 {
+    constexpr int SLOT = 4 * F::WORDS + 1;
+    __shared__ uint32_t lds[32 * SLOT];
     const size_t sig = blockIdx.y;
     const uint32_t nthreads = gridDim.x * 64, t = blockIdx.x * 64 + threadIdx.x, cnt = ones_count[sig];
     const uint32_t *list = ones_list + sig * m.n;
     XyzzT<F> acc = pt_identity<F>();
     for (uint32_t k = t; k < cnt; k += nthreads)
         acc = pt_add_affine(acc, load_row<F>(m.table + (size_t)list[k] * Grp<F>::PT_WORDS));      // window 0 of the table = the point itself
-    store_bucket<F>(partial_ones + (sig * NMSM_ONES_MAX + t) * (size_t)Grp<F>::BK_WORDS, acc);
+    const int lane = threadIdx.x;
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        if (lane >= stride && lane < 2 * stride) store_bucket<F>(lds + (lane - stride) * SLOT, acc);
+        __syncthreads();
+        if (lane < stride) acc = pt_add(acc, load_bucket<F>(lds + lane * SLOT));
+        __syncthreads();
+    }
+    if (lane == 0) store_bucket<F>(partial_ones + (sig * NMSM_ONES_GROUPS + blockIdx.x) * (size_t)Grp<F>::BK_WORDS, acc);
 }
+// bucket b = the sum of its items, by a workgroup of its own: the buckets of small digits hold many times the mean (the high
+// bytes of 14-bit values fall into 48 of them), and fifty items added up by one thread were the longest chain of the whole sum
+template <class F>
+__global__ __launch_bounds__(64, 2) void nmsm_combine_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+                                                             const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
+                                                             uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS] */)
+{
+    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
+    __shared__ uint32_t lds[32 * SLOT];
+    const size_t sig = blockIdx.y;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t c = counts[sig * NMSM_BUCKETS + b];
+    const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total);
+    const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
+    const uint32_t *src = partial_items + (sig * NMSM_MAX_ITEMS + item_first[sig * NMSM_BUCKETS + b]) * (size_t)BW;
+    XyzzT<F> acc = pt_identity<F>();
+    for (uint32_t j = lane; j < k; j += 64) acc = pt_add(acc, load_bucket<F>(src + (size_t)j * BW));
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        if ((int)lane >= stride && (int)lane < 2 * stride) store_bucket<F>(lds + (lane - stride) * SLOT, acc);
+        __syncthreads();
+        if ((int)lane < stride) acc = pt_add(acc, load_bucket<F>(lds + lane * SLOT));
+        __syncthreads();
+    }
+    if (lane == 0) store_bucket<F>(buckets + (sig * NMSM_BUCKETS + b) * (size_t)BW, acc);
+}
+
 // one workgroup per signature: threads 0..127 add up the items of their bucket and turn the 128 bucket sums into suffix sums
-// T_b = B_b + B_(b+1) + ... (sum_b (b + 1) B_b = sum_b T_b) by a scan through LDS; threads 128..383 each take `ones_each` of
-// the ones' partial sums; then one tree over all 384 values, one inversion, ark-ff's bytes out
+// T_b = B_b + B_(b+1) + ... (sum_b (b + 1) B_b = sum_b T_b) by a scan through LDS; the threads above 127 bring in the ones'
+// partial sums (one each, at most 64); then one tree over all values, one inversion, ark-ff's bytes out
 template <class F>
 __global__ __launch_bounds__(nmsm_finish_threads<F>()) void nmsm_finish_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
-                                                                          const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
-                                                                          const uint32_t *__restrict__ partial_ones, int ones_each,
-                                                                          uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
+                                                                               const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
+                                                                               const uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS], or null */,
+                                                                               const uint32_t *__restrict__ partial_ones, int ones_groups,
+                                                                               uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
 {
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, FT = nmsm_finish_threads<F>();
     __shared__ uint32_t lds[NMSM_BUCKETS * SLOT];                     // 29 KB (G1) / 58 KB (G2)
     __shared__ uint32_t longest;
     const size_t sig = blockIdx.x;
     const int t = threadIdx.x;
-    // ONE addition site in the whole kernel (a general addition in G2 is 1,500 instructions around 300 live registers: five
-    // inlined copies of it cost 2.9 KB of scratch per lane and most of the kernel's time): every step of every phase is
-    // "sum += the point at p", with p in global memory or in LDS.
+    // ONE addition site in the whole kernel: every step of every phase is "sum += the point at p", with p in global memory or in LDS
     const uint32_t *src;
-    uint32_t mine;                                                    // serial additions of this thread's own list
+    uint32_t mine = 0;                                                // serial additions of this thread's own list
     if (t < NMSM_BUCKETS) {
-        const uint32_t c = counts[sig * NMSM_BUCKETS + t];
-        const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total);
-        mine = (c <= split ? 1u : (c + split - 1) / split) - 1u;
-        src = partial_items + (sig * NMSM_MAX_ITEMS + item_first[sig * NMSM_BUCKETS + t]) * (size_t)BW;
+        if (buckets) {                                                // small batches: nmsm_combine_kernel has added the items up (latency)
+            src = buckets + (sig * NMSM_BUCKETS + t) * (size_t)BW;
+        } else {                                                      // large batches: the thread adds its bucket's items itself (work: a ninth of the combine's)
+            const uint32_t c = counts[sig * NMSM_BUCKETS + t];
+            const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total);
+            mine = (c <= split ? 1u : (c + split - 1) / split) - 1u;
+            src = partial_items + (sig * NMSM_MAX_ITEMS + item_first[sig * NMSM_BUCKETS + t]) * (size_t)BW;
+        }
     } else {
-        mine = (uint32_t)ones_each - 1u;
-        src = partial_ones + (sig * NMSM_ONES_MAX + (size_t)ones_each * (t - NMSM_BUCKETS)) * BW;
+        src = partial_ones + (sig * NMSM_ONES_GROUPS + (size_t)(t - NMSM_BUCKETS)) * BW;   // the ones: at most 64 partial sums, one per thread (the others start from the identity)
     }
     if (t == 0) longest = 0;
     __syncthreads();
     atomicMax(&longest, mine);
     __syncthreads();
     const uint32_t serial = longest;
-    XyzzT<F> sum = load_bucket<F>(src);
+    XyzzT<F> sum = t < NMSM_BUCKETS || t - NMSM_BUCKETS < ones_groups ? load_bucket<F>(src) : pt_identity<F>();
     // steps 0 .. serial - 1: the thread's own list; then 7 steps of the suffix scan over the buckets (offset 1, 2, .., 64), one
     // step 384 -> 256 (G1), 8 steps of the tree (stride 128, 64, .., 1)
     const uint32_t steps = serial + 7 + 1 + 8;
@@ -775,7 +814,7 @@ template <class F> size_t nmsm_workspace_per_signature(uint32_t n)
     // slice histograms, counts, offsets, first item of every bucket (all x 128), the item list + counter, the ones' list + counter,
     // the entries (32 n x 4 B), the items' and the ones' partial sums
     return ((size_t)frw::NMSM_SLICES + 3) * frw::NMSM_BUCKETS * 4 + ((size_t)frw::NMSM_MAX_ITEMS + 4) * 4 + ((size_t)n + 4) * 4 +
-           (size_t)frw::NMSM_W * n * 4 + ((size_t)frw::NMSM_MAX_ITEMS + frw::NMSM_ONES_MAX) * frw::Grp<F>::BK_WORDS * 4;
+           (size_t)frw::NMSM_W * n * 4 + ((size_t)frw::NMSM_MAX_ITEMS + frw::NMSM_ONES_GROUPS + frw::NMSM_BUCKETS) * frw::Grp<F>::BK_WORDS * 4;
 }
 
 template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, int window_bits, frw_msm **out)
@@ -919,6 +958,7 @@ int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t s
         uint32_t *partial_items = entries + cnt * (size_t)frw::NMSM_W * n;  // 16-byte aligned: every term above is a multiple of 4 words per signature but n
         partial_items += (4 - ((uintptr_t)partial_items >> 2 & 3)) & 3;     // ... and that is what the four spare words of the list are for
         uint32_t *partial_ones = partial_items + cnt * (size_t)frw::NMSM_MAX_ITEMS * BW;
+        uint32_t *bucket_sums = partial_ones + cnt * (size_t)frw::NMSM_ONES_GROUPS * BW;
         const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
         const size_t stride_words = scalar_stride * 8;
         const dim3 sgrid(frw::NMSM_SLICES, (unsigned)cnt);
@@ -934,8 +974,13 @@ int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t s
         hipLaunchKernelGGL((frw::nmsm_bucket_kernel<F, PREFETCH>), dim3(frw::NMSM_MAX_ITEMS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
                            items, item_count, entries, partial_items);
         constexpr int FT = frw::nmsm_finish_threads<F>();
+        // the items of a bucket: added up by a workgroup per bucket where latency counts (a lone proof: 12 ms -> 8.6), by the fold's own
+        // thread where throughput does (the combine is nine times the wave-level additions: 3 % of a 64-proof call)
+        const bool combine = cnt <= 16;
+        if (combine)
+            hipLaunchKernelGGL(frw::nmsm_combine_kernel<F>, dim3(frw::NMSM_BUCKETS, (unsigned)cnt), dim3(64), 0, st, counts, offsets, item_first, partial_items, bucket_sums);
         hipLaunchKernelGGL(frw::nmsm_finish_kernel<F>, dim3((unsigned)cnt), dim3(FT), 0, st, counts, offsets, item_first, partial_items,
-                           partial_ones, ones_threads / (FT - frw::NMSM_BUCKETS), (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
+                           combine ? bucket_sums : (uint32_t *)nullptr, partial_ones, ones_threads / 64, (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
         e = hipGetLastError();
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
