@@ -446,6 +446,17 @@ def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     assert int(bad.abs().sum()) == 0
+    # the reference's own call pattern (examples/pok_sig.rs: ONE proof): the same call with a batch of one, five times
+    one_proof = torch.empty((1, 48), dtype=torch.int64, device=dev)
+    eng.groth16_prove_dev(pk, handle, 1, d_wit, d_inst, rs_arr[:1], one_proof, ws, ws_bytes, bad[:1], stream.cuda_stream)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(5):
+        eng.groth16_prove_dev(pk, handle, 1, d_wit, d_inst, rs_arr[:1], one_proof, ws, ws_bytes, bad[:1], stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    one_ms = e0.elapsed_time(e1) / 5
+    assert torch.equal(one_proof[0], proofs[0]), "the proof of signature 0 made alone differs from the one made in the batch"
     eng.groth16_pk_free(pk)
     verifier = frw.Groth16Verifier(vk)
     inst_h = d_inst[:nsig].cpu().numpy().view(np.uint64)
@@ -461,6 +472,7 @@ def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn):
     return {"workload": "Groth16 proofs of resident Falcon-%d witnesses (ark-groth16 create_proof: witness map + 5 MSMs + assembly), "
                         "%d per call" % (L.n, nsig),
             "ms_per_call": round(ms, 3), "proofs_per_s": round(nsig / (ms * 1e-3), 1), "calls_timed": reps,
+            "one_proof_per_call_ms": round(one_ms, 3),
             "proving_key": {"points_g1": 2 * (ni + nw) + nw + n - 1 + 3, "points_g2": ni + nw + 2,
                             "frw_groth16_setup_s": round(key_s, 2)},
             "workspace_bytes_per_signature": ws_bytes // nsig,
