@@ -70,6 +70,10 @@ def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle
         assert want[1] == [0] * 12                                 # all-zero scalars: the point at infinity
         for got in (_run(engine, handle, canon, 0), _run(engine, handle, mont, 1), _run(engine, handle, mont, 1, chunk=3)):
             assert [g.tolist() for g in got] == want
+        # more than 16 signatures in one chunk: the narrow pipeline then adds a bucket's items up in the fold itself instead of
+        # giving every bucket a workgroup (both forms must agree with the CPU)
+        many = np.concatenate([canon, canon, canon])[:20]
+        assert [g.tolist() for g in _run(engine, handle, many, 0)] == (want * 3)[:20]
         # a longer stride than points: only the first n scalars of each vector count (how h is laid out: n + 1 per signature)
         padded = np.concatenate([canon, np.full((len(vectors), 5, 4), 0xFFFFFFFF, dtype=np.uint64)], axis=1)
         assert [g.tolist() for g in _run(engine, handle, padded, 0)] == want
