@@ -265,16 +265,18 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uin
 // size (a counting sort), so the 64 lanes of a wavefront run equally long; a bucket's items are neighbours, and
 // msm_combine_kernel adds them up.  At most 32,768 + 21,845 items whatever the scalars (sum of ceil(c_b / split)).
 constexpr int MSM_SIZE_CLASSES = 1024;         // sizes >= this share the first class
-constexpr int MSM_MAX_ITEMS = 54656;           // >= 32,768 + 32,768 / 1.5, a multiple of 64
-__device__ __forceinline__ uint32_t msm_split_of(uint32_t total)
+constexpr int MSM_MAX_ITEMS = 131072;          // >= 32,768 + 32,768 / (1.5 / 4): the finest split (a lone signature), a multiple of 64
+// `finer`: 1 for a batch, 4 for one or two signatures at a time -- a bucket of the mean size is then three items instead of one
+// (a lone proof waits for ~128 dependent additions otherwise), and msm_combine_kernel adds them up
+__device__ __forceinline__ uint32_t msm_split_of(uint32_t total, uint32_t finer)
 {
-    const uint32_t s = (uint32_t)(((uint64_t)total * 3 + 2 * MSM_BUCKETS - 1) / (2 * MSM_BUCKETS));
+    const uint32_t s = (uint32_t)(((uint64_t)total * 3 + 2 * MSM_BUCKETS - 1) / (2 * MSM_BUCKETS)) / finer;
     return s < 32u ? 32u : s;
 }
 __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
                                                          uint32_t *__restrict__ order, uint32_t *__restrict__ item_first /* [sig][buckets] */,
                                                          uint32_t *__restrict__ items /* [sig][MSM_MAX_ITEMS]: bucket | chunk << 15 */,
-                                                         uint32_t *__restrict__ item_count /* [sig] */)
+                                                         uint32_t *__restrict__ item_count /* [sig] */, uint32_t finer)
 {
     __shared__ uint32_t hist[MSM_SIZE_CLASSES];
     const size_t sig = blockIdx.x;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restr
     __threadfence_block();
     __syncthreads();
     // items: rank by rank, ceil(c / split) each (an empty bucket keeps one: its thread stores the identity)
-    const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + cnt[MSM_BUCKETS - 1], split = msm_split_of(total);
+    const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + cnt[MSM_BUCKETS - 1], split = msm_split_of(total, finer);
     constexpr int PER = MSM_BUCKETS / 1024;
     uint32_t k[PER], local = 0;
 #pragma unroll
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restr
 template <class F, bool PREFETCH>
 __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
-                                                           const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items)
+                                                           const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items, uint32_t finer)
 {
     constexpr int PW = Grp<F>::PT_WORDS;
     const size_t sig = blockIdx.y;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint3
     if (it >= item_count[sig]) return;
     const uint32_t item = items[sig * MSM_MAX_ITEMS + it], b = item & (MSM_BUCKETS - 1), chunk = item >> 15;
     const uint32_t c = counts[sig * MSM_BUCKETS + b];
-    const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total);
+    const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total, finer);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
     const uint32_t lo = (uint32_t)((uint64_t)c * chunk / k), cnt = (uint32_t)((uint64_t)c * (chunk + 1) / k) - lo;     // equal parts
     const uint32_t *ent = entries + sig * (size_t)MSM_W * m.n + offsets[sig * MSM_BUCKETS + b] + lo;
@@ -376,13 +378,13 @@ __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint3
 template <class F>
 __global__ __launch_bounds__(64, 2) void msm_combine_kernel(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                             const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
-                                                            uint32_t *__restrict__ buckets)
+                                                            uint32_t *__restrict__ buckets, uint32_t finer)
 {
     constexpr int BW = Grp<F>::BK_WORDS;
     const size_t sig = blockIdx.y;
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
     const uint32_t c = counts[sig * MSM_BUCKETS + b];
-    const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total);
+    const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total, finer);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
     const uint32_t *src = partial_items + (sig * MSM_MAX_ITEMS + item_first[sig * MSM_BUCKETS + b]) * (size_t)BW;
     XyzzT<F> acc = load_bucket<F>(src);
@@ -913,12 +915,13 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
         hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts);
         hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
-        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count);
+        const uint32_t finer = cnt <= 2 ? 4u : 1u;               // (four at a time: 12.6 ms with it, 12.1 without)
+        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count, finer);
         hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
         hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(frw::MSM_MAX_ITEMS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
-                           counts, items, item_count, entries, partial_items);
+                           counts, items, item_count, entries, partial_items, finer);
         hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, offsets, counts, item_first,
-                           partial_items, buckets);
+                           partial_items, buckets, finer);
         // first stage of the fold: enough threads to occupy the chip (~2^16), as few as that allows
         const int log_chunk = cnt >= 128 ? 6 : cnt >= 32 ? 5 : 3;
         const unsigned t1 = (unsigned)frw::MSM_BUCKETS >> log_chunk;
