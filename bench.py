@@ -2,7 +2,9 @@
 """bench.py -- Falcon-1024 verify-with-ntt R1CS witnesses per second on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+     -- or plainly: with no WORLD_SIZE in the environment this file starts its own N ranks as child processes, see
+     launch_ranks)
 
 A step = one pass of the hot path (falcon-r1cs/src/circuits/falcon_ntt.rs:26-123 of the reference) over one batch
 of synthetic signatures per GPU: BASELINE.json configs[2], "Falcon-1024 batch=65536 sigs, full verify-with-ntt
@@ -27,6 +29,79 @@ import os
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
+
+
+def _requested_gpus(argv):
+    """--gpus N / --gpus=N from a raw argument list (1 when absent or malformed: argparse reports that later)."""
+    n = 1
+    for i, a in enumerate(argv):
+        try:
+            if a == "--gpus" and i + 1 < len(argv):
+                n = int(argv[i + 1])
+            elif a.startswith("--gpus="):
+                n = int(a.split("=", 1)[1])
+        except ValueError:
+            return 1
+    return n
+
+
+def launch_ranks(argv, n, grace_s=30.0):
+    """`python bench.py --gpus N ...` started plainly (no WORLD_SIZE in the environment): start the N ranks as FRESH CHILD
+    PROCESSES of this one -- which has imported neither torch nor the HIP library and never will -- with the environment
+    torch.distributed's env:// rendezvous reads (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free
+    MASTER_PORT), let them write to this process's stdout / stderr (rank 0 prints the one JSON line), and return the
+    largest exit code.  Nothing is exec'ed.  When a rank fails the others get `grace_s` seconds to leave by themselves
+    (their own deadlines end a collective whose peer is gone) and are then terminated by PID."""
+    import socket
+    import subprocess
+    if any(a == "--plan" for a in argv):
+        return None
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    if "MASTER_PORT" not in env:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    # the host's cores are shared by the ranks (what torch.distributed.run's OMP_NUM_THREADS=1 default is about; the
+    # synthetic-input threads are sized by bench.py itself)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+    codes = [None] * n
+    first_failure = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0):
+                    first_failure = first_failure or time.monotonic()
+                    sys.stderr.write("bench.py launcher: rank %d exited with code %d\n" % (r, codes[r]))
+                    sys.stderr.flush()
+        if first_failure is not None and time.monotonic() - first_failure > grace_s:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    sys.stderr.write("bench.py launcher: terminating rank %d (pid %d) after a peer failed\n" % (r, p.pid))
+                    p.terminate()
+                    try:
+                        codes[r] = p.wait(10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    # a rank killed by a signal reports -SIG: any non-zero code is a failed run
+    return max(abs(c) for c in codes)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1:
+    # before `import torch` and before libfrw.so is mapped: this process must never touch a GPU
+    _rc = launch_ranks(sys.argv[1:], _requested_gpus(sys.argv[1:]))
+    if _rc is not None:
+        sys.exit(_rc)
 
 import numpy as np
 import torch
@@ -413,7 +488,72 @@ def groth16_h_query(eng, n, t=0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF
     return eng.g1_fixed_base(lim), (t, c)
 
 
-def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn):
+def witness_side_additions(inst_row, wit_row):
+    """Point additions the four witness-side sums of ONE proof perform in the narrow pipeline (frw_msm.hip: 8-bit signed
+    windows, scalars that are one summed apart, zeros skipped), counted on the host from one signature's assignment
+    z = instance ++ witness (Montgomery limbs): (scalars equal to one, non-zero digits of all the others).  The three
+    blinding scalars appended to z add at most 3 x 32 digits and are left out."""
+    r_inv = pow(1 << 256, -1, R_FR)
+    ones = digits = 0
+    for row in np.concatenate([inst_row, wit_row]).reshape(-1, 4):
+        if not row.any():
+            continue
+        v = int.from_bytes(row.tobytes(), "little") * r_inv % R_FR
+        if v == 1:
+            ones += 1
+            continue
+        carry = 0
+        for j in range(32):
+            d = ((v >> (8 * j)) & 0xFF) + carry
+            carry = 0
+            if j < 31 and d > 128:
+                d -= 256
+                carry = 1
+            digits += d != 0
+    return ones, digits
+
+
+def groth16_roofline(eng, log_n, n, ni, nw, inst_row, wit_row, proofs_per_s):
+    """VALU-issue roofline of a whole proof: the instructions of its field products -- the witness map's Fr products (as
+    `qap_witness_map_*` counts them) and the Fq products inside the point additions of the five sums (h_query through the 16-bit
+    pipeline as `groth16_msm_h_*` counts it; a_query, b_g1_query, l_query, b_g2_query through the 8-bit one, counted from one
+    witness) -- each class of instruction at the issue rate measured in this process.  peak = proofs/s if the chip issued
+    nothing else; frac = achieved / peak."""
+    rates = eng.valu_rates()
+    (mm, mo), (am, ao) = point_op_instructions(MADD_OPS), point_op_instructions(ADD_OPS)
+    ones, digits = witness_side_additions(inst_row, wit_row)
+    ones_w, digits_w = witness_side_additions(inst_row[:0], wit_row)          # l_query: the witness part alone
+    # mixed additions: every non-zero digit and every one; full additions: the items of the 128 buckets, the suffix scan and the
+    # tree of the one-workgroup fold (~2 per bucket + one per ones' partial sum), all small beside the former
+    g1_madds = 2 * (ones + digits) + (ones_w + digits_w)
+    g1_adds = 3 * (2 * 128 + 64)
+    g2_madds, g2_adds = ones + digits, 2 * 128 + 64
+    G2_FACTOR = 3                                                             # an Fq2 product = three Fq products (Karatsuba); frw_fq29.h
+    h_madds, h_adds = 16 * (n - 1), 2 * 32768
+    madds = h_madds + g1_madds + G2_FACTOR * g2_madds
+    adds = h_adds + g1_adds + G2_FACTOR * g2_adds
+    fq_products = madds * 10 + adds * 14
+    fr_products = qap_products_per_map(log_n)
+    wave_us = ((madds * mm + adds * am) / rates["v_mad_u64_u32"] + (madds * mo + adds * ao) / rates["v_add_u32"]
+               + fr_products * (F29_MUL_MAD64 / rates["v_mad_u64_u32"] + F29_MUL_OTHER / rates["v_add_u32"]))
+    peak_proofs = rates["simds"] * 64 / wave_us * 1e6
+    total = fq_products + fr_products
+    return {"bound": "valu_issue", "unit": "G field products/s (Fq products of the five sums + Fr products of the witness map)",
+            "achieved": round(total * proofs_per_s / 1e9, 2), "peak": round(total * peak_proofs / 1e9, 2),
+            "frac": round(proofs_per_s / peak_proofs, 4),
+            "per_proof": {"fq_products": fq_products, "fr_products": fr_products,
+                          "mixed_additions": {"h_query": h_madds, "a_query + b_g1_query + l_query": g1_madds, "b_g2_query (Fq2)": g2_madds},
+                          "scalars_equal_to_one": ones, "non_zero_8_bit_digits_of_the_others": digits,
+                          "g2_priced_as_g1_times": G2_FACTOR},
+            "peak_is": "%d SIMDs x 64 lanes issuing only the instructions of these products: an Fq product %d multiplies + %d others, "
+                       "an Fr product %d + %d; multiplies at %.1f, the others at %.1f wave-instructions/SIMD/us (measured in this "
+                       "process)" % (rates["simds"], FQ_MUL_MULTIPLY, FQ_MUL_OTHER, F29_MUL_MAD64, F29_MUL_OTHER,
+                                     rates["v_mad_u64_u32"], rates["v_add_u32"]),
+            "kernel": "frw_groth16_prove_dev: ntt_pass_kernel + r1cs_eval (witness map), msm_bucket_kernel (h_query), "
+                      "nmsm_bucket_kernel / nmsm_ones_kernel x 4 (witness-side sums), folds, tails"}
+
+
+def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn, before_timed=None, with_one_proof=True):
     """The whole of examples/pok_sig.rs:30-47, per signature: circuit_specific_setup -> frw_groth16_setup (toxic waste drawn
     here; the QAP at t on the host, the queries as fixed-base multiples on the device), create_random_proof ->
     frw_groth16_prove_dev = witness map + five multi-scalar multiplications (G1: h_query, a_query, b_g1_query, l_query; G2:
@@ -438,6 +578,8 @@ def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn):
     run = lambda: eng.groth16_prove_dev(pk, handle, nsig, d_wit, d_inst, rs_arr, proofs, ws, ws_bytes, bad, stream.cuda_stream)
     run()
     torch.cuda.synchronize()
+    if before_timed is not None:
+        before_timed()                       # N > 1: every rank starts its timed calls together (control plane only)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(reps):
@@ -446,17 +588,19 @@ def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     assert int(bad.abs().sum()) == 0
-    # the reference's own call pattern (examples/pok_sig.rs: ONE proof): the same call with a batch of one, five times
-    one_proof = torch.empty((1, 48), dtype=torch.int64, device=dev)
-    eng.groth16_prove_dev(pk, handle, 1, d_wit, d_inst, rs_arr[:1], one_proof, ws, ws_bytes, bad[:1], stream.cuda_stream)
-    torch.cuda.synchronize()
-    e0.record(stream)
-    for _ in range(5):
+    one_ms = None
+    if with_one_proof:
+        # the reference's own call pattern (examples/pok_sig.rs: ONE proof): the same call with a batch of one, ten times
+        one_proof = torch.empty((1, 48), dtype=torch.int64, device=dev)
         eng.groth16_prove_dev(pk, handle, 1, d_wit, d_inst, rs_arr[:1], one_proof, ws, ws_bytes, bad[:1], stream.cuda_stream)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    one_ms = e0.elapsed_time(e1) / 5
-    assert torch.equal(one_proof[0], proofs[0]), "the proof of signature 0 made alone differs from the one made in the batch"
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(10):
+            eng.groth16_prove_dev(pk, handle, 1, d_wit, d_inst, rs_arr[:1], one_proof, ws, ws_bytes, bad[:1], stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        one_ms = e0.elapsed_time(e1) / 10
+        assert torch.equal(one_proof[0], proofs[0]), "the proof of signature 0 made alone differs from the one made in the batch"
     eng.groth16_pk_free(pk)
     verifier = frw.Groth16Verifier(vk)
     inst_h = d_inst[:nsig].cpu().numpy().view(np.uint64)
@@ -472,7 +616,9 @@ def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn):
     return {"workload": "Groth16 proofs of resident Falcon-%d witnesses (ark-groth16 create_proof: witness map + 5 MSMs + assembly), "
                         "%d per call" % (L.n, nsig),
             "ms_per_call": round(ms, 3), "proofs_per_s": round(nsig / (ms * 1e-3), 1), "calls_timed": reps,
-            "one_proof_per_call_ms": round(one_ms, 3),
+            "one_proof_per_call_ms": None if one_ms is None else round(one_ms, 3),
+            "roofline": groth16_roofline(eng, int(q.log_domain_size), n, ni, nw, inst_h[0], d_wit[0].cpu().numpy().view(np.uint64),
+                                         nsig / (ms * 1e-3)),
             "proving_key": {"points_g1": 2 * (ni + nw) + nw + n - 1 + 3, "points_g2": ni + nw + 2,
                             "frw_groth16_setup_s": round(key_s, 2)},
             "workspace_bytes_per_signature": ws_bytes // nsig,
@@ -481,6 +627,41 @@ def time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn):
             "checked": "no unsatisfied rows; every proof of the last timed call accepted by frw_groth16_verify (pairing check "
                        "e(A,B) = e(alpha,beta) e(sum x_i gamma_abc_i, gamma) e(C, delta) on the host) for its own public "
                        "inputs and rejected with one public input changed"}
+
+
+def prove_leg(eng, handle, dev, cdev, d_wit, d_inst, held, L, logn, world, rank, reps=10):
+    """N > 1: what the reference does with the witness after generate_constraints (examples/pok_sig.rs:30-32), on every GPU of
+    the node.  Proofs shard by signature exactly like witnesses -- every rank loads the (replicated) proving key and proves 64
+    of the witnesses its own timed launches left in HBM; no collective on the data path.  The ranks start their timed calls
+    together (a barrier), every rank verifies its own proofs on its host cores, and the rate is what all ranks proved
+    over the slowest rank's time.  A rank that fails still reaches both collectives, so nobody waits for it."""
+    import traceback
+    nsig = min(64, held)
+    res, err, reached = None, None, {"barrier": False}
+
+    def together():
+        reached["barrier"] = True
+        sharding.barrier()
+    try:
+        res = time_groth16(eng, handle, dev, d_wit, d_inst, nsig, reps, L, logn, before_timed=together, with_one_proof=False)
+    except Exception as ex:                      # noqa: BLE001 -- reported in the line and on stderr
+        err = repr(ex)[:300]
+        sys.stderr.write("bench.py rank %d: the proof leg raised %r\n%s" % (rank, ex, traceback.format_exc()))
+        sys.stderr.flush()
+        if not reached["barrier"]:
+            sharding.barrier()
+    ms = torch.tensor([res["ms_per_call"] if res else -1.0], dtype=torch.float64, device=cdev)
+    all_ms = [float(x) for x in sharding.gather_per_signature(ms, world, rank, world).tolist()]
+    out = {"ranks": world, "proofs_per_call_per_rank": nsig, "calls_timed": reps, "ms_per_call_per_rank": [round(x, 3) for x in all_ms],
+           "sharding": "by signature index; proving key replicated; no data-path collective"}
+    if min(all_ms) <= 0:
+        out["error"] = err or "rank(s) %s failed" % [r for r, x in enumerate(all_ms) if x <= 0]
+        return out
+    out["proofs_per_s_all_gpus"] = round(world * nsig / (max(all_ms) * 1e-3), 1)
+    out["all_proofs_verified"] = True            # time_groth16 asserts it on every rank (frw_groth16_verify, every proof of the last call)
+    if res:
+        out["rank0"] = {k: res[k] for k in ("proofs_per_s", "proving_key", "workspace_bytes_per_signature", "verify", "roofline")}
+    return out
 
 
 def time_msm(eng, dev, d_h, reps, with_cpu):
@@ -948,9 +1129,15 @@ def main():
                          "(the profiling passes do: its small launches of the same kernels would blur the per-kernel averages)")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1 only: skip the second curve, 'generate + RCCL all-gather of the witness vectors'")
+    ap.add_argument("--no-prove", action="store_true",
+                    help="N > 1 only: skip the proof leg (every rank proves 64 of its own resident witnesses: Groth16 proofs per "
+                         "second over all GPUs, sharded by signature like the witnesses)")
     ap.add_argument("--allgather-chunk", type=int, default=0, help="signatures per rank per all-gather (default 4,096)")
     ap.add_argument("--allgather-deadline", type=int, default=240,
                     help="seconds the N > 1 gather legs may take before the run reports `value` without them")
+    ap.add_argument("--inject-leg-failure", type=int, default=-1, metavar="RANK",
+                    help="testing only: the N > 1 gather leg raises on this rank before its first collective (the run must "
+                         "print its primary line, say why on stderr and exit 3 through the launcher)")
     ap.add_argument("--force-pg", action="store_true",
                     help="initialise the process group and run the N > 1 legs even with one rank (rehearses the RCCL "
                          "calls on a single GPU)")
@@ -1092,7 +1279,7 @@ def main():
                 checked[name] = {"signatures": cnt, "grid": sh["grid"], "resident_workgroups_per_cu": sh["resident_per_cu"],
                                  "rounds": round(cnt / max(1, sh["grid"]), 2), "split_signatures": sh["split_signatures"]}
     r1cs = None
-    qap_result = msm_result = groth16_result = None
+    qap_result = msm_result = groth16_result = prove_info = None
     if not args.no_r1cs_check:
         # the reference's assert!(cs.is_satisfied()) (falcon_ntt.rs:159) for every witness in the buffer, on the device,
         # in place, against matrices emitted from the gadget definitions by the host mirror (not the kernels' closed form)
@@ -1107,9 +1294,12 @@ def main():
             s0 = int(slot_sig[0])
             qap_result, d_hvec = time_qap(eng, h, dev, d_wit, d_inst, min(64, held), 20, logn,
                                           None if args.no_cpu_baseline else (sig[s0:s0 + 1], pk[s0:s0 + 1], hm[s0:s0 + 1]))
-            msm_result = time_msm(eng, dev, d_hvec, 5, not args.no_cpu_baseline)
+            msm_result = time_msm(eng, dev, d_hvec, 10, not args.no_cpu_baseline)
             del d_hvec
-            groth16_result = time_groth16(eng, h, dev, d_wit, d_inst, min(64, held), 3, L, logn)
+            groth16_result = time_groth16(eng, h, dev, d_wit, d_inst, min(64, held), 10, L, logn)
+        if use_pg and not dual and not args.no_prove:
+            prove_info = prove_leg(eng, h, dev, cdev, d_wit, d_inst, held, L, logn, world, rank)
+            torch.cuda.empty_cache()             # the leg's workspace goes back to the device before the gather legs allocate
         eng.r1cs_free(h)
         n_unsat = sharding.sum_over_ranks(int((badrows != 0).sum().item()), cdev)
         assert n_unsat == 0, "%d witnesses left by the timed launches violate the constraint system" % n_unsat
@@ -1154,6 +1344,12 @@ def main():
         def legs():
             torch.cuda.set_device(dev_index)
             try:
+                if args.inject_leg_failure >= 0:
+                    # every rank skips the leg (no collective is left half-entered); the named rank reports the failure
+                    if rank == args.inject_leg_failure:
+                        raise RuntimeError("injected gather-leg failure on rank %d" % rank)
+                    box["r"] = {"skipped": "--inject-leg-failure"}
+                    return
                 box["r"] = gather_leg(args, plan, eng, dev, cdev, world, rank, logn, batch, chunk, L, (d_sig, d_pk, d_hm), d_wit,
                                       d_st, stream)
                 box["r"]["allgather_inputs_and_regenerate"] = regenerate_leg(
@@ -1161,7 +1357,10 @@ def main():
                 box["r"]["naive_32_byte_elements_probe"] = arkworks_gather_probe(
                     args, plan, eng, dev, cdev, world, rank, logn, L, (d_sig, d_pk, d_hm), d_wit, d_inst, d_st, stream, chunk)
             except Exception as ex:      # the primary metric must not depend on these legs
+                import traceback
                 box["e"] = repr(ex)[:300]
+                sys.stderr.write("bench.py rank %d: a gather leg raised %r\n%s" % (rank, ex, traceback.format_exc()))
+                sys.stderr.flush()
         th = threading.Thread(target=legs, daemon=True)
         th.start()
         th.join(args.allgather_deadline)
@@ -1223,9 +1422,13 @@ def main():
         }
         if r1cs is not None:
             result["r1cs_check"] = r1cs
-        if gather_info is not None:
-            result["scaling_curves"] = {"generate_only_signatures_per_s": round(value, 1),
-                                        "generate_plus_allgather": gather_info}
+        if gather_info is not None or prove_info is not None:
+            result["scaling_curves"] = {"generate_only_signatures_per_s": round(value, 1)}
+            if gather_info is not None:
+                result["scaling_curves"]["generate_plus_allgather"] = gather_info
+            if prove_info is not None:
+                result["scaling_curves"]["prove"] = prove_info
+                result["scaling_curves"]["prove_proofs_per_s"] = prove_info.get("proofs_per_s_all_gpus")
         if world == 1 and not args.no_secondary and not dual:
             # untimed w.r.t. `value`: the other two rooflines BASELINE / north_star name, measured in this process
             result["secondary"] = {
@@ -1246,7 +1449,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, slot_sig[slots], lambda i: digest_of[int(i)])
         emit(result)
     if use_pg:
-        leave(legs_hung, bool(gather_info and "error" in gather_info), rank)
+        leave(legs_hung, bool((gather_info and "error" in gather_info) or (prove_info and "error" in prove_info)), rank)
 
 
 def leave(legs_hung, legs_failed, rank, teardown_timeout=10.0):
@@ -1291,8 +1494,9 @@ def make_plan(args, world, rank):
     batch = args.batch or 65536
     chunk = min(args.chunk or (32768 if args.logn == 10 else 65536), batch)
     legs = (world > 1 or args.force_pg) and not args.no_allgather and not dual
+    prove = (world > 1 or args.force_pg) and not args.no_prove and not args.no_r1cs_check and not dual
     return sharding.step_plan(world, rank, batch, chunk, args.allgather_chunk, L.n, L.num_witness, L.num_instance,
-                              int(CL.bytes_per_signature), with_gather_legs=legs)
+                              int(CL.bytes_per_signature), with_gather_legs=legs, with_prove_leg=prove)
 
 
 def print_plans(args, only_this_world):

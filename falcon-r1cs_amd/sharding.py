@@ -85,8 +85,26 @@ HBM_BYTES_PER_GPU = 288 * 10**9          # MI355X: 288 GB of HBM3E (/opt/skills/
 HBM_PLAN_FRACTION = 0.9                  # a plan may claim at most this much of it
 
 
+def prove_leg_bytes(n, num_witness, num_instance, proofs_in_flight=64):
+    """HBM the N > 1 run's proof leg holds while it runs (bench.py::prove_leg; released before the gather legs start): the
+    proving key's five window tables (frw_msm.hip: 3,584 bytes per G1 point and 7,168 per G2 point for the witness-side
+    queries, 1,792 per point of h_query), the constraint matrices and transform tables of frw_r1cs_load (~1.3 KB per
+    constraint), and frw_groth16_workspace_bytes for `proofs_in_flight` proofs (per proof: the products, h and working
+    arrays of the witness map ~ 5 x 32 x domain + 96 C, the sort keys of the five sums ~ 64 x domain + 4 x 132 x (I + W), the
+    buckets, work items and partial sums of the 16-bit pipeline ~ 168,000 x 240).  Falcon-1024: 3.4 + 0.3 + 64 x 0.2 = 16.5 GB."""
+    nv = num_witness + num_instance
+    constraints = num_witness + 6 * n + 2
+    domain = 1
+    while domain < constraints + num_instance:
+        domain *= 2
+    key = 2 * 3584 * (nv + 2) + 3584 * num_witness + 7168 * (nv + 3) + 1792 * domain
+    matrices = 1300 * constraints + 9 * 32 * domain
+    per_proof = 5 * 32 * domain + 96 * constraints + 64 * domain + 4 * 132 * nv + (32768 + 131072 + 4096) * 240 + (1 << 20)
+    return int(key + matrices + proofs_in_flight * per_proof)
+
+
 def step_plan(world, rank, batch_per_gpu, chunk, allgather_chunk, n, num_witness, num_instance, compact_bytes,
-              with_gather_legs=True):
+              with_gather_legs=True, with_prove_leg=False):
     """Everything bench.py derives from (world, rank, per-GPU batch, launch size): this rank's global index range, the
     launches of a step, the chunking of the gather legs and the bytes of every HBM buffer the run allocates.
 
@@ -131,6 +149,8 @@ def step_plan(world, rank, batch_per_gpu, chunk, allgather_chunk, n, num_witness
             "status of the regenerated chunk": 4 * world * gc,
             "naive probe: gathered 32-byte witnesses": world * probe_gc * wit_row,
         })
+    if with_prove_leg:
+        buffers["proof leg: proving key, matrices, workspace of 64 proofs (transient)"] = prove_leg_bytes(n, num_witness, num_instance)
     plan["buffers"] = buffers
     plan["hbm_plan_bytes"] = int(sum(buffers.values()))
     plan["hbm_limit_bytes"] = int(HBM_PLAN_FRACTION * HBM_BYTES_PER_GPU)

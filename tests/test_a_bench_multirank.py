@@ -78,3 +78,40 @@ def test_failed_or_hung_gather_legs_exit_non_zero():
     assert hung.returncode == 3 and "did not complete" in hung.stderr
     stuck = _leave("dist.destroy_process_group = lambda: __import__('time').sleep(60); bench.leave(False, False, 0, 1.0)")
     assert stuck.returncode == 4 and "did not return" in stuck.stderr
+
+
+def _plain_env():
+    return {k: v for k, v in dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0").items()
+            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+
+
+@pytest.mark.gpu
+def test_plain_invocation_with_gpus_2_starts_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus N ...` in the form the driver records for N = 1 (no launcher, no WORLD_SIZE) must
+    run: the parent starts the ranks as child processes before it touches any GPU and forwards rank 0's one line."""
+    out = str(tmp_path / "plain")
+    run = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--batch", "256", "--chunk", "128",
+                          "--dump-digests", out] + COMMON, cwd=ROOT, capture_output=True, text=True, timeout=600, env=_plain_env())
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2 and j["config"]["signatures_per_step_all_gpus"] == 512
+    g = j["scaling_curves"]["generate_plus_allgather"]
+    assert "error" not in g and g["expanded_own_shard_equals_direct_output"] and g["expanded_digests_identical_on_all_ranks"]
+    b = np.concatenate([np.load("%s.rank%d.npy" % (out, r)) for r in range(2)], axis=1)
+    assert np.array_equal(b[0], np.arange(512)) and not b[1].any()
+    # proofs in the N > 1 run: sharded by signature like the witnesses, no collective on the data path
+    p = j["scaling_curves"]["prove"]
+    assert p["ranks"] == 2 and p["proofs_per_s_all_gpus"] > 0 and p["all_proofs_verified"]
+
+
+@pytest.mark.gpu
+def test_a_failed_gather_leg_reaches_the_caller_as_exit_code_3():
+    run = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--batch", "256", "--chunk", "128",
+                          "--inject-leg-failure", "1", "--no-r1cs-check"] + COMMON, cwd=ROOT, capture_output=True, text=True,
+                         timeout=600, env=_plain_env())
+    assert run.returncode == 3, (run.returncode, run.stderr[-3000:])
+    assert "injected gather-leg failure on rank 1" in run.stderr and "Traceback" in run.stderr
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["value"] > 0           # the primary line is still printed
