@@ -53,6 +53,12 @@ class Groth16PkDesc(C.Structure):
                 ("h_query", C.c_void_p), ("l_query", C.c_void_p)]
 
 
+class R1csInfoStruct(C.Structure):
+    _fields_ = [("num_statements", C.c_uint64), ("count_logn9", C.c_uint64), ("count_logn10", C.c_uint64),
+                ("num_instance", C.c_uint64), ("num_witness", C.c_uint64), ("num_constraints", C.c_uint64),
+                ("log_domain_size", C.c_int32), ("witness_map_on_device", C.c_int32)]
+
+
 class QapInfoStruct(C.Structure):
     _fields_ = [("log_domain_size", C.c_int32), ("domain_size", C.c_uint64), ("num_constraints", C.c_uint64),
                 ("num_instance", C.c_uint64), ("workspace_bytes_per_signature", C.c_uint64)]
@@ -116,6 +122,10 @@ PROTOTYPES = {
     "frw_r1cs_export": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_void_p]),
     "frw_r1cs_load": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "frw_r1cs_free": (None, [C.c_void_p]),
+    "frw_r1cs_load_aggregate": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "frw_r1cs_info": (C.c_int, [C.c_void_p, C.POINTER(R1csInfoStruct)]),
+    "frw_aggregate_assign_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_groth16_setup_r1cs": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "frw_r1cs_check_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_r1cs_eval_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_r1cs_eval_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int]),

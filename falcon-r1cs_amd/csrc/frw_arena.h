@@ -62,7 +62,7 @@ struct HostArena {
     hipError_t reserve_device(int slot, size_t bytes)
     {
         if (d_cap[slot] >= bytes) return hipSuccess;
-        if (d_slot[slot]) (void)hipFree(d_slot[slot]);      // no call is in flight: the entry points synchronise before they return
+        if (d_slot[slot]) (void)hipFree(d_slot[slot]);      // no call is in flight: the entry points synchronise before they return, DrainOnExit on every other way out
         d_slot[slot] = nullptr;
         d_cap[slot] = 0;
         const hipError_t e = hipMalloc(&d_slot[slot], bytes);
@@ -84,6 +84,22 @@ struct HostArena {
             allocations++;
         }
         return e;
+    }
+};
+
+// An entry point that gives up half way through its pipeline (a HIP error after the first enqueue) must not hand the caller's
+// buffers back while copies into them, or kernels on the arena's slots, are still running -- the caller may free them, and the
+// next call reuses the slot.  Declared right after the lock; `settled` is set once the call's own final synchronisations have
+// been made, so the successful path pays nothing.
+struct DrainOnExit {
+    HostArena &a;
+    bool settled = false;
+    explicit DrainOnExit(HostArena &arena) : a(arena) {}
+    ~DrainOnExit()
+    {
+        if (settled) return;
+        if (a.compute) (void)hipStreamSynchronize(a.compute);
+        if (a.copy) (void)hipStreamSynchronize(a.copy);
     }
 };
 

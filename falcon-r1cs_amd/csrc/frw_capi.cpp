@@ -230,6 +230,7 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
     if (!sig || !pk || !hm || !witness || (!instance && !compact) || !status) return FRW_E_INVALID_ARG;
     frw::HostArena &A = ctx->arena;
     std::lock_guard<std::mutex> lock(A.mu);
+    frw::DrainOnExit drain(A);
     FRW_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << logn;
     const size_t nb = logn == 9 ? 50 : 52;
@@ -285,6 +286,7 @@ int witness_host(frw_ctx *ctx, bool dual, int logn, size_t batch, const uint16_t
     }
     FRW_HIP(hipStreamSynchronize(A.compute));
     if (nbuf == 2) FRW_HIP(hipStreamSynchronize(A.copy));
+    drain.settled = true;
     bool any_bad = false;
     for (size_t i = 0; i < batch; i++) any_bad |= status[i] != FRW_ST_OK;
     return strict && any_bad ? FRW_E_RANGE : FRW_OK;
@@ -502,6 +504,7 @@ int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int
     if (!poly || !witness || !ntt_out || !status) return FRW_E_INVALID_ARG;
     frw::HostArena &A = ctx->arena;
     std::lock_guard<std::mutex> lock(A.mu);
+    frw::DrainOnExit drain(A);
     FRW_HIP(hipSetDevice(ctx->device));
     // same pipeline as witness_host: arena memory, one stream for a batch that fits a chunk, else the D2H of chunk k
     // overlaps the kernel of chunk k+1
@@ -543,6 +546,7 @@ int frw_ntt_modq(frw_ctx *ctx, int logn, size_t batch, const uint16_t *poly, int
     }
     FRW_HIP(hipStreamSynchronize(A.compute));
     if (nbuf == 2) FRW_HIP(hipStreamSynchronize(A.copy));
+    drain.settled = true;
     return FRW_OK;
 }
 
@@ -591,6 +595,7 @@ int frw_prepare_inputs(frw_ctx *ctx, int logn, size_t batch, const uint8_t *pk_b
         if (msg_off[i + 1] < msg_off[i]) return FRW_E_INVALID_ARG;        // offsets must be non-decreasing
     frw::HostArena &A = ctx->arena;
     std::lock_guard<std::mutex> lock(A.mu);
+    frw::DrainOnExit drain(A);
     FRW_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << logn, pk_len = FRW_PK_LEN(logn);
     const size_t msg_bytes = (size_t)(msg_off[batch] - msg_off[0]);
@@ -663,6 +668,7 @@ int frw_gadget(frw_ctx *ctx, int kind, size_t count, const void *a, const uint64
     if (!a || !out || (kind == FRW_G_ADD_MOD && !b)) return FRW_E_INVALID_ARG;
     frw::HostArena &A = ctx->arena;
     std::lock_guard<std::mutex> lock(A.mu);
+    frw::DrainOnExit drain(A);
     FRW_HIP(hipSetDevice(ctx->device));
     const size_t in_bytes = count * (kind == FRW_G_MOD_Q ? 20 : 8), b_bytes = kind == FRW_G_ADD_MOD ? count * 8 : 0;
     const size_t out_bytes = count * (size_t)frw_gadget_block_len(kind) * 32;
@@ -706,6 +712,7 @@ int frw_diag_valu_rates(frw_ctx *ctx, double out[4])
     if (!ctx || !out) return FRW_E_INVALID_ARG;
     frw::HostArena &A = ctx->arena;
     std::lock_guard<std::mutex> lock(A.mu);
+    frw::DrainOnExit drain(A);
     FRW_HIP(hipSetDevice(ctx->device));
     FRW_HIP(A.reserve_device(0, (size_t)ctx->num_cu * 8192));
     FRW_HIP(frw::diag_valu_rates(ctx->num_cu, A.d_slot[0], out, A.compute));

@@ -91,8 +91,12 @@ struct R1csMatrixDev {
 // limbs, one plane per limb (frw_fr29.h), padded with zero coefficients.
 constexpr uint32_t R1CS_LONG_ROW = 128;
 struct R1csLongRow { uint32_t matrix, row, first_chunk, num_chunks; };
+struct R1csAgg;
 struct R1csDev {
     uint32_t num_instance, num_witness, num_constraints;
+    // host side only: non-null for an aggregate statement (frw_r1cs_load_aggregate), whose matrices are the block-diagonal
+    // arrangement of the per-signature systems' and are never materialised -- see R1csAgg below; everything else is then unset
+    const R1csAgg *agg;
     R1csMatrixDev a, b, c;
     const uint32_t *order;      // constraint rows by decreasing length
     uint32_t num_long;
@@ -109,17 +113,69 @@ struct R1csDev {
     const uint32_t *long_cidx;  // [chunks][64] index into long_vars
     uint32_t k_rrp[9];          // R R' mod p (R = 2^256, R' = 2^261) as an integer, 29-bit limbs
 };
+// Where one launch of the evaluation kernels finds the statements ("signatures") of its batch and where their products go,
+// in 32-bit words unless said otherwise.  The plain batch of the witness entry points and a run of statements inside an
+// aggregate assignment differ in nothing else:
+//   variable col >= I of statement s   wit + s wit_stride + 8 (col - I)
+//   instance variable 1 <= col < I     inst + s inst_stride + 8 col
+//   instance variable 0 (the one)      one + s one_stride                  (an aggregate has ONE constant for all statements)
+//   (M z)_row, M = A, B, C             abc + 8 (s abc_sig_stride + m abc_mat_stride + row)
+//   violated rows of statement s       added to flags[s flag_stride]       (an aggregate counts into one word)
+struct R1csView {
+    const uint32_t *wit;  size_t wit_stride;
+    const uint32_t *inst; size_t inst_stride;
+    const uint32_t *one;  size_t one_stride;
+    uint32_t *abc;        size_t abc_sig_stride, abc_mat_stride;
+    unsigned int *flags;  size_t flag_stride;
+};
+// An aggregate statement: FalconNTTVerificationCircuit::generate_constraints run once per statement on ONE constraint system
+// (host/frw_host.hpp FalconAggregateVerificationCircuit).  Its instance vector is [1, public inputs of statement 0, of
+// statement 1, ...], its witness vector the concatenation of the statements' witness vectors, its constraint rows theirs in
+// order -- so its matrices are block diagonal but for column 0, and A z, B z, C z are the statements' own products laid end
+// to end: a run of consecutive statements of one parameter set is one launch of that set's kernels through an R1csView.
+struct R1csAggRun {
+    const R1csDev *base;        // the per-signature system of the run's parameter set
+    uint32_t first, count;      // statements [first, first + count)
+    uint64_t wit_off;           // elements before the run's first witness variable in the aggregate witness vector
+    uint64_t pub_off;           // public inputs before the run's first one (its instance variable j >= 1 is aggregate variable pub_off + j)
+    uint64_t row_off;           // constraint rows before the run's first one
+};
+struct R1csAgg {
+    uint32_t num_statements;
+    uint32_t num_runs;
+    const R1csAggRun *runs;     // host memory
+};
 size_t r1cs_check_scratch_bytes(const R1csDev &r, size_t batch, bool with_abc);
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
                              uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st, void *scratch = nullptr);
 // Tables of the QAP witness map's domain (frw_qap.hip), built by frw_r1cs_load.  Every entry is a field element times
 // R' = 2^261 (frw_fr29.h): the per-index factors packed in 8 x 32 bits (they are < p), the 64-th roots in nine limbs.
+constexpr int QAP_MAX_PASSES = 5;          // domains up to 2^30
+constexpr int QAP_MIN_LOG_N = 14, QAP_MAX_LOG_N = 30;
+// passes of a 2^L-point transform, lowest bits first; returns the number of passes (0: no schedule for this L)
+inline int qap_pass_schedule(int L, int t[QAP_MAX_PASSES], int sh[QAP_MAX_PASSES])
+{
+    if (L < QAP_MIN_LOG_N || L > QAP_MAX_LOG_N) return 0;
+    const int k = (L + 5) / 6;
+    int deficit = 6 * k - L;                       // taken off the upper passes, the top one first, at most two each
+    for (int i = 0; i < k; i++) t[i] = 6;
+    for (int round = 0; round < 2 && deficit; round++)
+        for (int i = k - 1; i >= 1 && deficit; i--) { t[i]--; deficit--; }
+    if (deficit) return 0;
+    for (int i = 0, s = 0; i < k; i++) { sh[i] = s; s += t[i]; }
+    return k;
+}
 struct QapDev {
     int log_n;                    // domain = the 2^log_n-th roots of unity, 2^log_n >= num_constraints + num_instance
     const uint32_t *roots_fwd;    // w^(k n/64), k < 32, 12 words apart
     const uint32_t *roots_inv;    // w^-(k n/64)
-    const uint32_t *twist_fwd[2]; // [n][8]: what a forward pass on bits [6,12) / [12,L) multiplies index i by on its way out
-    const uint32_t *twist_inv[2]; // [n][8]: what an inverse pass multiplies index i by for the NEXT pass on bits [6,12) / [12,L)
+    // The pass schedule: pass k works on the index bits [pass_sh[k], pass_sh[k] + pass_t[k]); pass 0 always takes the six lowest
+    // bits, the others four to six each (qap_pass_schedule: 17 = 6 + 6 + 5, 18 = 6 + 6 + 6, 19 = 6 + 5 + 4 + 4, 20 = 6 + 5 + 5 + 4,
+    // 22 = 6 + 6 + 5 + 5, 24 = 6 + 6 + 6 + 6, ...)
+    int num_passes;
+    int pass_t[QAP_MAX_PASSES], pass_sh[QAP_MAX_PASSES];
+    const uint32_t *twist_fwd[QAP_MAX_PASSES - 1]; // [n][8]: what the forward pass k + 1 multiplies index i by on its way out
+    const uint32_t *twist_inv[QAP_MAX_PASSES - 1]; // [n][8]: what the inverse pass k multiplies index i by for the NEXT pass, k + 1
     const uint32_t *scale_in;     // g^k / n                  (ifft's 1/n and coset_fft's distribute_powers, fused)
     const uint32_t *scale_in_a;   // 2^5 g^k / n              (for A z: the a b product divides by 2^261, the data carry 2^256)
     const uint32_t *scale_out;    // g^-k / (n (g^n - 1))     (ifft's 1/n, division by the vanishing polynomial, g^-k)

@@ -465,8 +465,20 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
 // arithmetic.  With 8-bit windows (32 of them: a table twice as long) the same scalars are 70,000 additions into 128 buckets
 // per signature, cut into ~2,048 equal work items, and the fold is one workgroup: a suffix scan and a tree over 128 points.
 constexpr int NMSM_C = 8, NMSM_W = 32, NMSM_BUCKETS = 128, NMSM_SLICES = 16;
-constexpr int NMSM_TARGET_ITEMS = 2048, NMSM_MAX_ITEMS = 2304;       // items <= buckets + total / split <= 128 + 2,048
-constexpr int NMSM_ONES_MAX = 4096, NMSM_ONES_GROUPS = NMSM_ONES_MAX / 64;   // ones: 256 .. 4,096 threads per signature, by the batch; one partial sum per 64
+// Work items per signature: 2,048 for the per-signature circuits (n < 2^18 points), n / 128 rounded up to a multiple of 2,048 beyond
+// (an aggregate statement is ONE "signature" with sixteen times the points: 2,048 items would be 32 wavefronts on 1,024 SIMDs, each
+// a chain of 550 additions); items <= buckets + total / split <= 128 + target, rounded up to whole wavefronts.
+constexpr int NMSM_TARGET_ITEMS_MIN = 2048, NMSM_TARGET_ITEMS_MAX = 65536;
+__host__ __device__ constexpr uint32_t nmsm_target_items(uint32_t n)
+{
+    const uint32_t t = (n / 128 + 2047) / 2048 * 2048;
+    return t < (uint32_t)NMSM_TARGET_ITEMS_MIN ? (uint32_t)NMSM_TARGET_ITEMS_MIN : t > (uint32_t)NMSM_TARGET_ITEMS_MAX ? (uint32_t)NMSM_TARGET_ITEMS_MAX : t;
+}
+__host__ __device__ constexpr uint32_t nmsm_max_items(uint32_t n) { return nmsm_target_items(n) + 256; }
+// the scalars equal to one: 256 .. 4,096 threads per signature, by the batch, one partial sum per 64 of them (<= 64: one per thread of
+// the fold); with more than 2^18 points up to 65,536 threads, whose <= 1,024 partial sums a small kernel brings down to 64 first
+constexpr int NMSM_ONES_MAX = 4096, NMSM_ONES_GROUPS = NMSM_ONES_MAX / 64, NMSM_ONES_MAX_LARGE = 65536;
+__host__ __device__ constexpr uint32_t nmsm_ones_max(uint32_t n) { return n > (1u << 18) ? (uint32_t)NMSM_ONES_MAX_LARGE : (uint32_t)NMSM_ONES_MAX; }
 // threads of the one-workgroup fold: 128 for the buckets + 256 (G1) / 128 (G2: four waves = one per SIMD, the whole register file
 // for an addition that needs 300 live registers) for the ones' partial sums
 template <class F> constexpr int nmsm_finish_threads() { return F::WORDS > NLQ ? 256 : 384; }        // ones: 256 .. 4,096 partial sums per signature, by the batch (latency against work)
@@ -484,9 +496,9 @@ __device__ __forceinline__ bool scalar_digits8(const uint32_t *src, int montgome
     }
     return false;
 }
-__device__ __forceinline__ uint32_t nmsm_split_of(uint32_t total)
+__device__ __forceinline__ uint32_t nmsm_split_of(uint32_t total, uint32_t target)
 {
-    const uint32_t s = (total + NMSM_TARGET_ITEMS - 1) / NMSM_TARGET_ITEMS;
+    const uint32_t s = (total + target - 1) / target;
     return s < 32u ? 32u : s;
 }
 __global__ __launch_bounds__(1024) void nmsm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words, int montgomery,
@@ -515,8 +527,8 @@ __global__ __launch_bounds__(1024) void nmsm_hist_kernel(uint32_t n, const uint3
 // one workgroup of 128 threads per signature: bucket sizes and starts, every slice's first position inside its buckets, the
 // work items (bucket | part << 8: equal parts of at most `split` entries)
 __global__ __launch_bounds__(NMSM_BUCKETS) void nmsm_plan_kernel(uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
-                                                                 uint32_t *__restrict__ item_first, uint32_t *__restrict__ items /* [sig][NMSM_MAX_ITEMS] */,
-                                                                 uint32_t *__restrict__ item_count /* [sig] */)
+                                                                 uint32_t *__restrict__ item_first, uint32_t *__restrict__ items /* [sig][max_items] */,
+                                                                 uint32_t *__restrict__ item_count /* [sig] */, uint32_t target, uint32_t max_items)
 {
     __shared__ uint32_t scan[NMSM_BUCKETS];
     const size_t sig = blockIdx.x;
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(NMSM_BUCKETS) void nmsm_plan_kernel(uint32_t *__res
     const uint32_t incl = inclusive_scan(c);
     scan[b] = incl;
     __syncthreads();
-    const uint32_t total = scan[NMSM_BUCKETS - 1], split = nmsm_split_of(total);
+    const uint32_t total = scan[NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
     __syncthreads();
     counts[sig * NMSM_BUCKETS + b] = c;
     offsets[sig * NMSM_BUCKETS + b] = incl - c;
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(NMSM_BUCKETS) void nmsm_plan_kernel(uint32_t *__res
     const uint32_t kincl = inclusive_scan(k), first = kincl - k;
     item_first[sig * NMSM_BUCKETS + b] = first;
     if (b == NMSM_BUCKETS - 1) item_count[sig] = kincl;
-    for (uint32_t part = 0; part < k; part++) items[sig * NMSM_MAX_ITEMS + first + part] = (uint32_t)b | (part << 8);
+    for (uint32_t part = 0; part < k; part++) items[sig * (size_t)max_items + first + part] = (uint32_t)b | (part << 8);
 }
 __global__ __launch_bounds__(1024) void nmsm_scatter_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words, int montgomery,
                                                             const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ slice_hist,
@@ -581,15 +593,16 @@ __global__ __launch_bounds__(1024) void nmsm_scatter_kernel(uint32_t n, const ui
 template <class F, bool PREFETCH>
 __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                             const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
-                                                            const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items)
+                                                            const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items,
+                                                            uint32_t target, uint32_t max_items)
 {
     constexpr int PW = Grp<F>::PT_WORDS;
     const size_t sig = blockIdx.y;
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     if (it >= item_count[sig]) return;
-    const uint32_t item = items[sig * NMSM_MAX_ITEMS + it], b = item & (NMSM_BUCKETS - 1), part = item >> 8;
+    const uint32_t item = items[sig * (size_t)max_items + it], b = item & (NMSM_BUCKETS - 1), part = item >> 8;
     const uint32_t c = counts[sig * NMSM_BUCKETS + b];
-    const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total);
+    const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
     const uint32_t lo = (uint32_t)((uint64_t)c * part / k), cnt = (uint32_t)((uint64_t)c * (part + 1) / k) - lo;     // equal parts
     const uint32_t *ent = entries + sig * (size_t)NMSM_W * m.n + offsets[sig * NMSM_BUCKETS + b] + lo;
@@ -613,14 +626,14 @@ __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(MsmDev m, const uint
             acc = pt_add_affine(acc, p);
         }
     }
-    store_bucket<F>(partial_items + (sig * NMSM_MAX_ITEMS + it) * (size_t)Grp<F>::BK_WORDS, acc);
+    store_bucket<F>(partial_items + (sig * (size_t)max_items + it) * (size_t)Grp<F>::BK_WORDS, acc);
 }
 // the points whose scalar is one: thread t of `gridDim.x * 64` per signature takes every such-th of the list, the 64 sums of a
 // workgroup are added up through LDS (six steps instead of the 64 / 128-fold serial addition they would cost the fold), and one
 // partial sum per workgroup goes out: gridDim.x <= 64 of them per signature
 template <class F>
 __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
-                                                          uint32_t *__restrict__ partial_ones /* [sig][64][BK_WORDS] */)
+                                                          uint32_t *__restrict__ partial_ones /* [sig][groups_stride][BK_WORDS] */, uint32_t groups_stride)
 {
     constexpr int SLOT = 4 * F::WORDS + 1;
     __shared__ uint32_t lds[32 * SLOT];
@@ -637,23 +650,44 @@ __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32
         if (lane < stride) acc = pt_add(acc, load_bucket<F>(lds + lane * SLOT));
         __syncthreads();
     }
-    if (lane == 0) store_bucket<F>(partial_ones + (sig * NMSM_ONES_GROUPS + blockIdx.x) * (size_t)Grp<F>::BK_WORDS, acc);
+    if (lane == 0) store_bucket<F>(partial_ones + (sig * (size_t)groups_stride + blockIdx.x) * (size_t)Grp<F>::BK_WORDS, acc);
+}
+// more than 64 partial sums of ones (sums over more than 2^18 points): workgroup g of 64 adds up the partial sums g, g + 64, ... of its
+// signature -- one per lane, then a tree through LDS -- and leaves sum g of 64 in the first 64 slots of the second stage's array
+template <class F>
+__global__ __launch_bounds__(64, 2) void nmsm_ones_fold_kernel(const uint32_t *__restrict__ partial_ones, uint32_t groups, uint32_t groups_stride,
+                                                               uint32_t *__restrict__ folded /* [sig][64][BK_WORDS] */)
+{
+    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
+    __shared__ uint32_t lds[32 * SLOT];
+    const size_t sig = blockIdx.y;
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    const uint32_t *src = partial_ones + sig * (size_t)groups_stride * BW;
+    XyzzT<F> acc = pt_identity<F>();
+    for (uint32_t k = g + 64 * lane; k < groups; k += 64 * 64) acc = pt_add(acc, load_bucket<F>(src + (size_t)k * BW));
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        if ((int)lane >= stride && (int)lane < 2 * stride) store_bucket<F>(lds + (lane - stride) * SLOT, acc);
+        __syncthreads();
+        if ((int)lane < stride) acc = pt_add(acc, load_bucket<F>(lds + lane * SLOT));
+        __syncthreads();
+    }
+    if (lane == 0) store_bucket<F>(folded + (sig * 64 + g) * (size_t)BW, acc);
 }
 // bucket b = the sum of its items, by a workgroup of its own: the buckets of small digits hold many times the mean (the high
 // bytes of 14-bit values fall into 48 of them), and fifty items added up by one thread were the longest chain of the whole sum
 template <class F>
 __global__ __launch_bounds__(64, 2) void nmsm_combine_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
                                                              const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
-                                                             uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS] */)
+                                                             uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS] */, uint32_t target, uint32_t max_items)
 {
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
     __shared__ uint32_t lds[32 * SLOT];
     const size_t sig = blockIdx.y;
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     const uint32_t c = counts[sig * NMSM_BUCKETS + b];
-    const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total);
+    const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
-    const uint32_t *src = partial_items + (sig * NMSM_MAX_ITEMS + item_first[sig * NMSM_BUCKETS + b]) * (size_t)BW;
+    const uint32_t *src = partial_items + (sig * (size_t)max_items + item_first[sig * NMSM_BUCKETS + b]) * (size_t)BW;
     XyzzT<F> acc = pt_identity<F>();
     for (uint32_t j = lane; j < k; j += 64) acc = pt_add(acc, load_bucket<F>(src + (size_t)j * BW));
     for (int stride = 32; stride >= 1; stride >>= 1) {
@@ -672,7 +706,8 @@ template <class F>
 __global__ __launch_bounds__(nmsm_finish_threads<F>()) void nmsm_finish_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
                                                                                const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
                                                                                const uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS], or null */,
-                                                                               const uint32_t *__restrict__ partial_ones, int ones_groups,
+                                                                               const uint32_t *__restrict__ partial_ones /* [sig][ones_stride][BK_WORDS] */,
+                                                                               int ones_groups, uint32_t ones_stride, uint32_t target, uint32_t max_items,
                                                                                uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
 {
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, FT = nmsm_finish_threads<F>();
@@ -688,12 +723,12 @@ __global__ __launch_bounds__(nmsm_finish_threads<F>()) void nmsm_finish_kernel(c
             src = buckets + (sig * NMSM_BUCKETS + t) * (size_t)BW;
         } else {                                                      // large batches: the thread adds its bucket's items itself (work: a ninth of the combine's)
             const uint32_t c = counts[sig * NMSM_BUCKETS + t];
-            const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total);
+            const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
             mine = (c <= split ? 1u : (c + split - 1) / split) - 1u;
-            src = partial_items + (sig * NMSM_MAX_ITEMS + item_first[sig * NMSM_BUCKETS + t]) * (size_t)BW;
+            src = partial_items + (sig * (size_t)max_items + item_first[sig * NMSM_BUCKETS + t]) * (size_t)BW;
         }
     } else {
-        src = partial_ones + (sig * NMSM_ONES_GROUPS + (size_t)(t - NMSM_BUCKETS)) * BW;   // the ones: at most 64 partial sums, one per thread (the others start from the identity)
+        src = partial_ones + (sig * (size_t)ones_stride + (size_t)(t - NMSM_BUCKETS)) * BW;   // the ones: at most 64 partial sums, one per thread (the others start from the identity)
     }
     if (t == 0) longest = 0;
     __syncthreads();
@@ -815,8 +850,10 @@ template <class F> size_t nmsm_workspace_per_signature(uint32_t n)
 {
     // slice histograms, counts, offsets, first item of every bucket (all x 128), the item list + counter, the ones' list + counter,
     // the entries (32 n x 4 B), the items' and the ones' partial sums
-    return ((size_t)frw::NMSM_SLICES + 3) * frw::NMSM_BUCKETS * 4 + ((size_t)frw::NMSM_MAX_ITEMS + 4) * 4 + ((size_t)n + 4) * 4 +
-           (size_t)frw::NMSM_W * n * 4 + ((size_t)frw::NMSM_MAX_ITEMS + frw::NMSM_ONES_GROUPS + frw::NMSM_BUCKETS) * frw::Grp<F>::BK_WORDS * 4;
+    // (n + 8 words for the list: the four after it are the alignment pad of what follows, budgeted here rather than borrowed)
+    const size_t items = frw::nmsm_max_items(n), ones_groups = frw::nmsm_ones_max(n) / 64;
+    return ((size_t)frw::NMSM_SLICES + 3) * frw::NMSM_BUCKETS * 4 + (items + 4) * 4 + ((size_t)n + 8) * 4 +
+           (size_t)frw::NMSM_W * n * 4 + (items + ones_groups + (ones_groups > 64 ? 64 : 0) + frw::NMSM_BUCKETS) * frw::Grp<F>::BK_WORDS * 4;
 }
 
 template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, int window_bits, frw_msm **out)
@@ -954,36 +991,50 @@ int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t s
         uint32_t *offsets = counts + cnt * frw::NMSM_BUCKETS;
         uint32_t *item_first = offsets + cnt * frw::NMSM_BUCKETS;
         uint32_t *items = item_first + cnt * frw::NMSM_BUCKETS;
-        uint32_t *item_count = items + cnt * (size_t)frw::NMSM_MAX_ITEMS;  // [cnt], padded to four words per signature in the budget
+        const uint32_t target = frw::nmsm_target_items(n), max_items = frw::nmsm_max_items(n), ones_stride = frw::nmsm_ones_max(n) / 64;
+        uint32_t *item_count = items + cnt * (size_t)max_items;             // [cnt], padded to four words per signature in the budget
         uint32_t *ones_count = item_count + cnt * 4;                        // likewise
         uint32_t *ones_list = ones_count + cnt * 4;
         uint32_t *entries = ones_list + cnt * (size_t)n;
         uint32_t *partial_items = entries + cnt * (size_t)frw::NMSM_W * n;  // 16-byte aligned: every term above is a multiple of 4 words per signature but n
-        partial_items += (4 - ((uintptr_t)partial_items >> 2 & 3)) & 3;     // ... and that is what the four spare words of the list are for
-        uint32_t *partial_ones = partial_items + cnt * (size_t)frw::NMSM_MAX_ITEMS * BW;
-        uint32_t *bucket_sums = partial_ones + cnt * (size_t)frw::NMSM_ONES_GROUPS * BW;
+        partial_items += (4 - ((uintptr_t)partial_items >> 2 & 3)) & 3;     // ... at most three words, out of the four the budget adds to the list for it
+        uint32_t *partial_ones = partial_items + cnt * (size_t)max_items * BW;
+        uint32_t *folded_ones = partial_ones + cnt * (size_t)ones_stride * BW;   // second stage, only when ones_stride > 64
+        uint32_t *bucket_sums = folded_ones + (ones_stride > 64 ? cnt * (size_t)64 * BW : 0);
         const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
         const size_t stride_words = scalar_stride * 8;
         const dim3 sgrid(frw::NMSM_SLICES, (unsigned)cnt);
         e = hipMemsetAsync(ones_count, 0, cnt * 4, st);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::nmsm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
-        hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3((unsigned)cnt), dim3(frw::NMSM_BUCKETS), 0, st, slice_hist, counts, offsets, item_first, items, item_count);
+        hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3((unsigned)cnt), dim3(frw::NMSM_BUCKETS), 0, st, slice_hist, counts, offsets, item_first, items, item_count,
+                           target, max_items);
         hipLaunchKernelGGL(frw::nmsm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
         // the ones' partial sums: enough threads to occupy the chip (~2^16 over the batch), between 256 and 4,096 per signature
         int ones_threads = 256;
-        while (ones_threads < frw::NMSM_ONES_MAX && (size_t)ones_threads * cnt < 65536) ones_threads <<= 1;
-        hipLaunchKernelGGL(frw::nmsm_ones_kernel<F>, dim3((unsigned)ones_threads / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list, partial_ones);
-        hipLaunchKernelGGL((frw::nmsm_bucket_kernel<F, PREFETCH>), dim3(frw::NMSM_MAX_ITEMS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
-                           items, item_count, entries, partial_items);
+        while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * cnt < 65536) ones_threads <<= 1;
+        hipLaunchKernelGGL(frw::nmsm_ones_kernel<F>, dim3((unsigned)ones_threads / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list, partial_ones,
+                           ones_stride);
+        const uint32_t *ones_for_finish = partial_ones;
+        uint32_t ones_groups = (uint32_t)ones_threads / 64, ones_finish_stride = ones_stride;
+        if (ones_groups > 64) {
+            hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<F>, dim3(64, (unsigned)cnt), dim3(64), 0, st, partial_ones, ones_groups, ones_stride, folded_ones);
+            ones_for_finish = folded_ones;
+            ones_groups = 64;
+            ones_finish_stride = 64;
+        }
+        hipLaunchKernelGGL((frw::nmsm_bucket_kernel<F, PREFETCH>), dim3((max_items + 63) / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
+                           items, item_count, entries, partial_items, target, max_items);
         constexpr int FT = frw::nmsm_finish_threads<F>();
         // the items of a bucket: added up by a workgroup per bucket where latency counts (a lone proof: 12 ms -> 8.6), by the fold's own
         // thread where throughput does (the combine is nine times the wave-level additions: 3 % of a 64-proof call)
         const bool combine = cnt <= 16;
         if (combine)
-            hipLaunchKernelGGL(frw::nmsm_combine_kernel<F>, dim3(frw::NMSM_BUCKETS, (unsigned)cnt), dim3(64), 0, st, counts, offsets, item_first, partial_items, bucket_sums);
+            hipLaunchKernelGGL(frw::nmsm_combine_kernel<F>, dim3(frw::NMSM_BUCKETS, (unsigned)cnt), dim3(64), 0, st, counts, offsets, item_first, partial_items, bucket_sums,
+                               target, max_items);
         hipLaunchKernelGGL(frw::nmsm_finish_kernel<F>, dim3((unsigned)cnt), dim3(FT), 0, st, counts, offsets, item_first, partial_items,
-                           combine ? bucket_sums : (uint32_t *)nullptr, partial_ones, ones_threads / 64, (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
+                           combine ? bucket_sums : (uint32_t *)nullptr, ones_for_finish, (int)ones_groups, ones_finish_stride, target, max_items,
+                           (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
         e = hipGetLastError();
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
@@ -1290,11 +1341,14 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
     if (chunk == 0 || ((uintptr_t)d_workspace & 255)) return FRW_E_INVALID_ARG;
     const size_t I = (size_t)pk->num_instance, W = (size_t)pk->num_witness, nv = I + W, n = (size_t)pk->domain_size, stride = nv + 3;
     hipStream_t st = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lock(const_cast<frw_groth16_pk *>(pk)->enqueue);
     hipError_t e = hipSetDevice(pk->device);
     int rc = FRW_OK;
     bool forked = false;
+    // The key's side streams and events take one chunk's work at a time (pk->enqueue); the host-side wait for the upload of r, s
+    // happens BEFORE the lock is taken, so provers that share a key wait for their own stream only, not for each other's.
+    std::unique_lock<std::mutex> lock(const_cast<frw_groth16_pk *>(pk)->enqueue, std::defer_lock);
     for (size_t lo = 0; e == hipSuccess && rc == FRW_OK && lo < batch; lo += chunk) {
+        if (lock.owns_lock()) lock.unlock();
         const size_t cnt = std::min(chunk, batch - lo);
         char *base = (char *)d_workspace;
         void *qap_ws = base;                          base += cnt * sz.qap;
@@ -1318,6 +1372,7 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (e == hipSuccess) e = hipMemcpyAsync(d_split, halves.data(), cnt * 64, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);                                  // `rs` may be pageable and short-lived; `halves` is
         if (e != hipSuccess) break;
+        lock.lock();
         // z ++ [1, r, s] per signature, then the witness-side sums on their own streams ...
         e = hipMemcpy2DAsync(zext, stride * 32, inst, I * 32, I * 32, cnt, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipMemcpy2DAsync(zext + I * 4, stride * 32, wit, W * 32, W * 32, cnt, hipMemcpyDeviceToDevice, st);

@@ -189,7 +189,10 @@ FRW_HD Fp12 line_value(const Fp2 &lambda, const Fp2 &xt, const Fp2 &yt, const G1
 
 // prod_k f_{|z|, Q_k}(P_k), conjugated; pairs with a point at infinity contribute one.  m <= MAX_PAIRS.
 constexpr int MAX_PAIRS = 4;
-FRW_HD Fp12 miller_loop(const G1 *ps, const G2 *qs, int m)
+// `degenerate` (optional) is set when a step met a zero denominator -- a vertical tangent or chord, which points of the
+// order-r subgroup never produce (T runs over multiples k Q, 0 < k < |z| < r, and T = +-Q only for k = +-1 mod r): the value
+// returned is then meaningless and the caller must reject (a G2 point off the subgroup, vouched for by the caller, can do this).
+FRW_HD Fp12 miller_loop(const G1 *ps, const G2 *qs, int m, bool *degenerate = nullptr)
 {
     G1 p[MAX_PAIRS];
     G2 q[MAX_PAIRS], t[MAX_PAIRS];
@@ -197,12 +200,14 @@ FRW_HD Fp12 miller_loop(const G1 *ps, const G2 *qs, int m)
     for (int k = 0; k < m && n < MAX_PAIRS; k++)
         if (!ps[k].inf && !qs[k].inf) { p[n] = ps[k]; q[n] = qs[k]; t[n] = qs[k]; n++; }
     Fp12 f = fp12_one();
+    if (degenerate) *degenerate = false;
     if (n == 0) return f;
     // the denominators of one step, inverted together: inv[k] = 1 / den[k]
     auto invert_all = [&](Fp2 *den) {
         Fp2 pre[MAX_PAIRS];
         Fp2 acc = fp2_one();
         for (int k = 0; k < n; k++) { pre[k] = acc; acc = fp2_mul(acc, den[k]); }
+        if (degenerate && fp2_is_zero(acc)) *degenerate = true;
         acc = fp2_inv(acc);
         for (int k = n - 1; k >= 0; k--) { const Fp2 d = den[k]; den[k] = fp2_mul(acc, pre[k]); acc = fp2_mul(acc, d); }
     };

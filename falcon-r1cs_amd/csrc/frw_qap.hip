@@ -190,7 +190,18 @@ __device__ __forceinline__ void round_low(F29 (&x)[8], const F29 &w8, const F29 
 template <bool DIF, int T, bool LAZY = false>
 __device__ __forceinline__ void round_high(F29 (&x)[8], const uint32_t *roots, int g)
 {
-    if (DIF && LAZY) {                                     // inputs < 2 p; T == 6: -> < 16 p, T == 5: -> < 8 p
+    if (T == 4) {
+        // one stage: rows (e & 1) 8 + g + 2 (e >> 1), g < 2 -- four pairs (x[2 m], x[2 m + 1]) whose lower row is g + 2 m, twiddle
+        // (16-th root)^(g + 2 m); values < 2 p in, < 4 p out (decimation in frequency, lazy) / < 18 p (decimation in time)
+        static_for<4>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const F29 w = root_get(roots, (g + 2 * m) << 2);
+            if (!DIF) dit_mul(x[2 * m], x[2 * m + 1], w);
+            else if (LAZY) dif_mul_lazy<2>(x[2 * m], x[2 * m + 1], w);
+            else dif_mul(x[2 * m], x[2 * m + 1], w);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    } else if (DIF && LAZY) {                              // inputs < 2 p; T == 6: -> < 16 p, T == 5: -> < 8 p
         if (T == 6) {
             dif_mul_lazy<2>(x[0], x[4], root_get(roots, g)); dif_mul_lazy<2>(x[1], x[5], root_get(roots, g + 8));
             dif_mul_lazy<2>(x[2], x[6], root_get(roots, g + 16)); dif_mul_lazy<2>(x[3], x[7], root_get(roots, g + 24));
@@ -255,10 +266,10 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
     constexpr bool FUSED = MODE == PASS_DIT_DIF;                                 // in as PASS_DIT, out as PASS_DIF
     constexpr bool MEMORDER = MODE == PASS_DIT_SH0 || MODE == PASS_DIF_SH0;     // tile = 512 consecutive elements
     constexpr int CB = 9 - T, COLS = 1 << CB;
-    static_assert(T == 6 || (T == 5 && (MODE == PASS_DIT || MODE == PASS_DIF || MODE == PASS_DIT_DIF)), "five-stage passes only above bit 0");
+    static_assert(T == 6 || ((T == 5 || T == 4) && (MODE == PASS_DIT || MODE == PASS_DIF || MODE == PASS_DIT_DIF)), "four- and five-stage passes only above bit 0");
     static_assert(!FUSED || (LOAD == LOAD_PLAIN && (STORE == STORE_FACTOR || STORE == STORE_FACTOR_A)), "the fused pass: plain in, factor between and after");
     __shared__ uint32_t lds[NL29 * QAP_HALF];
-    const int tid = threadIdx.x, c = tid & (COLS - 1), g = tid >> CB;           // T == 6: 8 columns x 8 g; T == 5: 16 x 4
+    const int tid = threadIdx.x, c = tid & (COLS - 1), g = tid >> CB;           // T == 6: 8 columns x 8 g; T == 5: 16 x 4; T == 4: 32 x 2
     const uint32_t tileid = blockIdx.x;
     const size_t n = (size_t)1 << p.L;
     const uint32_t turns = LIST ? *p.list_count : 1u;                // LIST is a template parameter: the loop costs the usual kernels nothing
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
 
     // rows of the eight elements a thread holds in the low round (stages 1..3) and in the high round (stages 4..T)
     auto row_low = [&](int e) { return g * 8 + e; };
-    auto row_high = [&](int e) { return T == 6 ? e * 8 + g : (e & 3) * 8 + g + 4 * (e >> 2); };
+    auto row_high = [&](int e) { return T == 6 ? e * 8 + g : T == 5 ? (e & 3) * 8 + g + 4 * (e >> 2) : (e & 1) * 8 + g + 2 * (e >> 1); };
     // working index of (row, column)
     uint32_t lowmid = 0, high = 0;
     if (MODE == PASS_FIRST) high = (__brev(tileid) >> (32 - (p.L - 9))) << 6;
@@ -331,7 +342,10 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
     //           (they read j' = g & 3, g' = e) differ in j'
     //   T == 5: ((4 g + j) 16 + c) with bit 4 XOR-ed by g: writers (two g, all c) differ in g & 1, readers (they read
     //           g' = e & 3, j' = g) in j' & 1
-    auto xslot = [&](int j, int gg) { return T == 6 ? (((8 * j + gg) * 8 + c) ^ (j << 3)) : (((4 * gg + j) * 16 + c) ^ ((gg & 1) << 4)); };
+    //   T == 4: ((2 j + g) 32 + c): a 32-lane group is one g and all c
+    auto xslot = [&](int j, int gg) {
+        return T == 6 ? (((8 * j + gg) * 8 + c) ^ (j << 3)) : T == 5 ? (((4 * gg + j) * 16 + c) ^ ((gg & 1) << 4)) : ((2 * j + gg) * 32 + c);
+    };
     auto exchange = [&](F29 (&x)[8]) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -350,10 +364,16 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
                 } else {
                     static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; x[4 + j] = lds_get(xslot(g & 3, 4 + j)); });
                 }
-            } else {
+            } else if (T == 5) {
                 static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_put(xslot(j, g), x[4 * h + j]); });
                 wave_sync();
                 static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; x[4 * h + j] = lds_get(xslot(g, j)); });
+            } else {
+                // T == 4: row 8 g + e (e = 4 h + j) <-> row (e' & 1) 8 + g' + 2 (e' >> 1): register e' = 4 h + j' of thread g' comes from
+                // thread j' & 1, its register 4 h + g' + 2 (j' >> 1) -- a 2 x 2 transpose between the two g of a column, both ways
+                static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; lds_put(xslot(j, g), x[4 * h + j]); });
+                wave_sync();
+                static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; x[4 * h + j] = lds_get(xslot(g + 2 * (j >> 1), j & 1)); });
             }
             wave_sync();
         }
@@ -462,6 +482,14 @@ hipError_t launch_pass(const NttPass &p, unsigned arrays, hipStream_t st)
     else hipLaunchKernelGGL((ntt_pass_kernel<MODE, T, LOAD, STORE>), dim3(tiles, arrays), dim3(QAP_THREADS), 0, st, p);
     return hipGetLastError();
 }
+// an upper pass (sh > 0) of four, five or six stages
+template <int MODE, int STORE>
+hipError_t launch_upper(int t, const NttPass &p, unsigned arrays, hipStream_t st)
+{
+    return t == 6 ? launch_pass<MODE, 6, LOAD_PLAIN, STORE>(p, arrays, st)
+         : t == 5 ? launch_pass<MODE, 5, LOAD_PLAIN, STORE>(p, arrays, st)
+                  : launch_pass<MODE, 4, LOAD_PLAIN, STORE>(p, arrays, st);
+}
 
 enum { XF_IFFT_FROM_PRODUCTS, XF_FFT, XF_IFFT_POINTWISE_TO_H,
        XF_IFFT_FROM_PRODUCTS_PSI, XF_IFFT_AB_TO_H, XF_IFFT_PRODUCTS_AB_ADD_H };
@@ -470,11 +498,15 @@ enum { XF_IFFT_FROM_PRODUCTS, XF_FFT, XF_IFFT_POINTWISE_TO_H,
 //   XF_IFFT_FROM_PRODUCTS     bit-reversed -> natural; reads A z, B z, C z (constraint order); x g^k / n at the end
 //   XF_FFT                    natural -> bit-reversed, in place
 //   XF_IFFT_POINTWISE_TO_H    bit-reversed -> natural; a b - c at the start; x g^-k / (n (g^n - 1)), canonical, into h
-// L = 6 + 6 + T3 with T3 = 5 or 6 (domains 2^17 and 2^18).
+// An inverse transform runs its passes from the lowest index bits up (q.pass_sh / q.pass_t: pass 0 = bits [0, 6), K passes
+// in all), every pass but the last leaving the twist towards the next one; a forward transform runs them from the top down.
+// Unless built with -DFRW_QAP_NO_FUSE, the last (top) pass of an inverse transform that is followed by a forward one also
+// does that one's first (top) pass: PASS_DIT_DIF.
 hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *work, size_t work_stride, uint32_t *h,
                      unsigned arrays, hipStream_t st)
 {
-    const int L = q.log_n, T3 = L - 12;
+    const int L = q.log_n, K = q.num_passes, top = K - 1;
+    if (K < 2) return hipErrorInvalidValue;
     NttPass p = base;
     p.L = L;
     hipError_t e;
@@ -482,33 +514,41 @@ hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *w
         p.roots = q.roots_fwd;
         p.src = work; p.dst = work; p.src_stride = p.dst_stride = work_stride;
 #if defined(FRW_QAP_NO_FUSE)
-        p.sh = 12; p.factor = q.twist_fwd[1];
-        e = T3 == 6 ? launch_pass<PASS_DIF, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
-                    : launch_pass<PASS_DIF, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
-        if (e != hipSuccess) return e;
-#endif                                                       // (otherwise the inverse transform before it has done this pass: PASS_DIT_DIF)
-        p.sh = 6; p.factor = q.twist_fwd[0];
-        if ((e = launch_pass<PASS_DIF, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
+        const int first = top;
+#else
+        const int first = top - 1;                          // the inverse transform before it has done the top pass: PASS_DIT_DIF
+#endif
+        for (int k = first; k >= 1; k--) {
+            p.sh = q.pass_sh[k]; p.factor = q.twist_fwd[k - 1];
+            if ((e = launch_upper<PASS_DIF, STORE_FACTOR>(q.pass_t[k], p, arrays, st)) != hipSuccess) return e;
+        }
         p.sh = 0; p.factor = nullptr;
         return launch_pass<PASS_DIF_SH0, 6, LOAD_PLAIN, STORE_PLAIN>(p, arrays, st);
     }
     p.roots = q.roots_inv;
+    // the passes between the first and the last of an inverse transform
+    auto middle = [&]() -> hipError_t {
+        for (int k = 1; k < top; k++) {
+            p.sh = q.pass_sh[k]; p.factor = q.twist_inv[k];
+            const hipError_t me = launch_upper<PASS_DIT, STORE_FACTOR>(q.pass_t[k], p, arrays, st);
+            if (me != hipSuccess) return me;
+        }
+        return hipSuccess;
+    };
+    const int tt = q.pass_t[top];
     if (kind == XF_IFFT_FROM_PRODUCTS_PSI) {
         // the two-array variant of XF_IFFT_FROM_PRODUCTS for the six-transform quotient: x psi^k / n at the end
         p.src = work; p.dst = work; p.src_stride = p.dst_stride = work_stride;
         p.per_sig = 2;
         p.sh = 0; p.factor = q.twist_inv[0];
         if ((e = launch_pass<PASS_FIRST, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-        p.sh = 6; p.factor = q.twist_inv[1];
-        if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-        p.sh = 12; p.factor = q.scale_psi_in;
+        if ((e = middle()) != hipSuccess) return e;
+        p.sh = q.pass_sh[top]; p.factor = q.scale_psi_in;
 #if defined(FRW_QAP_NO_FUSE)
-        return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
-                       : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
+        return launch_upper<PASS_DIT, STORE_FACTOR>(tt, p, arrays, st);
 #else
-        p.roots2 = q.roots_fwd; p.factor2 = q.twist_fwd[1];     // ... and the first pass of the XF_FFT that follows
-        return T3 == 6 ? launch_pass<PASS_DIT_DIF, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
-                       : launch_pass<PASS_DIT_DIF, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
+        p.roots2 = q.roots_fwd; p.factor2 = q.twist_fwd[top - 1];     // ... and the first pass of the XF_FFT that follows
+        return launch_upper<PASS_DIT_DIF, STORE_FACTOR>(tt, p, arrays, st);
 #endif
     }
     if (kind == XF_IFFT_AB_TO_H) {
@@ -516,11 +556,9 @@ hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *w
         p.src = work; p.src_stride = 2 * work_stride; p.dst = work; p.dst_stride = 2 * work_stride;
         p.sh = 0; p.factor = q.twist_inv[0];
         if ((e = launch_pass<PASS_DIT_SH0, 6, LOAD_AB, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-        p.sh = 6; p.factor = q.twist_inv[1];
-        if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-        p.sh = 12; p.factor = q.scale_psi_out; p.dst = h; p.dst_stride = work_stride;
-        return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)
-                       : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st);
+        if ((e = middle()) != hipSuccess) return e;
+        p.sh = q.pass_sh[top]; p.factor = q.scale_psi_out; p.dst = h; p.dst_stride = work_stride;
+        return launch_upper<PASS_DIT, STORE_FACTOR>(tt, p, arrays, st);
     }
     if (kind == XF_IFFT_PRODUCTS_AB_ADD_H) {
         // (A z)_i (B z)_i on the domain itself -> coefficients of (a b) mod (X^n - 1), x 16 / n, added to what h holds
@@ -528,39 +566,32 @@ hipError_t transform(int kind, const QapDev &q, const NttPass &base, uint32_t *w
         p.per_sig = 1;
         p.sh = 0; p.factor = q.twist_inv[0];
         if ((e = launch_pass<PASS_FIRST, 6, LOAD_PRODUCTS_AB, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-        p.sh = 6; p.factor = q.twist_inv[1];
-        if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-        p.sh = 12; p.factor = nullptr; p.dst = h; p.dst_stride = work_stride;
+        if ((e = middle()) != hipSuccess) return e;
+        p.sh = q.pass_sh[top]; p.factor = nullptr; p.dst = h; p.dst_stride = work_stride;
         for (int k = 0; k < 9; k++) p.cfac[k] = q.sixteen_over_n[k];
-        return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_CONST_ADD_CANONICAL>(p, arrays, st)
-                       : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_CONST_ADD_CANONICAL>(p, arrays, st);
+        return launch_upper<PASS_DIT, STORE_CONST_ADD_CANONICAL>(tt, p, arrays, st);
     }
     if (kind == XF_IFFT_FROM_PRODUCTS) {
         p.per_sig = 3;
         p.src = work; p.dst = work; p.src_stride = p.dst_stride = work_stride;
         p.sh = 0; p.factor = q.twist_inv[0];
         if ((e = launch_pass<PASS_FIRST, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-        p.sh = 6; p.factor = q.twist_inv[1];
-        if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-        p.sh = 12; p.factor = q.scale_in; p.factor_a = q.scale_in_a;
+        if ((e = middle()) != hipSuccess) return e;
+        p.sh = q.pass_sh[top]; p.factor = q.scale_in; p.factor_a = q.scale_in_a;
 #if defined(FRW_QAP_NO_FUSE)
-        return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st)
-                       : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st);
+        return launch_upper<PASS_DIT, STORE_FACTOR_A>(tt, p, arrays, st);
 #else
-        p.roots2 = q.roots_fwd; p.factor2 = q.twist_fwd[1];     // ... and the first pass of the XF_FFT that follows
-        return T3 == 6 ? launch_pass<PASS_DIT_DIF, 6, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st)
-                       : launch_pass<PASS_DIT_DIF, 5, LOAD_PLAIN, STORE_FACTOR_A>(p, arrays, st);
+        p.roots2 = q.roots_fwd; p.factor2 = q.twist_fwd[top - 1];     // ... and the first pass of the XF_FFT that follows
+        return launch_upper<PASS_DIT_DIF, STORE_FACTOR_A>(tt, p, arrays, st);
 #endif
     }
     // a b - c from the three arrays of each signature, in place on the first of them; the last pass writes h
     p.src = work; p.src_stride = 3 * work_stride; p.dst = work; p.dst_stride = 3 * work_stride;
     p.sh = 0; p.factor = q.twist_inv[0];
     if ((e = launch_pass<PASS_DIT_SH0, 6, LOAD_AB_MINUS_C, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-    p.sh = 6; p.factor = q.twist_inv[1];
-    if ((e = launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR>(p, arrays, st)) != hipSuccess) return e;
-    p.sh = 12; p.factor = q.scale_out; p.dst = h; p.dst_stride = work_stride;
-    return T3 == 6 ? launch_pass<PASS_DIT, 6, LOAD_PLAIN, STORE_FACTOR_CANONICAL>(p, arrays, st)
-                   : launch_pass<PASS_DIT, 5, LOAD_PLAIN, STORE_FACTOR_CANONICAL>(p, arrays, st);
+    if ((e = middle()) != hipSuccess) return e;
+    p.sh = q.pass_sh[top]; p.factor = q.scale_out; p.dst = h; p.dst_stride = work_stride;
+    return launch_upper<PASS_DIT, STORE_FACTOR_CANONICAL>(tt, p, arrays, st);
 }
 }  // namespace
 
@@ -665,7 +696,7 @@ hipError_t qap_run(int mode, const R1csDev &r, const QapDev &q, size_t batch, co
 {
     if (batch == 0) return hipSuccess;
     const int L = q.log_n;
-    if (L != 17 && L != 18) return hipErrorInvalidValue;         // three passes of 6 + 6 + (5 | 6) stages
+    if (q.num_passes < 2) return hipErrorInvalidValue;           // no pass schedule for this domain (qap_pass_schedule)
     const size_t n = (size_t)1 << L, per_sig = qap_workspace_bytes_per_signature(r, q);
     size_t chunk = workspace_bytes / per_sig;
     if (chunk == 0) return hipErrorInvalidValue;

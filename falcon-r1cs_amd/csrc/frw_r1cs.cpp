@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <array>
 #include <cstring>
+#include <thread>
 #include <stdexcept>
 #include <exception>
 #include <numeric>
@@ -33,10 +35,16 @@ frw::host::ConstraintMatrices build_matrices(int circuit, int logn)
 // Device-resident matrices for frw_r1cs_check_dev
 struct frw_r1cs {
     int device;
+    int circuit = FRW_CIRCUIT_NTT, logn = 0;            // logn == 0: an aggregate statement
     frw::R1csDev dev;
     frw::QapDev qap;
     std::vector<void *> allocs;
     mutable frw::HostArena arena;     // working memory of frw_qap_witness_map (host buffers in, host buffers out)
+    // an aggregate (frw_r1cs_load_aggregate): the per-signature systems it is made of (owned), its statements and its runs
+    frw_r1cs *base[2] = {nullptr, nullptr};             // Falcon-512, Falcon-1024
+    std::vector<int32_t> statement_logn;
+    std::vector<frw::R1csAggRun> runs;
+    frw::R1csAgg agg{};
 };
 
 namespace {
@@ -97,13 +105,19 @@ uint32_t bitrev(uint32_t x, int bits)
     for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
     return r;
 }
-struct QapTables { int log_n; std::vector<uint32_t> roots_fwd, roots_inv, twist_fwd[2], twist_inv[2], scale_in, scale_in_a, scale_out, scale_psi_in, scale_psi_out; uint32_t sixteen_over_n[9]; };
+struct QapTables {
+    int log_n, num_passes = 0, pass_t[frw::QAP_MAX_PASSES], pass_sh[frw::QAP_MAX_PASSES];
+    std::vector<uint32_t> roots_fwd, roots_inv, twist_fwd[frw::QAP_MAX_PASSES - 1], twist_inv[frw::QAP_MAX_PASSES - 1], scale_in, scale_in_a,
+        scale_out, scale_psi_in, scale_psi_out;
+    uint32_t sixteen_over_n[9];
+};
 QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
 {
     QapTables t;
     t.log_n = domain_log(num_constraints + num_instance);
     if (t.log_n > 32) throw std::runtime_error("PolynomialDegreeTooLarge");
-    if (t.log_n < 13) return t;                                 // no device witness map for such a domain (frw_qap.hip)
+    t.num_passes = frw::qap_pass_schedule(t.log_n, t.pass_t, t.pass_sh);
+    if (!t.num_passes) return t;                                // no device witness map for such a domain (frw_qap.hip)
     const int L = t.log_n;
     const size_t n = (size_t)1 << L;
     const uint64_t root_limbs[4] = {0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL};
@@ -133,13 +147,15 @@ QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
     std::vector<uint32_t> pw_fwd, pw_inv;
     fill(pw_fwd, n, Fr::one(), w);
     fill(pw_inv, n, Fr::one(), winv);
-    const int shs[2] = {6, 12}, ts[2] = {6, L - 12 < 6 ? L - 12 : 6};
-    for (int k = 0; k < 2; k++) {
+    // table k goes with pass k + 1: the inverse transform's pass k leaves it for the next pass, the forward transform's pass
+    // k + 1 applies it on its way out
+    for (int k = 0; k + 1 < t.num_passes; k++) {
+        const int sh = t.pass_sh[k + 1], ts = t.pass_t[k + 1];
         t.twist_fwd[k].resize(n * 8);
         t.twist_inv[k].resize(n * 8);
         for (size_t i = 0; i < n; i++) {
-            const uint64_t low = i & (((uint64_t)1 << shs[k]) - 1), r = (i >> shs[k]) & (((uint64_t)1 << ts[k]) - 1);
-            const size_t e = (size_t)((low * bitrev((uint32_t)r, ts[k])) << (L - shs[k] - ts[k]));
+            const uint64_t low = i & (((uint64_t)1 << sh) - 1), r = (i >> sh) & (((uint64_t)1 << ts) - 1);
+            const size_t e = (size_t)((low * bitrev((uint32_t)r, ts)) << (L - sh - ts));
             std::memcpy(&t.twist_fwd[k][8 * i], &pw_fwd[8 * e], 32);
             std::memcpy(&t.twist_inv[k][8 * i], &pw_inv[8 * e], 32);
         }
@@ -160,11 +176,43 @@ QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
 extern "C" void frw_r1cs_free(frw_r1cs *r)
 {
     if (!r) return;
+    for (frw_r1cs *b : r->base) frw_r1cs_free(b);
     (void)hipSetDevice(r->device);
     for (void *p : r->allocs) (void)hipFree(p);
     r->arena.destroy();
     delete r;
 }
+
+namespace {
+// the transform tables of the domain of (num_constraints + num_instance) coefficients, uploaded; r->qap.num_passes == 0 if the
+// device has no pass schedule for that domain
+void upload_qap_tables(frw_r1cs *r, uint64_t num_constraints, uint64_t num_instance)
+{
+    auto upload = [&](const void *src, size_t bytes) -> void * {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) throw std::runtime_error("hipMalloc");
+        r->allocs.push_back(d);
+        if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy");
+        return d;
+    };
+    const QapTables qt = build_qap_tables(num_constraints, num_instance);
+    r->qap = frw::QapDev{};
+    r->qap.log_n = qt.log_n;
+    r->qap.num_passes = qt.num_passes;
+    if (!qt.num_passes) return;
+    for (int k = 0; k < qt.num_passes; k++) { r->qap.pass_t[k] = qt.pass_t[k]; r->qap.pass_sh[k] = qt.pass_sh[k]; }
+    auto up = [&](const std::vector<uint32_t> &v) { return (const uint32_t *)upload(v.data(), v.size() * 4); };
+    r->qap.roots_fwd = up(qt.roots_fwd);
+    r->qap.roots_inv = up(qt.roots_inv);
+    for (int k = 0; k + 1 < qt.num_passes; k++) { r->qap.twist_fwd[k] = up(qt.twist_fwd[k]); r->qap.twist_inv[k] = up(qt.twist_inv[k]); }
+    r->qap.scale_in = up(qt.scale_in);
+    r->qap.scale_in_a = up(qt.scale_in_a);
+    r->qap.scale_out = up(qt.scale_out);
+    r->qap.scale_psi_in = up(qt.scale_psi_in);
+    r->qap.scale_psi_out = up(qt.scale_psi_out);
+    std::memcpy(r->qap.sixteen_over_n, qt.sixteen_over_n, sizeof(qt.sixteen_over_n));
+}
+}  // namespace
 
 extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
 {
@@ -178,6 +226,9 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
         const frw::host::ConstraintMatrices m = build_matrices(circuit, logn);
         r = new frw_r1cs;
         r->device = device;
+        r->circuit = circuit;
+        r->logn = logn;
+        r->dev = frw::R1csDev{};
         if (r->arena.init() != hipSuccess) throw std::runtime_error("stream / event creation");
         r->dev.num_instance = (uint32_t)m.num_instance_variables;
         r->dev.num_witness = (uint32_t)m.num_witness_variables;
@@ -264,25 +315,118 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
         r->dev.long_coef = (const uint32_t *)upload(lcoef.data(), lcoef.size() * 4);
         r->dev.long_mask = (const uint8_t *)upload(lmask.data(), lmask.size());
         r->dev.long_slot = (const uint32_t *)upload(lslot.data(), lslot.size() * 4);
-        const QapTables qt = build_qap_tables(m.num_constraints, m.num_instance_variables);
-        r->qap = frw::QapDev{};
-        r->qap.log_n = qt.log_n;
-        auto up = [&](const std::vector<uint32_t> &v) { return (const uint32_t *)upload(v.data(), v.size() * 4); };
-        r->qap.roots_fwd = up(qt.roots_fwd);
-        r->qap.roots_inv = up(qt.roots_inv);
-        for (int k = 0; k < 2; k++) { r->qap.twist_fwd[k] = up(qt.twist_fwd[k]); r->qap.twist_inv[k] = up(qt.twist_inv[k]); }
-        r->qap.scale_in = up(qt.scale_in);
-        r->qap.scale_in_a = up(qt.scale_in_a);
-        r->qap.scale_out = up(qt.scale_out);
-        r->qap.scale_psi_in = up(qt.scale_psi_in);
-        r->qap.scale_psi_out = up(qt.scale_psi_out);
-        std::memcpy(r->qap.sixteen_over_n, qt.sixteen_over_n, sizeof(qt.sixteen_over_n));
+        upload_qap_tables(r, m.num_constraints, m.num_instance_variables);
         *out = r;
         return FRW_OK;
     } catch (const std::exception &) {
         frw_r1cs_free(r);
         return FRW_E_OUT_OF_MEMORY;
     }
+}
+
+// ---- an aggregate statement: `count` Falcon verifications on ONE constraint system ------------------------------------------------
+// (host/frw_host.hpp FalconAggregateVerificationCircuit: generate_constraints of FalconNTTVerificationCircuit once per statement,
+// in order.)  Nothing of the aggregate's size is built on the host or stored on the device but the transform tables of its
+// domain: the matrices are the per-signature systems' blocks (frw_device.h R1csAgg).
+extern "C" int frw_r1cs_load_aggregate(int device, size_t count, const int32_t *logn, frw_r1cs **out)
+{
+    if (!out || !logn || count == 0 || count > 65535) return FRW_E_INVALID_ARG;
+    for (size_t i = 0; i < count; i++)
+        if (logn[i] != 9 && logn[i] != 10) return FRW_E_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FRW_E_HIP;
+    frw_r1cs *r = new (std::nothrow) frw_r1cs;
+    if (!r) return FRW_E_OUT_OF_MEMORY;
+    r->device = device;
+    r->dev = frw::R1csDev{};
+    r->qap = frw::QapDev{};
+    int rc = FRW_OK;
+    try {
+        if (r->arena.init() != hipSuccess) throw std::runtime_error("stream / event creation");
+        r->statement_logn.assign(logn, logn + count);
+        for (int g = 0; g < 2 && rc == FRW_OK; g++)
+            if (std::find(r->statement_logn.begin(), r->statement_logn.end(), 9 + g) != r->statement_logn.end())
+                rc = frw_r1cs_load(device, FRW_CIRCUIT_NTT, 9 + g, &r->base[g]);
+        if (rc == FRW_OK) {
+            uint64_t wit = 0, pub = 0, rows = 0;
+            for (size_t i = 0; i < count;) {
+                size_t j = i;
+                while (j < count && logn[j] == logn[i]) j++;
+                const frw::R1csDev &b = r->base[logn[i] - 9]->dev;
+                r->runs.push_back(frw::R1csAggRun{&b, (uint32_t)i, (uint32_t)(j - i), wit, pub, rows});
+                wit += (uint64_t)(j - i) * b.num_witness;
+                pub += (uint64_t)(j - i) * (b.num_instance - 1);
+                rows += (uint64_t)(j - i) * b.num_constraints;
+                i = j;
+            }
+            if (wit + pub + 1 >= ((uint64_t)1 << 30) || rows >= ((uint64_t)1 << 31)) throw std::runtime_error("aggregate too large");
+            r->agg.num_statements = (uint32_t)count;
+            r->agg.num_runs = (uint32_t)r->runs.size();
+            r->agg.runs = r->runs.data();
+            r->dev.agg = &r->agg;
+            r->dev.num_instance = (uint32_t)(pub + 1);
+            r->dev.num_witness = (uint32_t)wit;
+            r->dev.num_constraints = (uint32_t)rows;
+            upload_qap_tables(r, rows, pub + 1);
+        }
+    } catch (const std::exception &) {
+        rc = FRW_E_OUT_OF_MEMORY;
+    }
+    if (rc != FRW_OK) {
+        frw_r1cs_free(r);
+        return rc;
+    }
+    *out = r;
+    return FRW_OK;
+}
+
+extern "C" int frw_r1cs_info(const frw_r1cs *r, frw_r1cs_info_t *out)
+{
+    if (!r || !out) return FRW_E_INVALID_ARG;
+    out->num_statements = r->dev.agg ? r->agg.num_statements : 1;
+    out->num_instance = r->dev.num_instance;
+    out->num_witness = r->dev.num_witness;
+    out->num_constraints = r->dev.num_constraints;
+    out->log_domain_size = r->qap.log_n;
+    out->witness_map_on_device = r->qap.num_passes >= 2;
+    out->count_logn9 = out->count_logn10 = 0;
+    if (r->dev.agg) {
+        for (int32_t l : r->statement_logn) (l == 9 ? out->count_logn9 : out->count_logn10)++;
+    } else {
+        (r->logn == 9 ? out->count_logn9 : out->count_logn10) = 1;
+    }
+    return FRW_OK;
+}
+
+// instance_assignment / witness_assignment of the aggregate's constraint system from the batches the witness entry points wrote:
+// statement i takes the next unused signature of its parameter set's batch (the order FalconAggregateVerificationCircuit feeds
+// them in).  Device-to-device copies on `stream`, one pair per run.
+extern "C" int frw_aggregate_assign_dev(const frw_r1cs *r, const uint64_t *d_witness_512, const uint64_t *d_instance_512,
+                                        const uint64_t *d_witness_1024, const uint64_t *d_instance_1024, uint64_t *d_witness,
+                                        uint64_t *d_instance, void *stream)
+{
+    if (!r || !r->dev.agg || !d_witness || !d_instance) return FRW_E_INVALID_ARG;
+    const uint64_t *wsrc[2] = {d_witness_512, d_witness_1024}, *isrc[2] = {d_instance_512, d_instance_1024};
+    for (int g = 0; g < 2; g++)
+        if (r->base[g] && (!wsrc[g] || !isrc[g])) return FRW_E_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(r->device);
+    static const uint64_t one[4] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};   // R mod p
+    if (e == hipSuccess) e = hipMemcpyAsync(d_instance, one, 32, hipMemcpyHostToDevice, st);
+    size_t used[2] = {0, 0};
+    for (const frw::R1csAggRun &run : r->runs) {
+        if (e != hipSuccess) break;
+        const int g = r->statement_logn[run.first] - 9;
+        const size_t W = run.base->num_witness, I = run.base->num_instance, cnt = run.count;
+        e = hipMemcpyAsync(d_witness + run.wit_off * 4, wsrc[g] + used[g] * W * 4, cnt * W * 32, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess)       // the public inputs of every statement of the run, without its own leading one
+            e = hipMemcpy2DAsync(d_instance + (1 + run.pub_off) * 4, (I - 1) * 32, isrc[g] + (used[g] * I + 1) * 4, I * 32, (I - 1) * 32, cnt,
+                                 hipMemcpyDeviceToDevice, st);
+        used[g] += cnt;
+    }
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_aggregate_assign_dev");
 }
 
 namespace {
@@ -342,7 +486,7 @@ extern "C" int frw_qap_witness_map_dev(const frw_r1cs *r, size_t batch, const ui
                                        void *stream)
 {
     if (!r || (batch && (!d_witness || !d_instance || !d_h || !d_workspace))) return FRW_E_INVALID_ARG;
-    if (r->qap.log_n != 17 && r->qap.log_n != 18) return FRW_E_INVALID_ARG;   // the pass schedule covers the Falcon circuits' domains
+    if (r->qap.num_passes < 2) return FRW_E_INVALID_ARG;                       // no pass schedule for this domain (frw_device.h qap_pass_schedule)
     if (batch && workspace_bytes < frw::qap_workspace_bytes_per_signature(r->dev, r->qap)) return FRW_E_INVALID_ARG;
     hipError_t e = hipSetDevice(r->device);
     if (e == hipSuccess)
@@ -356,7 +500,7 @@ extern "C" int frw_qap_quotient_dev(const frw_r1cs *r, size_t batch, const uint6
                                     void *stream)
 {
     if (!r || (batch && (!d_witness || !d_instance || !d_h || !d_workspace))) return FRW_E_INVALID_ARG;
-    if (r->qap.log_n != 17 && r->qap.log_n != 18) return FRW_E_INVALID_ARG;
+    if (r->qap.num_passes < 2) return FRW_E_INVALID_ARG;
     if (batch && workspace_bytes < frw::qap_workspace_bytes_per_signature(r->dev, r->qap)) return FRW_E_INVALID_ARG;
     hipError_t e = hipSetDevice(r->device);
     if (e == hipSuccess)
@@ -371,10 +515,11 @@ extern "C" int frw_qap_witness_map(const frw_r1cs *r, size_t batch, const uint64
                                    uint64_t *h, uint32_t *num_unsatisfied)
 {
     if (!r || (batch && (!witness || !instance || !h))) return FRW_E_INVALID_ARG;
-    if (r->qap.log_n != 17 && r->qap.log_n != 18) return FRW_E_INVALID_ARG;
+    if (r->qap.num_passes < 2) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
     frw::HostArena &A = r->arena;
     std::lock_guard<std::mutex> lock(A.mu);
+    frw::DrainOnExit drain(A);
     hipError_t e = hipSetDevice(r->device);
     if (e != hipSuccess) return frw::record_hip_error(e, "hipSetDevice");
     const size_t n = (size_t)1 << r->qap.log_n, W = r->dev.num_witness, I = r->dev.num_instance;
@@ -441,6 +586,110 @@ extern "C" int frw_r1cs_export(int circuit, int logn, const char *path, uint64_t
 // Host: the circuit's matrices, the Lagrange coefficients at t (instance_map_with_evaluation: u_i(t), v_i(t), w_i(t), zt), the
 // scalars of every query.  Device: the queries themselves, fixed-base multiples (frw_g1_fixed_base / frw_g2_fixed_base), and the
 // loaded proving key.  vk_out: alpha_g1 (12 u64) | beta_g2 (24) | gamma_g2 (24) | delta_g2 (24) | gamma_abc_g1 [I][12].
+namespace {
+// one block of a block-diagonal system: the matrices of a per-signature circuit and where its rows, public inputs and witness
+// variables sit in the whole (a single circuit is one block at zero)
+struct SetupBlock { const frw::host::ConstraintMatrices *m; size_t row_off, pub_off, wit_off; };
+
+int groth16_setup_blocks(int device, const std::vector<SetupBlock> &blocks, size_t ni, size_t nw, size_t nc, const uint64_t *toxic,
+                         frw_groth16_pk **pk_out, uint64_t *vk_out)
+{
+    using namespace frw::host;
+    const size_t nv = ni + nw;
+    const int L = domain_log(nc + ni);
+    if (L > 30) return FRW_E_INVALID_ARG;
+    const size_t n = (size_t)1 << L;
+    const Fr alpha = Fr::from_canonical(toxic), beta = Fr::from_canonical(toxic + 4), gamma = Fr::from_canonical(toxic + 8),
+             delta = Fr::from_canonical(toxic + 12), t = Fr::from_canonical(toxic + 16);
+    const uint64_t root_limbs[4] = {0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL};
+    Fr w = Fr::from_montgomery(root_limbs);
+    for (int i = L; i < 32; i++) w = w * w;
+    const Fr zt = t.pow(n) - Fr::one();
+    if (zt.is_zero() || gamma.is_zero() || delta.is_zero()) return FRW_E_INVALID_ARG;       // t must lie outside the domain
+    // L_i(t) = zt w^i / (n (t - w^i)); the n inversions by Montgomery's trick
+    std::vector<Fr> lag(n), den(n), pre(n);
+    {
+        Fr wi = Fr::one(), acc = Fr::one();
+        for (size_t i = 0; i < n; i++) { lag[i] = wi; den[i] = t - wi; pre[i] = acc; acc = acc * den[i]; wi = wi * w; }
+        Fr inv = inverse(acc);
+        const Fr c = zt * inverse(Fr::from(n));
+        for (size_t i = n; i-- > 0;) { lag[i] = c * lag[i] * (inv * pre[i]); inv = inv * den[i]; }
+    }
+    std::vector<Fr>().swap(den);
+    std::vector<Fr>().swap(pre);
+    std::vector<Fr> u(nv, Fr::zero()), v(nv, Fr::zero()), ww(nv, Fr::zero());
+    for (size_t i = 0; i < ni; i++) u[i] = lag[nc + i];                                    // r1cs_to_qap.rs: the input rows
+    // the blocks touch disjoint variables but for column 0 (the constant one): a few host threads, each with its own sums there
+    const unsigned hw = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
+    const size_t nthreads = std::min<size_t>(hw, blocks.size());
+    std::vector<std::array<Fr, 3>> col0(nthreads, {Fr::zero(), Fr::zero(), Fr::zero()});
+    auto work = [&](size_t tid) {
+        for (size_t b = tid; b < blocks.size(); b += nthreads) {
+            const SetupBlock &blk = blocks[b];
+            const size_t mi = blk.m->num_instance_variables;
+            std::vector<Fr> *dst[3] = {&u, &v, &ww};
+            const std::vector<ConstraintMatrices::Row> *mats[3] = {&blk.m->a, &blk.m->b, &blk.m->c};
+            for (int k = 0; k < 3; k++)
+                for (size_t r = 0; r < blk.m->num_constraints; r++) {
+                    const Fr &lr = lag[blk.row_off + r];
+                    for (const auto &e : (*mats[k])[r]) {
+                        const Fr x = lr * e.first;
+                        if (e.second == 0) col0[tid][k] = col0[tid][k] + x;
+                        else {
+                            const size_t col = e.second < mi ? blk.pub_off + e.second : ni + blk.wit_off + (e.second - mi);
+                            (*dst[k])[col] = (*dst[k])[col] + x;
+                        }
+                    }
+                }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t tid = 1; tid < nthreads; tid++) th.emplace_back(work, tid);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (size_t tid = 0; tid < nthreads; tid++) { u[0] = u[0] + col0[tid][0]; v[0] = v[0] + col0[tid][1]; ww[0] = ww[0] + col0[tid][2]; }
+    std::vector<Fr>().swap(lag);
+    const Fr dinv = inverse(delta), ginv = inverse(gamma);
+    auto canon = [](const std::vector<Fr> &x) { std::vector<uint64_t> o(4 * x.size()); for (size_t i = 0; i < x.size(); i++) x[i].to_canonical(&o[4 * i]); return o; };
+    std::vector<Fr> lq(nw), hq(n - 1), abc(ni), fixed = {alpha, beta, delta, gamma};
+    for (size_t i = 0; i < nv; i++) {
+        const Fr x = beta * u[i] + alpha * v[i] + ww[i];
+        if (i < ni) abc[i] = x * ginv; else lq[i - ni] = x * dinv;
+    }
+    { Fr x = zt * dinv; for (size_t i = 0; i + 1 < n; i++) { hq[i] = x; x = x * t; } }
+    std::vector<uint64_t> a_q(12 * nv), b1_q(12 * nv), b2_q(24 * nv), h_q(12 * (n - 1)), l_q(12 * nw), f1(12 * 4), f2(24 * 4), abc_q(12 * ni);
+    int rc = frw_g1_fixed_base(device, nv, canon(u).data(), a_q.data());
+    std::vector<Fr>().swap(u);
+    const std::vector<uint64_t> vc = canon(v);
+    std::vector<Fr>().swap(v);
+    if (rc == FRW_OK) rc = frw_g1_fixed_base(device, nv, vc.data(), b1_q.data());
+    if (rc == FRW_OK) rc = frw_g2_fixed_base(device, nv, vc.data(), b2_q.data());
+    if (rc == FRW_OK) rc = frw_g1_fixed_base(device, n - 1, canon(hq).data(), h_q.data());
+    std::vector<Fr>().swap(hq);
+    if (rc == FRW_OK) rc = frw_g1_fixed_base(device, nw, canon(lq).data(), l_q.data());
+    if (rc == FRW_OK) rc = frw_g1_fixed_base(device, 4, canon(fixed).data(), f1.data());
+    if (rc == FRW_OK) rc = frw_g2_fixed_base(device, 4, canon(fixed).data(), f2.data());
+    if (rc == FRW_OK && vk_out) rc = frw_g1_fixed_base(device, ni, canon(abc).data(), abc_q.data());
+    if (rc != FRW_OK) return rc;
+    frw_groth16_pk_desc_t d{};
+    d.num_instance = ni; d.num_witness = nw; d.domain_size = n;
+    d.alpha_g1 = &f1[0]; d.beta_g1 = &f1[12]; d.delta_g1 = &f1[24];
+    d.beta_g2 = &f2[24]; d.delta_g2 = &f2[48];
+    d.a_query = a_q.data(); d.b_g1_query = b1_q.data(); d.b_g2_query = b2_q.data(); d.h_query = h_q.data(); d.l_query = l_q.data();
+    rc = frw_groth16_pk_load(device, &d, pk_out);
+    if (rc == FRW_OK && vk_out) {
+        std::memcpy(vk_out, &f1[0], 96);                       // alpha_g1
+        std::memcpy(vk_out + 12, &f2[24], 192);                // beta_g2
+        std::memcpy(vk_out + 36, &f2[72], 192);                // gamma_g2
+        std::memcpy(vk_out + 60, &f2[48], 192);                // delta_g2
+        std::memcpy(vk_out + 84, abc_q.data(), ni * 96);       // gamma_abc_g1
+    }
+    return rc;
+}
+}  // namespace
+
 extern "C" int frw_groth16_setup(int device, int circuit, int logn, const uint64_t *toxic /* [5][4]: alpha, beta, gamma, delta, t; canonical */,
                                  frw_groth16_pk **pk_out, uint64_t *vk_out)
 {
@@ -449,65 +698,36 @@ extern "C" int frw_groth16_setup(int device, int circuit, int logn, const uint64
     *pk_out = nullptr;
     try {
         const ConstraintMatrices m = build_matrices(circuit, logn);
-        const size_t ni = m.num_instance_variables, nw = m.num_witness_variables, nc = m.num_constraints, nv = ni + nw;
-        const int L = domain_log(nc + ni);
-        const size_t n = (size_t)1 << L;
-        const Fr alpha = Fr::from_canonical(toxic), beta = Fr::from_canonical(toxic + 4), gamma = Fr::from_canonical(toxic + 8),
-                 delta = Fr::from_canonical(toxic + 12), t = Fr::from_canonical(toxic + 16);
-        const uint64_t root_limbs[4] = {0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL};
-        Fr w = Fr::from_montgomery(root_limbs);
-        for (int i = L; i < 32; i++) w = w * w;
-        const Fr zt = t.pow(n) - Fr::one();
-        if (zt.is_zero() || gamma.is_zero() || delta.is_zero()) return FRW_E_INVALID_ARG;       // t must lie outside the domain
-        // L_i(t) = zt w^i / (n (t - w^i)); the n inversions by Montgomery's trick
-        std::vector<Fr> lag(n), den(n), pre(n);
-        {
-            Fr wi = Fr::one(), acc = Fr::one();
-            for (size_t i = 0; i < n; i++) { lag[i] = wi; den[i] = t - wi; pre[i] = acc; acc = acc * den[i]; wi = wi * w; }
-            Fr inv = inverse(acc);
-            const Fr c = zt * inverse(Fr::from(n));
-            for (size_t i = n; i-- > 0;) { lag[i] = c * lag[i] * (inv * pre[i]); inv = inv * den[i]; }
+        return groth16_setup_blocks(device, {SetupBlock{&m, 0, 0, 0}}, m.num_instance_variables, m.num_witness_variables, m.num_constraints,
+                                    toxic, pk_out, vk_out);
+    } catch (const std::exception &) {
+        return FRW_E_OUT_OF_MEMORY;
+    }
+}
+
+// The same for the system behind any handle -- in particular an aggregate statement (frw_r1cs_load_aggregate): the QAP at t is
+// evaluated block by block from the per-signature matrices, the key has one query point per variable of the WHOLE statement
+// (a_query, b_g1_query, b_g2_query: 1 + sum (2 N_i + W_i) points; h_query: domain - 1), and vk_out takes 84 + 12 (1 + sum 2 N_i)
+// uint64_t.
+extern "C" int frw_groth16_setup_r1cs(const frw_r1cs *r, const uint64_t *toxic, frw_groth16_pk **pk_out, uint64_t *vk_out)
+{
+    using namespace frw::host;
+    if (!r || !toxic || !pk_out) return FRW_E_INVALID_ARG;
+    if (!r->dev.agg) return frw_groth16_setup(r->device, r->circuit, r->logn, toxic, pk_out, vk_out);
+    *pk_out = nullptr;
+    try {
+        ConstraintMatrices mats[2];
+        for (int g = 0; g < 2; g++)
+            if (r->base[g]) mats[g] = build_matrices(FRW_CIRCUIT_NTT, 9 + g);
+        std::vector<SetupBlock> blocks;
+        for (const frw::R1csAggRun &run : r->runs) {
+            const ConstraintMatrices &m = mats[r->statement_logn[run.first] - 9];
+            for (uint32_t k = 0; k < run.count; k++)
+                blocks.push_back(SetupBlock{&m, (size_t)(run.row_off + (uint64_t)k * m.num_constraints),
+                                            (size_t)(run.pub_off + (uint64_t)k * (m.num_instance_variables - 1)),
+                                            (size_t)(run.wit_off + (uint64_t)k * m.num_witness_variables)});
         }
-        std::vector<Fr> u(nv, Fr::zero()), v(nv, Fr::zero()), ww(nv, Fr::zero());
-        for (size_t i = 0; i < ni; i++) u[i] = lag[nc + i];                                    // r1cs_to_qap.rs: the input rows
-        for (size_t r = 0; r < nc; r++) {
-            for (const auto &e : m.a[r]) u[e.second] = u[e.second] + lag[r] * e.first;
-            for (const auto &e : m.b[r]) v[e.second] = v[e.second] + lag[r] * e.first;
-            for (const auto &e : m.c[r]) ww[e.second] = ww[e.second] + lag[r] * e.first;
-        }
-        const Fr dinv = inverse(delta), ginv = inverse(gamma);
-        auto canon = [](const std::vector<Fr> &x) { std::vector<uint64_t> o(4 * x.size()); for (size_t i = 0; i < x.size(); i++) x[i].to_canonical(&o[4 * i]); return o; };
-        std::vector<Fr> lq(nw), hq(n - 1), abc(ni), fixed = {alpha, beta, delta, gamma};
-        for (size_t i = 0; i < nv; i++) {
-            const Fr x = beta * u[i] + alpha * v[i] + ww[i];
-            if (i < ni) abc[i] = x * ginv; else lq[i - ni] = x * dinv;
-        }
-        { Fr x = zt * dinv; for (size_t i = 0; i + 1 < n; i++) { hq[i] = x; x = x * t; } }
-        std::vector<uint64_t> a_q(12 * nv), b1_q(12 * nv), b2_q(24 * nv), h_q(12 * (n - 1)), l_q(12 * nw), f1(12 * 4), f2(24 * 4), abc_q(12 * ni);
-        int rc = frw_g1_fixed_base(device, nv, canon(u).data(), a_q.data());
-        const std::vector<uint64_t> vc = canon(v);
-        if (rc == FRW_OK) rc = frw_g1_fixed_base(device, nv, vc.data(), b1_q.data());
-        if (rc == FRW_OK) rc = frw_g2_fixed_base(device, nv, vc.data(), b2_q.data());
-        if (rc == FRW_OK) rc = frw_g1_fixed_base(device, n - 1, canon(hq).data(), h_q.data());
-        if (rc == FRW_OK) rc = frw_g1_fixed_base(device, nw, canon(lq).data(), l_q.data());
-        if (rc == FRW_OK) rc = frw_g1_fixed_base(device, 4, canon(fixed).data(), f1.data());
-        if (rc == FRW_OK) rc = frw_g2_fixed_base(device, 4, canon(fixed).data(), f2.data());
-        if (rc == FRW_OK && vk_out) rc = frw_g1_fixed_base(device, ni, canon(abc).data(), abc_q.data());
-        if (rc != FRW_OK) return rc;
-        frw_groth16_pk_desc_t d{};
-        d.num_instance = ni; d.num_witness = nw; d.domain_size = n;
-        d.alpha_g1 = &f1[0]; d.beta_g1 = &f1[12]; d.delta_g1 = &f1[24];
-        d.beta_g2 = &f2[24]; d.delta_g2 = &f2[48];
-        d.a_query = a_q.data(); d.b_g1_query = b1_q.data(); d.b_g2_query = b2_q.data(); d.h_query = h_q.data(); d.l_query = l_q.data();
-        rc = frw_groth16_pk_load(device, &d, pk_out);
-        if (rc == FRW_OK && vk_out) {
-            std::memcpy(vk_out, &f1[0], 96);                       // alpha_g1
-            std::memcpy(vk_out + 12, &f2[24], 192);                // beta_g2
-            std::memcpy(vk_out + 36, &f2[72], 192);                // gamma_g2
-            std::memcpy(vk_out + 60, &f2[48], 192);                // delta_g2
-            std::memcpy(vk_out + 84, abc_q.data(), ni * 96);       // gamma_abc_g1
-        }
-        return rc;
+        return groth16_setup_blocks(r->device, blocks, r->dev.num_instance, r->dev.num_witness, r->dev.num_constraints, toxic, pk_out, vk_out);
     } catch (const std::exception &) {
         return FRW_E_OUT_OF_MEMORY;
     }

@@ -20,8 +20,9 @@
 
 namespace frw {
 
+struct StatementVars;
 __device__ __forceinline__ Fr8 row_dot(const R1csMatrixDev &m, uint32_t row, const uint32_t *__restrict__ wit,
-                                       const uint32_t *__restrict__ inst, uint32_t num_instance)
+                                       const uint32_t *__restrict__ inst, const uint32_t *__restrict__ one, uint32_t num_instance)
 {
     Fr8 acc;
 #pragma unroll
@@ -29,10 +30,29 @@ __device__ __forceinline__ Fr8 row_dot(const R1csMatrixDev &m, uint32_t row, con
     const uint64_t lo = m.row_ptr[row], hi = m.row_ptr[row + 1];
     for (uint64_t t = lo; t < hi; t++) {
         const uint32_t col = m.col[t];
-        const Fr8 z = fr_load(col < num_instance ? inst + (size_t)col * 8 : wit + (size_t)(col - num_instance) * 8);
+        const Fr8 z = fr_load(col >= num_instance ? wit + (size_t)(col - num_instance) * 8 : col ? inst + (size_t)col * 8 : one);
         acc = fr_add(acc, fr_mul(fr_load(m.val + t * 8), z));
     }
     return acc;
+}
+
+// One statement's variables through a view (frw_device.h R1csView): the plain batch of the witness entry points, or a run
+// of statements inside an aggregate assignment.
+struct StatementVars {
+    const uint32_t *wit, *inst, *one;
+    uint32_t num_instance;
+    __device__ __forceinline__ const uint32_t *at(uint32_t col) const
+    {
+        return col >= num_instance ? wit + (size_t)(col - num_instance) * 8 : col ? inst + (size_t)col * 8 : one;
+    }
+};
+__device__ __forceinline__ StatementVars statement_vars(const R1csDev &r, const R1csView &v, size_t sig)
+{
+    return StatementVars{v.wit + sig * v.wit_stride, v.inst + sig * v.inst_stride, v.one + sig * v.one_stride, r.num_instance};
+}
+__device__ __forceinline__ uint32_t *product_ptr(const R1csView &v, size_t sig, uint32_t matrix, uint32_t row)
+{
+    return v.abc + (sig * v.abc_sig_stride + (size_t)matrix * v.abc_mat_stride + row) * 8;
 }
 
 // The fast path of frw_r1cs_eval_dev (abc != nullptr): thread per row in nine-limb arithmetic (frw_fr29.h).
@@ -41,8 +61,7 @@ __device__ __forceinline__ Fr8 row_dot(const R1csMatrixDev &m, uint32_t row, con
 // decreasing length (r.order), so the 64 rows of a wavefront have similar length; matrices in which the row is long
 // (r.long_mask) are skipped -- r1cs_long_rows_kernel has already put their product into abc.
 constexpr uint32_t TERM_PLUS_ONE = 1u, TERM_MINUS_ONE = 2u;      // 0: general coefficient
-__device__ __forceinline__ F29 row_dot29(const R1csMatrixDev &m, uint32_t row, const uint32_t *__restrict__ wit,
-                                         const uint32_t *__restrict__ inst, uint32_t num_instance)
+__device__ __forceinline__ F29 row_dot29(const R1csMatrixDev &m, uint32_t row, const StatementVars &z_of)
 {
     F29 acc;
 #pragma unroll
@@ -50,7 +69,7 @@ __device__ __forceinline__ F29 row_dot29(const R1csMatrixDev &m, uint32_t row, c
     const uint64_t lo = m.row_ptr[row], hi = m.row_ptr[row + 1];
     for (uint64_t t = lo; t < hi; t++) {
         const uint32_t cc = m.col_class[t], col = cc & 0x3fffffffu, cls = cc >> 30;
-        const F29 z = f29_unpack(fr_load(col < num_instance ? inst + (size_t)col * 8 : wit + (size_t)(col - num_instance) * 8));
+        const F29 z = f29_unpack(fr_load(z_of.at(col)));
         if (cls == TERM_PLUS_ONE) acc = f29_reduce_4p(f29_add(acc, z));
         else if (cls == TERM_MINUS_ONE) acc = f29_reduce_4p(f29_sub_2p(acc, z));
         else acc = f29_reduce_4p(f29_add(acc, f29_mul(z, f29_unpack(fr_load(m.val29 + t * 8)))));
@@ -64,16 +83,12 @@ __device__ __forceinline__ F29 row_dot29(const R1csMatrixDev &m, uint32_t row, c
 #define FRW_EVAL_WAVES 4
 #endif
 template <bool STORE>
-__global__ __launch_bounds__(BLOCK, FRW_EVAL_WAVES) void r1cs_eval_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
-                                                          const uint32_t *__restrict__ instance,
-                                                          unsigned int *__restrict__ num_unsatisfied,
-                                                          uint32_t *__restrict__ abc, const uint32_t *__restrict__ long_out)
+__global__ __launch_bounds__(BLOCK, FRW_EVAL_WAVES) void r1cs_eval_kernel(R1csDev r, size_t batch, const R1csView view,
+                                                          const uint32_t *__restrict__ long_out)
 {
     const size_t sig = blockIdx.y;
     if (sig >= batch) return;
-    const uint32_t *wit = witness + sig * (size_t)r.num_witness * 8;
-    const uint32_t *inst = instance + sig * (size_t)r.num_instance * 8;
-    uint32_t *o = STORE ? abc + sig * (size_t)3 * r.num_constraints * 8 : nullptr;
+    const StatementVars z_of = statement_vars(r, view, sig);
     const uint32_t *lo = STORE ? nullptr : long_out + sig * (size_t)r.num_long * 8;
     constexpr uint32_t R32[8] = FRW_R32;
     Fr8 one_r;
@@ -87,11 +102,11 @@ __global__ __launch_bounds__(BLOCK, FRW_EVAL_WAVES) void r1cs_eval_kernel(R1csDe
 #pragma unroll
         for (int m = 0; m < 3; m++) {
             const R1csMatrixDev &mat = m == 0 ? r.a : m == 1 ? r.b : r.c;
-            uint32_t *om = STORE ? o + ((size_t)m * r.num_constraints + row) * 8 : nullptr;
+            uint32_t *om = STORE ? product_ptr(view, sig, m, row) : nullptr;
             if (mask & (1u << m)) {
                 v[m] = f29_unpack(fr_load(STORE ? om : lo + (size_t)r.long_slot[(size_t)m * r.num_constraints + row] * 8));
             } else {
-                v[m] = f29_canonical(row_dot29(mat, row, wit, inst, r.num_instance));
+                v[m] = f29_canonical(row_dot29(mat, row, z_of));
                 if (STORE) fr_store(om, f29_pack(v[m]));
             }
         }
@@ -104,25 +119,22 @@ __global__ __launch_bounds__(BLOCK, FRW_EVAL_WAVES) void r1cs_eval_kernel(R1csDe
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, WAVE);
-    if ((threadIdx.x & (WAVE - 1)) == 0 && bad && num_unsatisfied) atomicAdd(&num_unsatisfied[sig], bad);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && bad && view.flags) atomicAdd(&view.flags[sig * view.flag_stride], bad);
 }
 
 // Check only, when no scratch is to be had for the long rows' products: one thread per row in the 8 x 32-bit form, longest
 // rows first, so that the dense ladder rows spread over many waves.
-__global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
-                                                           const uint32_t *__restrict__ instance,
-                                                           unsigned int *__restrict__ num_unsatisfied)
+__global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t batch, const R1csView view)
 {
     const size_t sig = blockIdx.y;
     if (sig >= batch) return;
-    const uint32_t *wit = witness + sig * (size_t)r.num_witness * 8;
-    const uint32_t *inst = instance + sig * (size_t)r.num_instance * 8;
+    const uint32_t *wit = view.wit + sig * view.wit_stride, *inst = view.inst + sig * view.inst_stride, *one = view.one + sig * view.one_stride;
     unsigned bad = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < r.num_constraints; i += gridDim.x * BLOCK) {
         const uint32_t row = r.order[i];
-        const Fr8 az = row_dot(r.a, row, wit, inst, r.num_instance);
-        const Fr8 bz = row_dot(r.b, row, wit, inst, r.num_instance);
-        const Fr8 cz = row_dot(r.c, row, wit, inst, r.num_instance);
+        const Fr8 az = row_dot(r.a, row, wit, inst, one, r.num_instance);
+        const Fr8 bz = row_dot(r.b, row, wit, inst, one, r.num_instance);
+        const Fr8 cz = row_dot(r.c, row, wit, inst, one, r.num_instance);
         const Fr8 ab = fr_mul(az, bz);              // (Az R)(Bz R)/R = Az Bz R
         bool eq = true;
 #pragma unroll
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, WAVE);
-    if ((threadIdx.x & (WAVE - 1)) == 0 && bad && num_unsatisfied) atomicAdd(&num_unsatisfied[sig], bad);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && bad && view.flags) atomicAdd(&view.flags[sig * view.flag_stride], bad);
 }
 
 // One wavefront per (long row, group of LONG_SIGS signatures): lane l multiplies terms l, l + 64, ... (coefficient loaded
@@ -140,14 +152,12 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
 // (a product with R' mod p) every sixteen, so the running value stays far below 2^261 = 70 p.
 constexpr int LONG_SIGS = 4;
 // where a long row's product goes: its slot in abc, or (check only) [signature][long row] of the scratch
-__device__ __forceinline__ uint32_t *long_row_out(const R1csDev &r, const R1csLongRow &d, uint32_t *abc, uint32_t *long_out, size_t sig)
+__device__ __forceinline__ uint32_t *long_row_out(const R1csDev &r, const R1csLongRow &d, const R1csView &view, uint32_t *long_out, size_t sig)
 {
-    return abc ? abc + ((sig * 3 + d.matrix) * (size_t)r.num_constraints + d.row) * 8 : long_out + (sig * r.num_long + blockIdx.x) * 8;
+    return view.abc ? product_ptr(view, sig, d.matrix, d.row) : long_out + (sig * r.num_long + blockIdx.x) * 8;
 }
 
-__global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
-                                                              const uint32_t *__restrict__ instance, uint32_t *__restrict__ abc,
-                                                              uint32_t *__restrict__ long_out)
+__global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t batch, const R1csView view, uint32_t *__restrict__ long_out)
 {
     const R1csLongRow d = r.long_rows[blockIdx.x];
     const int lane = threadIdx.x;
@@ -175,9 +185,7 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t 
 #pragma unroll
         for (int s = 0; s < LONG_SIGS; s++) {
             const size_t sig = sig0 + s < batch ? sig0 + s : batch - 1;       // a ragged last group repeats the last signature
-            const uint32_t *zp = col < r.num_instance ? instance + (sig * r.num_instance + col) * 8
-                                                       : witness + (sig * r.num_witness + (col - r.num_instance)) * 8;
-            const F29 z = f29_unpack(fr_load(zp));
+            const F29 z = f29_unpack(fr_load(statement_vars(r, view, sig).at(col)));
             const F29 prod = f29_mul(z, c);                       // < 2 p, normalised
 #pragma unroll
             for (int k = 0; k < NL29; k++) acc[s].l[k] += prod.l[k];          // lazily: limbs < 4 x 2^29 between carries
@@ -202,20 +210,18 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_kernel(R1csDev r, size_t 
             for (int k = 0; k < NL29; k++) other.l[k] = (uint32_t)__shfl_xor((int)acc[s].l[k], off, WAVE);
             acc[s] = f29_reduce_4p(f29_add(acc[s], other));
         }
-        if (lane == 0 && sig0 + s < batch) fr_store(long_row_out(r, d, abc, long_out, sig0 + s), f29_pack(f29_canonical(acc[s])));
+        if (lane == 0 && sig0 + s < batch) fr_store(long_row_out(r, d, view, long_out, sig0 + s), f29_pack(f29_canonical(acc[s])));
     }
 }
 
 // The plain value of every variable the long rows read, when it is below 2^28 (else ~0): f29_mul(z R, 32) = z.
-__global__ __launch_bounds__(BLOCK) void r1cs_zsmall_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
-                                                            const uint32_t *__restrict__ instance, uint32_t *__restrict__ zs)
+__global__ __launch_bounds__(BLOCK) void r1cs_zsmall_kernel(R1csDev r, size_t batch, const R1csView view, uint32_t *__restrict__ zs)
 {
     const size_t sig = blockIdx.y;
     const uint32_t u = blockIdx.x * BLOCK + threadIdx.x;
     if (sig >= batch || u >= r.num_long_vars) return;
     const uint32_t col = r.long_vars[u];
-    const uint32_t *zp = col < r.num_instance ? instance + (sig * r.num_instance + col) * 8
-                                               : witness + (sig * r.num_witness + (col - r.num_instance)) * 8;
+    const uint32_t *zp = statement_vars(r, view, sig).at(col);
     F29 c32;
 #pragma unroll
     for (int k = 0; k < NL29; k++) c32.l[k] = k ? 0u : 32u;
@@ -231,10 +237,8 @@ __global__ __launch_bounds__(BLOCK) void r1cs_zsmall_kernel(R1csDev r, size_t ba
 // limb instead of a field product.  A term whose variable is not small takes the field product and enters the same
 // columns as 32 z c R.  At the end the 64 lanes' columns are carried into 29-bit limbs, added across the wavefront, and
 // X = 32 R sum(c z) becomes sum(c z) R through one Montgomery reduction (X / R') and one product with R R' mod p.
-__global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, size_t batch, const uint32_t *__restrict__ witness,
-                                                                    const uint32_t *__restrict__ instance,
-                                                                    const uint32_t *__restrict__ zs, uint32_t *__restrict__ abc,
-                                                                    uint32_t *__restrict__ long_out)
+__global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, size_t batch, const R1csView view,
+                                                                    const uint32_t *__restrict__ zs, uint32_t *__restrict__ long_out)
 {
     const R1csLongRow d = r.long_rows[blockIdx.x];
     const int lane = threadIdx.x;
@@ -265,9 +269,7 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, s
             for (int s = 0; s < LONG_SIGS; s++) {
                 if (zv[s] == 0xffffffffu) {
                     const size_t sig = sig0 + s < batch ? sig0 + s : batch - 1;
-                    const uint32_t *zp = colv < r.num_instance ? instance + (sig * r.num_instance + colv) * 8
-                                                                : witness + (sig * r.num_witness + (colv - r.num_instance)) * 8;
-                    const F29 prod = f29_mul(f29_unpack(fr_load(zp)), c);
+                    const F29 prod = f29_mul(f29_unpack(fr_load(statement_vars(r, view, sig).at(colv))), c);
 #pragma unroll
                     for (int k = 0; k < NL29; k++) col[s][k] += (uint64_t)prod.l[k] << 5;
                     zv[s] = 0;
@@ -310,34 +312,37 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, s
         }
         const F29 sum = f29_redc_wide(x);                          // X / R' = sum(c z), < 2 p
         const F29 res = f29_canonical(f29_mul(sum, krrp));         // sum(c z) R
-        if (lane == 0 && sig0 + s < batch) fr_store(long_row_out(r, d, abc, long_out, sig0 + s), f29_pack(res));
+        if (lane == 0 && sig0 + s < batch) fr_store(long_row_out(r, d, view, long_out, sig0 + s), f29_pack(res));
     }
 }
 
 // Scratch of the evaluation: the small values of the long rows' variables (batch x num_long_vars x 4 bytes) and, when
-// the products are not kept (abc == nullptr), the long rows' results (batch x num_long x 32 bytes).
+// the products are not kept (abc == nullptr), the long rows' results (batch x num_long x 32 bytes).  An aggregate's runs
+// are evaluated one after the other on one stream: they share the scratch of the largest.
 size_t r1cs_check_scratch_bytes(const R1csDev &r, size_t batch, bool with_abc)
 {
+    if (r.agg) {
+        size_t need = 0;
+        for (uint32_t k = 0; k < r.agg->num_runs; k++) {
+            const size_t b = r1cs_check_scratch_bytes(*r.agg->runs[k].base, r.agg->runs[k].count, with_abc);
+            need = b > need ? b : need;
+        }
+        return need;
+    }
     if (!r.num_long) return 0;
     const size_t zs = (batch * (size_t)r.num_long_vars * sizeof(uint32_t) + 255) & ~(size_t)255;
     return zs + (with_abc ? 0 : batch * (size_t)r.num_long * 32);
 }
 
-// `caller_scratch` (optional, at least r1cs_check_scratch_bytes): the QAP entry points lend part of their workspace, and
-// frw_r1cs_eval_scratch_dev passes the caller's buffer -- then nothing is allocated and the call is capture-safe.  Without
-// it a stream-ordered allocation is made for the duration of the call (and the slow kernels run should that fail).
-hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
-                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st, void *caller_scratch)
+namespace {
+// one launch sequence over `batch` statements of the system `r` as `view` lays them out
+hipError_t launch_view(const R1csDev &r, size_t batch, const R1csView &view, hipStream_t st, void *caller_scratch)
 {
     if (batch == 0) return hipSuccess;
     if (batch > 65535) return hipErrorInvalidValue;
-    if (num_unsatisfied) {
-        hipError_t e = hipMemsetAsync(num_unsatisfied, 0, batch * sizeof(uint32_t), st);
-        if (e != hipSuccess) return e;
-    }
     const unsigned gx = (r.num_constraints + BLOCK - 1) / BLOCK;
     const dim3 egrid(gx > 64 ? 64 : gx, (unsigned)batch);
-    const uint32_t *wit = (const uint32_t *)witness, *inst = (const uint32_t *)instance;
+    const bool abc = view.abc != nullptr;
     // stream-ordered scratch: the small values of the long rows' variables, and (check only) the long rows' products
     uint32_t *zs = nullptr, *long_out = nullptr;
     bool scratch = true;
@@ -355,21 +360,59 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
             const dim3 grid(r.num_long, (unsigned)((batch + LONG_SIGS - 1) / LONG_SIGS));
             if (scratch) {
                 hipLaunchKernelGGL(r1cs_zsmall_kernel, dim3((r.num_long_vars + BLOCK - 1) / BLOCK, (unsigned)batch), dim3(BLOCK), 0, st,
-                                   r, batch, wit, inst, zs);
-                hipLaunchKernelGGL(r1cs_long_rows_small_kernel, grid, dim3(WAVE), 0, st, r, batch, wit, inst, zs, (uint32_t *)abc, long_out);
+                                   r, batch, view, zs);
+                hipLaunchKernelGGL(r1cs_long_rows_small_kernel, grid, dim3(WAVE), 0, st, r, batch, view, zs, long_out);
             } else {                                              // abc given, no scratch: every term a field product
-                hipLaunchKernelGGL(r1cs_long_rows_kernel, grid, dim3(WAVE), 0, st, r, batch, wit, inst, (uint32_t *)abc, long_out);
+                hipLaunchKernelGGL(r1cs_long_rows_kernel, grid, dim3(WAVE), 0, st, r, batch, view, long_out);
             }
         }
-        if (abc) hipLaunchKernelGGL(r1cs_eval_kernel<true>, egrid, dim3(BLOCK), 0, st, r, batch, wit, inst, num_unsatisfied, (uint32_t *)abc, long_out);
-        else hipLaunchKernelGGL(r1cs_eval_kernel<false>, egrid, dim3(BLOCK), 0, st, r, batch, wit, inst, num_unsatisfied, (uint32_t *)abc, long_out);
+        if (abc) hipLaunchKernelGGL(r1cs_eval_kernel<true>, egrid, dim3(BLOCK), 0, st, r, batch, view, long_out);
+        else hipLaunchKernelGGL(r1cs_eval_kernel<false>, egrid, dim3(BLOCK), 0, st, r, batch, view, long_out);
     } else {
-        hipLaunchKernelGGL(r1cs_check_kernel, egrid, dim3(BLOCK), 0, st, r, batch, wit, inst, num_unsatisfied);
+        hipLaunchKernelGGL(r1cs_check_kernel, egrid, dim3(BLOCK), 0, st, r, batch, view);
     }
     const hipError_t e = hipGetLastError();
     if (zs && !lent) (void)hipFreeAsync(zs, st);
     if (long_out && !lent) (void)hipFreeAsync(long_out, st);
     return e;
+}
+}  // namespace
+
+// `caller_scratch` (optional, at least r1cs_check_scratch_bytes): the QAP entry points lend part of their workspace, and
+// frw_r1cs_eval_scratch_dev passes the caller's buffer -- then nothing is allocated and the call is capture-safe.  Without
+// it a stream-ordered allocation is made for the duration of the call (and the slow kernels run should that fail).
+// witness / instance / abc are [batch][W][4], [batch][I][4], [batch][3][C][4] of the system `r` -- for an aggregate the
+// aggregate's own vectors, which every run reads in place.
+hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,
+                             uint32_t *num_unsatisfied, uint64_t *abc, hipStream_t st, void *caller_scratch)
+{
+    if (batch == 0) return hipSuccess;
+    if (batch > 65535) return hipErrorInvalidValue;
+    if (num_unsatisfied) {
+        hipError_t e = hipMemsetAsync(num_unsatisfied, 0, batch * sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t *wit = (const uint32_t *)witness, *inst = (const uint32_t *)instance;
+    const size_t W = r.num_witness, I = r.num_instance, C = r.num_constraints;
+    if (!r.agg) {
+        const R1csView v{wit, W * 8, inst, I * 8, inst, I * 8, (uint32_t *)abc, 3 * C, C, num_unsatisfied, 1};
+        return launch_view(r, batch, v, st, caller_scratch);
+    }
+    for (size_t b = 0; b < batch; b++) {
+        const uint32_t *bw = wit + b * W * 8, *bi = inst + b * I * 8;
+        uint32_t *ba = abc ? (uint32_t *)abc + b * 3 * C * 8 : nullptr;
+        for (uint32_t k = 0; k < r.agg->num_runs; k++) {
+            const R1csAggRun &run = r.agg->runs[k];
+            const size_t pub = (size_t)run.base->num_instance - 1;        // public inputs per statement
+            const R1csView v{bw + run.wit_off * 8, (size_t)run.base->num_witness * 8,
+                             bi + run.pub_off * 8, pub * 8, bi, 0,
+                             ba ? ba + run.row_off * 8 : nullptr, run.base->num_constraints, C,
+                             num_unsatisfied ? num_unsatisfied + b : nullptr, 0};
+            const hipError_t e = launch_view(*run.base, run.count, v, st, caller_scratch);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
 }
 
 }  // namespace frw

@@ -61,6 +61,25 @@ AffineT<Fq2Field> g2_lazy(const G2 &p)
     return r;
 }
 
+// ark's deserialiser rejects a field element whose representation is not below the modulus; raw limbs are taken here, so the
+// same is asked of them BEFORE any arithmetic reduces them silently (x and x + q would otherwise be one point with two encodings)
+constexpr uint64_t FQ_MODULUS[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
+                                    0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
+bool fq_limbs_below_modulus(const uint64_t *w)
+{
+    for (int k = 5; k >= 0; k--) {
+        if (w[k] < FQ_MODULUS[k]) return true;
+        if (w[k] > FQ_MODULUS[k]) return false;
+    }
+    return false;
+}
+bool coordinates_canonical(const uint64_t *w, int coordinates)
+{
+    for (int k = 0; k < coordinates; k++)
+        if (!fq_limbs_below_modulus(w + 6 * k)) return false;
+    return true;
+}
+
 int bit_length(const uint64_t c[4])
 {
     for (int k = 3; k >= 0; k--)
@@ -94,14 +113,31 @@ extern "C" int frw_groth16_vk_load(const uint64_t *vk, size_t num_instance, frw_
     try {
         k->num_instance = num_instance;
         k->fc = frobenius_constants();
+        if (!coordinates_canonical(vk, 2 + 4 + 4 + 4)) { delete k; return FRW_E_INVALID_ARG; }
         const G1Affine29 alpha = g1_lazy_from_ark(vk);
         const G2 beta = g2_from_ark(vk + 12), gamma = g2_from_ark(vk + 36), delta = g2_from_ark(vk + 60);
         bool ok = g1_on_curve(g1_strict(alpha)) && g2_on_curve(beta) && g2_on_curve(gamma) && g2_on_curve(delta) &&
                   in_subgroup(alpha) && in_subgroup(g2_lazy(beta)) && in_subgroup(g2_lazy(gamma)) && in_subgroup(g2_lazy(delta));
         k->gamma_abc.resize(num_instance);
-        for (size_t i = 0; i < num_instance && ok; i++) {
-            k->gamma_abc[i] = g1_lazy_from_ark(vk + 84 + 12 * i);
-            ok = g1_on_curve(g1_strict(k->gamma_abc[i]));            // on the curve; membership of the subgroup is the key maker's business
+        // gamma_abc_g1: canonical limbs, on the curve, in the subgroup of order r -- what ark's deserialiser checks of a key it
+        // reads (a ladder per point: a few host threads for the 32,769 points of a sixteen-statement aggregate's key)
+        if (ok) {
+            const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+            const size_t threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(num_instance / 256, hw), 32));
+            std::atomic<bool> good{true};
+            auto work = [&](size_t tid) {
+                for (size_t i = tid; i < num_instance && good; i += threads) {
+                    const uint64_t *w = vk + 84 + 12 * i;
+                    if (!coordinates_canonical(w, 2)) { good = false; break; }
+                    k->gamma_abc[i] = g1_lazy_from_ark(w);
+                    if (!g1_on_curve(g1_strict(k->gamma_abc[i])) || !in_subgroup(k->gamma_abc[i])) good = false;
+                }
+            };
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < threads; t++) pool.emplace_back(work, t);
+            work(0);
+            for (auto &t : pool) t.join();
+            ok = good;
         }
         if (!ok) { delete k; return FRW_E_INVALID_ARG; }
         k->gamma_neg = g2_neg(gamma);
@@ -147,11 +183,13 @@ int verify_one(const frw_groth16_vk &vk, const uint64_t *inputs, int encoding, c
     const size_t n = vk.num_instance;
     std::vector<uint64_t> canon(4 * n);
     for (size_t i = 0; i < n; i++) {
+        // the raw limbs, in either encoding, must be a representation below r: checked before the conversion, which reduces
+        if (!below_modulus(inputs + 4 * i)) return -1;
         if (encoding == FRW_ENC_MONTGOMERY) Fr::from_montgomery(inputs + 4 * i).to_canonical(&canon[4 * i]);
         else std::memcpy(&canon[4 * i], inputs + 4 * i, 32);
-        if (!below_modulus(&canon[4 * i])) return -1;
     }
     if (canon[0] != 1 || canon[1] || canon[2] || canon[3]) return -1;         // the instance vector starts with the constant one
+    if (!coordinates_canonical(proof, 8)) return -1;                          // A (x, y), B (x.c0, x.c1, y.c0, y.c1), C (x, y)
     const G1Affine29 a = g1_lazy_from_ark(proof), c = g1_lazy_from_ark(proof + 36);
     const G2 b = g2_from_ark(proof + 12);
     const G1 as = g1_strict(a), cs = g1_strict(c);
@@ -161,7 +199,10 @@ int verify_one(const frw_groth16_vk &vk, const uint64_t *inputs, int encoding, c
     // e(A, B) e(acc, -gamma) e(C, -delta) == e(alpha, beta)
     const G1 ps[3] = {as, g1_strict(acc), cs};
     const G2 qs[3] = {b, vk.gamma_neg, vk.delta_neg};
-    return fp12_eq(final_exponentiation(miller_loop(ps, qs, 3), vk.fc), vk.alpha_beta) ? 1 : 0;
+    bool degenerate = false;
+    const Fp12 f = miller_loop(ps, qs, 3, &degenerate);
+    if (degenerate) return -1;              // only a point outside the subgroup gets here (FRW_VERIFY_POINTS_ARE_CHECKED and not true)
+    return fp12_eq(final_exponentiation(f, vk.fc), vk.alpha_beta) ? 1 : 0;
 }
 }  // namespace
 

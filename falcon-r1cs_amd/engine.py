@@ -379,6 +379,39 @@ class WitnessEngine:
     def r1cs_free(self, handle):
         self._lib.frw_r1cs_free(handle)
 
+    def r1cs_load_aggregate(self, logns):
+        """The constraint system of an aggregate statement: FalconNTTVerificationCircuit once per entry of `logns` (9 / 10, in
+        order) on one system.  The handle goes wherever an r1cs_load handle goes; its witness / instance vectors are the
+        aggregate's own (aggregate_assign_dev makes them).  Free with r1cs_free."""
+        arr = np.ascontiguousarray(logns, dtype=np.int32)
+        h = C.c_void_p()
+        check(self._lib.frw_r1cs_load_aggregate(self.device, len(arr), arr.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_r1cs_load_aggregate")
+        return h
+
+    def r1cs_info(self, handle):
+        from ._lib import R1csInfoStruct
+        q = R1csInfoStruct()
+        check(self._lib.frw_r1cs_info(handle, C.byref(q)), "frw_r1cs_info")
+        return q
+
+    def aggregate_assign_dev(self, handle, d_wit512, d_inst512, d_wit1024, d_inst1024, d_wit, d_inst, stream=0):
+        """instance_assignment / witness_assignment of the aggregate from the per-parameter-set batches of the witness entry points
+        (either pair may be None when the aggregate has no such statement)."""
+        P = lambda t: self._ptr(t) if t is not None else None
+        check(self._lib.frw_aggregate_assign_dev(handle, P(d_wit512), P(d_inst512), P(d_wit1024), P(d_inst1024), self._ptr(d_wit),
+                                                 self._ptr(d_inst), C.c_void_p(stream)), "frw_aggregate_assign_dev")
+
+    def groth16_setup_r1cs(self, handle, alpha, beta, gamma, delta, t):
+        """groth16_setup for the system behind an r1cs handle (a per-signature circuit or an aggregate statement)."""
+        tox = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in (alpha, beta, gamma, delta, t)), dtype=np.uint64).copy()
+        ni = int(self.r1cs_info(handle).num_instance)
+        vk = np.zeros(84 + 12 * ni, dtype=np.uint64)
+        h = C.c_void_p()
+        check(self._lib.frw_groth16_setup_r1cs(handle, tox.ctypes.data_as(C.c_void_p), C.byref(h), vk.ctypes.data_as(C.c_void_p)),
+              "frw_groth16_setup_r1cs")
+        return h, {"alpha_g1": vk[:12], "beta_g2": vk[12:36], "gamma_g2": vk[36:60], "delta_g2": vk[60:84],
+                   "gamma_abc_g1": vk[84:].reshape(-1, 12)}
+
     def r1cs_check_dev(self, handle, batch, d_wit, d_inst, d_num_unsatisfied, stream=0):
         check(self._lib.frw_r1cs_check_dev(handle, batch, self._ptr(d_wit), self._ptr(d_inst),
                                            self._ptr(d_num_unsatisfied), C.c_void_p(stream)), "frw_r1cs_check_dev")

@@ -266,8 +266,9 @@ int frw_r1cs_eval_scratch_dev(const frw_r1cs *r, size_t batch, const uint64_t *d
  *     d_num_unsatisfied optional uint32_t[batch]: constraint rows the witness violates (h is then not a quotient)
  *     d_workspace       at least workspace_bytes_per_signature bytes; the batch is processed in chunks of as many
  *                       signatures as fit.
- * Returns FRW_E_INVALID_ARG for a null pointer, a workspace smaller than one signature's, or a domain other than 2^17 /
- * 2^18 (the transform schedule is built for the four Falcon circuits).  Stream-ordered: everything is enqueued on
+ * Returns FRW_E_INVALID_ARG for a null pointer, a workspace smaller than one signature's, or a domain outside 2^14 .. 2^30
+ * (the transforms run as passes of six, five or four radix-2 stages: 2^17 = 6 + 6 + 5 and 2^18 = 6 + 6 + 6 for the Falcon
+ * circuits, 2^19 = 6 + 5 + 4 + 4 .. 2^24 = 6 + 6 + 6 + 6 for aggregate statements).  Stream-ordered: everything is enqueued on
  * `stream` and NOTHING is allocated -- the sparse products borrow the working arrays, idle at that point, as their
  * scratch -- so a call may be captured in a HIP graph.  A HIP failure is recorded for frw_last_error().
  * Precondition: every witness / instance element is canonical Montgomery form (limbs < p), which is what arkworks and
@@ -300,6 +301,42 @@ int frw_qap_witness_map(const frw_r1cs *r, size_t batch, const uint64_t *witness
                         uint64_t *h, uint32_t *num_unsatisfied);
 int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
 
+/* ---- an aggregate statement: many Falcon verifications, ONE constraint system, ONE proof ---------------------------------------
+ * BASELINE configs[4] / SURVEY 8-f row 4.  The reference's falcon-aggregate-sig crate is an empty stub
+ * (falcon-aggregate-sig/src/main.rs:1-3); the statement is defined the only way the reference's own circuits allow:
+ * FalconNTTVerificationCircuit::generate_constraints (falcon_ntt.rs:26-123) run once per (pk, msg, sig) on one constraint
+ * system, in order (host mirror: FalconAggregateVerificationCircuit in csrc/host/frw_host.hpp), proved by the flow of
+ * examples/pok_sig.rs:30-47.  For statements i = 0 .. count-1 with parameter sets logn[i] (9 or 10, freely mixed):
+ *     instance_assignment = [1, pk_ntt_0, hm_ntt_0, pk_ntt_1, hm_ntt_1, ...]            I = 1 + sum 2 N_i
+ *     witness_assignment  = witness_0 ++ witness_1 ++ ...                              W = sum W_i
+ *     constraints         = those of statement 0, then of statement 1, ...            C = sum C_i
+ *     QAP domain          = next_power_of_two(C + I):  2^18 for 512 + 1024, 2^19 for two Falcon-1024, 2^20 for four, 2^22 for sixteen
+ * frw_r1cs_load_aggregate returns a handle that every entry point taking a `frw_r1cs *` accepts (frw_r1cs_check_dev,
+ * frw_r1cs_eval_dev, frw_qap_info, frw_qap_witness_map_dev, frw_qap_quotient_dev, frw_groth16_workspace_bytes,
+ * frw_groth16_prove_dev), with d_witness = uint64_t[batch][W][4] and d_instance = uint64_t[batch][I][4] the aggregate's OWN
+ * vectors (batch = number of aggregate statements of this shape, normally 1) -- which frw_aggregate_assign_dev makes from the
+ * batches the witness entry points wrote: statement i takes the next unused signature of its parameter set's batch, so
+ * d_witness_512 / d_instance_512 hold the Falcon-512 statements in order and d_witness_1024 / d_instance_1024 the Falcon-1024
+ * ones (either pair may be NULL if the aggregate has no such statement).  The aggregate's matrices are never materialised: they
+ * are the per-signature systems' blocks, and a run of consecutive statements of one parameter set is one launch of that set's
+ * kernels reading the aggregate vectors in place.  d_num_unsatisfied counts the violated rows of the whole statement.
+ * frw_groth16_setup_r1cs is frw_groth16_setup for the system behind any handle; the proving key of an aggregate has one query
+ * point per variable of the whole statement (Falcon-1024: 3.6 KB of G1 window tables x 3 and 7.2 KB of G2 per variable, 1.8 KB
+ * per domain point for h_query: 53 GB for sixteen statements).  A 1,024-signature statement needs the 2^28 domain: 268 M
+ * points of h_query alone are 480 GB of window tables -- not one GPU's; it is proved as aggregates of <= 64 statements. */
+typedef struct {
+    uint64_t num_statements;                    /* 1 for the handles of frw_r1cs_load */
+    uint64_t count_logn9, count_logn10;
+    uint64_t num_instance, num_witness, num_constraints;    /* I (with the constant one), W, C of the whole system */
+    int32_t log_domain_size;
+    int32_t witness_map_on_device;              /* 0: the device has no transform schedule for this domain (2^14 .. 2^30 have) */
+} frw_r1cs_info_t;
+int frw_r1cs_load_aggregate(int device, size_t count, const int32_t *logn, frw_r1cs **out);
+int frw_r1cs_info(const frw_r1cs *r, frw_r1cs_info_t *out);
+int frw_aggregate_assign_dev(const frw_r1cs *aggregate, const uint64_t *d_witness_512, const uint64_t *d_instance_512,
+                             const uint64_t *d_witness_1024, const uint64_t *d_instance_1024, uint64_t *d_witness,
+                             uint64_t *d_instance, void *stream);
+
 /* ---- multi-scalar multiplication over BLS12-381 G1 (the step after the witness map in a Groth16 prover) --------------
  * ark-groth16 0.3.0 prover.rs, create_proof_with_reduction_and_matrices (what examples/pok_sig.rs:30-47 runs):
  *     h_acc = VariableBaseMSM::multi_scalar_mul(&pk.h_query, &h_assignment)
@@ -317,7 +354,8 @@ int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
  * Stream-ordered, allocates nothing.  Scalars that are zero cost nothing and scalars that are one are summed apart from the
  * buckets, so the witness-side sums of the prover (a_query, b_g1_query, l_query with a Falcon witness: 91 % of its elements
  * are 0 or 1) run as fast as h_acc, whose coefficients are uniform field elements.  Any other heavy repetition of ONE digit
- * (all scalars equal to 2, say) is computed correctly but slowly -- one bucket, one thread.
+ * (all scalars equal to 2, say) is computed correctly and still in parallel: a bucket above 1.5 x the mean size is cut into
+ * equal work items, one thread each, whose sums a second kernel adds up.
  * frw_groth16_msm_h_dev is the call for h_acc: scalars = the first domain_size - 1 coefficients of every h as the witness
  * map left them (stride domain_size, Montgomery form); num_points must equal domain_size - 1. */
 /* k_i G1 for `count` canonical scalars (uint64_t[count][4], < r) -> uint64_t[count][12] affine points in ark-ff's bytes, host
@@ -331,8 +369,10 @@ typedef struct {
     uint64_t num_points;
     int32_t window_bits, num_windows;          /* 16, 16; a _narrow handle: 8, 32 */
     uint64_t table_bytes;                      /* 16 x num_points x 112 */
-    uint64_t workspace_bytes_per_signature;    /* sort keys (64 num_points bytes) + 32,768 buckets x 240 bytes + counters; a _narrow
-                                                * handle: 128 num_points bytes of keys, 2,304 + 4,096 partial sums */
+    uint64_t workspace_bytes_per_signature;    /* sort keys (64 num_points bytes), the list of scalars equal to one (4 num_points),
+                                                * 32,768 buckets + 131,072 work items + 4,096 partial sums x 240 bytes (G2: 464),
+                                                * counters; a _narrow handle: 128 + 4 num_points bytes of keys and list, the partial
+                                                * sums of its work items and of the ones */
 } frw_msm_info_t;
 int frw_msm_g1_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out);
 void frw_msm_free(frw_msm *m);
@@ -370,7 +410,10 @@ int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, si
  * sums run on streams of the key's own, forked from and joined back into `stream` by events, beside the witness map and the sum
  * over h_query -- except for the upload of `rs`, which is waited for before the call goes on (the array may be short-lived).
  * Calls with one key may come from several host threads: they take turns putting their work on the key's streams (each with a
- * workspace of its own).  A call that returns an error has waited for whatever it had already started. */
+ * workspace of its own).  A call that returns an error has waited for whatever it had already started.
+ * NOT stream-capture safe, unlike the witness map it wraps: once per chunk the call waits on the host (hipStreamSynchronize on
+ * `stream`) for the upload of r, s and their split halves -- i.e. also for whatever `stream` held before -- and only then takes the
+ * key's lock, so concurrent provers do not wait for each other's streams. */
 typedef struct frw_groth16_pk frw_groth16_pk;
 typedef struct {
     uint64_t num_instance, num_witness, domain_size;      /* I (with the constant one), W, n */
@@ -391,6 +434,9 @@ int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *desc, frw_groth
  * A key whose toxic waste somebody knows proves nothing to anybody else; this is for tests, benchmarks and ceremonies that
  * combine contributions. */
 int frw_groth16_setup(int device, int circuit, int logn, const uint64_t *toxic, frw_groth16_pk **pk_out, uint64_t *vk_out);
+/* the same for the system behind a handle (a per-signature circuit or an aggregate statement), on the handle's device;
+ * vk_out: 84 + 12 x num_instance uint64_t */
+int frw_groth16_setup_r1cs(const frw_r1cs *r, const uint64_t *toxic, frw_groth16_pk **pk_out, uint64_t *vk_out);
 void frw_groth16_pk_free(frw_groth16_pk *pk);
 size_t frw_groth16_workspace_bytes(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch_in_flight);
 int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch, const uint64_t *d_witness,
@@ -403,14 +449,17 @@ int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t ba
  * as one product of three Miller loops and one final exponentiation.  HOST code like the reference's (about 15 ms per proof on
  * one core; a batch runs one proof per host thread); no device is needed.
  *     vk          the layout frw_groth16_setup writes: alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | gamma_abc_g1[num_instance]
- *                 (FRW_E_INVALID_ARG if a point is not on its curve, or one of the first four not in the subgroup of order r)
+ *                 (FRW_E_INVALID_ARG if a coordinate's limbs are not below the field modulus, a point is not on its curve or
+ *                 not in the subgroup of order r -- every point, gamma_abc_g1 included: what ark's deserialiser checks)
  *     instance    uint64_t[batch][num_instance][4], encoding FRW_ENC_MONTGOMERY or FRW_ENC_CANONICAL: the instance vector AS THE
  *                 WITNESS ENTRY POINTS WRITE IT, i.e. the constant one first and then ark's public inputs (pk_ntt || hm_ntt)
  *     proofs      uint64_t[batch][48]: A | B | C as frw_groth16_prove_dev writes them
  *     flags       FRW_VERIFY_POINTS_ARE_CHECKED: skip the subgroup checks of A, B, C (ark checks them when it deserialises a proof;
  *                 these are raw limbs, so the check is made here unless the caller vouches for the points)
- *     accepted    int32_t[batch]: 1 the proof verifies, 0 it does not, -1 malformed (a value >= r, instance[0] != 1, a point off
- *                 its curve or outside the subgroup) */
+ *     accepted    int32_t[batch]: 1 the proof verifies, 0 it does not, -1 malformed: an instance value whose limbs (in either
+ *                 encoding) are >= r, instance[0] != 1, a coordinate whose limbs are >= the field modulus (x + q is not accepted
+ *                 for x), a point off its curve or outside the subgroup -- or, with FRW_VERIFY_POINTS_ARE_CHECKED, a point the
+ *                 caller vouched for wrongly that drives the Miller loop into a vertical line */
 #define FRW_VERIFY_POINTS_ARE_CHECKED 1
 typedef struct frw_groth16_vk frw_groth16_vk;
 int frw_groth16_vk_load(const uint64_t *vk, size_t num_instance, frw_groth16_vk **out);

@@ -156,6 +156,41 @@ def prove_exponents(pk, z, h, r, s):
     return a, b, c, h_acc
 
 
+def prove_exponents_from_products(toxic, domain, az, bz, cz, z_instance, instance_terms, h, r, s):
+    """prove_exponents for a system too large to hold as Python rows (an aggregate statement: millions of terms), from what
+    the proof actually depends on.  With L_row = the Lagrange coefficients at t and nc = len(az):
+        sum_j z_j u_j(t) = sum_row L_row (A z)_row + sum_(i < ni) z_i L_(nc + i)       (r1cs_to_qap.rs: the input rows)
+        sum_j z_j v_j(t) = sum_row L_row (B z)_row,   sum_j z_j w_j(t) = sum_row L_row (C z)_row
+    and the witness-only sum of l_query is those minus the instance variables' share, for which only the matrix entries in
+    instance columns are needed: instance_terms = [(matrix 0/1/2, row, column < ni, coefficient), ...].
+    Returns (a, b, c, h_acc, gamma_abc) -- the same (a, b, c, h_acc) prove_exponents gives for the same system (pinned on a
+    small one in tests/test_bls12_381.py), and the verifying key's gamma_abc exponents for verify_exponents."""
+    t, alpha, beta, gamma, delta = (toxic[k] % R for k in ("t", "alpha", "beta", "gamma", "delta"))
+    nc, ni, n = len(az), len(z_instance), domain.size
+    lag, zt = _lagrange_at(n, domain.group_gen, t)
+    dot = lambda vec: sum(l * x for l, x in zip(lag, vec)) % R
+    a_t = (dot(az) + sum(lag[nc + i] * z_instance[i] for i in range(ni))) % R
+    b_t, c_t = dot(bz), dot(cz)
+    uvw = [[0] * ni for _ in range(3)]
+    for i in range(ni):
+        uvw[0][i] = lag[nc + i]
+    for m, row, col, coeff in instance_terms:
+        assert col < ni and row < nc
+        uvw[m][col] = (uvw[m][col] + lag[row] * coeff) % R
+    share = [sum(x * zi for x, zi in zip(uvw[m], z_instance)) % R for m in range(3)]
+    dinv, ginv = pow(delta, -1, R), pow(gamma, -1, R)
+    l_acc = (beta * (a_t - share[0]) + alpha * (b_t - share[1]) + (c_t - share[2])) * dinv % R
+    h_acc, x = 0, zt * dinv % R
+    for hi in h[:n - 1]:                                            # the prover's zip with h_query stops at n - 1
+        h_acc = (h_acc + hi * x) % R
+        x = x * t % R
+    a = (alpha + a_t + r * delta) % R
+    b = (beta + b_t + s * delta) % R
+    c = (s * a + r * b - r * s * delta + l_acc + h_acc) % R
+    gamma_abc = [(beta * uvw[0][i] + alpha * uvw[1][i] + uvw[2][i]) * ginv % R for i in range(ni)]
+    return a, b, c, h_acc, gamma_abc
+
+
 def verify_exponents(pk, public_inputs, proof):
     """verifier.rs verify_proof in the exponent: e(A, B) = e(alpha, beta) e(sum x_i gamma_abc_i, gamma) e(C, delta)."""
     a, b, c = proof[:3]

@@ -508,6 +508,28 @@ def encode_elements(values, montgomery: bool) -> bytes:
     return bytes(out)
 
 
+class FalconAggregateVerificationCircuit:
+    """An aggregate statement (BASELINE configs[4]).  The reference's falcon-aggregate-sig crate is an
+    empty stub (falcon-aggregate-sig/src/main.rs:1-3), so there is no reference behaviour to restate beyond what its own
+    circuit fixes: FalconNTTVerificationCircuit::generate_constraints (falcon_ntt.rs:26-123) once per statement, in order,
+    on ONE constraint system -- public inputs then come out as [pk_ntt_0, hm_ntt_0, pk_ntt_1, hm_ntt_1, ...] (the order
+    examples/pok_sig.rs:38-45 builds for one statement), witnesses and constraints as the statements' own, end to end."""
+
+    def __init__(self, statements):
+        """statements: [(sig, pk, hm, logn), ...]"""
+        self.statements = [FalconNTTVerificationCircuit(sig, pk, hm, logn) for sig, pk, hm, logn in statements]
+
+    def generate_constraints(self, cs: ConstraintSystem, strict=False):
+        for c in self.statements:
+            c.generate_constraints(cs, strict)
+
+
+def run_reference_flow_aggregate(statements, strict=False):
+    cs = ConstraintSystem()
+    FalconAggregateVerificationCircuit(statements).generate_constraints(cs, strict)
+    return cs
+
+
 def run_reference_flow(sig, pk, hm, logn, strict=False):
     """One fresh ConstraintSystem + generate_constraints, as falcon_ntt.rs:143-151 does."""
     cs = ConstraintSystem()

@@ -77,6 +77,19 @@ pub struct frw_msm_info_t {
 }
 
 #[repr(C)]
+#[derive(Debug, Clone, Copy, Default)]
+pub struct frw_r1cs_info_t {
+    pub num_statements: u64,
+    pub count_logn9: u64,
+    pub count_logn10: u64,
+    pub num_instance: u64,
+    pub num_witness: u64,
+    pub num_constraints: u64,
+    pub log_domain_size: i32,
+    pub witness_map_on_device: i32,
+}
+
+#[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct frw_qap_info_t {
     pub log_domain_size: i32,
@@ -163,6 +176,13 @@ extern "C" {
     pub fn frw_r1cs_export(circuit: c_int, logn: c_int, path: *const c_char, counts: *mut u64) -> c_int;
     pub fn frw_r1cs_load(device: c_int, circuit: c_int, logn: c_int, out: *mut *mut frw_r1cs) -> c_int;
     pub fn frw_r1cs_free(r: *mut frw_r1cs);
+    pub fn frw_r1cs_load_aggregate(device: c_int, count: usize, logn: *const i32, out: *mut *mut frw_r1cs) -> c_int;
+    pub fn frw_r1cs_info(r: *const frw_r1cs, out: *mut frw_r1cs_info_t) -> c_int;
+    pub fn frw_aggregate_assign_dev(aggregate: *const frw_r1cs, d_witness_512: *const u64, d_instance_512: *const u64,
+                                    d_witness_1024: *const u64, d_instance_1024: *const u64, d_witness: *mut u64,
+                                    d_instance: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn frw_groth16_setup_r1cs(r: *const frw_r1cs, toxic: *const u64, pk_out: *mut *mut frw_groth16_pk,
+                                  vk_out: *mut u64) -> c_int;
     pub fn frw_r1cs_check_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,
                               d_num_unsatisfied: *mut u32, stream: *mut c_void) -> c_int;
     pub fn frw_r1cs_eval_dev(r: *const frw_r1cs, batch: usize, d_witness: *const u64, d_instance: *const u64,

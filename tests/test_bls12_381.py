@@ -90,6 +90,30 @@ def test_groth16_verification_equation_holds_in_the_exponent():
     assert not E.verify_exponents(pk, z[1:ni], E.prove_exponents(pk, zbad, hbad, 5, 6))
 
 
+def test_prover_from_products_equals_the_prover_from_the_matrices():
+    """prove_exponents_from_products (the form that scales to aggregate statements: only A z, B z, C z and the matrix entries
+    in instance columns) gives the same exponents as prove_exponents on the toy system and on a random one with public
+    inputs inside long rows."""
+    from test_qap import small_system
+    rng = random.Random(11)
+    toy = _toy_system()
+    random_mats, random_z = small_system(rng, 40, 6, 20)
+    for mats, ni, z in [(toy[0], 3, toy[3]), (random_mats, 6, random_z)]:
+        nw = len(z) - ni
+        d = Q.Domain(len(mats[0]) + ni)
+        toxic = {k: rng.randrange(2, E.R) for k in ("alpha", "beta", "gamma", "delta", "t")}
+        pk = E.setup_exponents(mats, ni, nw, d, toxic)
+        h = Q.witness_map(mats, ni, z)
+        az, bz, cz = Q.matvec(mats, z)
+        terms = [(m, row, col, coeff) for m in range(3) for row, r_ in enumerate(mats[m]) for coeff, col in r_ if col < ni]
+        for r, s in ((0, 0), (rng.randrange(E.R), rng.randrange(E.R))):
+            a, b, c, h_acc = E.prove_exponents(pk, z, h, r, s)
+            a2, b2, c2, h2, gamma_abc = E.prove_exponents_from_products(toxic, d, az, bz, cz, z[:ni], terms, h, r, s)
+            assert (a, b, c, h_acc) == (a2, b2, c2, h2)
+            assert gamma_abc == pk["gamma_abc"]
+            assert E.verify_exponents({"toxic": toxic, "gamma_abc": gamma_abc}, z[1:ni], (a2, b2, c2))
+
+
 def test_h_query_msm_has_an_msm_free_value(oracle):
     """sum h_i h_query[i] = (h(t) zt / delta) G1: what the GPU's multi-scalar multiplication is compared with at full size,
     checked here with real points on the toy system -- bases from the C oracle's fixed-base routine, sum by Python integers,

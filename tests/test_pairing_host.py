@@ -139,6 +139,40 @@ def test_points_outside_the_subgroup_are_malformed_unless_vouched_for():
     assert ver.verify(inst, bad).tolist() == [-1]
     assert ver.verify(inst, bad, flags=frw.VERIFY_POINTS_ARE_CHECKED).tolist() == [0]
     assert ver.verify(inst, proof_limbs(proof)[None]).tolist() == [1]
+    # ark's deserialiser rejects representations that are not below the modulus; the raw limbs are held to the same.
+    # (1) a coordinate given as x + q (the same residue, another encoding): malformed, not "the same point"
+    def plus_q(limbs6):
+        v = int.from_bytes(np.asarray(limbs6, dtype=np.uint64).tobytes(), "little") + E.Q
+        assert v < 1 << 384
+        return np.frombuffer(v.to_bytes(48, "little"), dtype=np.uint64)
+    good = proof_limbs(proof)
+    for first in (0, 12, 18, 36, 42):                               # A.x, B.x.c0, B.x.c1, C.x, C.y
+        alias = good.copy()
+        alias[first:first + 6] = plus_q(good[first:first + 6])
+        assert ver.verify(inst, alias[None]).tolist() == [-1], first
+        assert ver.verify(inst, alias[None], flags=frw.VERIFY_POINTS_ARE_CHECKED).tolist() == [-1], first
+    # (2) an instance value whose limbs are >= r, in Montgomery form too (the conversion would reduce it silently)
+    big = fr_limbs(x, True).copy()
+    v = int.from_bytes(big[1].tobytes(), "little") + E.R
+    assert v < 1 << 256
+    big[1] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint64)
+    assert ver.verify(big[None], good[None]).tolist() == [-1]
+    # (3) a verifying key whose gamma_abc holds a point outside the subgroup, or a non-canonical coordinate, does not load
+    k = vk_limbs(vk)
+    k["gamma_abc_g1"] = k["gamma_abc_g1"].copy()
+    k["gamma_abc_g1"][1] = u64(E.to_limbs(stray))
+    with pytest.raises(frw.FrwError):
+        frw.Groth16Verifier(k)
+    k = vk_limbs(vk)
+    k["gamma_abc_g1"] = k["gamma_abc_g1"].copy()
+    k["gamma_abc_g1"][2][:6] = plus_q(k["gamma_abc_g1"][2][:6])
+    with pytest.raises(frw.FrwError):
+        frw.Groth16Verifier(k)
+    k = vk_limbs(vk)
+    k["alpha_g1"] = k["alpha_g1"].copy()
+    k["alpha_g1"][6:] = plus_q(k["alpha_g1"][6:])
+    with pytest.raises(frw.FrwError):
+        frw.Groth16Verifier(k)
     # a verifying key with a point off its curve does not load
     k = vk_limbs(vk)
     k["gamma_g2"] = k["gamma_g2"].copy()
