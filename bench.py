@@ -664,6 +664,124 @@ def prove_leg(eng, handle, dev, cdev, d_wit, d_inst, held, L, logn, world, rank,
     return out
 
 
+def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True):
+    """BASELINE configs[4] as written: ONE Groth16 proof for an aggregate statement -- FalconNTTVerificationCircuit once per
+    (pk, msg, sig) on one constraint system (falcon_ntt.rs:26-123 per statement; the flow of examples/pok_sig.rs:30-47 on the
+    whole).  The statements' witnesses come from the witness kernel (one launch per parameter set), frw_aggregate_assign_dev lays
+    them out as the aggregate's assignment, frw_groth16_setup_r1cs makes the key, and what is timed is frw_groth16_prove_dev on
+    the aggregate handle: the witness map over the aggregate's domain, five sums, one proof.  The proof is verified
+    (frw_groth16_verify, host pairing; also against a statement with one public input of the LAST statement changed), and
+    h_acc is checked against the MSM-free value (h(t) zt / delta) G1.  `separate`: the per-signature prover's line
+    (time_groth16) for the break-even against k separate proofs."""
+    import random
+    rng = random.Random(SEED ^ len(logns))
+    stream = torch.cuda.current_stream()
+    s0 = stream.cuda_stream
+    batches = {}
+    t_wit = time.perf_counter()
+    for g in (9, 10):
+        cnt = list(logns).count(g)
+        if not cnt:
+            continue
+        L = frw.layout(g)
+        sig, pk, hm = frw.synth_triples(g, cnt, SEED, (1 << 43) + (g << 20))
+        d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
+        wit = torch.empty((cnt, L.num_witness, 4), dtype=torch.int64, device=dev)
+        inst = torch.empty((cnt, L.num_instance, 4), dtype=torch.int64, device=dev)
+        st = torch.empty(cnt, dtype=torch.int32, device=dev)
+        eng.witness_ntt_verify_dev(g, cnt, d[0], d[1], d[2], wit, inst, st, frw.ENC_MONTGOMERY, s0)
+        torch.cuda.synchronize()
+        assert not st.any()
+        batches[g] = (wit, inst)
+    handle = eng.r1cs_load_aggregate(list(logns))
+    info = eng.r1cs_info(handle)
+    ni, nw, nc, n = int(info.num_instance), int(info.num_witness), int(info.num_constraints), 1 << int(info.log_domain_size)
+    d_wit = torch.empty((1, nw, 4), dtype=torch.int64, device=dev)
+    d_inst = torch.empty((1, ni, 4), dtype=torch.int64, device=dev)
+    b9, b10 = batches.get(9, (None, None)), batches.get(10, (None, None))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    eng.aggregate_assign_dev(handle, b9[0], b9[1], b10[0], b10[1], d_wit, d_inst, s0)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    assign_ms = e0.elapsed_time(e1)
+    load_s = time.perf_counter() - t_wit
+    toxic = [rng.randrange(2, R_FR) for _ in range(5)]
+    t0 = time.perf_counter()
+    pk_h, vk = eng.groth16_setup_r1cs(handle, *toxic)
+    key_s = time.perf_counter() - t0
+    ws_bytes = eng.groth16_workspace_bytes(pk_h, handle, 1)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    proof = torch.empty((1, 48), dtype=torch.int64, device=dev)
+    bad = torch.empty(1, dtype=torch.int32, device=dev)
+    lim = lambda ks: np.frombuffer(b"".join(int(k).to_bytes(32, "little") for k in ks), dtype=np.uint64).reshape(-1, 4)
+    rs = np.stack([lim([rng.randrange(R_FR), rng.randrange(R_FR)])])
+    run = lambda: eng.groth16_prove_dev(pk_h, handle, 1, d_wit, d_inst, rs, proof, ws, ws_bytes, bad, s0)
+    run()
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    assert bad.tolist() == [0], "the aggregate's witness violates its constraint system"
+    # the witness map on its own (timed), and h_acc against the value no MSM is needed for
+    q = eng.qap_info(handle)
+    qws = torch.empty(int(q.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+    h = torch.empty((1, n, 4), dtype=torch.int64, device=dev)
+    eng.qap_witness_map_dev(handle, 1, d_wit, d_inst, h, qws, qws.numel(), None, s0)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        eng.qap_witness_map_dev(handle, 1, d_wit, d_inst, h, qws, qws.numel(), None, s0)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    map_ms = e0.elapsed_time(e1) / reps
+    assert int(h[0, -1].abs().sum()) == 0, "deg h must be <= n - 2 for a satisfied system"
+    eng.groth16_pk_free(pk_h)
+    del ws, qws
+    k = len(logns)
+    verifier = frw.Groth16Verifier(vk)
+    inst_h = d_inst.cpu().numpy().view(np.uint64)
+    proof_h = proof.cpu().numpy().view(np.uint64)
+    t0 = time.perf_counter()
+    ok = verifier.verify(inst_h, proof_h).tolist()
+    verify_s = time.perf_counter() - t0
+    assert ok == [1], "frw_groth16_verify rejects the aggregate proof"
+    other = inst_h.copy()
+    other[0, ni - 3, 0] ^= np.uint64(1)
+    assert verifier.verify(other, proof_h).tolist() == [0], "the aggregate proof verifies for another statement"
+    verifier.close()
+    eng.r1cs_free(handle)
+    out = {"workload": "ONE Groth16 proof for %d Falcon statements (%d x Falcon-512, %d x Falcon-1024) on one constraint system: "
+                       "I = %d, W = %d, C = %d, QAP domain 2^%d" % (k, list(logns).count(9), list(logns).count(10), ni, nw, nc,
+                                                                  int(info.log_domain_size)),
+           "ms_per_proof": round(ms, 3), "signatures_per_s": round(k / (ms * 1e-3), 1), "calls_timed": reps,
+           "witness_map_ms": round(map_ms, 3), "assignment_ms": round(assign_ms, 3),
+           "proof_bytes": {"this_aggregate": 48 * 8, "k_separate_proofs": k * 48 * 8,
+                           "note": "uncompressed ark-ff limbs (A 96 B, B 192 B, C 96 B); 192 B compressed either way"},
+           "proving_key": {"points_g1": 3 * (ni + nw) - ni + n - 1 + 3, "points_g2": ni + nw + 2, "frw_groth16_setup_r1cs_s": round(key_s, 2)},
+           "workspace_bytes": ws_bytes,
+           "verify": {"seconds": round(verify_s, 4), "public_inputs": ni - 1, "pairings": 3,
+                      "what": "frw_groth16_verify, one host thread: prepare_inputs over %d public inputs + 3 Miller loops + 1 final "
+                              "exponentiation" % (ni - 1)},
+           "checked": "constraint system satisfied (0 violated rows of %d); deg h <= n - 2; proof accepted by frw_groth16_verify for its "
+                      "%d public inputs and rejected with one input of the last statement changed; bit-exactness of (A, B, C) against the "
+                      "prover restated in the exponent: tests/test_gpu_aggregate.py" % (nc, ni - 1)}
+    if separate is not None and k and all(g == 10 for g in logns):
+        per = separate["proofs_per_s"]
+        out["against_k_separate_proofs"] = {
+            "separate_ms_for_k_proofs_at_64_per_call": round(k / per * 1e3, 3),
+            "separate_ms_for_k_proofs_one_per_call": None if separate.get("one_proof_per_call_ms") is None else round(k * separate["one_proof_per_call_ms"], 3),
+            "aggregate_over_separate_time": round(ms / (k / per * 1e3), 3),
+            "separate_verify_s_for_k_proofs_one_thread": round(k * separate["verify"]["seconds"] * separate["verify"]["host_threads"] / separate["verify"]["proofs"], 4),
+            "verifier_pairings": {"aggregate": 3, "separate": 3 * k},
+            "break_even": "one proof instead of %d: %dx fewer proof bytes and pairings for %.2fx the proving time of %d separate proofs made 64 "
+                          "per call" % (k, k, ms / (k / per * 1e3), k)}
+    return out
+
+
 def time_msm(eng, dev, d_h, reps, with_cpu):
     """The step after the witness map in the reference's consumer (examples/pok_sig.rs:30-47 -> ark-groth16 prover.rs):
     h_acc = VariableBaseMSM(pk.h_query, h) over BLS12-381 G1, for the h vectors the witness map left in HBM."""
@@ -1147,7 +1265,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL over xGMI, the default) or gloo (rehearsal of "
                          "the N > 1 code path with several ranks sharing one GPU)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "ntt_modq", "prepare", "qap"],
+    ap.add_argument("--aggregate", default="10x16", help="--workload aggregate: the statement as <logn>x<count>[,<logn>x<count>...] in order "
+                                                         "(10x16 = sixteen Falcon-1024 statements; 10x1,9x1,10x2 = a mixed four)")
+    ap.add_argument("--workload", default="verify", choices=["verify", "ntt_modq", "prepare", "qap", "aggregate"],
                     help="verify = full verify-with-ntt witness (default, BASELINE configs[2]); ntt_modq = the "
                          "NTT + mod_q witness kernel alone (BASELINE configs[1]: --logn 9 --batch 4096)")
     ap.add_argument("--dump-digests", default="",
@@ -1194,6 +1314,14 @@ def main():
         if not args.batch:
             args.batch = 256
         return bench_qap(args, world, rank, dev)
+    if args.workload == "aggregate":
+        logns = [int(part.split("x")[0]) for part in args.aggregate.split(",") for _ in range(int(part.split("x")[1]))]
+        eng = frw.WitnessEngine(dev_index)
+        r = time_aggregate_proof(eng, dev, logns, max(1, args.steps), None)
+        return emit({"metric": "aggregate_proof_signatures_per_sec", "value": r["signatures_per_s"], "unit": "signatures/s", "n_gpus": world,
+                     "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_proof"], "higher_is_better": True,
+                     "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                     "config": {"workload": r["workload"]}, "aggregate": r})
     logn = args.logn
     dual = args.circuit == "dual"
     L = frw.layout_dual(logn) if dual else frw.layout(logn)
@@ -1439,6 +1567,12 @@ def main():
                 result["secondary"]["qap_witness_map_falcon%d" % n] = qap_result
                 result["secondary"]["groth16_msm_h_falcon%d" % n] = msm_result
                 result["secondary"]["groth16_prove_falcon%d" % n] = groth16_result
+            if not args.no_aggregate and logn == 10:
+                torch.cuda.empty_cache()
+                result["secondary"]["aggregate_proof_4_mixed"] = time_aggregate_proof(eng, dev, (10, 9, 10, 10), 10, None)
+                torch.cuda.empty_cache()
+                result["secondary"]["aggregate_proof_16_falcon1024"] = time_aggregate_proof(eng, dev, (10,) * 16, 10, groth16_result)
+                torch.cuda.empty_cache()
             if not args.no_aggregate:
                 result["secondary"]["host_call_one_signature_falcon%d" % n] = time_host_call(eng, logn)
                 result["secondary"]["aggregate_1024_mixed"] = time_aggregate(eng, dev, 1024, 50, threads)

@@ -188,6 +188,21 @@ __host__ __device__ __forceinline__ void fq_sqr_cols(const Fq29 &a, uint64_t (&c
     }
     col[2 * NLQ - 1] = 0;
 }
+// the columns of a b + c d at once (normalised operands: 2 x 14 2^58 per column, and the reduction's 14 2^58 on top still fit)
+__host__ __device__ __forceinline__ void fq_mul2_cols(const Fq29 &a, const Fq29 &b, const Fq29 &c, const Fq29 &d, uint64_t (&col)[2 * NLQ])
+{
+#pragma unroll
+    for (int k = 0; k < 2 * NLQ - 1; k++) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = (k < NLQ ? 0 : k - (NLQ - 1)); i <= (k < NLQ ? k : NLQ - 1); i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+        }
+        col[k] = acc;
+    }
+    col[2 * NLQ - 1] = 0;
+}
 __host__ __device__ __forceinline__ Fq29 fq_reduce_cols(uint64_t (&col)[2 * NLQ])
 {
 #pragma unroll
@@ -305,7 +320,8 @@ __host__ __device__ __forceinline__ Fq2_29 fq2_sqr(const Fq2_29 &a)           //
 struct FqField {
     typedef Fq29 El;
     static constexpr uint32_t K_MUL = 4, K_2MUL = 4, K_X = 16, K_Y = 16;
-    static constexpr int WORDS = NLQ, ARK_WORDS = 12;
+    static constexpr uint32_t K_AFFINE = K_MUL;      // bound of a window-table row's coordinates (products of this policy)
+    static constexpr int WORDS = NLQ, ARK_WORDS = 12, LANES = 1;
     __host__ __device__ static __forceinline__ El mul(const El &a, const El &b) { return fq_mul(a, b); }
     __host__ __device__ static __forceinline__ El sqr(const El &a) { return fq_sqr(a); }
     // a b - c d (c < KC q), one reduction
@@ -335,7 +351,8 @@ struct FqField {
 struct Fq2Field {
     typedef Fq2_29 El;
     static constexpr uint32_t K_MUL = 16, K_2MUL = 64, K_X = 256, K_Y = 64;
-    static constexpr int WORDS = 2 * NLQ, ARK_WORDS = 24;
+    static constexpr uint32_t K_AFFINE = K_MUL;
+    static constexpr int WORDS = 2 * NLQ, ARK_WORDS = 24, LANES = 1;
     __host__ __device__ static __forceinline__ El mul(const El &a, const El &b) { return fq2_mul(a, b); }
     __host__ __device__ static __forceinline__ El sqr(const El &a) { return fq2_sqr(a); }
     template <uint32_t KC> __host__ __device__ static __forceinline__ El mul_sub(const El &a, const El &b, const El &c, const El &d)
@@ -361,6 +378,93 @@ struct Fq2Field {
     __host__ __device__ static __forceinline__ void store(const El &a, uint32_t *w) { FqField::store(a.c0, w); FqField::store(a.c1, w + NLQ); }
     __host__ __device__ static __forceinline__ El load(const uint32_t *w) { El r; r.c0 = FqField::load(w); r.c1 = FqField::load(w + NLQ); return r; }
 };
+
+#if defined(__HIPCC__)
+// Fq2 with the two components in two ADJACENT LANES of a wavefront (even lane: c0, odd lane: c1) -- device only.  A G2 point in
+// XYZZ coordinates is 112 registers with both components in one lane, its mixed addition twice what a lane has (the kernels of
+// Fq2Field run with 1.4 - 3.8 KB of scratch per lane); here every lane holds one Fq value per coordinate, exactly what a G1
+// lane holds, and the cross terms of a product come from the neighbour by DPP (quad_perm [1, 0, 3, 2]: no LDS, no extra wait):
+//     (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u      even lane: a b + (-a') b'      odd lane: a' b + a b'
+// -- TWO products and ONE reduction per lane (columns add: frw_fq29.h fq_mul_cols), i.e. the same 4 Fq products per Fq2 product
+// over the pair that Karatsuba's 3 + its extra additions cost one lane, but no spills; a square is ONE product per lane:
+//     (a0 + a1)(a0 - a1) in the even lane, (2 a1) a0 in the odd one.
+// Both lanes of a pair must take the same branches (they do wherever a branch depends on F::is_zero or a point's `inf`, which
+// are pair-wide by construction).  Results of products are < 2 q per component; operands may be anything below 2^10 q.
+struct Fq2Half { Fq29 v; };
+__device__ __forceinline__ uint32_t pair_swap_u32(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ Fq29 pair_swap(const Fq29 &a)
+{
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) r.l[i] = pair_swap_u32(a.l[i]);
+    return r;
+}
+__device__ __forceinline__ Fq29 fq_select(bool take_a, const Fq29 &a, const Fq29 &b)
+{
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < NLQ; i++) r.l[i] = take_a ? a.l[i] : b.l[i];
+    return r;
+}
+struct Fq2PairField {
+    typedef Fq2Half El;
+    static constexpr uint32_t K_MUL = 4, K_2MUL = 16, K_X = 256, K_Y = 64;     // a product < 2 q per component; X, Y as stored by either G2 policy
+    static constexpr uint32_t K_AFFINE = 16;         // the window tables are written by Fq2Field kernels: rows < 10 q per component
+    static constexpr int WORDS = 2 * NLQ, ARK_WORDS = 24, LANES = 2;
+    __device__ static __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
+    __device__ static __forceinline__ El mul(const El &a, const El &b)
+    {
+        const Fq29 ap = pair_swap(a.v), bp = pair_swap(b.v);
+        const bool o = odd();
+        // even: a b + (-a') b';  odd: a' b + a b'
+        const Fq29 x = fq_select(o, ap, a.v), y = fq_select(o, a.v, fq_neg<1024>(ap));
+        uint64_t col[2 * NLQ];
+        fq_mul2_cols(x, b.v, y, bp, col);
+        El r;
+        r.v = fq_reduce_cols(col);
+        return r;
+    }
+    __device__ static __forceinline__ El sqr(const El &a)
+    {
+        const Fq29 ap = pair_swap(a.v);
+        const bool o = odd();
+        // even: (a0 + a1)(a0 - a1);  odd: (a1 + a1) a0
+        const Fq29 x = fq_add(a.v, fq_select(o, a.v, ap)), y = fq_select(o, ap, fq_sub<1024>(a.v, ap));
+        El r;
+        r.v = fq_mul(x, y);
+        return r;
+    }
+    template <uint32_t KC> __device__ static __forceinline__ El mul_sub(const El &a, const El &b, const El &c, const El &d)
+    {
+        return sub<K_MUL>(mul(a, b), mul(c, d));
+    }
+    __device__ static __forceinline__ El add(const El &a, const El &b) { El r; r.v = fq_add(a.v, b.v); return r; }
+    template <uint32_t K> __device__ static __forceinline__ El sub(const El &a, const El &b) { El r; r.v = fq_sub<K>(a.v, b.v); return r; }
+    template <uint32_t K> __device__ static __forceinline__ El neg(const El &a) { El r; r.v = fq_neg<K>(a.v); return r; }
+    __device__ static __forceinline__ El zero() { El r; r.v = fq_zero(); return r; }
+    __device__ static __forceinline__ El one() { El r; r.v = fq_select(odd(), fq_zero(), fq_const(FQ29_ONE)); return r; }
+    __device__ static __forceinline__ bool is_zero(const El &a)                  // of the Fq2 element: the same answer in both lanes
+    {
+        const uint32_t mine = fq_is_zero(a.v) ? 1u : 0u;
+        return (mine & pair_swap_u32(mine)) != 0;
+    }
+    __device__ static inline El inv(const El &a)                                  // conj(a) / (c0^2 + c1^2)
+    {
+        const Fq29 sq = fq_sqr(a.v);
+        const Fq29 n = fq_inv(fq_add(sq, pair_swap(sq)));
+        El r;
+        r.v = fq_mul(fq_select(odd(), fq_neg<1024>(a.v), a.v), n);
+        return r;
+    }
+    __device__ static __forceinline__ El from_ark(const uint32_t *w) { El r; r.v = fq_from_ark(w + (odd() ? 12 : 0)); return r; }
+    __device__ static __forceinline__ void to_ark(const El &a, uint32_t *w) { fq_to_ark(a.v, w + (odd() ? 12 : 0)); }
+    __device__ static __forceinline__ void store(const El &a, uint32_t *w) { FqField::store(a.v, w + (odd() ? NLQ : 0)); }
+    __device__ static __forceinline__ El load(const uint32_t *w) { El r; r.v = FqField::load(w + (odd() ? NLQ : 0)); return r; }
+};
+#endif
 
 // the published generators (ark-bls12-381 g1.rs / g2.rs), x 2^406; tests/test_fq29_host.py re-derives the limbs
 constexpr LimbsQ G1_GEN_X29 = {{0x0af58fd1u, 0x1662a68eu, 0x07d2c530u, 0x08993c24u, 0x1e4f4756u, 0x0c5f7ae2u, 0x0f589991u,

@@ -41,7 +41,7 @@ constexpr int MSM_FOLD_THREADS = 512;           // second stage: one workgroup p
 // ZZZ limbs + the infinity flag (padded to 16 bytes); ark-ff's bytes of an affine point
 template <class F> struct Grp {
     static constexpr int PT_WORDS = 2 * F::WORDS, BK_WORDS = 4 * F::WORDS + 4, ARK_WORDS = 2 * F::ARK_WORDS;
-    static constexpr uint32_t K_AFFINE_Y = F::K_MUL;          // bound of a table row's y: what its negation adds
+    static constexpr uint32_t K_AFFINE_Y = F::K_AFFINE;       // bound of a table row's y: what its negation adds
 };
 
 struct MsmDev {
@@ -65,6 +65,23 @@ template <class F> __device__ __forceinline__ AffineT<F> load_row(const uint32_t
     for (int k = 0; k < PW; k++) any |= w[k];
     p.x = F::load(w);
     p.y = F::load(w + F::WORDS);
+    p.inf = any == 0;
+    return p;
+}
+// the two-lane Fq2: every lane fetches its own component of x and y (56 bytes each, 8-byte aligned) and the pair agrees on `inf`
+template <> __device__ __forceinline__ AffineT<Fq2PairField> load_row<Fq2PairField>(const uint32_t *row)
+{
+    AffineT<Fq2PairField> p;
+    const uint32_t *mine = row + (Fq2PairField::odd() ? NLQ : 0);
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < NLQ / 2; k++) {
+        const uint2 a = *(const uint2 *)(mine + 2 * k), b = *(const uint2 *)(mine + 2 * NLQ + 2 * k);
+        p.x.v.l[2 * k] = a.x; p.x.v.l[2 * k + 1] = a.y;
+        p.y.v.l[2 * k] = b.x; p.y.v.l[2 * k + 1] = b.y;
+        any |= a.x | a.y | b.x | b.y;
+    }
+    any |= pair_swap_u32(any);
     p.inf = any == 0;
     return p;
 }
@@ -167,14 +184,16 @@ __device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomer
 // 160 KB), the histograms are turned into per-slice starting positions inside every bucket, and the same workgroups then hand
 // out positions from LDS again.  (With one global atomicAdd per pair the sort took a third of the whole call: 10^10 atomics
 // per second is what the L2 gives, and a signature has 4 x 10^6 pairs to place twice.)
-constexpr int MSM_SLICES = 32;
+// 32 slices per signature for a batch; a call with ONE signature (an aggregate statement's sum over 2^22 points) would keep 32 of
+// the 256 CUs busy with them, so it cuts 56 -- as many as fit where the per-slice histograms live (the buckets' memory: 60).
+constexpr int MSM_SLICES = 32, MSM_SLICES_LONE = 56;
 __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
                                                         int montgomery, uint32_t *__restrict__ slice_hist /* [sig][slice][buckets] */,
                                                         uint32_t *__restrict__ ones_count /* [sig] */, uint32_t *__restrict__ ones_list /* [sig][n] */)
 {
     __shared__ uint32_t hist[MSM_BUCKETS];
     const size_t sig = blockIdx.y;
-    const uint32_t slice = blockIdx.x, per = (n + MSM_SLICES - 1) / MSM_SLICES;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
     const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
     for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) hist[b] = 0;
     __syncthreads();
@@ -189,19 +208,19 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32
             if (d[j]) atomicAdd(&hist[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
     }
     __syncthreads();
-    uint32_t *out = slice_hist + (sig * MSM_SLICES + slice) * MSM_BUCKETS;
+    uint32_t *out = slice_hist + (sig * slices + slice) * MSM_BUCKETS;
     for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) out[b] = hist[b];
 }
 
 // per bucket: its size (counts) and, in place of every slice's count, the slice's first position inside the bucket
-__global__ __launch_bounds__(256) void msm_slice_offsets_kernel(uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ counts)
+__global__ __launch_bounds__(256) void msm_slice_offsets_kernel(uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ counts, int slices)
 {
     const size_t sig = blockIdx.y;
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    uint32_t *h = slice_hist + sig * MSM_SLICES * (size_t)MSM_BUCKETS + b;
+    uint32_t *h = slice_hist + sig * slices * (size_t)MSM_BUCKETS + b;
     uint32_t run = 0;
 #pragma unroll 4
-    for (int s_ = 0; s_ < MSM_SLICES; s_++) {
+    for (int s_ = 0; s_ < slices; s_++) {
         const uint32_t c = h[(size_t)s_ * MSM_BUCKETS];
         h[(size_t)s_ * MSM_BUCKETS] = run;
         run += c;
@@ -239,9 +258,9 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uin
 {
     __shared__ uint32_t cursor[MSM_BUCKETS];
     const size_t sig = blockIdx.y;
-    const uint32_t slice = blockIdx.x, per = (n + MSM_SLICES - 1) / MSM_SLICES;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
     const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
-    const uint32_t *first = slice_hist + (sig * MSM_SLICES + slice) * MSM_BUCKETS, *off = offsets + sig * MSM_BUCKETS;
+    const uint32_t *first = slice_hist + (sig * slices + slice) * MSM_BUCKETS, *off = offsets + sig * MSM_BUCKETS;
     for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) cursor[b] = off[b] + first[b];
     __syncthreads();
     uint32_t *ent = entries + sig * (size_t)MSM_W * n;
@@ -266,6 +285,12 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uin
 // msm_combine_kernel adds them up.  At most 32,768 + 21,845 items whatever the scalars (sum of ceil(c_b / split)).
 constexpr int MSM_SIZE_CLASSES = 1024;         // sizes >= this share the first class
 constexpr int MSM_MAX_ITEMS = 131072;          // >= 32,768 + 32,768 / (1.5 / 4): the finest split (a lone signature), a multiple of 64
+// Sums over more than 2^18 points (an aggregate statement's h_query: ONE signature, 2^22 points, buckets of 2,048 entries) are cut
+// finer still: `finer` = 12 makes a bucket of the mean size 8 items of 256 entries -- 262,144 items, two full rounds of the chip's
+// 131,072 thread slots at two wavefronts per SIMD (with 4 it was 98,304 items: a quarter of the slots idle and half the SIMDs with a
+// single wavefront, 1.55 x the time per addition of a 64-signature call).  Bound: 32,768 + 32,768 finer / 1.5.
+constexpr int MSM_MAX_ITEMS_LARGE = 32768 + 32768 * 12 * 2 / 3;     // 294,912
+__host__ __device__ constexpr uint32_t msm_max_items(uint32_t n) { return n > (1u << 18) ? (uint32_t)MSM_MAX_ITEMS_LARGE : (uint32_t)MSM_MAX_ITEMS; }
 // `finer`: 1 for a batch, 4 for one or two signatures at a time -- a bucket of the mean size is then three items instead of one
 // (a lone proof waits for ~128 dependent additions otherwise), and msm_combine_kernel adds them up
 __device__ __forceinline__ uint32_t msm_split_of(uint32_t total, uint32_t finer)
@@ -275,8 +300,8 @@ __device__ __forceinline__ uint32_t msm_split_of(uint32_t total, uint32_t finer)
 }
 __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
                                                          uint32_t *__restrict__ order, uint32_t *__restrict__ item_first /* [sig][buckets] */,
-                                                         uint32_t *__restrict__ items /* [sig][MSM_MAX_ITEMS]: bucket | chunk << 15 */,
-                                                         uint32_t *__restrict__ item_count /* [sig] */, uint32_t finer)
+                                                         uint32_t *__restrict__ items /* [sig][max_items]: bucket | chunk << 15 */,
+                                                         uint32_t *__restrict__ item_count /* [sig] */, uint32_t finer, uint32_t max_items)
 {
     __shared__ uint32_t hist[MSM_SIZE_CLASSES];
     const size_t sig = blockIdx.x;
@@ -328,7 +353,7 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restr
     for (int j = 0; j < PER; j++) {
         const uint32_t b = ord[t * PER + j];
         item_first[sig * MSM_BUCKETS + b] = pos;
-        for (uint32_t c = 0; c < k[j]; c++) items[sig * MSM_MAX_ITEMS + pos + c] = b | (c << 15);
+        for (uint32_t c = 0; c < k[j]; c++) items[sig * (size_t)max_items + pos + c] = b | (c << 15);
         pos += k[j];
     }
 }
@@ -339,13 +364,14 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restr
 template <class F, bool PREFETCH>
 __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
-                                                           const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items, uint32_t finer)
+                                                           const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items, uint32_t finer,
+                                                           uint32_t max_items)
 {
     constexpr int PW = Grp<F>::PT_WORDS;
     const size_t sig = blockIdx.y;
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     if (it >= item_count[sig]) return;
-    const uint32_t item = items[sig * MSM_MAX_ITEMS + it], b = item & (MSM_BUCKETS - 1), chunk = item >> 15;
+    const uint32_t item = items[sig * (size_t)max_items + it], b = item & (MSM_BUCKETS - 1), chunk = item >> 15;
     const uint32_t c = counts[sig * MSM_BUCKETS + b];
     const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total, finer);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
@@ -371,14 +397,14 @@ __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint3
             acc = pt_add_affine(acc, p);
         }
     }
-    store_bucket<F>(partial_items + (sig * MSM_MAX_ITEMS + it) * (size_t)Grp<F>::BK_WORDS, acc);
+    store_bucket<F>(partial_items + (sig * (size_t)max_items + it) * (size_t)Grp<F>::BK_WORDS, acc);
 }
 
 // bucket b = the sum of its items (one for almost every bucket: a copy)
 template <class F>
 __global__ __launch_bounds__(64, 2) void msm_combine_kernel(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                             const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
-                                                            uint32_t *__restrict__ buckets, uint32_t finer)
+                                                            uint32_t *__restrict__ buckets, uint32_t finer, uint32_t max_items)
 {
     constexpr int BW = Grp<F>::BK_WORDS;
     const size_t sig = blockIdx.y;
@@ -386,7 +412,7 @@ __global__ __launch_bounds__(64, 2) void msm_combine_kernel(const uint32_t *__re
     const uint32_t c = counts[sig * MSM_BUCKETS + b];
     const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total, finer);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
-    const uint32_t *src = partial_items + (sig * MSM_MAX_ITEMS + item_first[sig * MSM_BUCKETS + b]) * (size_t)BW;
+    const uint32_t *src = partial_items + (sig * (size_t)max_items + item_first[sig * MSM_BUCKETS + b]) * (size_t)BW;
     XyzzT<F> acc = load_bucket<F>(src);
     for (uint32_t j = 1; j < k; j++) acc = pt_add(acc, load_bucket<F>(src + (size_t)j * BW));
     store_bucket<F>(buckets + (sig * MSM_BUCKETS + b) * (size_t)BW, acc);
@@ -477,11 +503,10 @@ __host__ __device__ constexpr uint32_t nmsm_target_items(uint32_t n)
 __host__ __device__ constexpr uint32_t nmsm_max_items(uint32_t n) { return nmsm_target_items(n) + 256; }
 // the scalars equal to one: 256 .. 4,096 threads per signature, by the batch, one partial sum per 64 of them (<= 64: one per thread of
 // the fold); with more than 2^18 points up to 65,536 threads, whose <= 1,024 partial sums a small kernel brings down to 64 first
-constexpr int NMSM_ONES_MAX = 4096, NMSM_ONES_GROUPS = NMSM_ONES_MAX / 64, NMSM_ONES_MAX_LARGE = 65536;
+constexpr int NMSM_ONES_MAX = 4096, NMSM_ONES_MAX_LARGE = 65536;
 __host__ __device__ constexpr uint32_t nmsm_ones_max(uint32_t n) { return n > (1u << 18) ? (uint32_t)NMSM_ONES_MAX_LARGE : (uint32_t)NMSM_ONES_MAX; }
 // threads of the one-workgroup fold: 128 for the buckets + 256 (G1) / 128 (G2: four waves = one per SIMD, the whole register file
 // for an addition that needs 300 live registers) for the ones' partial sums
-template <class F> constexpr int nmsm_finish_threads() { return F::WORDS > NLQ ? 256 : 384; }        // ones: 256 .. 4,096 partial sums per signature, by the batch (latency against work)
 __device__ __forceinline__ bool scalar_digits8(const uint32_t *src, int montgomery, int (&d)[NMSM_W])
 {
     const Fr8 w = scalar_canonical(src, montgomery);
@@ -598,7 +623,7 @@ __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(MsmDev m, const uint
 {
     constexpr int PW = Grp<F>::PT_WORDS;
     const size_t sig = blockIdx.y;
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t it = (blockIdx.x * 64 + threadIdx.x) / F::LANES;            // F::LANES adjacent lanes share an item (the two-lane Fq2)
     if (it >= item_count[sig]) return;
     const uint32_t item = items[sig * (size_t)max_items + it], b = item & (NMSM_BUCKETS - 1), part = item >> 8;
     const uint32_t c = counts[sig * NMSM_BUCKETS + b];
@@ -635,16 +660,16 @@ template <class F>
 __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
                                                           uint32_t *__restrict__ partial_ones /* [sig][groups_stride][BK_WORDS] */, uint32_t groups_stride)
 {
-    constexpr int SLOT = 4 * F::WORDS + 1;
+    constexpr int SLOT = 4 * F::WORDS + 1, PER = 64 / F::LANES;                 // PER chains per workgroup (F::LANES lanes each)
     __shared__ uint32_t lds[32 * SLOT];
     const size_t sig = blockIdx.y;
-    const uint32_t nthreads = gridDim.x * 64, t = blockIdx.x * 64 + threadIdx.x, cnt = ones_count[sig];
+    const uint32_t nthreads = gridDim.x * PER, t = blockIdx.x * PER + threadIdx.x / F::LANES, cnt = ones_count[sig];
     const uint32_t *list = ones_list + sig * m.n;
     XyzzT<F> acc = pt_identity<F>();
     for (uint32_t k = t; k < cnt; k += nthreads)
         acc = pt_add_affine(acc, load_row<F>(m.table + (size_t)list[k] * Grp<F>::PT_WORDS));      // window 0 of the table = the point itself
-    const int lane = threadIdx.x;
-    for (int stride = 32; stride >= 1; stride >>= 1) {
+    const int lane = threadIdx.x / F::LANES;
+    for (int stride = PER / 2; stride >= 1; stride >>= 1) {
         if (lane >= stride && lane < 2 * stride) store_bucket<F>(lds + (lane - stride) * SLOT, acc);
         __syncthreads();
         if (lane < stride) acc = pt_add(acc, load_bucket<F>(lds + lane * SLOT));
@@ -652,20 +677,24 @@ __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32
     }
     if (lane == 0) store_bucket<F>(partial_ones + (sig * (size_t)groups_stride + blockIdx.x) * (size_t)Grp<F>::BK_WORDS, acc);
 }
+// the policy a group's narrow sum runs with: G2 in two lanes per point (frw_fq29.h Fq2PairField) -- the layout in memory is that of
+// either G2 policy; the window tables and the dense pipeline keep the one-lane form
+template <class F> struct BulkPolicy { typedef F type; };
+template <> struct BulkPolicy<Fq2Field> { typedef Fq2PairField type; };
 // more than 64 partial sums of ones (sums over more than 2^18 points): workgroup g of 64 adds up the partial sums g, g + 64, ... of its
 // signature -- one per lane, then a tree through LDS -- and leaves sum g of 64 in the first 64 slots of the second stage's array
 template <class F>
 __global__ __launch_bounds__(64, 2) void nmsm_ones_fold_kernel(const uint32_t *__restrict__ partial_ones, uint32_t groups, uint32_t groups_stride,
                                                                uint32_t *__restrict__ folded /* [sig][64][BK_WORDS] */)
 {
-    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
+    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES;   // one wavefront: PER chains of F::LANES lanes
     __shared__ uint32_t lds[32 * SLOT];
     const size_t sig = blockIdx.y;
-    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    const uint32_t g = blockIdx.x, lane = threadIdx.x / F::LANES;
     const uint32_t *src = partial_ones + sig * (size_t)groups_stride * BW;
     XyzzT<F> acc = pt_identity<F>();
-    for (uint32_t k = g + 64 * lane; k < groups; k += 64 * 64) acc = pt_add(acc, load_bucket<F>(src + (size_t)k * BW));
-    for (int stride = 32; stride >= 1; stride >>= 1) {
+    for (uint32_t k = g + 64 * lane; k < groups; k += 64 * PER) acc = pt_add(acc, load_bucket<F>(src + (size_t)k * BW));
+    for (int stride = PER / 2; stride >= 1; stride >>= 1) {
         if ((int)lane >= stride && (int)lane < 2 * stride) store_bucket<F>(lds + (lane - stride) * SLOT, acc);
         __syncthreads();
         if ((int)lane < stride) acc = pt_add(acc, load_bucket<F>(lds + lane * SLOT));
@@ -680,17 +709,17 @@ __global__ __launch_bounds__(64, 2) void nmsm_combine_kernel(const uint32_t *__r
                                                              const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
                                                              uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS] */, uint32_t target, uint32_t max_items)
 {
-    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
+    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES;
     __shared__ uint32_t lds[32 * SLOT];
     const size_t sig = blockIdx.y;
-    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x / F::LANES;
     const uint32_t c = counts[sig * NMSM_BUCKETS + b];
     const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
     const uint32_t *src = partial_items + (sig * (size_t)max_items + item_first[sig * NMSM_BUCKETS + b]) * (size_t)BW;
     XyzzT<F> acc = pt_identity<F>();
-    for (uint32_t j = lane; j < k; j += 64) acc = pt_add(acc, load_bucket<F>(src + (size_t)j * BW));
-    for (int stride = 32; stride >= 1; stride >>= 1) {
+    for (uint32_t j = lane; j < k; j += PER) acc = pt_add(acc, load_bucket<F>(src + (size_t)j * BW));
+    for (int stride = PER / 2; stride >= 1; stride >>= 1) {
         if ((int)lane >= stride && (int)lane < 2 * stride) store_bucket<F>(lds + (lane - stride) * SLOT, acc);
         __syncthreads();
         if ((int)lane < stride) acc = pt_add(acc, load_bucket<F>(lds + lane * SLOT));
@@ -699,79 +728,109 @@ __global__ __launch_bounds__(64, 2) void nmsm_combine_kernel(const uint32_t *__r
     if (lane == 0) store_bucket<F>(buckets + (sig * NMSM_BUCKETS + b) * (size_t)BW, acc);
 }
 
-// one workgroup per signature: threads 0..127 add up the items of their bucket and turn the 128 bucket sums into suffix sums
-// T_b = B_b + B_(b+1) + ... (sum_b (b + 1) B_b = sum_b T_b) by a scan through LDS; the threads above 127 bring in the ones'
-// partial sums (one each, at most 64); then one tree over all values, one inversion, ark-ff's bytes out
+// ONE WAVEFRONT per signature folds the 128 buckets and the ones' partial sums into the result.  (The first version was one
+// workgroup of 384 / 256 threads: a workgroup of several wavefronts that is issued while the 2^18-point bucket kernel occupies the
+// chip -- two wavefronts of 240 registers on every SIMD -- finds no CU with room for all of it until that kernel ends; 42 ms late in
+// profiles/r04_groth16_timeline_64_starved.txt.  A single wavefront takes whatever slot frees up next.)
+// PER = 64 / F::LANES chains, NB = 128 / PER adjacent buckets each; bucket b = i NB + k has weight b + 1 = i NB + (k + 1):
+//     result = sum_i [ sum_k (k + 1) B_(i,k) ] + NB sum_(i >= 1) Suffix_i + ones,   Suffix_i = sum_(j >= i) sum_k B_(j,k)
+//   phase 0   chain i adds up its buckets from the last to the first (their items one after the other, unless nmsm_combine_kernel has
+//             done that), parking run_k = B_k + .. + B_(NB-1) after each: run_0 is the chain's total, sum_k run_k its weighted sum
+//   phase 1   suffix scan of the totals over the chains (log2 PER steps through LDS)
+//   phase 2   x NB (the value added to itself log2 NB times; chain 0 contributes nothing), + the chain's weighted sum, + the ones
+//   phase 3   tree over the chains, one inversion, ark-ff's bytes out
+// ONE addition site: every step is "sum (+)= the point at p", p in global memory or in LDS.
 template <class F>
-__global__ __launch_bounds__(nmsm_finish_threads<F>()) void nmsm_finish_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
-                                                                               const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
-                                                                               const uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS], or null */,
-                                                                               const uint32_t *__restrict__ partial_ones /* [sig][ones_stride][BK_WORDS] */,
-                                                                               int ones_groups, uint32_t ones_stride, uint32_t target, uint32_t max_items,
-                                                                               uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
+__global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+                                                         const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
+                                                         const uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS], or null */,
+                                                         const uint32_t *__restrict__ partial_ones /* [sig][ones_stride][BK_WORDS] */,
+                                                         int ones_groups, uint32_t ones_stride, uint32_t target, uint32_t max_items,
+                                                         uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
 {
-    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, FT = nmsm_finish_threads<F>();
-    __shared__ uint32_t lds[NMSM_BUCKETS * SLOT];                     // 29 KB (G1) / 58 KB (G2)
-    __shared__ uint32_t longest;
+    constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES, NB = NMSM_BUCKETS / PER;
+    constexpr int LOG_PER = PER == 64 ? 6 : 5, LOG_NB = NB == 2 ? 1 : 2;
+    static_assert(PER * NB == NMSM_BUCKETS && (1 << LOG_PER) == PER && (1 << LOG_NB) == NB, "64 or 32 chains of 2 or 4 buckets");
+    __shared__ uint32_t lds[NMSM_BUCKETS * SLOT];                     // 29 KB (G1) / 58 KB (G2): slot i NB + k
+    __shared__ uint32_t longest[NB];
     const size_t sig = blockIdx.x;
-    const int t = threadIdx.x;
-    // ONE addition site in the whole kernel: every step of every phase is "sum += the point at p", with p in global memory or in LDS
-    const uint32_t *src;
-    uint32_t mine = 0;                                                // serial additions of this thread's own list
-    if (t < NMSM_BUCKETS) {
-        if (buckets) {                                                // small batches: nmsm_combine_kernel has added the items up (latency)
-            src = buckets + (sig * NMSM_BUCKETS + t) * (size_t)BW;
-        } else {                                                      // large batches: the thread adds its bucket's items itself (work: a ninth of the combine's)
-            const uint32_t c = counts[sig * NMSM_BUCKETS + t];
-            const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
-            mine = (c <= split ? 1u : (c + split - 1) / split) - 1u;
-            src = partial_items + (sig * (size_t)max_items + item_first[sig * NMSM_BUCKETS + t]) * (size_t)BW;
-        }
-    } else {
-        src = partial_ones + (sig * (size_t)ones_stride + (size_t)(t - NMSM_BUCKETS)) * BW;   // the ones: at most 64 partial sums, one per thread (the others start from the identity)
-    }
-    if (t == 0) longest = 0;
+    const int i = threadIdx.x / F::LANES;
+    // the items of the chain's buckets (one each when they come combined)
+    const uint32_t *src[NB];
+    uint32_t mine[NB];
+    if (threadIdx.x < NB) longest[threadIdx.x] = 1;
     __syncthreads();
-    atomicMax(&longest, mine);
-    __syncthreads();
-    const uint32_t serial = longest;
-    XyzzT<F> sum = t < NMSM_BUCKETS || t - NMSM_BUCKETS < ones_groups ? load_bucket<F>(src) : pt_identity<F>();
-    // steps 0 .. serial - 1: the thread's own list; then 7 steps of the suffix scan over the buckets (offset 1, 2, .., 64), one
-    // step 384 -> 256 (G1), 8 steps of the tree (stride 128, 64, .., 1)
-    const uint32_t steps = serial + 7 + 1 + 8;
-    for (uint32_t step = 0; step < steps; step++) {
-        bool store_me = false, add_me = false;
-        int store_slot = 0, load_slot = 0;
-        const uint32_t *p = src;
-        if (step < serial) {
-            add_me = step < mine;
-            p = src + (size_t)(step + 1) * BW;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int b = i * NB + k;
+        if (buckets) {
+            src[k] = buckets + (sig * NMSM_BUCKETS + b) * (size_t)BW;
+            mine[k] = 1;
         } else {
-            const uint32_t ph = step - serial;
-            if (ph < 7) {                                              // after the step with offset `off`, thread b holds B_b + ... + B_(b + 2 off - 1)
-                const int off = 1 << ph;
-                store_me = t < NMSM_BUCKETS; store_slot = t;
-                add_me = t + off < NMSM_BUCKETS; load_slot = t + off;
-            } else if (ph == 7) {                                      // 384 -> 256
-                if (FT <= 2 * NMSM_BUCKETS) continue;
-                store_me = t >= 2 * NMSM_BUCKETS; store_slot = t - 2 * NMSM_BUCKETS;
-                add_me = t < NMSM_BUCKETS; load_slot = t;
-            } else {
-                const int stride = NMSM_BUCKETS >> (ph - 8);
-                store_me = t >= stride && t < 2 * stride; store_slot = t - stride;
-                add_me = t < stride; load_slot = t;
-            }
-            if (store_me) store_bucket<F>(lds + store_slot * SLOT, sum);
-            __syncthreads();
-            p = lds + load_slot * SLOT;
+            const uint32_t c = counts[sig * NMSM_BUCKETS + b];
+            const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
+            mine[k] = c <= split ? 1u : (c + split - 1) / split;
+            src[k] = partial_items + (sig * (size_t)max_items + item_first[sig * NMSM_BUCKETS + b]) * (size_t)BW;
+            atomicMax(&longest[k], mine[k]);
         }
-        if (add_me) {
-            // one layout for both sources: a bucket in global memory and a slot in LDS hold X, Y, ZZ, ZZZ and the flag alike
-            sum = pt_add(sum, load_bucket<F>(p));
-        }
-        if (step >= serial) __syncthreads();
     }
-    if (t == 0) store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
+    __syncthreads();
+    uint32_t phase0 = 0;
+#pragma unroll
+    for (int k = 0; k < NB; k++) phase0 += longest[k] + 1;            // the items of bucket k, then the step that parks run_k
+    const int ones_steps = (ones_groups + PER - 1) / PER;
+    const uint32_t at_local = phase0, at_reload = at_local + (NB - 1) + 1, at_scan = at_reload + 1, at_weight = at_scan + LOG_PER,
+                   at_final = at_weight + LOG_NB, at_ones = at_final + 1, at_tree = at_ones + ones_steps, steps = at_tree + LOG_PER;
+    XyzzT<F> sum = pt_identity<F>();
+    for (uint32_t step = 0; step < steps; step++) {
+        int store_slot = -1;
+        bool reset = false, add = false;
+        const uint32_t *p = lds;
+        if (step < phase0) {
+            // bucket k = NB - 1 .. 0
+            uint32_t s = step;
+            int k = NB - 1;
+#pragma unroll
+            for (int kk = NB - 1; kk >= 1; kk--)
+                if (k == kk && s >= longest[kk] + 1) { s -= longest[kk] + 1; k = kk - 1; }
+            const uint32_t *sp = src[0];
+            uint32_t mk = mine[0], lk = longest[0];
+#pragma unroll
+            for (int kk = 1; kk < NB; kk++)
+                if (k == kk) { sp = src[kk]; mk = mine[kk]; lk = longest[kk]; }     // (selects: a register array indexed at run time would live in scratch)
+            if (s < lk) { add = s < mk; p = sp + (size_t)s * BW; }
+            else store_slot = i * NB + k;                              // run_k
+        } else if (step < at_reload - 1) {                             // weighted sum: run_0 (held) + run_1 + .. + run_(NB-1)
+            add = true; p = lds + (i * NB + 1 + (int)(step - at_local)) * SLOT;
+        } else if (step == at_reload - 1) {
+            store_slot = i * NB + 1;                                   // the chain's weighted sum parks where run_1 was
+        } else if (step == at_reload) {
+            reset = true; add = true; p = lds + (i * NB) * SLOT;       // the chain's total again
+        } else if (step < at_weight) {                                 // suffix scan, offset 1, 2, .., PER / 2
+            const int off = 1 << (step - at_scan);
+            store_slot = i * NB;
+            add = i + off < PER; p = lds + ((i + off) * NB) * SLOT;
+        } else if (step < at_final) {                                  // x 2, log2 NB times
+            store_slot = i * NB;
+            add = true; p = lds + (i * NB) * SLOT;
+        } else if (step == at_final) {
+            reset = i == 0;                                            // weight i NB: nothing from the first chain
+            add = true; p = lds + (i * NB + 1) * SLOT;
+        } else if (step < at_tree) {
+            const int g = i + PER * (int)(step - at_ones);
+            add = g < ones_groups; p = partial_ones + (sig * (size_t)ones_stride + (size_t)g) * BW;
+        } else {
+            const int stride = PER >> (step - at_tree + 1);
+            if (i >= stride && i < 2 * stride) store_slot = (i - stride) * NB;
+            add = i < stride; p = lds + (i * NB) * SLOT;
+        }
+        if (store_slot >= 0) store_bucket<F>(lds + store_slot * SLOT, sum);
+        __syncthreads();
+        if (reset) sum = pt_identity<F>();
+        if (add) sum = pt_add(sum, load_bucket<F>(p));
+        __syncthreads();
+    }
+    if (i == 0) store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
 }
 
 // ---- k G for many scalars: the FixedBaseMSM of ark-groth16's generator (generator.rs builds h_query, a_query, l_query and
@@ -839,11 +898,12 @@ template <class F> size_t msm_workspace_per_signature(uint32_t n)
     // counts, offsets, order (3 x 32,768 x 4 B), entries (16 n x 4 B), buckets (32,768 buckets; the sort's per-slice
     // histograms, 32 x 32,768 x 4 B, live there before the buckets are written), the list of scalars that are one (n x 4 B +
     // a counter) and their 512 partial sums
-    static_assert((size_t)frw::MSM_SLICES * 4 <= (size_t)frw::Grp<F>::BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
+    static_assert((size_t)frw::MSM_SLICES_LONE * 4 <= (size_t)frw::Grp<F>::BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
     // + the work items: first item of every bucket, the item list, a counter, and the items' partial sums
+    const size_t items = frw::msm_max_items(n);
     return 4 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::Grp<F>::BK_WORDS * 4 +
            ((size_t)n + 4) * 4 + (size_t)frw::MSM_FOLD1_THREADS * frw::Grp<F>::BK_WORDS * 4 +
-           ((size_t)frw::MSM_MAX_ITEMS + 4) * 4 + (size_t)frw::MSM_MAX_ITEMS * frw::Grp<F>::BK_WORDS * 4;
+           (items + 4) * 4 + items * frw::Grp<F>::BK_WORDS * 4;
 }
 
 template <class F> size_t nmsm_workspace_per_signature(uint32_t n)
@@ -942,23 +1002,26 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         uint32_t *ones_count = ones_list + cnt * (size_t)n;             // [cnt], padded to four words per signature in the budget
         uint32_t *item_first = ones_count + cnt * 4;
         uint32_t *items = item_first + cnt * (size_t)frw::MSM_BUCKETS;
-        uint32_t *item_count = items + cnt * (size_t)frw::MSM_MAX_ITEMS; // [cnt], padded likewise
+        const uint32_t max_items = frw::msm_max_items(n);
+        uint32_t *item_count = items + cnt * (size_t)max_items;          // [cnt], padded likewise
         uint32_t *partial_items = item_count + cnt * 4;
         const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
         const size_t stride_words = scalar_stride * 8;
-        const dim3 sgrid(frw::MSM_SLICES, (unsigned)cnt);
+        const int slices = cnt == 1 ? frw::MSM_SLICES_LONE : frw::MSM_SLICES;
+        const dim3 sgrid((unsigned)slices, (unsigned)cnt);
         e = hipMemsetAsync(ones_count, 0, cnt * 4, st);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
-        hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts);
+        hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts, slices);
         hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
-        const uint32_t finer = cnt <= 2 ? 4u : 1u;               // (four at a time: 12.6 ms with it, 12.1 without)
-        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count, finer);
+        // (four at a time: 12.6 ms with the finer split, 12.1 without); beyond 2^18 points: see MSM_MAX_ITEMS_LARGE
+        const uint32_t finer = cnt <= 2 ? (n > (1u << 18) ? 12u : 4u) : 1u;
+        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count, finer, max_items);
         hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
-        hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(frw::MSM_MAX_ITEMS / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
-                           counts, items, item_count, entries, partial_items, finer);
+        hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(max_items / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
+                           counts, items, item_count, entries, partial_items, finer, max_items);
         hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, offsets, counts, item_first,
-                           partial_items, buckets, finer);
+                           partial_items, buckets, finer, max_items);
         // first stage of the fold: enough threads to occupy the chip (~2^16), as few as that allows
         const int log_chunk = cnt >= 128 ? 6 : cnt >= 32 ? 5 : 3;
         const unsigned t1 = (unsigned)frw::MSM_BUCKETS >> log_chunk;
@@ -972,6 +1035,81 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
 }
+// ---- the narrow pipeline in two halves: the counting sort of the scalars' digits (which knows nothing of the points), and the sums
+// over one window table with a sort's result.  The four witness-side sums of a proof take the SAME scalars -- z ++ [1, r, s] against
+// a_query, b_g1_query, b_g2_query and l_query, each table padded to the same length with points at infinity -- so a proof sorts once
+// (frw_groth16_prove_dev); frw_msm_g1_dev / _g2_dev on a narrow handle are one sort and one sum.
+struct NmsmBufs {
+    uint32_t *slice_hist, *counts, *offsets, *item_first, *items, *item_count, *ones_count, *ones_list, *entries;      // the sort's
+    uint32_t *partial_items, *partial_ones, *folded_ones, *bucket_sums;                                              // a table's own
+    uint32_t target, max_items, ones_stride;
+};
+template <class F> NmsmBufs nmsm_carve(void *d_workspace, size_t cnt, uint32_t n)
+{
+    constexpr int BW = frw::Grp<F>::BK_WORDS;
+    NmsmBufs b;
+    b.target = frw::nmsm_target_items(n); b.max_items = frw::nmsm_max_items(n); b.ones_stride = frw::nmsm_ones_max(n) / 64;
+    b.slice_hist = (uint32_t *)d_workspace;
+    b.counts = b.slice_hist + cnt * (size_t)frw::NMSM_SLICES * frw::NMSM_BUCKETS;
+    b.offsets = b.counts + cnt * frw::NMSM_BUCKETS;
+    b.item_first = b.offsets + cnt * frw::NMSM_BUCKETS;
+    b.items = b.item_first + cnt * frw::NMSM_BUCKETS;
+    b.item_count = b.items + cnt * (size_t)b.max_items;                    // [cnt], padded to four words per signature in the budget
+    b.ones_count = b.item_count + cnt * 4;                                 // likewise
+    b.ones_list = b.ones_count + cnt * 4;
+    b.entries = b.ones_list + cnt * (size_t)n;
+    b.partial_items = b.entries + cnt * (size_t)frw::NMSM_W * n;           // 16-byte aligned: every term above is a multiple of 4 words per signature but n
+    b.partial_items += (4 - ((uintptr_t)b.partial_items >> 2 & 3)) & 3;    // ... at most three words, out of the four the budget adds to the list for it
+    b.partial_ones = b.partial_items + cnt * (size_t)b.max_items * BW;
+    b.folded_ones = b.partial_ones + cnt * (size_t)b.ones_stride * BW;     // second stage, only when ones_stride > 64
+    b.bucket_sums = b.folded_ones + (b.ones_stride > 64 ? cnt * (size_t)64 * BW : 0);
+    return b;
+}
+hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *sc, size_t stride_words, int montgomery, hipStream_t st)
+{
+    const dim3 sgrid(frw::NMSM_SLICES, (unsigned)cnt);
+    hipError_t e = hipMemsetAsync(b.ones_count, 0, cnt * 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(frw::nmsm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.slice_hist, b.ones_count, b.ones_list);
+    hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3((unsigned)cnt), dim3(frw::NMSM_BUCKETS), 0, st, b.slice_hist, b.counts, b.offsets, b.item_first, b.items,
+                       b.item_count, b.target, b.max_items);
+    hipLaunchKernelGGL(frw::nmsm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.offsets, b.slice_hist, b.entries);
+    return hipGetLastError();
+}
+// `sorted`: whose sort arrays to read; `own`: where this table's partial sums go (the same carve for a sum on its own).  Every kernel
+// here is a grid of single wavefronts: none of them can be kept waiting by a kernel that fills the chip.
+template <class F, bool PREFETCH>
+hipError_t nmsm_accumulate(const frw_msm *m, const NmsmBufs &sorted, const NmsmBufs &own, size_t cnt, uint32_t *d_out, hipStream_t st)
+{
+    const uint32_t n = m->dev.n;
+    typedef typename frw::BulkPolicy<F>::type FB;
+    constexpr bool BULK_PREFETCH = PREFETCH || FB::LANES > 1;       // two lanes per point: the registers for the prefetch are there
+    // the ones' partial sums: enough threads to occupy the chip (~2^16 over the batch), between 256 and 4,096 per signature
+    int ones_threads = 256;
+    while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * cnt < 65536) ones_threads <<= 1;
+    hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, sorted.ones_count, sorted.ones_list,
+                       own.partial_ones, own.ones_stride);
+    const uint32_t *ones_for_finish = own.partial_ones;
+    uint32_t ones_groups = (uint32_t)ones_threads / 64, ones_finish_stride = own.ones_stride;
+    if (ones_groups > 64) {
+        hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<FB>, dim3(64, (unsigned)cnt), dim3(64), 0, st, own.partial_ones, ones_groups, own.ones_stride, own.folded_ones);
+        ones_for_finish = own.folded_ones;
+        ones_groups = 64;
+        ones_finish_stride = 64;
+    }
+    hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((sorted.max_items * FB::LANES + 63) / 64, (unsigned)cnt), dim3(64), 0, st, m->dev,
+                       sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items);
+    // the items of a bucket: added up by a workgroup per bucket where latency counts (a lone proof: 12 ms -> 8.6), by the fold's own
+    // thread where throughput does (the combine is nine times the wave-level additions: 3 % of a 64-proof call)
+    const bool combine = cnt <= 16;
+    if (combine)
+        hipLaunchKernelGGL(frw::nmsm_combine_kernel<FB>, dim3(frw::NMSM_BUCKETS, (unsigned)cnt), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first,
+                           own.partial_items, own.bucket_sums, sorted.target, sorted.max_items);
+    hipLaunchKernelGGL(frw::nmsm_finish_kernel<FB>, dim3((unsigned)cnt), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first, own.partial_items,
+                       combine ? own.bucket_sums : (uint32_t *)nullptr, ones_for_finish, (int)ones_groups, ones_finish_stride, sorted.target, sorted.max_items,
+                       d_out);
+    return hipGetLastError();
+}
 // the narrow pipeline for one group
 template <class F, bool PREFETCH>
 int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery, uint64_t *d_out,
@@ -982,60 +1120,12 @@ int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t s
     size_t chunk = workspace_bytes / per;
     if (chunk == 0 || ((uintptr_t)d_workspace & 15)) return FRW_E_INVALID_ARG;
     if (chunk > 32768) chunk = 32768;                                  // grid.y
-    constexpr int BW = frw::Grp<F>::BK_WORDS;
     hipError_t e = hipSetDevice(m->device);
     for (size_t lo = 0; e == hipSuccess && lo < batch; lo += chunk) {
         const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
-        uint32_t *slice_hist = (uint32_t *)d_workspace;
-        uint32_t *counts = slice_hist + cnt * (size_t)frw::NMSM_SLICES * frw::NMSM_BUCKETS;
-        uint32_t *offsets = counts + cnt * frw::NMSM_BUCKETS;
-        uint32_t *item_first = offsets + cnt * frw::NMSM_BUCKETS;
-        uint32_t *items = item_first + cnt * frw::NMSM_BUCKETS;
-        const uint32_t target = frw::nmsm_target_items(n), max_items = frw::nmsm_max_items(n), ones_stride = frw::nmsm_ones_max(n) / 64;
-        uint32_t *item_count = items + cnt * (size_t)max_items;             // [cnt], padded to four words per signature in the budget
-        uint32_t *ones_count = item_count + cnt * 4;                        // likewise
-        uint32_t *ones_list = ones_count + cnt * 4;
-        uint32_t *entries = ones_list + cnt * (size_t)n;
-        uint32_t *partial_items = entries + cnt * (size_t)frw::NMSM_W * n;  // 16-byte aligned: every term above is a multiple of 4 words per signature but n
-        partial_items += (4 - ((uintptr_t)partial_items >> 2 & 3)) & 3;     // ... at most three words, out of the four the budget adds to the list for it
-        uint32_t *partial_ones = partial_items + cnt * (size_t)max_items * BW;
-        uint32_t *folded_ones = partial_ones + cnt * (size_t)ones_stride * BW;   // second stage, only when ones_stride > 64
-        uint32_t *bucket_sums = folded_ones + (ones_stride > 64 ? cnt * (size_t)64 * BW : 0);
-        const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
-        const size_t stride_words = scalar_stride * 8;
-        const dim3 sgrid(frw::NMSM_SLICES, (unsigned)cnt);
-        e = hipMemsetAsync(ones_count, 0, cnt * 4, st);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(frw::nmsm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
-        hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3((unsigned)cnt), dim3(frw::NMSM_BUCKETS), 0, st, slice_hist, counts, offsets, item_first, items, item_count,
-                           target, max_items);
-        hipLaunchKernelGGL(frw::nmsm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
-        // the ones' partial sums: enough threads to occupy the chip (~2^16 over the batch), between 256 and 4,096 per signature
-        int ones_threads = 256;
-        while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * cnt < 65536) ones_threads <<= 1;
-        hipLaunchKernelGGL(frw::nmsm_ones_kernel<F>, dim3((unsigned)ones_threads / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list, partial_ones,
-                           ones_stride);
-        const uint32_t *ones_for_finish = partial_ones;
-        uint32_t ones_groups = (uint32_t)ones_threads / 64, ones_finish_stride = ones_stride;
-        if (ones_groups > 64) {
-            hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<F>, dim3(64, (unsigned)cnt), dim3(64), 0, st, partial_ones, ones_groups, ones_stride, folded_ones);
-            ones_for_finish = folded_ones;
-            ones_groups = 64;
-            ones_finish_stride = 64;
-        }
-        hipLaunchKernelGGL((frw::nmsm_bucket_kernel<F, PREFETCH>), dim3((max_items + 63) / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets, counts,
-                           items, item_count, entries, partial_items, target, max_items);
-        constexpr int FT = frw::nmsm_finish_threads<F>();
-        // the items of a bucket: added up by a workgroup per bucket where latency counts (a lone proof: 12 ms -> 8.6), by the fold's own
-        // thread where throughput does (the combine is nine times the wave-level additions: 3 % of a 64-proof call)
-        const bool combine = cnt <= 16;
-        if (combine)
-            hipLaunchKernelGGL(frw::nmsm_combine_kernel<F>, dim3(frw::NMSM_BUCKETS, (unsigned)cnt), dim3(64), 0, st, counts, offsets, item_first, partial_items, bucket_sums,
-                               target, max_items);
-        hipLaunchKernelGGL(frw::nmsm_finish_kernel<F>, dim3((unsigned)cnt), dim3(FT), 0, st, counts, offsets, item_first, partial_items,
-                           combine ? bucket_sums : (uint32_t *)nullptr, ones_for_finish, (int)ones_groups, ones_finish_stride, target, max_items,
-                           (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
-        e = hipGetLastError();
+        const NmsmBufs b = nmsm_carve<F>(d_workspace, cnt, n);
+        e = nmsm_sort(b, n, cnt, (const uint32_t *)(d_scalars + lo * scalar_stride * 4), scalar_stride * 8, montgomery, st);
+        if (e == hipSuccess) e = nmsm_accumulate<F, PREFETCH>(m, b, b, cnt, (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)), st);
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
 }
@@ -1195,10 +1285,19 @@ struct frw_groth16_pk {
     int device;
     uint64_t num_instance, num_witness, domain_size;
     frw_msm *h, *a, *b1, *l, *b2;
-    // the four witness-side sums run beside the sum over h_query, each on a stream of its own: their folds and the sorting
-    // of a few ten thousand pairs are latency, not throughput, and hide behind the 2^18-point sum
-    hipStream_t side[4];
-    hipEvent_t fork, join[4];
+    // FOUR streams of the key's own, created one after the other -- as many as the device has hardware queues (HIP's default),
+    // so that no two of them wait in line for the same queue: the witness map + the sum over h_query on `main`, the sums over
+    // a_query, b_g1_query and b_g2_query on the three `side` streams; their folds and the sorting of a few ten thousand pairs are
+    // latency, not throughput, and hide behind the 2^18-point sum.  The caller's stream forks into them, carries the shortest
+    // chain itself (the sum over l_query, enqueued FIRST: whichever of the key's streams shares a hardware queue with the caller's
+    // waits for that one short chain and nothing else) and joins them again.  Two things learnt from timelines
+    // (profiles/r03_groth16_timeline_64.txt, r04_groth16_timeline_64.txt, r04_aggregate16_timeline.txt): when the caller's stream
+    // carried the witness map it sat behind a side stream's whole chain on a shared queue (a quarter of the call); and a sum whose
+    // sorting kernels (workgroups of 1,024 threads) are issued once the 2^18-point bucket kernel runs does not start before that
+    // kernel ends -- two wavefronts of 240 registers per SIMD leave no CU with room for such a workgroup -- so every sum must be
+    // on a stream where nothing delays its first kernels.
+    hipStream_t main, side[3];
+    hipEvent_t fork, join[4];           // join[3]: main
     std::mutex enqueue;         // the side streams and events are the key's: one call at a time puts its work on them
 };
 
@@ -1208,9 +1307,10 @@ extern "C" void frw_groth16_pk_free(frw_groth16_pk *pk)
     for (frw_msm *m : {pk->h, pk->a, pk->b1, pk->l, pk->b2}) frw_msm_free(m);
     (void)hipSetDevice(pk->device);
     for (int i = 0; i < 4; i++) {
-        if (pk->side[i]) (void)hipStreamDestroy(pk->side[i]);
+        if (i < 3 && pk->side[i]) (void)hipStreamDestroy(pk->side[i]);
         if (pk->join[i]) (void)hipEventDestroy(pk->join[i]);
     }
+    if (pk->main) (void)hipStreamDestroy(pk->main);
     if (pk->fork) (void)hipEventDestroy(pk->fork);
     delete pk;
 }
@@ -1227,14 +1327,16 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
     pk->num_instance = d->num_instance; pk->num_witness = d->num_witness; pk->domain_size = d->domain_size;
     pk->h = pk->a = pk->b1 = pk->l = pk->b2 = nullptr;
     pk->fork = nullptr;
-    for (int i = 0; i < 4; i++) { pk->side[i] = nullptr; pk->join[i] = nullptr; }
+    pk->main = nullptr;
+    for (int i = 0; i < 4; i++) { if (i < 3) pk->side[i] = nullptr; pk->join[i] = nullptr; }
     const size_t nv = (size_t)(d->num_instance + d->num_witness);
     int rc = FRW_OK;
     {
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&pk->main, hipStreamNonBlocking);
         for (int i = 0; i < 4 && e == hipSuccess; i++) {
-            e = hipStreamCreateWithFlags(&pk->side[i], hipStreamNonBlocking);
+            if (i < 3) e = hipStreamCreateWithFlags(&pk->side[i], hipStreamNonBlocking);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->join[i], hipEventDisableTiming);
         }
         if (e != hipSuccess) {
@@ -1243,17 +1345,27 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
         }
     }
     try {
-        std::vector<uint64_t> g1(12 * (nv + 2)), g2(24 * (nv + 3), 0);
+        // The four witness-side sums take the same scalars, z ++ [1, r, s] (nv + 3 of them), and so ONE sort of their digits: every
+        // table has nv + 3 rows, the points that a sum does not have being the point at infinity (all-zero rows, which cost an
+        // addition nothing): a_query ++ [alpha, delta, O], b_g1_query ++ [beta, O, O], O x I ++ l_query ++ [O, O, O], and
+        // b_g2_query ++ [beta2, O, delta2].
+        std::vector<uint64_t> g1(12 * (nv + 3)), g2(24 * (nv + 3), 0);
+        std::fill(g1.begin(), g1.end(), 0);
         std::memcpy(g1.data(), d->a_query, nv * 96);
         std::memcpy(g1.data() + 12 * nv, d->alpha_g1, 96);
         std::memcpy(g1.data() + 12 * (nv + 1), d->delta_g1, 96);
-        rc = frw_msm_g1_load_narrow(device, nv + 2, g1.data(), &pk->a);       // the four witness-side sums: narrow windows
+        rc = frw_msm_g1_load_narrow(device, nv + 3, g1.data(), &pk->a);       // the four witness-side sums: narrow windows
         if (rc == FRW_OK) {
+            std::fill(g1.begin(), g1.end(), 0);
             std::memcpy(g1.data(), d->b_g1_query, nv * 96);
             std::memcpy(g1.data() + 12 * nv, d->beta_g1, 96);
-            rc = frw_msm_g1_load_narrow(device, nv + 1, g1.data(), &pk->b1);
+            rc = frw_msm_g1_load_narrow(device, nv + 3, g1.data(), &pk->b1);
         }
-        if (rc == FRW_OK) rc = frw_msm_g1_load_narrow(device, (size_t)d->num_witness, d->l_query, &pk->l);
+        if (rc == FRW_OK) {
+            std::fill(g1.begin(), g1.end(), 0);
+            std::memcpy(g1.data() + 12 * (size_t)d->num_instance, d->l_query, (size_t)d->num_witness * 96);
+            rc = frw_msm_g1_load_narrow(device, nv + 3, g1.data(), &pk->l);
+        }
         if (rc == FRW_OK) rc = frw_msm_g1_load(device, (size_t)d->domain_size - 1, d->h_query, &pk->h);
         if (rc == FRW_OK) {
             std::memcpy(g2.data(), d->b_g2_query, nv * 192);
@@ -1379,26 +1491,36 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
                            (uint32_t *)zext, stride * 8, nv);
+        // ONE counting sort of the digits of z ++ [1, r, s] for all four witness-side sums (its arrays live in a_query's workspace)
+        const NmsmBufs sorted = nmsm_carve<FqField>(msm_ws[1], cnt, (uint32_t)stride);
+        e = nmsm_sort(sorted, (uint32_t)stride, cnt, (const uint32_t *)zext, stride * 8, 1, st);
+        if (e != hipSuccess) break;
         e = hipEventRecord(pk->fork, st);
         forked = true;
-        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(pk->side[i], pk->fork, 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pk->main, pk->fork, 0);
+        for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipStreamWaitEvent(pk->side[i], pk->fork, 0);
         if (e != hipSuccess) break;
-        rc = frw_msm_g2_dev(pk->b2, cnt, zext, stride, 1, pB2, msm_ws[4], cnt * sz.msm[4], pk->side[3]);      // the longest of the four first
-        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->a, cnt, zext, stride, 1, pA, msm_ws[1], cnt * sz.msm[1], pk->side[0]);
-        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->b1, cnt, zext, stride, 1, pB1, msm_ws[2], cnt * sz.msm[2], pk->side[1]);
-        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->l, cnt, zext + I * 4, stride, 1, pL, msm_ws[3], cnt * sz.msm[3], pk->side[2]);
+        // the two chains that end in a scalar multiplication first (the longest of a proof made alone), then G2 with l_query behind
+        // it, then the witness map and the sum over h_query
+        e = nmsm_accumulate<FqField, true>(pk->a, sorted, nmsm_carve<FqField>(msm_ws[1], cnt, (uint32_t)stride), cnt, (uint32_t *)pA, pk->side[0]);
+        if (e == hipSuccess)
+            e = nmsm_accumulate<FqField, true>(pk->b1, sorted, nmsm_carve<FqField>(msm_ws[2], cnt, (uint32_t)stride), cnt, (uint32_t *)pB1, pk->side[1]);
+        if (e == hipSuccess)
+            e = nmsm_accumulate<Fq2Field, false>(pk->b2, sorted, nmsm_carve<Fq2Field>(msm_ws[4], cnt, (uint32_t)stride), cnt, (uint32_t *)pB2, pk->side[2]);
+        if (e == hipSuccess)
+            e = nmsm_accumulate<FqField, true>(pk->l, sorted, nmsm_carve<FqField>(msm_ws[3], cnt, (uint32_t)stride), cnt, (uint32_t *)pL, pk->side[2]);
+        if (e != hipSuccess) break;
+        rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
+        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->h, cnt, h, n, 1, pH, msm_ws[0], cnt * sz.msm[0], pk->main);
         if (rc != FRW_OK) break;
         // s g_a and r (g1_b - s delta1) as soon as their points exist, on the streams that made them
         hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[0], cnt, (const uint32_t *)d_split, 1,
                            (const uint32_t *)pA, (uint32_t *)pSA);
         hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[1], cnt, (const uint32_t *)d_split, 0,
                            (const uint32_t *)pB1, (uint32_t *)pRB1);
-        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
+        for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
+        if (e == hipSuccess) e = hipEventRecord(pk->join[3], pk->main);
         if (e != hipSuccess) break;
-        // ... while this stream does the witness map and the sum over h_query
-        rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, st);
-        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->h, cnt, h, n, 1, pH, msm_ws[0], cnt * sz.msm[0], st);
-        if (rc != FRW_OK) break;
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st, pk->join[i], 0);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)pA,
