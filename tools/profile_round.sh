@@ -1,7 +1,8 @@
 #!/bin/bash
-# Profiles of one round, on the GPU box:  bash tools/profile_round.sh r02
-# Three rocprofv3 passes over the SAME command (kernel trace + stats; then WRITE_SIZE and FETCH_SIZE in passes of their own,
-# as /opt/skills/guides/MI355X_MICROARCH.md prescribes), condensed into profiles/<tag>_* by tools/summarize_profiles.py.
+# Profiles of one round, on the GPU box, from ONE command:  bash tools/profile_round.sh r04
+# Three rocprofv3 passes over the SAME bench.py command (kernel trace + stats; then WRITE_SIZE and FETCH_SIZE in passes of their own,
+# as /opt/skills/guides/MI355X_MICROARCH.md prescribes), condensed into profiles/<tag>_* by tools/summarize_profiles.py; then the
+# prover's set (witness map, h_query sum, whole proofs, the aggregate proof: tools/refresh_prover_profiles.sh).
 set -e
 TAG=${1:-r02}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
@@ -20,3 +21,5 @@ python3 tools/summarize_profiles.py ${TAG}_cfg2 $OUT/${TAG}_trace $OUT/${TAG}_pm
 # gpurun merges only gpurun_out/ back: leave copies of the summaries there
 mkdir -p $OUT/profiles_$TAG && cp $REPO/profiles/${TAG}_*hbm_traffic.json $REPO/profiles/${TAG}_*kernel_stats.csv $OUT/profiles_$TAG/
 cp $OUT/${TAG}_trace.json $OUT/profiles_$TAG/${TAG}_bench_under_rocprof.json
+# the prover's tables and timelines, into the same directory
+bash tools/refresh_prover_profiles.sh $TAG
