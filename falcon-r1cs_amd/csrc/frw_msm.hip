@@ -1264,7 +1264,8 @@ __global__ __launch_bounds__(64) void groth16_scale_kernel(size_t batch, const u
 }
 // (A/B, negative, round 4: a workgroup of three wavefronts per scalar multiplication -- one running the 128 doublings from the LOW end
 // of the scalar and parking 2^i P in LDS, two adding the parked points where k0 / k1 have bits set, a tree, phi on the k1 sum -- is
-// bit-exact and SLOWER for a proof made alone: 5.5 ms against the 3.3 ms of the chain below, profiles/r04_groth16_scale_wave_ab.txt.)
+// bit-exact and SLOWER for a proof made alone, in two builds (the second with nothing but the doubled point live in the doubler's loop
+// and the doubling inlined): 5.5 and 4.9 ms against the 3.3 ms of the chain above; profiles/r04_groth16_scale_wave_ab.txt.  Removed.)
 // C = L + H + s A + r B1', then the proof row A (12 u64) | B (24) | C (12)
 __global__ __launch_bounds__(64) void groth16_finish_kernel(size_t batch, const uint32_t *__restrict__ a_pts, const uint32_t *__restrict__ sa_pts,
                                                             const uint32_t *__restrict__ rb1_pts, const uint32_t *__restrict__ l_pts,
