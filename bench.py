@@ -782,6 +782,35 @@ def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True):
     return out
 
 
+def aggregate_leg(eng, dev, cdev, k, world, rank, reps=5):
+    """N > 1, BASELINE configs[4] on the node: aggregates shard like signatures -- every rank makes ONE proof for k Falcon-1024
+    statements of its own (time_aggregate_proof: witnesses, assignment, key, proof, verification), no collective on the data path; the
+    node's rate is all ranks' signatures over the slowest rank's proof time (1,024 signatures = 64 such aggregates of 16, eight per GPU).
+    A rank that fails still reaches the two control-plane collectives."""
+    import traceback
+    res, err = None, None
+    try:
+        res = time_aggregate_proof(eng, dev, (10,) * k, reps, None)
+    except Exception as ex:                      # noqa: BLE001 -- reported in the line and on stderr
+        err = repr(ex)[:300]
+        sys.stderr.write("bench.py rank %d: the aggregate leg raised %r\n%s" % (rank, ex, traceback.format_exc()))
+        sys.stderr.flush()
+    sharding.barrier()
+    ms = torch.tensor([res["ms_per_proof"] if res else -1.0], dtype=torch.float64, device=cdev)
+    all_ms = [float(x) for x in sharding.gather_per_signature(ms, world, rank, world).tolist()]
+    out = {"ranks": world, "statements_per_proof": k, "ms_per_proof_per_rank": [round(x, 3) for x in all_ms],
+           "sharding": "by aggregate; every rank holds the aggregate's key; no data-path collective"}
+    if min(all_ms) <= 0:
+        out["error"] = err or "rank(s) %s failed" % [r for r, x in enumerate(all_ms) if x <= 0]
+        return out
+    out["signatures_per_s_all_gpus"] = round(world * k / (max(all_ms) * 1e-3), 1)
+    out["proofs_per_s_all_gpus"] = round(world / (max(all_ms) * 1e-3), 2)
+    out["seconds_for_1024_signatures_on_this_node"] = round(1024.0 / (world * k) * max(all_ms) * 1e-3, 3)
+    if res:
+        out["rank0"] = {key: res[key] for key in ("workload", "proving_key", "verify", "witness_map_ms", "workspace_bytes")}
+    return out
+
+
 def time_msm(eng, dev, d_h, reps, with_cpu):
     """The step after the witness map in the reference's consumer (examples/pok_sig.rs:30-47 -> ark-groth16 prover.rs):
     h_acc = VariableBaseMSM(pk.h_query, h) over BLS12-381 G1, for the h vectors the witness map left in HBM."""
@@ -1250,6 +1279,9 @@ def main():
     ap.add_argument("--no-prove", action="store_true",
                     help="N > 1 only: skip the proof leg (every rank proves 64 of its own resident witnesses: Groth16 proofs per "
                          "second over all GPUs, sharded by signature like the witnesses)")
+    ap.add_argument("--aggregate-leg", type=int, default=16, metavar="K",
+                    help="N > 1 only (with the proof leg): every rank also makes ONE proof for an aggregate of K Falcon-1024 statements "
+                         "(BASELINE configs[4] on the node: 1,024 signatures = 64 aggregates of 16, eight per GPU); 0 = skip")
     ap.add_argument("--allgather-chunk", type=int, default=0, help="signatures per rank per all-gather (default 4,096)")
     ap.add_argument("--allgather-deadline", type=int, default=240,
                     help="seconds the N > 1 gather legs may take before the run reports `value` without them")
@@ -1428,6 +1460,9 @@ def main():
         if use_pg and not dual and not args.no_prove:
             prove_info = prove_leg(eng, h, dev, cdev, d_wit, d_inst, held, L, logn, world, rank)
             torch.cuda.empty_cache()             # the leg's workspace goes back to the device before the gather legs allocate
+            if args.aggregate_leg and logn == 10:
+                prove_info["aggregate"] = aggregate_leg(eng, dev, cdev, args.aggregate_leg, world, rank)
+                torch.cuda.empty_cache()
         eng.r1cs_free(h)
         n_unsat = sharding.sum_over_ranks(int((badrows != 0).sum().item()), cdev)
         assert n_unsat == 0, "%d witnesses left by the timed launches violate the constraint system" % n_unsat
@@ -1583,7 +1618,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, slot_sig[slots], lambda i: digest_of[int(i)])
         emit(result)
     if use_pg:
-        leave(legs_hung, bool((gather_info and "error" in gather_info) or (prove_info and "error" in prove_info)), rank)
+        leave(legs_hung, bool((gather_info and "error" in gather_info) or (prove_info and ("error" in prove_info or "error" in prove_info.get("aggregate", {})))),
+              rank)
 
 
 def leave(legs_hung, legs_failed, rank, teardown_timeout=10.0):
@@ -1629,8 +1665,9 @@ def make_plan(args, world, rank):
     chunk = min(args.chunk or (32768 if args.logn == 10 else 65536), batch)
     legs = (world > 1 or args.force_pg) and not args.no_allgather and not dual
     prove = (world > 1 or args.force_pg) and not args.no_prove and not args.no_r1cs_check and not dual
+    agg = args.aggregate_leg if prove and args.logn == 10 else 0
     return sharding.step_plan(world, rank, batch, chunk, args.allgather_chunk, L.n, L.num_witness, L.num_instance,
-                              int(CL.bytes_per_signature), with_gather_legs=legs, with_prove_leg=prove)
+                              int(CL.bytes_per_signature), with_gather_legs=legs, with_prove_leg=prove, aggregate_statements=agg)
 
 
 def print_plans(args, only_this_world):

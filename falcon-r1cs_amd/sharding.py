@@ -103,8 +103,24 @@ def prove_leg_bytes(n, num_witness, num_instance, proofs_in_flight=64):
     return int(key + matrices + proofs_in_flight * per_proof)
 
 
+def aggregate_leg_bytes(statements, n, num_witness, num_instance):
+    """HBM of the N > 1 run's aggregate leg (bench.py::aggregate_leg: ONE proof for `statements` signatures of this parameter set;
+    released before the gather legs start, and never held together with the proof leg): the aggregate key's window tables (one point per
+    variable of the whole statement), the transform tables of its domain (11 x 32 x domain), the per-signature matrices, the statements'
+    own witnesses and the aggregate's assignment (2 x 32 bytes per variable), and the workspace of one proof."""
+    nv = statements * (num_witness + num_instance - 1) + 1
+    constraints = statements * (num_witness + 6 * n + 2)
+    domain = 1
+    while domain < constraints + statements * (num_instance - 1) + 1:
+        domain *= 2
+    key = 3 * 3584 * (nv + 3) + 7168 * (nv + 3) + 1792 * domain
+    tables = 11 * 32 * domain + 1300 * (num_witness + 6 * n + 2) + 9 * 32 * (1 << 18)
+    proof = 5 * 32 * domain + 96 * constraints + 64 * domain + 4 * 132 * nv + (32768 + 294912 + 4096) * 240 + (1 << 20)
+    return int(key + tables + 2 * 32 * nv + proof)
+
+
 def step_plan(world, rank, batch_per_gpu, chunk, allgather_chunk, n, num_witness, num_instance, compact_bytes,
-              with_gather_legs=True, with_prove_leg=False):
+              with_gather_legs=True, with_prove_leg=False, aggregate_statements=0):
     """Everything bench.py derives from (world, rank, per-GPU batch, launch size): this rank's global index range, the
     launches of a step, the chunking of the gather legs and the bytes of every HBM buffer the run allocates.
 
@@ -149,8 +165,11 @@ def step_plan(world, rank, batch_per_gpu, chunk, allgather_chunk, n, num_witness
             "status of the regenerated chunk": 4 * world * gc,
             "naive probe: gathered 32-byte witnesses": world * probe_gc * wit_row,
         })
-    if with_prove_leg:
-        buffers["proof leg: proving key, matrices, workspace of 64 proofs (transient)"] = prove_leg_bytes(n, num_witness, num_instance)
+    if with_prove_leg or aggregate_statements:
+        # the two legs run one after the other and give their memory back in between: the plan holds the larger
+        p = prove_leg_bytes(n, num_witness, num_instance) if with_prove_leg else 0
+        a = aggregate_leg_bytes(aggregate_statements, n, num_witness, num_instance) if aggregate_statements else 0
+        buffers["proof legs (transient, the larger of the two): 64 per-signature proofs | one proof for %d statements" % aggregate_statements] = max(p, a)
     plan["buffers"] = buffers
     plan["hbm_plan_bytes"] = int(sum(buffers.values()))
     plan["hbm_limit_bytes"] = int(HBM_PLAN_FRACTION * HBM_BYTES_PER_GPU)

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"]
+COMMON = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--aggregate-leg", "0"]
 
 
 def _run(cmd, timeout=600):
@@ -90,8 +90,9 @@ def test_plain_invocation_with_gpus_2_starts_its_own_ranks(tmp_path):
     """`python3 bench.py --gpus N ...` in the form the driver records for N = 1 (no launcher, no WORLD_SIZE) must
     run: the parent starts the ranks as child processes before it touches any GPU and forwards rank 0's one line."""
     out = str(tmp_path / "plain")
+    common = [a for a in COMMON if a not in ("--aggregate-leg", "0")] + ["--aggregate-leg", "2"]     # one proof for two statements (2^19) per rank
     run = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--batch", "256", "--chunk", "128",
-                          "--dump-digests", out] + COMMON, cwd=ROOT, capture_output=True, text=True, timeout=600, env=_plain_env())
+                          "--dump-digests", out] + common, cwd=ROOT, capture_output=True, text=True, timeout=900, env=_plain_env())
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, run.stdout
@@ -104,6 +105,10 @@ def test_plain_invocation_with_gpus_2_starts_its_own_ranks(tmp_path):
     # proofs in the N > 1 run: sharded by signature like the witnesses, no collective on the data path
     p = j["scaling_curves"]["prove"]
     assert p["ranks"] == 2 and p["proofs_per_s_all_gpus"] > 0 and p["all_proofs_verified"]
+    # ... and BASELINE configs[4] on the "node": every rank makes ONE proof for an aggregate of its own (time_aggregate_proof verifies it)
+    a = p["aggregate"]
+    assert "error" not in a and a["ranks"] == 2 and a["statements_per_proof"] == 2 and a["signatures_per_s_all_gpus"] > 0
+    assert "QAP domain 2^19" in a["rank0"]["workload"]
 
 
 @pytest.mark.gpu

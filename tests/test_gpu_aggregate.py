@@ -197,10 +197,10 @@ def test_two_mixed_statements_against_the_oracles_own_aggregate_system(engine, o
         agg.close()
 
 
-@pytest.mark.parametrize("logns", [(10, 10), (9, 9, 9), (10,) * 8], ids=["2^19", "2^18-three-512", "2^21"])
+@pytest.mark.parametrize("logns", [(10, 10), (9, 9, 9), (10,) * 8, (10,) * 32], ids=["2^19", "2^18-three-512", "2^21", "2^23"])
 def test_witness_map_on_the_other_domains(engine, oracle, tmp_path, logns):
-    """The transform schedules beyond the two per-signature domains (2^19 = 6 + 5 + 4 + 4 stages, 2^21 = 6 + 5 + 5 + 5; 2^20 and 2^22
-    are the proof tests below): h of an aggregate against the oracle's witness map on the statements' products end to end, the
+    """The transform schedules beyond the two per-signature domains (2^19 = 6 + 5 + 4 + 4 stages, 2^21 = 6 + 5 + 5 + 5, 2^23 = 6 + 6 + 6 + 5:
+    thirty-two Falcon-1024 statements, 5.2 M constraints; 2^20 and 2^22 are the proof tests below): h of an aggregate against the oracle's witness map on the statements' products end to end, the
     six-transform quotient against the seven-transform map, and a spoilt witness through the exact (list-mode) route."""
     import torch
     agg = Aggregate(engine, logns, seed=77 + len(logns))
