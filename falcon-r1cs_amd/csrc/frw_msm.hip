@@ -184,9 +184,11 @@ __device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomer
 // 160 KB), the histograms are turned into per-slice starting positions inside every bucket, and the same workgroups then hand
 // out positions from LDS again.  (With one global atomicAdd per pair the sort took a third of the whole call: 10^10 atomics
 // per second is what the L2 gives, and a signature has 4 x 10^6 pairs to place twice.)
-// 32 slices per signature for a batch; a call with ONE signature (an aggregate statement's sum over 2^22 points) would keep 32 of
-// the 256 CUs busy with them, so it cuts 56 -- as many as fit where the per-slice histograms live (the buckets' memory: 60).
-constexpr int MSM_SLICES = 32, MSM_SLICES_LONE = 56;
+// 32 slices per signature for a batch (their histograms live in the buckets' memory until the first bucket is stored: room for 60);
+// a call with ONE signature (an aggregate statement's sum over 2^22 points) would keep 32 of the 256 CUs busy with them, so it cuts
+// 224, and parks their histograms in the work items' partial sums instead (131,072 x 240 bytes and more: room for 240), which
+// nothing writes before the bucket kernel.
+constexpr int MSM_SLICES = 32, MSM_SLICES_LONE = 224;
 __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
                                                         int montgomery, uint32_t *__restrict__ slice_hist /* [sig][slice][buckets] */,
                                                         uint32_t *__restrict__ ones_count /* [sig] */, uint32_t *__restrict__ ones_list /* [sig][n] */)
@@ -490,7 +492,10 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
 // empty buckets, ten kernels of one wavefront per SIMD each: a third of a whole proof's time for a thirtieth of its
 // arithmetic.  With 8-bit windows (32 of them: a table twice as long) the same scalars are 70,000 additions into 128 buckets
 // per signature, cut into ~2,048 equal work items, and the fold is one workgroup: a suffix scan and a tree over 128 points.
-constexpr int NMSM_C = 8, NMSM_W = 32, NMSM_BUCKETS = 128, NMSM_SLICES = 16;
+constexpr int NMSM_C = 8, NMSM_W = 32, NMSM_BUCKETS = 128;
+// slices of the counting sort (a workgroup of 1,024 threads each): 16 per signature, 128 beyond 2^18 scalars (an aggregate statement is
+// one "signature": 16 workgroups for 2.5 M scalars were 1.2 ms at the head of every other kernel of its proof)
+__host__ __device__ constexpr uint32_t nmsm_slices(uint32_t n) { return n > (1u << 18) ? 128u : 16u; }
 // Work items per signature: 2,048 for the per-signature circuits (n < 2^18 points), n / 128 rounded up to a multiple of 2,048 beyond
 // (an aggregate statement is ONE "signature" with sixteen times the points: 2,048 items would be 32 wavefronts on 1,024 SIMDs, each
 // a chain of 550 additions); items <= buckets + total / split <= 128 + target, rounded up to whole wavefronts.
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(1024) void nmsm_hist_kernel(uint32_t n, const uint3
 {
     __shared__ uint32_t hist[NMSM_BUCKETS];
     const size_t sig = blockIdx.y;
-    const uint32_t slice = blockIdx.x, per = (n + NMSM_SLICES - 1) / NMSM_SLICES;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
     const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
     if (threadIdx.x < NMSM_BUCKETS) hist[threadIdx.x] = 0;
     __syncthreads();
@@ -547,20 +552,20 @@ __global__ __launch_bounds__(1024) void nmsm_hist_kernel(uint32_t n, const uint3
             if (d[j]) atomicAdd(&hist[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < NMSM_BUCKETS) slice_hist[(sig * NMSM_SLICES + slice) * NMSM_BUCKETS + threadIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x < NMSM_BUCKETS) slice_hist[(sig * slices + slice) * NMSM_BUCKETS + threadIdx.x] = hist[threadIdx.x];
 }
 // one workgroup of 128 threads per signature: bucket sizes and starts, every slice's first position inside its buckets, the
 // work items (bucket | part << 8: equal parts of at most `split` entries)
 __global__ __launch_bounds__(NMSM_BUCKETS) void nmsm_plan_kernel(uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
                                                                  uint32_t *__restrict__ item_first, uint32_t *__restrict__ items /* [sig][max_items] */,
-                                                                 uint32_t *__restrict__ item_count /* [sig] */, uint32_t target, uint32_t max_items)
+                                                                 uint32_t *__restrict__ item_count /* [sig] */, uint32_t target, uint32_t max_items, uint32_t slices)
 {
     __shared__ uint32_t scan[NMSM_BUCKETS];
     const size_t sig = blockIdx.x;
     const int b = threadIdx.x;
-    uint32_t *h = slice_hist + sig * NMSM_SLICES * (size_t)NMSM_BUCKETS + b;
+    uint32_t *h = slice_hist + sig * slices * (size_t)NMSM_BUCKETS + b;
     uint32_t c = 0;
-    for (int s_ = 0; s_ < NMSM_SLICES; s_++) {
+    for (uint32_t s_ = 0; s_ < slices; s_++) {
         const uint32_t v = h[(size_t)s_ * NMSM_BUCKETS];
         h[(size_t)s_ * NMSM_BUCKETS] = c;
         c += v;
@@ -597,10 +602,10 @@ __global__ __launch_bounds__(1024) void nmsm_scatter_kernel(uint32_t n, const ui
 {
     __shared__ uint32_t cursor[NMSM_BUCKETS];
     const size_t sig = blockIdx.y;
-    const uint32_t slice = blockIdx.x, per = (n + NMSM_SLICES - 1) / NMSM_SLICES;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
     const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
     if (threadIdx.x < NMSM_BUCKETS)
-        cursor[threadIdx.x] = offsets[sig * NMSM_BUCKETS + threadIdx.x] + slice_hist[(sig * NMSM_SLICES + slice) * NMSM_BUCKETS + threadIdx.x];
+        cursor[threadIdx.x] = offsets[sig * NMSM_BUCKETS + threadIdx.x] + slice_hist[(sig * slices + slice) * NMSM_BUCKETS + threadIdx.x];
     __syncthreads();
     uint32_t *ent = entries + sig * (size_t)NMSM_W * n;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
@@ -898,7 +903,8 @@ template <class F> size_t msm_workspace_per_signature(uint32_t n)
     // counts, offsets, order (3 x 32,768 x 4 B), entries (16 n x 4 B), buckets (32,768 buckets; the sort's per-slice
     // histograms, 32 x 32,768 x 4 B, live there before the buckets are written), the list of scalars that are one (n x 4 B +
     // a counter) and their 512 partial sums
-    static_assert((size_t)frw::MSM_SLICES_LONE * 4 <= (size_t)frw::Grp<F>::BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
+    static_assert((size_t)frw::MSM_SLICES * 4 <= (size_t)frw::Grp<F>::BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
+    static_assert((size_t)frw::MSM_SLICES_LONE * frw::MSM_BUCKETS <= (size_t)frw::MSM_MAX_ITEMS * frw::Grp<F>::BK_WORDS, "... or, for a lone signature, the work items'");
     // + the work items: first item of every bucket, the item list, a counter, and the items' partial sums
     const size_t items = frw::msm_max_items(n);
     return 4 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::Grp<F>::BK_WORDS * 4 +
@@ -912,7 +918,7 @@ template <class F> size_t nmsm_workspace_per_signature(uint32_t n)
     // the entries (32 n x 4 B), the items' and the ones' partial sums
     // (n + 8 words for the list: the four after it are the alignment pad of what follows, budgeted here rather than borrowed)
     const size_t items = frw::nmsm_max_items(n), ones_groups = frw::nmsm_ones_max(n) / 64;
-    return ((size_t)frw::NMSM_SLICES + 3) * frw::NMSM_BUCKETS * 4 + (items + 4) * 4 + ((size_t)n + 8) * 4 +
+    return ((size_t)frw::nmsm_slices(n) + 3) * frw::NMSM_BUCKETS * 4 + (items + 4) * 4 + ((size_t)n + 8) * 4 +
            (size_t)frw::NMSM_W * n * 4 + (items + ones_groups + (ones_groups > 64 ? 64 : 0) + frw::NMSM_BUCKETS) * frw::Grp<F>::BK_WORDS * 4;
 }
 
@@ -996,7 +1002,7 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         uint32_t *order = offsets + cnt * frw::MSM_BUCKETS;
         uint32_t *entries = order + cnt * frw::MSM_BUCKETS;
         uint32_t *buckets = entries + cnt * (size_t)frw::MSM_W * n;
-        uint32_t *slice_hist = buckets;                                  // [cnt][32][32,768], dead before the first bucket is stored
+        uint32_t *slice_hist = buckets;                                  // [cnt][32][32,768], dead before the first bucket is stored (cnt == 1: see below)
         uint32_t *partial = buckets + cnt * (size_t)frw::MSM_BUCKETS * BW;
         uint32_t *ones_list = partial + cnt * (size_t)frw::MSM_FOLD1_THREADS * BW;
         uint32_t *ones_count = ones_list + cnt * (size_t)n;             // [cnt], padded to four words per signature in the budget
@@ -1008,6 +1014,7 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
         const size_t stride_words = scalar_stride * 8;
         const int slices = cnt == 1 ? frw::MSM_SLICES_LONE : frw::MSM_SLICES;
+        if (cnt == 1) slice_hist = partial_items;                        // [224][32,768], dead before the first work item's sum is stored
         const dim3 sgrid((unsigned)slices, (unsigned)cnt);
         e = hipMemsetAsync(ones_count, 0, cnt * 4, st);
         if (e != hipSuccess) break;
@@ -1050,7 +1057,7 @@ template <class F> NmsmBufs nmsm_carve(void *d_workspace, size_t cnt, uint32_t n
     NmsmBufs b;
     b.target = frw::nmsm_target_items(n); b.max_items = frw::nmsm_max_items(n); b.ones_stride = frw::nmsm_ones_max(n) / 64;
     b.slice_hist = (uint32_t *)d_workspace;
-    b.counts = b.slice_hist + cnt * (size_t)frw::NMSM_SLICES * frw::NMSM_BUCKETS;
+    b.counts = b.slice_hist + cnt * (size_t)frw::nmsm_slices(n) * frw::NMSM_BUCKETS;
     b.offsets = b.counts + cnt * frw::NMSM_BUCKETS;
     b.item_first = b.offsets + cnt * frw::NMSM_BUCKETS;
     b.items = b.item_first + cnt * frw::NMSM_BUCKETS;
@@ -1067,12 +1074,13 @@ template <class F> NmsmBufs nmsm_carve(void *d_workspace, size_t cnt, uint32_t n
 }
 hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *sc, size_t stride_words, int montgomery, hipStream_t st)
 {
-    const dim3 sgrid(frw::NMSM_SLICES, (unsigned)cnt);
+    const uint32_t slices = frw::nmsm_slices(n);
+    const dim3 sgrid(slices, (unsigned)cnt);
     hipError_t e = hipMemsetAsync(b.ones_count, 0, cnt * 4, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(frw::nmsm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.slice_hist, b.ones_count, b.ones_list);
     hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3((unsigned)cnt), dim3(frw::NMSM_BUCKETS), 0, st, b.slice_hist, b.counts, b.offsets, b.item_first, b.items,
-                       b.item_count, b.target, b.max_items);
+                       b.item_count, b.target, b.max_items, slices);
     hipLaunchKernelGGL(frw::nmsm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.offsets, b.slice_hist, b.entries);
     return hipGetLastError();
 }

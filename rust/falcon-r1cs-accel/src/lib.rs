@@ -198,11 +198,59 @@ impl Drop for R1cs {
     }
 }
 
+/// ONE constraint system for several signatures -- what `falcon-aggregate-sig` (upstream a stub: `falcon-aggregate-sig/src/main.rs:1-3`)
+/// would build by running `FalconNTTVerificationCircuit::generate_constraints` once per `(pk, msg, sig)` on the same
+/// `ConstraintSystemRef` -- as the engine holds it: the per-signature systems' blocks, never the aggregate's own matrices.
+/// (`LOG_N` is a cargo feature of falcon-rust, so one build of this crate aggregates one parameter set; the C ABI mixes them freely.)
+pub struct AggregateR1cs {
+    inner: R1cs,
+    statements: usize,
+}
+
+impl AggregateR1cs {
+    pub fn load(device: i32, statements: usize) -> Result<Self, EngineError> {
+        let logn = vec![LOG_N as i32; statements];
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { sys::frw_r1cs_load_aggregate(device, statements, logn.as_ptr(), &mut raw) })?;
+        let mut info = sys::frw_qap_info_t::default();
+        check(unsafe { sys::frw_qap_info(raw, &mut info) })?;
+        Ok(Self { inner: R1cs { raw, info }, statements })
+    }
+
+    /// `instance_assignment` / `witness_assignment` of the aggregate's constraint system from the statements' own: the
+    /// constant one, then every statement's public inputs; the statements' witnesses end to end.  (Device-resident batches go
+    /// through `frw_aggregate_assign_dev` instead.)
+    pub fn assign(&self, parts: &[Assignment]) -> Assignment {
+        assert_eq!(parts.len(), self.statements);
+        let mut instance = vec![parts[0].instance[0]];
+        let mut witness = Vec::new();
+        for p in parts {
+            instance.extend_from_slice(&p.instance[1..]);
+            witness.extend_from_slice(&p.witness);
+        }
+        Assignment { witness, instance }
+    }
+
+    /// The aggregate's h(X): `R1CStoQAP::witness_map` over `Radix2EvaluationDomain::new(sum C_i + 1 + sum 2 N_i)`.
+    pub fn witness_map(&self, full: &Assignment) -> Result<Vec<Fr>, EngineError> {
+        Ok(self.inner.witness_map(&[(&full.instance[..], &full.witness[..])])?.remove(0))
+    }
+
+    pub fn domain_size(&self) -> usize {
+        self.inner.domain_size()
+    }
+}
+
 /// The public inputs a verifier feeds `verify_proof` with, as examples/pok_sig.rs:33-45 computes them.
 pub fn public_inputs(pk: &PublicKey, msg: &[u8], sig: &Signature) -> Vec<Fr> {
     let pk_ntt = NTTPolynomial::from(&Polynomial::from(pk));
     let hm_ntt = NTTPolynomial::from(&Polynomial::from_hash_of_message(msg, sig.nonce()));
     pk_ntt.coeff().iter().chain(hm_ntt.coeff().iter()).map(|e| Fr::from(*e)).collect()
+}
+
+/// ... and for an aggregate statement: the statements' public inputs one after the other.
+pub fn aggregate_public_inputs(statements: &[(PublicKey, Vec<u8>, Signature)]) -> Vec<Fr> {
+    statements.iter().flat_map(|(pk, msg, sig)| public_inputs(pk, msg, sig)).collect()
 }
 
 #[cfg(test)]
