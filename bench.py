@@ -466,6 +466,7 @@ FQ_MUL_MULTIPLY, FQ_MUL_OTHER = 406, 90
 FQ_SQR_MULTIPLY, FQ_SQR_OTHER = 315, 101
 FQ_PAIR_MULTIPLY, FQ_PAIR_OTHER = 602, 135
 # the point formulas in those units (frw_fq29.h): mixed addition = 8 M + 2 S of which one M pair shares a reduction; full addition 12 M + 2 S
+MSM_VALU_PER_MADD = 5805          # all vector instructions msm_bucket_kernel<FqField, true> issues per wavefront per mixed addition (PMC, round 4)
 MADD_OPS = {"mul": 6, "sqr": 2, "pair": 1}
 ADD_OPS = {"mul": 10, "sqr": 2, "pair": 1}
 
@@ -858,6 +859,13 @@ def time_msm(eng, dev, d_h, reps, with_cpu):
            "roofline": {"bound": "valu_issue", "unit": "G Fq products/s", "achieved": round(products * per_s / 1e9, 2),
                         "peak": round(peak, 2), "frac": round(per_s / peak_sig_per_s, 4),
                         "kernel": "msm_bucket_kernel (+ count / scan / scatter / fold)", "fq_products_per_signature": products,
+                        "all_instructions": {
+                            "valu_instructions_per_wavefront_addition": MSM_VALU_PER_MADD, "of_which_multiplies": mm,
+                            "from": "SQ_INSTS_VALU of msm_bucket_kernel<FqField, true>, profiles/r04_msm_counters.txt (tools/pmc_msm.sh)",
+                            "frac_of_issue_bound": round(per_s / (rates["simds"] * 64 / (madds * (mm / rates["v_mad_u64_u32"] + (MSM_VALU_PER_MADD - mm) / rates["v_add_u32"])) * 1e6), 4),
+                            "note": "`frac` above prices the field products' instructions only; with EVERY vector instruction the bucket kernel issues per "
+                                    "addition (carry passes of the sums and differences, zero tests, sign select, unpacking) the same time is this "
+                                    "fraction of what the vector ALU can issue: the kernel is issue-bound, what is left is instruction count"},
                         "peak_is": "%d SIMDs x 64 lanes; a mixed addition = 6 products (%d multiplies + %d other instructions) + 2 squares "
                                    "(%d + %d) + one a b - c d with a shared reduction (%d + %d), a full addition 10 + 2 + 1 of the same; "
                                    "multiplies at %.1f, the others at %.1f wave-instructions/SIMD/us"

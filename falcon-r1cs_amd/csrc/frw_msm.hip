@@ -47,6 +47,11 @@ template <class F> struct Grp {
 struct MsmDev {
     uint32_t n;                 // points
     const uint32_t *table;      // [MSM_W][n][PT_WORDS]
+    // narrow handles of up to 2^18 points: sum_(j in m) P_(8 g + j) for every group g of eight consecutive points and every non-empty
+    // subset m of it, affine: [ceil(n / 8)][255][PT_WORDS] (as many bytes per point as the window table).  A Falcon witness is 45 % ones
+    // in long runs of booleans (bit decompositions, gate outputs): with the pattern of ones of a group as ONE byte, the points whose
+    // scalar is one cost one addition per group of eight instead of 3.6.  null: the ones are summed point by point from a list.
+    const uint32_t *ones_table;
 };
 
 template <class F> __device__ __forceinline__ AffineT<F> load_row(const uint32_t *row)
@@ -141,6 +146,21 @@ __global__ __launch_bounds__(64) void msm_precompute_kernel(uint32_t n, const ui
         for (int k = 0; k < window_bits; k++) d = pt_double(d);
         p = pt_to_affine(d);
     }
+}
+
+// load time: ones_table[g][m - 1] = the sum of the points 8 g + j with bit j of m set (window 0 of the table holds the points)
+template <class F>
+__global__ __launch_bounds__(64) void msm_ones_table_kernel(uint32_t n, const uint32_t *__restrict__ table, uint32_t *__restrict__ ones_table)
+{
+    const size_t id = (size_t)blockIdx.x * 64 + threadIdx.x, g = id / 255;
+    const uint32_t m = (uint32_t)(id % 255) + 1u;
+    if (g >= ((size_t)n + 7) / 8) return;
+    XyzzT<F> acc = pt_identity<F>();
+    for (int j = 0; j < 8; j++) {
+        const size_t i = g * 8 + j;
+        if (((m >> j) & 1u) && i < n) acc = pt_add_affine(acc, load_row<F>(table + i * Grp<F>::PT_WORDS));
+    }
+    store_row<F>(ones_table + id * Grp<F>::PT_WORDS, pt_to_affine(acc));
 }
 
 // ---- the scalars: canonical integer, sixteen signed 16-bit digits ---------------------------------------------------------------
@@ -533,7 +553,8 @@ __device__ __forceinline__ uint32_t nmsm_split_of(uint32_t total, uint32_t targe
 }
 __global__ __launch_bounds__(1024) void nmsm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words, int montgomery,
                                                          uint32_t *__restrict__ slice_hist /* [sig][slice][128] */,
-                                                         uint32_t *__restrict__ ones_count /* [sig] */, uint32_t *__restrict__ ones_list /* [sig][n] */)
+                                                         uint32_t *__restrict__ ones_count /* [sig] */, uint32_t *__restrict__ ones_list /* [sig][n] */,
+                                                         int ones_as_mask)
 {
     __shared__ uint32_t hist[NMSM_BUCKETS];
     const size_t sig = blockIdx.y;
@@ -544,7 +565,9 @@ __global__ __launch_bounds__(1024) void nmsm_hist_kernel(uint32_t n, const uint3
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
         int d[NMSM_W];
         if (scalar_digits8(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d)) {
-            ones_list[sig * n + atomicAdd(&ones_count[sig], 1u)] = i;
+            // the scalar is one: a bit of the signature's mask (zeroed by the caller; the first n / 32 words of its list), or an entry of its list
+            if (ones_as_mask) atomicOr(&ones_list[sig * n + (i >> 5)], 1u << (i & 31));
+            else ones_list[sig * n + atomicAdd(&ones_count[sig], 1u)] = i;
             continue;
         }
 #pragma unroll
@@ -668,11 +691,21 @@ __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32
     constexpr int SLOT = 4 * F::WORDS + 1, PER = 64 / F::LANES;                 // PER chains per workgroup (F::LANES lanes each)
     __shared__ uint32_t lds[32 * SLOT];
     const size_t sig = blockIdx.y;
-    const uint32_t nthreads = gridDim.x * PER, t = blockIdx.x * PER + threadIdx.x / F::LANES, cnt = ones_count[sig];
+    const uint32_t nthreads = gridDim.x * PER, t = blockIdx.x * PER + threadIdx.x / F::LANES;
     const uint32_t *list = ones_list + sig * m.n;
     XyzzT<F> acc = pt_identity<F>();
-    for (uint32_t k = t; k < cnt; k += nthreads)
-        acc = pt_add_affine(acc, load_row<F>(m.table + (size_t)list[k] * Grp<F>::PT_WORDS));      // window 0 of the table = the point itself
+    if (m.ones_table) {
+        // `list` is the mask of ones: one addition per group of eight points whose byte of it is not zero
+        const uint32_t groups = (m.n + 7) / 8;
+        for (uint32_t g = t; g < groups; g += nthreads) {
+            const uint32_t byte = (list[g >> 2] >> (8 * (g & 3))) & 0xffu;
+            if (byte) acc = pt_add_affine(acc, load_row<F>(m.ones_table + ((size_t)g * 255 + (byte - 1)) * Grp<F>::PT_WORDS));
+        }
+    } else {
+        const uint32_t cnt = ones_count[sig];
+        for (uint32_t k = t; k < cnt; k += nthreads)
+            acc = pt_add_affine(acc, load_row<F>(m.table + (size_t)list[k] * Grp<F>::PT_WORDS));  // window 0 of the table = the point itself
+    }
     const int lane = threadIdx.x / F::LANES;
     for (int stride = PER / 2; stride >= 1; stride >>= 1) {
         if (lane >= stride && lane < 2 * stride) store_bucket<F>(lds + (lane - stride) * SLOT, acc);
@@ -893,6 +926,7 @@ struct frw_msm {
     int window_bits;            // 16: the dense pipeline (32,768 buckets), 8: the narrow one (128 buckets)
     frw::MsmDev dev;
     void *table;
+    void *ones_table;           // narrow handles of up to 2^18 points (MsmDev::ones_table), else null
 };
 
 namespace {
@@ -936,6 +970,8 @@ template <class F> int msm_load(int device, int group, size_t num_points, const 
     m->group = group;
     m->window_bits = window_bits;
     m->table = nullptr;
+    m->ones_table = nullptr;
+    m->dev.ones_table = nullptr;
     m->dev.n = (uint32_t)num_points;
     void *d_bases = nullptr;
     const size_t table_bytes = (size_t)(256 / window_bits) * num_points * frw::Grp<F>::PT_WORDS * 4, ark_bytes = (size_t)frw::Grp<F>::ARK_WORDS * 4;
@@ -949,11 +985,25 @@ template <class F> int msm_load(int device, int group, size_t num_points, const 
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (d_bases) (void)hipFree(d_bases);
+    d_bases = nullptr;
+    // the subset sums of every group of eight points, for the scalars equal to one (narrow handles of per-signature size: an aggregate
+    // statement's tables are tens of gigabytes as it is, and its ones go through the list)
+    if (e == hipSuccess && window_bits == 8 && num_points <= ((size_t)1 << 18)) {
+        const size_t entries = (num_points + 7) / 8 * 255;
+        e = hipMalloc(&m->ones_table, entries * frw::Grp<F>::PT_WORDS * 4);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(frw::msm_ones_table_kernel<F>, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)num_points,
+                               (const uint32_t *)m->table, (uint32_t *)m->ones_table);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
     if (e != hipSuccess) {
         frw_msm_free(m);
         return frw::record_hip_error(e, "frw_msm_load");
     }
     m->dev.table = (const uint32_t *)m->table;
+    m->dev.ones_table = (const uint32_t *)m->ones_table;
     *out = m;
     return FRW_OK;
 }
@@ -1072,13 +1122,17 @@ template <class F> NmsmBufs nmsm_carve(void *d_workspace, size_t cnt, uint32_t n
     b.bucket_sums = b.folded_ones + (b.ones_stride > 64 ? cnt * (size_t)64 * BW : 0);
     return b;
 }
-hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *sc, size_t stride_words, int montgomery, hipStream_t st)
+// ones_as_mask: every table that will be summed with this sort has the subset sums of its groups of eight (MsmDev::ones_table): the
+// scalars equal to one are then recorded as a bit mask (the first n / 32 words of each signature's list) instead of a list
+hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *sc, size_t stride_words, int montgomery, bool ones_as_mask, hipStream_t st)
 {
     const uint32_t slices = frw::nmsm_slices(n);
     const dim3 sgrid(slices, (unsigned)cnt);
     hipError_t e = hipMemsetAsync(b.ones_count, 0, cnt * 4, st);
+    if (e == hipSuccess && ones_as_mask) e = hipMemsetAsync(b.ones_list, 0, cnt * (size_t)n * 4, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(frw::nmsm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.slice_hist, b.ones_count, b.ones_list);
+    hipLaunchKernelGGL(frw::nmsm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.slice_hist, b.ones_count, b.ones_list,
+                       ones_as_mask ? 1 : 0);
     hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3((unsigned)cnt), dim3(frw::NMSM_BUCKETS), 0, st, b.slice_hist, b.counts, b.offsets, b.item_first, b.items,
                        b.item_count, b.target, b.max_items, slices);
     hipLaunchKernelGGL(frw::nmsm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.offsets, b.slice_hist, b.entries);
@@ -1087,15 +1141,17 @@ hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *
 // `sorted`: whose sort arrays to read; `own`: where this table's partial sums go (the same carve for a sum on its own).  Every kernel
 // here is a grid of single wavefronts: none of them can be kept waiting by a kernel that fills the chip.
 template <class F, bool PREFETCH>
-hipError_t nmsm_accumulate(const frw_msm *m, const NmsmBufs &sorted, const NmsmBufs &own, size_t cnt, uint32_t *d_out, hipStream_t st)
+hipError_t nmsm_accumulate(const frw_msm *m, const NmsmBufs &sorted, const NmsmBufs &own, size_t cnt, uint32_t *d_out, bool ones_as_mask, hipStream_t st)
 {
     const uint32_t n = m->dev.n;
+    frw::MsmDev dev = m->dev;
+    if (!ones_as_mask) dev.ones_table = nullptr;                    // the sort left a list of the ones, not a mask
     typedef typename frw::BulkPolicy<F>::type FB;
     constexpr bool BULK_PREFETCH = PREFETCH || FB::LANES > 1;       // two lanes per point: the registers for the prefetch are there
     // the ones' partial sums: enough threads to occupy the chip (~2^16 over the batch), between 256 and 4,096 per signature
     int ones_threads = 256;
     while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * cnt < 65536) ones_threads <<= 1;
-    hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, sorted.ones_count, sorted.ones_list,
+    hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, (unsigned)cnt), dim3(64), 0, st, dev, sorted.ones_count, sorted.ones_list,
                        own.partial_ones, own.ones_stride);
     const uint32_t *ones_for_finish = own.partial_ones;
     uint32_t ones_groups = (uint32_t)ones_threads / 64, ones_finish_stride = own.ones_stride;
@@ -1105,7 +1161,7 @@ hipError_t nmsm_accumulate(const frw_msm *m, const NmsmBufs &sorted, const NmsmB
         ones_groups = 64;
         ones_finish_stride = 64;
     }
-    hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((sorted.max_items * FB::LANES + 63) / 64, (unsigned)cnt), dim3(64), 0, st, m->dev,
+    hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((sorted.max_items * FB::LANES + 63) / 64, (unsigned)cnt), dim3(64), 0, st, dev,
                        sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items);
     // the items of a bucket: added up by a workgroup per bucket where latency counts (a lone proof: 12 ms -> 8.6), by the fold's own
     // thread where throughput does (the combine is nine times the wave-level additions: 3 % of a 64-proof call)
@@ -1132,8 +1188,9 @@ int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t s
     for (size_t lo = 0; e == hipSuccess && lo < batch; lo += chunk) {
         const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
         const NmsmBufs b = nmsm_carve<F>(d_workspace, cnt, n);
-        e = nmsm_sort(b, n, cnt, (const uint32_t *)(d_scalars + lo * scalar_stride * 4), scalar_stride * 8, montgomery, st);
-        if (e == hipSuccess) e = nmsm_accumulate<F, PREFETCH>(m, b, b, cnt, (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)), st);
+        e = nmsm_sort(b, n, cnt, (const uint32_t *)(d_scalars + lo * scalar_stride * 4), scalar_stride * 8, montgomery, m->ones_table != nullptr, st);
+        if (e == hipSuccess)
+            e = nmsm_accumulate<F, PREFETCH>(m, b, b, cnt, (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)), m->ones_table != nullptr, st);
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
 }
@@ -1144,6 +1201,7 @@ extern "C" void frw_msm_free(frw_msm *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->table) (void)hipFree(m->table);
+    if (m->ones_table) (void)hipFree(m->ones_table);
     delete m;
 }
 
@@ -1181,6 +1239,7 @@ extern "C" int frw_msm_info(const frw_msm *m, frw_msm_info_t *out)
     out->window_bits = m->window_bits;
     out->num_windows = 256 / m->window_bits;
     out->table_bytes = (uint64_t)out->num_windows * m->dev.n * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
+    if (m->ones_table) out->table_bytes += (uint64_t)((m->dev.n + 7) / 8) * 255 * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
     out->workspace_bytes_per_signature = narrow ? (g2 ? nmsm_workspace_per_signature<Fq2Field>(m->dev.n) : nmsm_workspace_per_signature<FqField>(m->dev.n))
                                                 : (g2 ? msm_workspace_per_signature<Fq2Field>(m->dev.n) : msm_workspace_per_signature<FqField>(m->dev.n));
     return FRW_OK;
@@ -1505,7 +1564,8 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
                            (uint32_t *)zext, stride * 8, nv);
         // ONE counting sort of the digits of z ++ [1, r, s] for all four witness-side sums (its arrays live in a_query's workspace)
         const NmsmBufs sorted = nmsm_carve<FqField>(msm_ws[1], cnt, (uint32_t)stride);
-        e = nmsm_sort(sorted, (uint32_t)stride, cnt, (const uint32_t *)zext, stride * 8, 1, st);
+        const bool ones_as_mask = pk->a->ones_table && pk->b1->ones_table && pk->l->ones_table && pk->b2->ones_table;
+        e = nmsm_sort(sorted, (uint32_t)stride, cnt, (const uint32_t *)zext, stride * 8, 1, ones_as_mask, st);
         if (e != hipSuccess) break;
         e = hipEventRecord(pk->fork, st);
         forked = true;
@@ -1514,13 +1574,13 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (e != hipSuccess) break;
         // the two chains that end in a scalar multiplication first (the longest of a proof made alone), then G2 with l_query behind
         // it, then the witness map and the sum over h_query
-        e = nmsm_accumulate<FqField, true>(pk->a, sorted, nmsm_carve<FqField>(msm_ws[1], cnt, (uint32_t)stride), cnt, (uint32_t *)pA, pk->side[0]);
+        e = nmsm_accumulate<FqField, true>(pk->a, sorted, nmsm_carve<FqField>(msm_ws[1], cnt, (uint32_t)stride), cnt, (uint32_t *)pA, ones_as_mask, pk->side[0]);
         if (e == hipSuccess)
-            e = nmsm_accumulate<FqField, true>(pk->b1, sorted, nmsm_carve<FqField>(msm_ws[2], cnt, (uint32_t)stride), cnt, (uint32_t *)pB1, pk->side[1]);
+            e = nmsm_accumulate<FqField, true>(pk->b1, sorted, nmsm_carve<FqField>(msm_ws[2], cnt, (uint32_t)stride), cnt, (uint32_t *)pB1, ones_as_mask, pk->side[1]);
         if (e == hipSuccess)
-            e = nmsm_accumulate<Fq2Field, false>(pk->b2, sorted, nmsm_carve<Fq2Field>(msm_ws[4], cnt, (uint32_t)stride), cnt, (uint32_t *)pB2, pk->side[2]);
+            e = nmsm_accumulate<Fq2Field, false>(pk->b2, sorted, nmsm_carve<Fq2Field>(msm_ws[4], cnt, (uint32_t)stride), cnt, (uint32_t *)pB2, ones_as_mask, pk->side[2]);
         if (e == hipSuccess)
-            e = nmsm_accumulate<FqField, true>(pk->l, sorted, nmsm_carve<FqField>(msm_ws[3], cnt, (uint32_t)stride), cnt, (uint32_t *)pL, pk->side[2]);
+            e = nmsm_accumulate<FqField, true>(pk->l, sorted, nmsm_carve<FqField>(msm_ws[3], cnt, (uint32_t)stride), cnt, (uint32_t *)pL, ones_as_mask, pk->side[2]);
         if (e != hipSuccess) break;
         rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
         if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->h, cnt, h, n, 1, pH, msm_ws[0], cnt * sz.msm[0], pk->main);

@@ -32,7 +32,7 @@ for name, c in per.items():
     print(name)
     for k, v in sorted(c.items()):
         print("    %-22s %.4g" % (k, v))
-b = per.get("msm_bucket_kernel<frw::FqField, true>") or {}
+b = per.get("msm_bucket_kernel<FqField, true>") or {}
 if b.get("SQ_INSTS_VALU"):
     madds = 64 * 16 * 262143            # one per (signature, window, point) with a non-zero digit: an upper bound (digits are zero with probability 2^-16)
     print()
