@@ -489,19 +489,22 @@ def groth16_h_query(eng, n, t=0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF
     return eng.g1_fixed_base(lim), (t, c)
 
 
-def witness_side_additions(inst_row, wit_row):
+def witness_side_additions(inst_row, wit_row, first_index=0):
     """Point additions the four witness-side sums of ONE proof perform in the narrow pipeline (frw_msm.hip: 8-bit signed
     windows, scalars that are one summed apart, zeros skipped), counted on the host from one signature's assignment
     z = instance ++ witness (Montgomery limbs): (scalars equal to one, non-zero digits of all the others).  The three
-    blinding scalars appended to z add at most 3 x 32 digits and are left out."""
+    blinding scalars appended to z add at most 3 x 32 digits and are left out.  Third value: the groups of eight consecutive points
+    (index = first_index + position) with at least one such scalar -- what the ones cost through the byte-pattern tables."""
     r_inv = pow(1 << 256, -1, R_FR)
     ones = digits = 0
-    for row in np.concatenate([inst_row, wit_row]).reshape(-1, 4):
+    groups = set()                                   # groups of eight consecutive points holding at least one scalar equal to one
+    for idx, row in enumerate(np.concatenate([inst_row, wit_row]).reshape(-1, 4)):
         if not row.any():
             continue
         v = int.from_bytes(row.tobytes(), "little") * r_inv % R_FR
         if v == 1:
             ones += 1
+            groups.add((idx + first_index) >> 3)
             continue
         carry = 0
         for j in range(32):
@@ -511,7 +514,7 @@ def witness_side_additions(inst_row, wit_row):
                 d -= 256
                 carry = 1
             digits += d != 0
-    return ones, digits
+    return ones, digits, len(groups)
 
 
 def groth16_roofline(eng, log_n, n, ni, nw, inst_row, wit_row, proofs_per_s):
@@ -522,13 +525,14 @@ def groth16_roofline(eng, log_n, n, ni, nw, inst_row, wit_row, proofs_per_s):
     nothing else; frac = achieved / peak."""
     rates = eng.valu_rates()
     (mm, mo), (am, ao) = point_op_instructions(MADD_OPS), point_op_instructions(ADD_OPS)
-    ones, digits = witness_side_additions(inst_row, wit_row)
-    ones_w, digits_w = witness_side_additions(inst_row[:0], wit_row)          # l_query: the witness part alone
-    # mixed additions: every non-zero digit and every one; full additions: the items of the 128 buckets, the suffix scan and the
-    # tree of the one-workgroup fold (~2 per bucket + one per ones' partial sum), all small beside the former
-    g1_madds = 2 * (ones + digits) + (ones_w + digits_w)
+    ones, digits, one_groups = witness_side_additions(inst_row, wit_row)
+    ones_w, digits_w, one_groups_w = witness_side_additions(inst_row[:0], wit_row, first_index=ni)     # l_query: the witness part alone
+    # mixed additions: every non-zero digit, and ONE per group of eight points that holds a scalar equal to one (the byte-pattern
+    # tables of frw_msm.hip); full additions: the items of the 128 buckets, the suffix scan and the tree of the one-wavefront fold
+    # (~2 per bucket + one per ones' partial sum), all small beside the former
+    g1_madds = 2 * (one_groups + digits) + (one_groups_w + digits_w)
     g1_adds = 3 * (2 * 128 + 64)
-    g2_madds, g2_adds = ones + digits, 2 * 128 + 64
+    g2_madds, g2_adds = one_groups + digits, 2 * 128 + 64
     G2_FACTOR = 3                                                             # an Fq2 product = three Fq products (Karatsuba); frw_fq29.h
     h_madds, h_adds = 16 * (n - 1), 2 * 32768
     madds = h_madds + g1_madds + G2_FACTOR * g2_madds
@@ -544,7 +548,7 @@ def groth16_roofline(eng, log_n, n, ni, nw, inst_row, wit_row, proofs_per_s):
             "frac": round(proofs_per_s / peak_proofs, 4),
             "per_proof": {"fq_products": fq_products, "fr_products": fr_products,
                           "mixed_additions": {"h_query": h_madds, "a_query + b_g1_query + l_query": g1_madds, "b_g2_query (Fq2)": g2_madds},
-                          "scalars_equal_to_one": ones, "non_zero_8_bit_digits_of_the_others": digits,
+                          "scalars_equal_to_one": ones, "groups_of_eight_points_holding_one": one_groups, "non_zero_8_bit_digits_of_the_others": digits,
                           "g2_priced_as_g1_times": G2_FACTOR},
             "peak_is": "%d SIMDs x 64 lanes issuing only the instructions of these products: an Fq product %d multiplies + %d others, "
                        "an Fr product %d + %d; multiplies at %.1f, the others at %.1f wave-instructions/SIMD/us (measured in this "
