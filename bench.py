@@ -466,7 +466,7 @@ FQ_MUL_MULTIPLY, FQ_MUL_OTHER = 406, 90
 FQ_SQR_MULTIPLY, FQ_SQR_OTHER = 315, 101
 FQ_PAIR_MULTIPLY, FQ_PAIR_OTHER = 602, 135
 # the point formulas in those units (frw_fq29.h): mixed addition = 8 M + 2 S of which one M pair shares a reduction; full addition 12 M + 2 S
-MSM_VALU_PER_MADD = 5805          # all vector instructions msm_bucket_kernel<FqField, true> issues per wavefront per mixed addition (PMC, round 4)
+MSM_VALU_PER_MADD = 5803          # all vector instructions msm_bucket_kernel<FqField, true> issues per wavefront per mixed addition (PMC, round 4)
 MADD_OPS = {"mul": 6, "sqr": 2, "pair": 1}
 ADD_OPS = {"mul": 10, "sqr": 2, "pair": 1}
 

@@ -38,7 +38,8 @@ if b.get("SQ_INSTS_VALU"):
     print()
     print("msm_bucket_kernel<FqField, true>: %.0f vector instructions per wavefront per mixed addition of its 64 lanes"
           % (b["SQ_INSTS_VALU"] / (madds / 64.0)))
-    print("  (the instruction-priced roofline of bench.py counts 4,074 multiplies + 967 others = 5,041 of them: the field products alone)")
+    print("  (the instruction-priced roofline of bench.py counts 3,668 multiplies + 877 others = 4,545 of them: the field products alone -- six products,")
+    print("   two squares and one a b - c d with a shared reduction per mixed addition)")
     if b.get("SQ_ACTIVE_INST_VALU") and b.get("SQ_BUSY_CYCLES"):
         print("  SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = %.3f   SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = %.3f" % (
             b["SQ_ACTIVE_INST_VALU"] / b["SQ_WAVE_CYCLES"], b["SQ_WAIT_INST_ANY"] / b["SQ_WAVE_CYCLES"]))
