@@ -69,3 +69,30 @@ def test_pok_sig_example_produces_a_proof_the_oracle_verifier_accepts():
     assert E.verify_proof(vk, public, proof)
     public[0] = (public[0] + 1) % 12289
     assert not E.verify_proof(vk, public, proof)
+
+
+@pytest.mark.gpu
+def test_aggregate_sig_example_one_proof_for_four_genuine_signatures():
+    """examples/aggregate_sig.py = what the reference's falcon-aggregate-sig (upstream a stub) would do, for the four genuine signatures of
+    tests/golden/falcon_signed.json in a mixed order (512, 1024, 1024, 512): encoded (pk, msg, sig) -> decoders + SHAKE256 -> witnesses ->
+    ONE proof on the 2^19 domain, all on the device; the example exits non-zero unless the product's verifier accepts the statement and
+    rejects another.  Independently: ark-groth16's verify_proof restated with a real pairing (oracle/bls12_381.py) accepts the printed
+    proof for the printed 6,144 public inputs and rejects it when one of them changes."""
+    import json
+    import sys
+    from oracle import bls12_381 as E
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "aggregate_sig.py"), os.path.join(ROOT, "tests", "golden", "falcon_signed.json"),
+                          "--cases", "0,2,3,1", "--seed", "9", "--json"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    ints = lambda hx: [int(v, 16) for v in hx]
+    vk = {"alpha_g1": E.from_limbs(ints(j["vk"]["alpha_g1"])), "beta_g2": E.g2_from_limbs(ints(j["vk"]["beta_g2"])),
+          "gamma_g2": E.g2_from_limbs(ints(j["vk"]["gamma_g2"])), "delta_g2": E.g2_from_limbs(ints(j["vk"]["delta_g2"])),
+          "gamma_abc_g1": [E.from_limbs(ints(r)) for r in j["vk"]["gamma_abc_g1"]]}
+    proof = (E.from_limbs(ints(j["proof"]["a"])), E.g2_from_limbs(ints(j["proof"]["b"])), E.from_limbs(ints(j["proof"]["c"])))
+    public = [int(x) for x in j["public_inputs"]]
+    assert j["verified"] is True and j["logn"] == [9, 10, 10, 9]
+    assert len(public) == 2 * (512 + 1024 + 1024 + 512) and all(x < 12289 for x in public)
+    assert E.verify_proof(vk, public, proof)
+    public[3000] = (public[3000] + 1) % 12289                          # inside the third statement
+    assert not E.verify_proof(vk, public, proof)
