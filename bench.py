@@ -774,6 +774,10 @@ def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True):
            "checked": "constraint system satisfied (0 violated rows of %d); deg h <= n - 2; proof accepted by frw_groth16_verify for its "
                       "%d public inputs and rejected with one input of the last statement changed; bit-exactness of (A, B, C) against the "
                       "prover restated in the exponent: tests/test_gpu_aggregate.py" % (nc, ni - 1)}
+    out["configs4_on_one_gpu"] = {"signatures": 1024, "aggregates_of_%d" % k: -(-1024 // k), "seconds": round(-(-1024 // k) * ms * 1e-3, 3),
+                                  "note": "BASELINE configs[4]'s 1,024 signatures as aggregates of this size, one after the other on ONE GPU (the 2^28 "
+                                          "domain of a single 1,024-statement proof is not one GPU's: DESIGN 5.7); on a node the aggregates shard "
+                                          "over the GPUs (bench.py --gpus N: scaling_curves.prove.aggregate)"}
     if separate is not None and k and all(g == 10 for g in logns):
         per = separate["proofs_per_s"]
         out["against_k_separate_proofs"] = {

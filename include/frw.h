@@ -368,7 +368,8 @@ typedef struct frw_msm frw_msm;
 typedef struct {
     uint64_t num_points;
     int32_t window_bits, num_windows;          /* 16, 16; a _narrow handle: 8, 32 */
-    uint64_t table_bytes;                      /* 16 x num_points x 112 */
+    uint64_t table_bytes;                      /* 16 x num_points x 112 (G2: 224); a _narrow handle: 32 x num_points x 112, and for up to 2^18
+                                                * points as much again for the sums of the 255 non-empty subsets of every group of eight points */
     uint64_t workspace_bytes_per_signature;    /* sort keys (64 num_points bytes), the list of scalars equal to one (4 num_points),
                                                 * 32,768 buckets + 131,072 work items + 4,096 partial sums x 240 bytes (G2: 464),
                                                 * counters; a _narrow handle: 128 + 4 num_points bytes of keys and list, the partial
@@ -390,6 +391,8 @@ int frw_msm_g2_load(int device, size_t num_points, const uint64_t *bases, frw_ms
  * instead of 32,768, so nothing is spent on folding empty buckets.  For sums whose scalars are mostly zero, one or small -- a
  * witness as scalars (the sums over a_query, b_g1_query, b_g2_query, l_query: frw_groth16_pk_load uses these) -- this is three
  * times faster than the 16-bit tables; for dense 255-bit scalars (h) it is twice the additions and the 16-bit tables win.
+ * A narrow handle of up to 2^18 points also holds, for every group of eight consecutive points, the sums of its 255 non-empty subsets:
+ * the scalars equal to one (45 % of a Falcon witness, in long runs of booleans) then cost one addition per group instead of one each.
  * Every other call (frw_msm_info, frw_msm_g1_dev / _g2_dev, frw_msm_free) takes either kind of handle. */
 int frw_msm_g1_load_narrow(int device, size_t num_points, const uint64_t *bases, frw_msm **out);
 int frw_msm_g2_load_narrow(int device, size_t num_points, const uint64_t *bases, frw_msm **out);
