@@ -308,10 +308,11 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uin
 constexpr int MSM_SIZE_CLASSES = 1024;         // sizes >= this share the first class
 constexpr int MSM_MAX_ITEMS = 131072;          // >= 32,768 + 32,768 / (1.5 / 4): the finest split (a lone signature), a multiple of 64
 // Sums over more than 2^18 points (an aggregate statement's h_query: ONE signature, 2^22 points, buckets of 2,048 entries) are cut
-// finer still: `finer` = 12 makes a bucket of the mean size 8 items of 256 entries -- 262,144 items, two full rounds of the chip's
+// finer still: `finer` = 24 makes a bucket of the mean size 16 items of 128 entries -- 524,288 items, four rounds of the chip's
 // 131,072 thread slots at two wavefronts per SIMD (with 4 it was 98,304 items: a quarter of the slots idle and half the SIMDs with a
-// single wavefront, 1.55 x the time per addition of a 64-signature call).  Bound: 32,768 + 32,768 finer / 1.5.
-constexpr int MSM_MAX_ITEMS_LARGE = 32768 + 32768 * 12 * 2 / 3;     // 294,912
+// single wavefront, 1.55 x the time per addition of a 64-signature call: 16.7 ms; with 12, two rounds: 14.4 ms; with 24: 13.4 ms, the
+// combine's extra additions included).  Bound: 32,768 + 32,768 finer / 1.5.
+constexpr int MSM_MAX_ITEMS_LARGE = 32768 + 32768 * 24 * 2 / 3;     // 557,056
 __host__ __device__ constexpr uint32_t msm_max_items(uint32_t n) { return n > (1u << 18) ? (uint32_t)MSM_MAX_ITEMS_LARGE : (uint32_t)MSM_MAX_ITEMS; }
 // `finer`: 1 for a batch, 4 for one or two signatures at a time -- a bucket of the mean size is then three items instead of one
 // (a lone proof waits for ~128 dependent additions otherwise), and msm_combine_kernel adds them up
@@ -1072,7 +1073,7 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts, slices);
         hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
         // (four at a time: 12.6 ms with the finer split, 12.1 without); beyond 2^18 points: see MSM_MAX_ITEMS_LARGE
-        const uint32_t finer = cnt <= 2 ? (n > (1u << 18) ? 12u : 4u) : 1u;
+        const uint32_t finer = cnt <= 2 ? (n > (1u << 18) ? 24u : 4u) : 1u;
         hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count, finer, max_items);
         hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
         hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(max_items / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
