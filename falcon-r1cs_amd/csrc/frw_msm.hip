@@ -488,7 +488,8 @@ __global__ __launch_bounds__(64, 2) void msm_fold1_kernel(const uint32_t *__rest
 }
 // Stage 2: 512 threads add `each` partial sums each, a tree through LDS, one inversion, ark-ff's bytes out
 template <class F>
-__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint32_t *__restrict__ partial, int each, uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
+__global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint32_t *__restrict__ partial, int each,
+                                                                     uint32_t *__restrict__ out /* [batch][ARK_WORDS], or [batch][BK_WORDS] */, int xyzz_out)
 {
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
     __shared__ uint32_t lds[MSM_FOLD_THREADS / 2 * SLOT];            // 58 KB (G1) / 116 KB (G2): the upper half of a tree level parks here
@@ -503,7 +504,11 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
         if (t < stride) sum = pt_add(sum, load_bucket<F>(lds + t * SLOT));
         __syncthreads();
     }
-    if (t == 0) store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
+    // xyzz_out: the sum as it stands, no inversion -- for a caller that goes on adding (frw_groth16_prove_dev)
+    if (t == 0) {
+        if (xyzz_out) store_bucket<F>(out + sig * BW, sum);
+        else store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
+    }
 }
 
 // ---- narrow windows: the witness-side sums ---------------------------------------------------------------------------------------
@@ -785,7 +790,7 @@ __global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restr
                                                          const uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS], or null */,
                                                          const uint32_t *__restrict__ partial_ones /* [sig][ones_stride][BK_WORDS] */,
                                                          int ones_groups, uint32_t ones_stride, uint32_t target, uint32_t max_items,
-                                                         uint32_t *__restrict__ out /* [batch][ARK_WORDS] */)
+                                                         uint32_t *__restrict__ out /* [batch][ARK_WORDS], or [batch][BK_WORDS] */, int xyzz_out)
 {
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES, NB = NMSM_BUCKETS / PER;
     constexpr int LOG_PER = PER == 64 ? 6 : 5, LOG_NB = NB == 2 ? 1 : 2;
@@ -869,7 +874,10 @@ __global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restr
         if (add) sum = pt_add(sum, load_bucket<F>(p));
         __syncthreads();
     }
-    if (i == 0) store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
+    if (i == 0) {
+        if (xyzz_out) store_bucket<F>(out + sig * BW, sum);          // as msm_fold2_kernel
+        else store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
+    }
 }
 
 // ---- k G for many scalars: the FixedBaseMSM of ark-groth16's generator (generator.rs builds h_query, a_query, l_query and
@@ -1037,7 +1045,7 @@ template <class F> int fixed_base(int device, size_t count, const uint64_t *scal
 // the whole call for one group; `d_out` rows are ARK_WORDS / 2 uint64_t
 template <class F, bool PREFETCH>
 int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery, uint64_t *d_out,
-            void *d_workspace, size_t workspace_bytes, hipStream_t st)
+            void *d_workspace, size_t workspace_bytes, hipStream_t st, bool xyzz_out = false)
 {
     const uint32_t n = m->dev.n;
     const size_t per = msm_workspace_per_signature<F>(n);
@@ -1088,7 +1096,7 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         else if (log_chunk == 5) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 5>), dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, buckets, partial);
         else hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 3>), dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, buckets, partial);
         hipLaunchKernelGGL(frw::msm_fold2_kernel<F>, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, partial,
-                           (int)(t1 / frw::MSM_FOLD_THREADS), (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)));
+                           (int)(t1 / frw::MSM_FOLD_THREADS), (uint32_t *)d_out + lo * (xyzz_out ? BW : frw::Grp<F>::ARK_WORDS), xyzz_out ? 1 : 0);
         e = hipGetLastError();
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
@@ -1142,7 +1150,8 @@ hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *
 // `sorted`: whose sort arrays to read; `own`: where this table's partial sums go (the same carve for a sum on its own).  Every kernel
 // here is a grid of single wavefronts: none of them can be kept waiting by a kernel that fills the chip.
 template <class F, bool PREFETCH>
-hipError_t nmsm_accumulate(const frw_msm *m, const NmsmBufs &sorted, const NmsmBufs &own, size_t cnt, uint32_t *d_out, bool ones_as_mask, hipStream_t st)
+hipError_t nmsm_accumulate(const frw_msm *m, const NmsmBufs &sorted, const NmsmBufs &own, size_t cnt, uint32_t *d_out, bool ones_as_mask, hipStream_t st,
+                           bool xyzz_out = false)
 {
     const uint32_t n = m->dev.n;
     frw::MsmDev dev = m->dev;
@@ -1172,7 +1181,7 @@ hipError_t nmsm_accumulate(const frw_msm *m, const NmsmBufs &sorted, const NmsmB
                            own.partial_items, own.bucket_sums, sorted.target, sorted.max_items);
     hipLaunchKernelGGL(frw::nmsm_finish_kernel<FB>, dim3((unsigned)cnt), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first, own.partial_items,
                        combine ? own.bucket_sums : (uint32_t *)nullptr, ones_for_finish, (int)ones_groups, ones_finish_stride, sorted.target, sorted.max_items,
-                       d_out);
+                       d_out, xyzz_out ? 1 : 0);
     return hipGetLastError();
 }
 // the narrow pipeline for one group
@@ -1306,50 +1315,70 @@ __global__ __launch_bounds__(64) void groth16_tails_kernel(size_t batch, const u
 // k P for one point per signature (s g_a and r (g1_b - s delta1) of g_c); runs on the side stream that made P.  One thread
 // per signature and a point that exists only now: the chain of doublings is the latency of a proof made alone, so the scalar
 // comes split by the endomorphism (k = k0 + lambda k1, done on the host where r and s arrive: glv_split) and the two 128-bit
-// halves share their doublings (P, phi(P) and P + phi(P): 128 doublings and ~96 additions instead of 256 and ~128).
+// halves share their doublings: 128 doublings and ~96 additions of P, phi(P) or P + phi(P) instead of 256 and ~128.
+// P arrives in XYZZ coordinates as its sum left it and k P leaves the same way (an inversion is a fifth of this kernel, and
+// the proof needs one at the very end only: groth16_finish_kernel).  phi(P) and P + phi(P) come for free in the same
+// denominators -- phi(x, y) = (beta x, y), and since the two have the same y their chord is horizontal:
+// P + phi(P) = (-(1 + beta) x, -y) -- so the loop is ONE doubling and ONE addition whose operand is selected: the same
+// instructions for every lane of the wavefront whatever its bits, and a loop small enough for the instruction cache (the
+// three-way branch over two mixed additions and a full one was 0.4 ms slower for a proof made alone).
 __global__ __launch_bounds__(64) void groth16_scale_kernel(size_t batch, const uint32_t *__restrict__ split /* [batch][2][8]: k0 | k1, 128 bits each */,
-                                                           int which, const uint32_t *__restrict__ pts, uint32_t *__restrict__ out /* [batch][24] */)
+                                                           int which, const uint32_t *__restrict__ pts /* [batch][BK_WORDS] */,
+                                                           uint32_t *__restrict__ out /* [batch][BK_WORDS] */)
 {
+    typedef FqField F;
+    constexpr int BW = Grp<F>::BK_WORDS;
     const size_t sig = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (sig >= batch) return;
-    const AffineT<FqField> base = load_ark_point<FqField>(pts + sig * 24);
-    AffineT<FqField> endo = base;
-    endo.x = fq_mul(base.x, fq_const(G1_ENDO_BETA29));
-    const XyzzT<FqField> both = pt_add_affine(pt_from_affine(base), endo);     // (1 + lambda) P: never the identity for P != O
+    const XyzzT<F> base = load_bucket<F>(pts + sig * BW);                                  // X < 10 q, Y < 6 q
+    const Fq29 endo_x = fq_mul(base.x, fq_const(G1_ENDO_BETA29));                         // < 2 q
+    const Fq29 both_x = fq_neg<16>(fq_add(base.x, endo_x)), neg_y = fq_neg<16>(base.y);   // <= 16 q: operands of products only
     const uint32_t *k = split + (sig * 2 + which) * 8;
     uint32_t k0[4], k1[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { k0[i] = k[i]; k1[i] = k[4 + i]; }
-    XyzzT<FqField> m = pt_identity<FqField>();
+    XyzzT<F> m = pt_identity<F>();
+#pragma nounroll
     for (int bit = 127; bit >= 0; bit--) {
         m = pt_double(m);
         const uint32_t sel = ((k0[bit >> 5] >> (bit & 31)) & 1u) | (((k1[bit >> 5] >> (bit & 31)) & 1u) << 1);
-        if (sel == 1) m = pt_add_affine(m, base);
-        else if (sel == 2) m = pt_add_affine(m, endo);
-        else if (sel == 3) m = pt_add(m, both);
+        if (sel) {
+            XyzzT<F> q = base;
+            q.x = fq_select(sel == 1, base.x, fq_select(sel == 2, endo_x, both_x));
+            q.y = fq_select(sel == 3, neg_y, base.y);
+            m = pt_add(m, q);
+        }
     }
-    store_ark_point<FqField>(out + sig * 24, pt_to_affine(m));
+    store_bucket<F>(out + sig * BW, m);
 }
 // (A/B, negative, round 4: a workgroup of three wavefronts per scalar multiplication -- one running the 128 doublings from the LOW end
 // of the scalar and parking 2^i P in LDS, two adding the parked points where k0 / k1 have bits set, a tree, phi on the k1 sum -- is
 // bit-exact and SLOWER for a proof made alone, in two builds (the second with nothing but the doubled point live in the doubler's loop
 // and the doubling inlined): 5.5 and 4.9 ms against the 3.3 ms of the chain above; profiles/r04_groth16_scale_wave_ab.txt.  Removed.)
-// C = L + H + s A + r B1', then the proof row A (12 u64) | B (24) | C (12)
+// C = L + H + s A + r B1', then the proof row A (12 u64) | B (24) | C (12).  TWO lanes per proof: the even one adds up C, the odd one
+// holds A, and both turn their XYZZ point into ark-ff's affine bytes at once -- the one inversion on a proof's critical path
+// (the sums and the scalar multiplications hand their results over in XYZZ coordinates).
 __global__ __launch_bounds__(64) void groth16_finish_kernel(size_t batch, const uint32_t *__restrict__ a_pts, const uint32_t *__restrict__ sa_pts,
                                                             const uint32_t *__restrict__ rb1_pts, const uint32_t *__restrict__ l_pts,
-                                                            const uint32_t *__restrict__ h_pts, const uint32_t *__restrict__ b2_pts,
+                                                            const uint32_t *__restrict__ h_pts /* all five [batch][BK_WORDS] */,
+                                                            const uint32_t *__restrict__ b2_pts /* [batch][48], affine */,
                                                             uint32_t *__restrict__ proofs /* [batch][96] */)
 {
-    const size_t sig = (size_t)blockIdx.x * 64 + threadIdx.x;
+    typedef FqField F;
+    constexpr int BW = Grp<F>::BK_WORDS;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x, sig = t >> 1;
+    const bool holds_a = (t & 1) != 0;
     if (sig >= batch) return;
-    XyzzT<FqField> acc = pt_from_affine(load_ark_point<FqField>(l_pts + sig * 24));
-    acc = pt_add_affine(acc, load_ark_point<FqField>(h_pts + sig * 24));
-    acc = pt_add_affine(acc, load_ark_point<FqField>(sa_pts + sig * 24));
-    acc = pt_add_affine(acc, load_ark_point<FqField>(rb1_pts + sig * 24));
+    XyzzT<F> acc = load_bucket<F>((holds_a ? a_pts : l_pts) + sig * BW);
+#pragma nounroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t *p = j == 0 ? h_pts : j == 1 ? sa_pts : rb1_pts;
+        if (!holds_a) acc = pt_add(acc, load_bucket<F>(p + sig * BW));
+    }
     uint32_t *o = proofs + sig * 96;
-    for (int k = 0; k < 24; k++) o[k] = a_pts[sig * 24 + k];
-    for (int k = 0; k < 48; k++) o[24 + k] = b2_pts[sig * 48 + k];
-    store_ark_point<FqField>(o + 72, pt_to_affine(acc));
+    if (!holds_a)
+        for (int k = 0; k < 48; k++) o[24 + k] = b2_pts[sig * 48 + k];
+    store_ark_point<F>(o + (holds_a ? 0 : 72), pt_to_affine(acc));
 }
 }  // namespace frw
 
@@ -1500,7 +1529,8 @@ Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
         s.msm[i] = (mi.workspace_bytes_per_signature + 255) & ~(size_t)255;
         s.msm_all += s.msm[i++];
     }
-    s.pts = 6 * 96 + 192 + 64 + 64;                                   // A, B1', L, H, s A, r B1' (G1), B (G2), r and s, and their split halves
+    // A, B1', L, H, s A, r B1' (G1, XYZZ: 240 bytes each), B (G2, affine), r and s, and their split halves
+    s.pts = 6 * (size_t)frw::Grp<FqField>::BK_WORDS * 4 + 192 + 64 + 64;
     s.per = ((s.qap + s.h + s.zext + s.msm_all + s.pts) + 255) & ~(size_t)255;
     return s;
 }
@@ -1540,8 +1570,9 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         uint64_t *zext = (uint64_t *)base;            base += cnt * sz.zext;
         char *msm_ws[5];
         for (int i = 0; i < 5; i++) { msm_ws[i] = base; base += cnt * sz.msm[i]; }
-        uint64_t *pA = (uint64_t *)base, *pB1 = pA + cnt * 12, *pL = pB1 + cnt * 12, *pH = pL + cnt * 12, *pSA = pH + cnt * 12;
-        uint64_t *pRB1 = pSA + cnt * 12, *pB2 = pRB1 + cnt * 12, *d_rs = pB2 + cnt * 24, *d_split = d_rs + cnt * 8;
+        constexpr size_t XW = frw::Grp<FqField>::BK_WORDS;               // the G1 points stay in XYZZ coordinates until the proof is put together
+        uint32_t *pA = (uint32_t *)base, *pB1 = pA + cnt * XW, *pL = pB1 + cnt * XW, *pH = pL + cnt * XW, *pSA = pH + cnt * XW, *pRB1 = pSA + cnt * XW;
+        uint64_t *pB2 = (uint64_t *)(pRB1 + cnt * XW), *d_rs = pB2 + cnt * 24, *d_split = d_rs + cnt * 8;
         const uint64_t *wit = d_witness + lo * W * 4, *inst = d_instance + lo * I * 4;
         // the blinding factors: a host array (the prover draws them), uploaded before anything reads them
         e = hipMemcpyAsync(d_rs, rs + lo * 8, cnt * 64, hipMemcpyHostToDevice, st);
@@ -1575,28 +1606,29 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (e != hipSuccess) break;
         // the two chains that end in a scalar multiplication first (the longest of a proof made alone), then G2 with l_query behind
         // it, then the witness map and the sum over h_query
-        e = nmsm_accumulate<FqField, true>(pk->a, sorted, nmsm_carve<FqField>(msm_ws[1], cnt, (uint32_t)stride), cnt, (uint32_t *)pA, ones_as_mask, pk->side[0]);
+        e = nmsm_accumulate<FqField, true>(pk->a, sorted, nmsm_carve<FqField>(msm_ws[1], cnt, (uint32_t)stride), cnt, pA, ones_as_mask, pk->side[0], true);
         if (e == hipSuccess)
-            e = nmsm_accumulate<FqField, true>(pk->b1, sorted, nmsm_carve<FqField>(msm_ws[2], cnt, (uint32_t)stride), cnt, (uint32_t *)pB1, ones_as_mask, pk->side[1]);
+            e = nmsm_accumulate<FqField, true>(pk->b1, sorted, nmsm_carve<FqField>(msm_ws[2], cnt, (uint32_t)stride), cnt, pB1, ones_as_mask, pk->side[1], true);
         if (e == hipSuccess)
             e = nmsm_accumulate<Fq2Field, false>(pk->b2, sorted, nmsm_carve<Fq2Field>(msm_ws[4], cnt, (uint32_t)stride), cnt, (uint32_t *)pB2, ones_as_mask, pk->side[2]);
         if (e == hipSuccess)
-            e = nmsm_accumulate<FqField, true>(pk->l, sorted, nmsm_carve<FqField>(msm_ws[3], cnt, (uint32_t)stride), cnt, (uint32_t *)pL, ones_as_mask, pk->side[2]);
+            e = nmsm_accumulate<FqField, true>(pk->l, sorted, nmsm_carve<FqField>(msm_ws[3], cnt, (uint32_t)stride), cnt, pL, ones_as_mask, pk->side[2], true);
         if (e != hipSuccess) break;
         rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
-        if (rc == FRW_OK) rc = frw_msm_g1_dev(pk->h, cnt, h, n, 1, pH, msm_ws[0], cnt * sz.msm[0], pk->main);
+        // (h_query has n - 1 points and the dense pipeline: frw_groth16_pk_load; the scalars are h's coefficients 0 .. n - 2)
+        if (rc == FRW_OK) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
         if (rc != FRW_OK) break;
         // s g_a and r (g1_b - s delta1) as soon as their points exist, on the streams that made them
         hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[0], cnt, (const uint32_t *)d_split, 1,
-                           (const uint32_t *)pA, (uint32_t *)pSA);
+                           (const uint32_t *)pA, pSA);
         hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[1], cnt, (const uint32_t *)d_split, 0,
-                           (const uint32_t *)pB1, (uint32_t *)pRB1);
+                           (const uint32_t *)pB1, pRB1);
         for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
         if (e == hipSuccess) e = hipEventRecord(pk->join[3], pk->main);
         if (e != hipSuccess) break;
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st, pk->join[i], 0);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)pA,
+        hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3((unsigned)((2 * cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)pA,
                            (const uint32_t *)pSA, (const uint32_t *)pRB1, (const uint32_t *)pL, (const uint32_t *)pH, (const uint32_t *)pB2,
                            (uint32_t *)(d_proofs + lo * 48));
         e = hipGetLastError();
