@@ -277,8 +277,9 @@ __host__ __device__ __forceinline__ bool fq_is_zero(const Fq29 &a)
 __host__ __device__ __forceinline__ Fq29 fq_from_ark(const uint32_t *w) { return fq_mul(fq_unpack(w), fq_const(FQ29_C_IN)); }
 __host__ __device__ __forceinline__ void fq_to_ark(const Fq29 &a, uint32_t *w) { fq_pack(fq_canonical(fq_mul(a, fq_const(FQ29_C_OUT))), w); }
 
-// a^(q - 2): the inverse (a != 0 mod q); ~380 squarings + ~230 products, for the one conversion to affine per result
-__host__ __device__ inline Fq29 fq_inv(const Fq29 &a)
+// a^(q - 2): the inverse (a != 0 mod q) by Fermat; ~380 squarings + ~230 products.  Kept as the cross-check of fq_inv below
+// (tests/test_fq29_host.py); the kernels call fq_inv.
+__host__ __device__ inline Fq29 fq_inv_fermat(const Fq29 &a)
 {
     // q - 2 in 32-bit words
     uint32_t e[12];
@@ -291,6 +292,77 @@ __host__ __device__ inline Fq29 fq_inv(const Fq29 &a)
         if ((e[i >> 5] >> (i & 31)) & 1u) acc = fq_mul(acc, a);
     }
     return acc;
+}
+// The inverse by the binary extended Euclidean algorithm on twelve 32-bit words: the conversion of a result to affine
+// coordinates is the tail of every sum and of a proof (one inversion on the critical path of a proof made alone), and
+// Fermat's 610 dependent products are 0.6 ms of one lane.  Invariant u = x1 A, v = x2 A (mod q), v odd: if u is odd
+// make it the larger of the two and subtract (u -= v, x1 -= x2), then halve u and x1; u reaches 0 in at most 2 x 382 rounds of
+// ~170 plain integer instructions, v is then 1 and x2 = 1 / A.  A = a 2^406 comes in, (1 / a) 2^406 = x2 2^(3 x 406) / 2^406 goes out.
+// 2^1218 mod q; tests/test_fq29_host.py re-derives it
+constexpr LimbsQ FQ29_R3 = {{0x09217d6au, 0x1d6118bau, 0x1114b11cu, 0x0126aee7u, 0x0a55e2c4u, 0x04d63ce0u, 0x154ff87du,
+                             0x14555478u, 0x1d1bdc0du, 0x161f98d4u, 0x1d74e921u, 0x09b4345au, 0x1e5ecfb8u, 0x0000000au}};
+__host__ __device__ __forceinline__ uint32_t w12_sub(uint32_t (&r)[12], const uint32_t (&a)[12], const uint32_t (&b)[12])   // -> borrow
+{
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const uint64_t d = (uint64_t)a[k] - b[k] - borrow;
+        r[k] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 32) & 1u;
+    }
+    return borrow;
+}
+__host__ __device__ inline Fq29 fq_inv(const Fq29 &a)
+{
+    uint32_t u[12], v[12], x1[12], x2[12], d[12];
+    fq_pack(fq_reduce(a), u);
+#pragma unroll
+    for (int k = 0; k < 12; k++) { v[k] = Q32_[k]; x1[k] = k == 0 ? 1u : 0u; x2[k] = 0u; }
+    for (int round = 0; round < 2 * 382; round++) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= u[k];
+        if (any == 0) break;
+        const bool odd = (u[0] & 1u) != 0;
+        const bool swap = odd && w12_sub(d, u, v) != 0;                  // u odd and u < v: exchange the two pairs
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const uint32_t tu = u[k], tx = x1[k];
+            u[k] = swap ? v[k] : tu;   v[k] = swap ? tu : v[k];
+            x1[k] = swap ? x2[k] : tx; x2[k] = swap ? tx : x2[k];
+        }
+        // u -= v, x1 -= x2 mod q  (if u is odd)
+        (void)w12_sub(d, u, v);
+#pragma unroll
+        for (int k = 0; k < 12; k++) u[k] = odd ? d[k] : u[k];
+        const uint32_t below = w12_sub(d, x1, x2);
+        {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const uint64_t t = (uint64_t)d[k] + (below ? Q32_[k] : 0u) + carry;
+                d[k] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) x1[k] = odd ? d[k] : x1[k];
+        // u /= 2 (even now), x1 /= 2 mod q: (x1 + q) / 2 when x1 is odd; x1 + q < 2^382
+        const bool xodd = (x1[0] & 1u) != 0;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const uint64_t t = (uint64_t)x1[k] + (xodd ? Q32_[k] : 0u) + carry;
+            x1[k] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            u[k] = (u[k] >> 1) | (k + 1 < 12 ? u[k + 1] << 31 : 0u);
+            x1[k] = (x1[k] >> 1) | (k + 1 < 12 ? x1[k + 1] << 31 : 0u);
+        }
+    }
+    return fq_mul(fq_unpack(x2), fq_const(FQ29_R3));
 }
 
 // ---- Fq2 = Fq[u] / (u^2 + 1): the field of G2's coordinates ------------------------------------------------------------------------

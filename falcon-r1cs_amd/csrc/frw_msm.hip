@@ -28,6 +28,7 @@
 #include "../../include/frw.h"
 #include "frw_device.h"
 #include "frw_fq29.h"
+#include "frw_quad.h"
 #include "frw_fr29.h"
 
 namespace frw {
@@ -52,6 +53,25 @@ struct MsmDev {
     // in long runs of booleans (bit decompositions, gate outputs): with the pattern of ones of a group as ONE byte, the points whose
     // scalar is one cost one addition per group of eight instead of 3.6.  null: the ones are summed point by point from a list.
     const uint32_t *ones_table;
+};
+
+// The narrow sums of ONE sort over up to three window tables in one launch: a proof's a_query, b_g1_query and l_query sums take the
+// same scalars, so their digits are sorted once -- and with the tables side by side in the grid the three sums are ONE chain of
+// kernels instead of three (a proof made alone waits for the longest chain of small kernels, not for any one of them).  Grid row
+// `slot` = table * sigs + signature: the sort's arrays are indexed by the signature, a table's own partial sums and its result by the slot.
+struct NmsmTables {
+    uint32_t n, sigs;
+    const uint32_t *table[3], *ones_table[3];
+    __device__ __forceinline__ MsmDev of(uint32_t slot, size_t &sig) const
+    {
+        const uint32_t t = slot / sigs;
+        sig = slot - t * sigs;
+        MsmDev m;
+        m.n = n;
+        m.table = t == 0 ? table[0] : t == 1 ? table[1] : table[2];
+        m.ones_table = t == 0 ? ones_table[0] : t == 1 ? ones_table[1] : ones_table[2];
+        return m;
+    }
 };
 
 template <class F> __device__ __forceinline__ AffineT<F> load_row(const uint32_t *row)
@@ -650,13 +670,15 @@ __global__ __launch_bounds__(1024) void nmsm_scatter_kernel(uint32_t n, const ui
 }
 // one thread per (signature, item): the sum of the item's table rows
 template <class F, bool PREFETCH>
-__global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
+__global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(NmsmTables tables, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                             const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
                                                             const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items,
                                                             uint32_t target, uint32_t max_items)
 {
     constexpr int PW = Grp<F>::PT_WORDS;
-    const size_t sig = blockIdx.y;
+    const size_t slot = blockIdx.y;
+    size_t sig;
+    const MsmDev m = tables.of(blockIdx.y, sig);
     const uint32_t it = (blockIdx.x * 64 + threadIdx.x) / F::LANES;            // F::LANES adjacent lanes share an item (the two-lane Fq2)
     if (it >= item_count[sig]) return;
     const uint32_t item = items[sig * (size_t)max_items + it], b = item & (NMSM_BUCKETS - 1), part = item >> 8;
@@ -685,18 +707,20 @@ __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(MsmDev m, const uint
             acc = pt_add_affine(acc, p);
         }
     }
-    store_bucket<F>(partial_items + (sig * (size_t)max_items + it) * (size_t)Grp<F>::BK_WORDS, acc);
+    store_bucket<F>(partial_items + (slot * (size_t)max_items + it) * (size_t)Grp<F>::BK_WORDS, acc);
 }
 // the points whose scalar is one: thread t of `gridDim.x * 64` per signature takes every such-th of the list, the 64 sums of a
 // workgroup are added up through LDS (six steps instead of the 64 / 128-fold serial addition they would cost the fold), and one
 // partial sum per workgroup goes out: gridDim.x <= 64 of them per signature
 template <class F>
-__global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
-                                                          uint32_t *__restrict__ partial_ones /* [sig][groups_stride][BK_WORDS] */, uint32_t groups_stride)
+__global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(NmsmTables tables, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
+                                                          uint32_t *__restrict__ partial_ones /* [slot][groups_stride][BK_WORDS] */, uint32_t groups_stride)
 {
     constexpr int SLOT = 4 * F::WORDS + 1, PER = 64 / F::LANES;                 // PER chains per workgroup (F::LANES lanes each)
     __shared__ uint32_t lds[32 * SLOT];
-    const size_t sig = blockIdx.y;
+    const size_t slot = blockIdx.y;
+    size_t sig;
+    const MsmDev m = tables.of(blockIdx.y, sig);
     const uint32_t nthreads = gridDim.x * PER, t = blockIdx.x * PER + threadIdx.x / F::LANES;
     const uint32_t *list = ones_list + sig * m.n;
     XyzzT<F> acc = pt_identity<F>();
@@ -719,7 +743,7 @@ __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(MsmDev m, const uint32
         if (lane < stride) acc = pt_add(acc, load_bucket<F>(lds + lane * SLOT));
         __syncthreads();
     }
-    if (lane == 0) store_bucket<F>(partial_ones + (sig * (size_t)groups_stride + blockIdx.x) * (size_t)Grp<F>::BK_WORDS, acc);
+    if (lane == 0) store_bucket<F>(partial_ones + (slot * (size_t)groups_stride + blockIdx.x) * (size_t)Grp<F>::BK_WORDS, acc);
 }
 // the policy a group's narrow sum runs with: G2 in two lanes per point (frw_fq29.h Fq2PairField) -- the layout in memory is that of
 // either G2 policy; the window tables and the dense pipeline keep the one-lane form
@@ -751,16 +775,17 @@ __global__ __launch_bounds__(64, 2) void nmsm_ones_fold_kernel(const uint32_t *_
 template <class F>
 __global__ __launch_bounds__(64, 2) void nmsm_combine_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
                                                              const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
-                                                             uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS] */, uint32_t target, uint32_t max_items)
+                                                             uint32_t *__restrict__ buckets /* [slot][128][BK_WORDS] */, uint32_t target, uint32_t max_items,
+                                                             uint32_t sigs)
 {
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES;
     __shared__ uint32_t lds[32 * SLOT];
-    const size_t sig = blockIdx.y;
+    const size_t slot = blockIdx.y, sig = slot % sigs;
     const uint32_t b = blockIdx.x, lane = threadIdx.x / F::LANES;
     const uint32_t c = counts[sig * NMSM_BUCKETS + b];
     const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
-    const uint32_t *src = partial_items + (sig * (size_t)max_items + item_first[sig * NMSM_BUCKETS + b]) * (size_t)BW;
+    const uint32_t *src = partial_items + (slot * (size_t)max_items + item_first[sig * NMSM_BUCKETS + b]) * (size_t)BW;
     XyzzT<F> acc = pt_identity<F>();
     for (uint32_t j = lane; j < k; j += PER) acc = pt_add(acc, load_bucket<F>(src + (size_t)j * BW));
     for (int stride = PER / 2; stride >= 1; stride >>= 1) {
@@ -769,7 +794,7 @@ __global__ __launch_bounds__(64, 2) void nmsm_combine_kernel(const uint32_t *__r
         if ((int)lane < stride) acc = pt_add(acc, load_bucket<F>(lds + lane * SLOT));
         __syncthreads();
     }
-    if (lane == 0) store_bucket<F>(buckets + (sig * NMSM_BUCKETS + b) * (size_t)BW, acc);
+    if (lane == 0) store_bucket<F>(buckets + (slot * NMSM_BUCKETS + b) * (size_t)BW, acc);
 }
 
 // ONE WAVEFRONT per signature folds the 128 buckets and the ones' partial sums into the result.  (The first version was one
@@ -790,14 +815,15 @@ __global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restr
                                                          const uint32_t *__restrict__ buckets /* [sig][128][BK_WORDS], or null */,
                                                          const uint32_t *__restrict__ partial_ones /* [sig][ones_stride][BK_WORDS] */,
                                                          int ones_groups, uint32_t ones_stride, uint32_t target, uint32_t max_items,
-                                                         uint32_t *__restrict__ out /* [batch][ARK_WORDS], or [batch][BK_WORDS] */, int xyzz_out)
+                                                         uint32_t *__restrict__ out /* [slot][ARK_WORDS], or [slot][BK_WORDS] */, int xyzz_out,
+                                                         uint32_t sigs)
 {
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES, NB = NMSM_BUCKETS / PER;
     constexpr int LOG_PER = PER == 64 ? 6 : 5, LOG_NB = NB == 2 ? 1 : 2;
     static_assert(PER * NB == NMSM_BUCKETS && (1 << LOG_PER) == PER && (1 << LOG_NB) == NB, "64 or 32 chains of 2 or 4 buckets");
     __shared__ uint32_t lds[NMSM_BUCKETS * SLOT];                     // 29 KB (G1) / 58 KB (G2): slot i NB + k
     __shared__ uint32_t longest[NB];
-    const size_t sig = blockIdx.x;
+    const size_t slot = blockIdx.x, sig = slot % sigs;
     const int i = threadIdx.x / F::LANES;
     // the items of the chain's buckets (one each when they come combined)
     const uint32_t *src[NB];
@@ -808,13 +834,13 @@ __global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restr
     for (int k = 0; k < NB; k++) {
         const int b = i * NB + k;
         if (buckets) {
-            src[k] = buckets + (sig * NMSM_BUCKETS + b) * (size_t)BW;
+            src[k] = buckets + (slot * NMSM_BUCKETS + b) * (size_t)BW;
             mine[k] = 1;
         } else {
             const uint32_t c = counts[sig * NMSM_BUCKETS + b];
             const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
             mine[k] = c <= split ? 1u : (c + split - 1) / split;
-            src[k] = partial_items + (sig * (size_t)max_items + item_first[sig * NMSM_BUCKETS + b]) * (size_t)BW;
+            src[k] = partial_items + (slot * (size_t)max_items + item_first[sig * NMSM_BUCKETS + b]) * (size_t)BW;
             atomicMax(&longest[k], mine[k]);
         }
     }
@@ -862,7 +888,7 @@ __global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restr
             add = true; p = lds + (i * NB + 1) * SLOT;
         } else if (step < at_tree) {
             const int g = i + PER * (int)(step - at_ones);
-            add = g < ones_groups; p = partial_ones + (sig * (size_t)ones_stride + (size_t)g) * BW;
+            add = g < ones_groups; p = partial_ones + (slot * (size_t)ones_stride + (size_t)g) * BW;
         } else {
             const int stride = PER >> (step - at_tree + 1);
             if (i >= stride && i < 2 * stride) store_slot = (i - stride) * NB;
@@ -875,8 +901,8 @@ __global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restr
         __syncthreads();
     }
     if (i == 0) {
-        if (xyzz_out) store_bucket<F>(out + sig * BW, sum);          // as msm_fold2_kernel
-        else store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
+        if (xyzz_out) store_bucket<F>(out + slot * BW, sum);         // as msm_fold2_kernel
+        else store_ark_point<F>(out + slot * Grp<F>::ARK_WORDS, pt_to_affine(sum));
     }
 }
 
@@ -1147,41 +1173,48 @@ hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *
     hipLaunchKernelGGL(frw::nmsm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.offsets, b.slice_hist, b.entries);
     return hipGetLastError();
 }
-// `sorted`: whose sort arrays to read; `own`: where this table's partial sums go (the same carve for a sum on its own).  Every kernel
-// here is a grid of single wavefronts: none of them can be kept waiting by a kernel that fills the chip.
+// `sorted`: whose sort arrays to read; `own`: where the tables' partial sums go -- carved for `tables * cnt` signatures when there is
+// more than one table (the same carve as `sorted` for a sum on its own); d_out: [tables][cnt] results.  Every kernel here is a grid of
+// single wavefronts: none of them can be kept waiting by a kernel that fills the chip.
 template <class F, bool PREFETCH>
-hipError_t nmsm_accumulate(const frw_msm *m, const NmsmBufs &sorted, const NmsmBufs &own, size_t cnt, uint32_t *d_out, bool ones_as_mask, hipStream_t st,
-                           bool xyzz_out = false)
+hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs &sorted, const NmsmBufs &own, size_t cnt, uint32_t *d_out, bool ones_as_mask,
+                           hipStream_t st, bool xyzz_out = false)
 {
-    const uint32_t n = m->dev.n;
-    frw::MsmDev dev = m->dev;
-    if (!ones_as_mask) dev.ones_table = nullptr;                    // the sort left a list of the ones, not a mask
+    const uint32_t n = ms[0]->dev.n;
+    frw::NmsmTables dev;
+    dev.n = n; dev.sigs = (uint32_t)cnt;
+    for (int t = 0; t < 3; t++) {
+        const frw_msm *m = ms[t < tables ? t : 0];
+        dev.table[t] = m->dev.table;
+        dev.ones_table[t] = ones_as_mask ? m->dev.ones_table : nullptr;   // not as a mask: the sort left a list of the ones
+    }
+    const unsigned rows = (unsigned)(cnt * (size_t)tables);
     typedef typename frw::BulkPolicy<F>::type FB;
     constexpr bool BULK_PREFETCH = PREFETCH || FB::LANES > 1;       // two lanes per point: the registers for the prefetch are there
     // the ones' partial sums: enough threads to occupy the chip (~2^16 over the batch), between 256 and 4,096 per signature
     int ones_threads = 256;
-    while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * cnt < 65536) ones_threads <<= 1;
-    hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, (unsigned)cnt), dim3(64), 0, st, dev, sorted.ones_count, sorted.ones_list,
+    while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * rows < 65536) ones_threads <<= 1;
+    hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, rows), dim3(64), 0, st, dev, sorted.ones_count, sorted.ones_list,
                        own.partial_ones, own.ones_stride);
     const uint32_t *ones_for_finish = own.partial_ones;
     uint32_t ones_groups = (uint32_t)ones_threads / 64, ones_finish_stride = own.ones_stride;
     if (ones_groups > 64) {
-        hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<FB>, dim3(64, (unsigned)cnt), dim3(64), 0, st, own.partial_ones, ones_groups, own.ones_stride, own.folded_ones);
+        hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<FB>, dim3(64, rows), dim3(64), 0, st, own.partial_ones, ones_groups, own.ones_stride, own.folded_ones);
         ones_for_finish = own.folded_ones;
         ones_groups = 64;
         ones_finish_stride = 64;
     }
-    hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((sorted.max_items * FB::LANES + 63) / 64, (unsigned)cnt), dim3(64), 0, st, dev,
+    hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((sorted.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
                        sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items);
     // the items of a bucket: added up by a workgroup per bucket where latency counts (a lone proof: 12 ms -> 8.6), by the fold's own
     // thread where throughput does (the combine is nine times the wave-level additions: 3 % of a 64-proof call)
     const bool combine = cnt <= 16;
     if (combine)
-        hipLaunchKernelGGL(frw::nmsm_combine_kernel<FB>, dim3(frw::NMSM_BUCKETS, (unsigned)cnt), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first,
-                           own.partial_items, own.bucket_sums, sorted.target, sorted.max_items);
-    hipLaunchKernelGGL(frw::nmsm_finish_kernel<FB>, dim3((unsigned)cnt), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first, own.partial_items,
+        hipLaunchKernelGGL(frw::nmsm_combine_kernel<FB>, dim3(frw::NMSM_BUCKETS, rows), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first,
+                           own.partial_items, own.bucket_sums, sorted.target, sorted.max_items, (uint32_t)cnt);
+    hipLaunchKernelGGL(frw::nmsm_finish_kernel<FB>, dim3(rows), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first, own.partial_items,
                        combine ? own.bucket_sums : (uint32_t *)nullptr, ones_for_finish, (int)ones_groups, ones_finish_stride, sorted.target, sorted.max_items,
-                       d_out, xyzz_out ? 1 : 0);
+                       d_out, xyzz_out ? 1 : 0, (uint32_t)cnt);
     return hipGetLastError();
 }
 // the narrow pipeline for one group
@@ -1200,7 +1233,7 @@ int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t s
         const NmsmBufs b = nmsm_carve<F>(d_workspace, cnt, n);
         e = nmsm_sort(b, n, cnt, (const uint32_t *)(d_scalars + lo * scalar_stride * 4), scalar_stride * 8, montgomery, m->ones_table != nullptr, st);
         if (e == hipSuccess)
-            e = nmsm_accumulate<F, PREFETCH>(m, b, b, cnt, (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)), m->ones_table != nullptr, st);
+            e = nmsm_accumulate<F, PREFETCH>(&m, 1, b, b, cnt, (uint32_t *)(d_out + lo * (frw::Grp<F>::ARK_WORDS / 2)), m->ones_table != nullptr, st);
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
 }
@@ -1351,6 +1384,76 @@ __global__ __launch_bounds__(64) void groth16_scale_kernel(size_t batch, const u
     }
     store_bucket<F>(out + sig * BW, m);
 }
+// The same k P on FOUR lanes (frw_quad.h): the formulas' independent products side by side -- three dependent levels per
+// doubling instead of nine products, four per addition instead of fourteen -- with the results in a register file in LDS.  One
+// quad per workgroup: its lanes take the same branches (they depend on the scalar's bits and on zero tests every lane sees
+// alike), so nothing diverges, and a batch of scalar multiplications spreads over as many SIMDs.
+struct QuadLaneExec {
+    uint32_t *lds;
+    uint32_t lane;
+    // LDS serves a wavefront's requests in order; what must not happen is the COMPILER moving a level's reads above the previous
+    // level's writes (per lane they touch different slots)
+    static __device__ __forceinline__ void fence()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    static __device__ __forceinline__ uint32_t from_lane0(uint32_t x)
+    {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x00 /* quad_perm [0, 0, 0, 0] */, 0xf, 0xf, true);
+    }
+    template <const quad::Step &S> __device__ __forceinline__ void step(uint32_t qx, uint32_t qy)
+    {
+        Fq29 a;
+        const Fq29 r = quad::compute<S>(lds, lane, qx, qy, a);
+        quad::store<S>(lds, lane, r);
+        fence();
+    }
+    template <const quad::Step &S> __device__ __forceinline__ void step_test(uint32_t qx, uint32_t qy, bool &pz)
+    {
+        Fq29 a;
+        const Fq29 r = quad::compute<S>(lds, lane, qx, qy, a);
+        quad::store<S>(lds, lane, r);
+        fence();
+        pz = from_lane0(fq_is_zero(a) ? 1u : 0u) != 0;
+    }
+    __device__ __forceinline__ bool degenerate(uint32_t qx, uint32_t qy)
+    {
+        uint32_t inf = 0;
+        if (lane == 0) inf = quad::add_degenerate(lds, qx, qy) ? 1u : 0u;
+        fence();
+        return from_lane0(inf) != 0;
+    }
+};
+// Both scalar multiplications of a batch in one launch: workgroup b < batch is s g_a of signature b (the second scalar of its pair),
+// workgroup batch + b is r (g1_b - s delta1) (the first); pts = [2][batch] points as the sums left them, out likewise.
+__global__ __launch_bounds__(4) void groth16_scale_quad_kernel(size_t batch, const uint32_t *__restrict__ split /* [batch][2][8]: k0 | k1, 128 bits each */,
+                                                               const uint32_t *__restrict__ pts /* [2][batch][BK_WORDS] */,
+                                                               uint32_t *__restrict__ out /* [2][batch][BK_WORDS] */)
+{
+    typedef FqField F;
+    constexpr int BW = Grp<F>::BK_WORDS;
+    __shared__ __attribute__((aligned(16))) uint32_t file[quad::NSLOTS * quad::SLOT_WORDS];
+    const size_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (slot >= 2 * batch) return;
+    const size_t sig = slot < batch ? slot : slot - batch;
+    const int which = slot < batch ? 1 : 0;
+    if (pts[slot * BW + 4 * F::WORDS] != 0) {                                              // k O = O
+        if (lane == 0) store_bucket<F>(out + slot * BW, pt_identity<F>());
+        return;
+    }
+    if (lane == 0) quad::setup(file, load_bucket<F>(pts + slot * BW));
+    QuadLaneExec::fence();
+    const uint32_t *k = split + (sig * 2 + which) * 8;
+    uint32_t k0[4], k1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { k0[i] = k[i]; k1[i] = k[4 + i]; }
+    QuadLaneExec ex{file, lane};
+    const bool inf = quad::scalar_mul(ex, k0, k1);
+    if (lane == 0) store_bucket<F>(out + slot * BW, inf ? pt_identity<F>() : quad::running_point(file, false));
+}
 // (A/B, negative, round 4: a workgroup of three wavefronts per scalar multiplication -- one running the 128 doublings from the LOW end
 // of the scalar and parking 2^i P in LDS, two adding the parked points where k0 / k1 have bits set, a tree, phi on the k1 sum -- is
 // bit-exact and SLOWER for a proof made alone, in two builds (the second with nothing but the doubled point live in the doubler's loop
@@ -1398,7 +1501,7 @@ struct frw_groth16_pk {
     // kernel ends -- two wavefronts of 240 registers per SIMD leave no CU with room for such a workgroup -- so every sum must be
     // on a stream where nothing delays its first kernels.
     hipStream_t main, side[3];
-    hipEvent_t fork, join[4];           // join[3]: main
+    hipEvent_t fork, sorted, join[4];   // fork: the call's inputs are in place; sorted: the digits of its scalars too; join[3]: main
     std::mutex enqueue;         // the side streams and events are the key's: one call at a time puts its work on them
 };
 
@@ -1413,6 +1516,7 @@ extern "C" void frw_groth16_pk_free(frw_groth16_pk *pk)
     }
     if (pk->main) (void)hipStreamDestroy(pk->main);
     if (pk->fork) (void)hipEventDestroy(pk->fork);
+    if (pk->sorted) (void)hipEventDestroy(pk->sorted);
     delete pk;
 }
 
@@ -1427,7 +1531,7 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
     pk->device = device;
     pk->num_instance = d->num_instance; pk->num_witness = d->num_witness; pk->domain_size = d->domain_size;
     pk->h = pk->a = pk->b1 = pk->l = pk->b2 = nullptr;
-    pk->fork = nullptr;
+    pk->fork = pk->sorted = nullptr;
     pk->main = nullptr;
     for (int i = 0; i < 4; i++) { if (i < 3) pk->side[i] = nullptr; pk->join[i] = nullptr; }
     const size_t nv = (size_t)(d->num_instance + d->num_witness);
@@ -1435,6 +1539,7 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
     {
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->sorted, hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&pk->main, hipStreamNonBlocking);
         for (int i = 0; i < 4 && e == hipSuccess; i++) {
             if (i < 3) e = hipStreamCreateWithFlags(&pk->side[i], hipStreamNonBlocking);
@@ -1572,6 +1677,7 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         for (int i = 0; i < 5; i++) { msm_ws[i] = base; base += cnt * sz.msm[i]; }
         constexpr size_t XW = frw::Grp<FqField>::BK_WORDS;               // the G1 points stay in XYZZ coordinates until the proof is put together
         uint32_t *pA = (uint32_t *)base, *pB1 = pA + cnt * XW, *pL = pB1 + cnt * XW, *pH = pL + cnt * XW, *pSA = pH + cnt * XW, *pRB1 = pSA + cnt * XW;
+        (void)pB1;                                                       // [A | B1' | L] is what the three G1 sums write, [s A | r B1'] the scalar multiplications
         uint64_t *pB2 = (uint64_t *)(pRB1 + cnt * XW), *d_rs = pB2 + cnt * 24, *d_split = d_rs + cnt * 8;
         const uint64_t *wit = d_witness + lo * W * 4, *inst = d_instance + lo * I * 4;
         // the blinding factors: a host array (the prover draws them), uploaded before anything reads them
@@ -1594,35 +1700,35 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
                            (uint32_t *)zext, stride * 8, nv);
-        // ONE counting sort of the digits of z ++ [1, r, s] for all four witness-side sums (its arrays live in a_query's workspace)
-        const NmsmBufs sorted = nmsm_carve<FqField>(msm_ws[1], cnt, (uint32_t)stride);
-        const bool ones_as_mask = pk->a->ones_table && pk->b1->ones_table && pk->l->ones_table && pk->b2->ones_table;
-        e = nmsm_sort(sorted, (uint32_t)stride, cnt, (const uint32_t *)zext, stride * 8, 1, ones_as_mask, st);
-        if (e != hipSuccess) break;
+        // the witness map and the sum over h_query -- the longest chain of a proof made alone -- need nothing of what follows:
+        // they start now
         e = hipEventRecord(pk->fork, st);
         forked = true;
         if (e == hipSuccess) e = hipStreamWaitEvent(pk->main, pk->fork, 0);
-        for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipStreamWaitEvent(pk->side[i], pk->fork, 0);
-        if (e != hipSuccess) break;
-        // the two chains that end in a scalar multiplication first (the longest of a proof made alone), then G2 with l_query behind
-        // it, then the witness map and the sum over h_query
-        e = nmsm_accumulate<FqField, true>(pk->a, sorted, nmsm_carve<FqField>(msm_ws[1], cnt, (uint32_t)stride), cnt, pA, ones_as_mask, pk->side[0], true);
-        if (e == hipSuccess)
-            e = nmsm_accumulate<FqField, true>(pk->b1, sorted, nmsm_carve<FqField>(msm_ws[2], cnt, (uint32_t)stride), cnt, pB1, ones_as_mask, pk->side[1], true);
-        if (e == hipSuccess)
-            e = nmsm_accumulate<Fq2Field, false>(pk->b2, sorted, nmsm_carve<Fq2Field>(msm_ws[4], cnt, (uint32_t)stride), cnt, (uint32_t *)pB2, ones_as_mask, pk->side[2]);
-        if (e == hipSuccess)
-            e = nmsm_accumulate<FqField, true>(pk->l, sorted, nmsm_carve<FqField>(msm_ws[3], cnt, (uint32_t)stride), cnt, pL, ones_as_mask, pk->side[2], true);
         if (e != hipSuccess) break;
         rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
         // (h_query has n - 1 points and the dense pipeline: frw_groth16_pk_load; the scalars are h's coefficients 0 .. n - 2)
         if (rc == FRW_OK) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
         if (rc != FRW_OK) break;
-        // s g_a and r (g1_b - s delta1) as soon as their points exist, on the streams that made them
-        hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[0], cnt, (const uint32_t *)d_split, 1,
+        // ONE counting sort of the digits of z ++ [1, r, s] for all four witness-side sums (its arrays live in b_g2_query's workspace;
+        // the workspaces of a_query, b_g1_query and l_query, one after the other, are the three G1 sums' as one)
+        const NmsmBufs sorted = nmsm_carve<Fq2Field>(msm_ws[4], cnt, (uint32_t)stride);
+        const bool ones_as_mask = pk->a->ones_table && pk->b1->ones_table && pk->l->ones_table && pk->b2->ones_table;
+        e = nmsm_sort(sorted, (uint32_t)stride, cnt, (const uint32_t *)zext, stride * 8, 1, ones_as_mask, st);
+        if (e != hipSuccess) break;
+        e = hipEventRecord(pk->sorted, st);
+        for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
+        if (e != hipSuccess) break;
+        // the three G1 sums (A, B1' and L land one after the other) as ONE chain of kernels, then both scalar multiplications, as
+        // soon as their points exist, on the same stream; G2 on another.  (side[1] shares its hardware queue with the caller's
+        // stream on a default HIP runtime of four queues: it stays empty.)
+        const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
+        e = nmsm_accumulate<FqField, true>(g1s, 3, sorted, nmsm_carve<FqField>(msm_ws[1], 3 * cnt, (uint32_t)stride), cnt, pA, ones_as_mask, pk->side[0], true);
+        if (e == hipSuccess)
+            e = nmsm_accumulate<Fq2Field, false>(&pk->b2, 1, sorted, sorted, cnt, (uint32_t *)pB2, ones_as_mask, pk->side[2]);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(frw::groth16_scale_quad_kernel, dim3((unsigned)(2 * cnt)), dim3(4), 0, pk->side[0], cnt, (const uint32_t *)d_split,
                            (const uint32_t *)pA, pSA);
-        hipLaunchKernelGGL(frw::groth16_scale_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, pk->side[1], cnt, (const uint32_t *)d_split, 0,
-                           (const uint32_t *)pB1, pRB1);
         for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
         if (e == hipSuccess) e = hipEventRecord(pk->join[3], pk->main);
         if (e != hipSuccess) break;

@@ -28,6 +28,7 @@ extern "C" void t_fq(int op, const uint32_t *a, const uint32_t *b, uint32_t *out
     case 12: { Fq29 t = fq_unpack(a); store(t, out); break; }   // a: 12 words
     case 13: fq_pack(load(a), out); break;
     case 14: store(fq_sqr(load(a)), out); break;
+    case 15: store(fq_inv_fermat(load(a)), out); break;
     }
 }
 // a b - c d with one reduction; which = 0: c < 4 q, 1: c < 16 q
@@ -151,4 +152,29 @@ extern "C" void t_g1_chain(const uint32_t *pw, const uint32_t *qw, uint32_t *out
     G1Xyzz r = g1_from_affine(p);
     for (int k = 0; k < 40; k++) r = k % 7 == 6 ? g1_double(r) : g1_add_affine(r, q);
     store_point(r, out);
+}
+
+// ---- k P on four lanes (frw_quad.h), the lanes run one after the other -------------------------------------------------------------
+#include "frw_quad.h"
+// p: 24 words ark-ff; pre: how many times p is doubled first (so that ZZ != 1, as a sum leaves it); k: k0 | k1, 4 words each
+// (k = k0 + lambda k1); out: k (2^pre p), 24 words ark-ff.  Returns the number of slots the register file has | the number of additions that went through the complete one-lane formula << 8.
+extern "C" int t_g1_quad_scale(const uint32_t *pw, int pre, const uint32_t *k, uint32_t *out)
+{
+    alignas(16) static uint32_t file[quad::NSLOTS * quad::SLOT_WORDS];
+    G1Xyzz base = g1_from_affine(load_point(pw));
+    for (int i = 0; i < pre; i++) base = g1_double(base);
+    if (base.inf) { std::memset(out, 0, 96); return quad::NSLOTS; }
+    quad::setup(file, base);
+    struct Counting : quad::SerialExec {
+        int degenerate_calls = 0;
+        bool degenerate(uint32_t qx, uint32_t qy) { degenerate_calls++; return quad::SerialExec::degenerate(qx, qy); }
+    } ex;
+    ex.lds = file;
+    uint32_t k0[4], k1[4];
+    for (int i = 0; i < 4; i++) { k0[i] = k[i]; k1[i] = k[4 + i]; }
+    const bool inf = quad::scalar_mul(ex, k0, k1);
+    G1Xyzz r = quad::running_point(file, inf);
+    if (inf) r = g1_identity();
+    store_point(r, out);
+    return quad::NSLOTS | ex.degenerate_calls << 8;
 }

@@ -25,8 +25,9 @@ def lib():
     so = os.path.join(out, "libtest_fq29.so")
     src = os.path.join(HERE, "cpp", "test_fq29.cpp")
     hdr = os.path.join(ROOT, "falcon-r1cs_amd", "csrc", "frw_fq29.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in (src, hdr)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-I", os.path.join(HERE, "cpp", "hip_host"),
+    hdr2 = os.path.join(ROOT, "falcon-r1cs_amd", "csrc", "frw_quad.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in (src, hdr, hdr2)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-fno-strict-aliasing", "-I", os.path.join(HERE, "cpp", "hip_host"),
                                "-I", os.path.join(ROOT, "falcon-r1cs_amd", "csrc"), "-o", so, src])
     return C.CDLL(so)
 
@@ -58,7 +59,7 @@ def test_constants_of_the_header():
         body = re.search(name + r" = \{\{([^}]*)\}\}", src).group(1)
         return value([int(x.strip().rstrip("u"), 16) for x in body.split(",")])
     assert table("FQ29_ONE") == RQ % Q
-    assert table("FQ29_C_IN") == pow(2, 428, Q) and table("FQ29_C_OUT") == pow(2, 384, Q)
+    assert table("FQ29_C_IN") == pow(2, 428, Q) and table("FQ29_C_OUT") == pow(2, 384, Q) and table("FQ29_R3") == pow(2, 3 * 406, Q)
     assert (table("G1_GEN_X29"), table("G1_GEN_Y29")) == (E.G1[0] * RQ % Q, E.G1[1] * RQ % Q)
     # the endomorphism constant: a primitive cube root of unity, and the one that belongs to lambda = z^2 - 1
     beta = table("G1_ENDO_BETA29") * pow(RQ, -1, Q) % Q
@@ -136,7 +137,14 @@ def test_conversions_and_inverse(lib):
         assert value(back, 32) == ark
         if x:
             got = value(fq(lib, 9, (C.c_uint32 * 14)(*mont)))
-            assert got % Q == pow(x, -1, Q) * RQ % Q
+            assert got % Q == pow(x, -1, Q) * RQ % Q and got < 2 * Q                  # binary extended Euclid (fq_inv)
+            assert value(fq(lib, 15, (C.c_uint32 * 14)(*mont))) % Q == got % Q        # Fermat
+    # lazily reduced operands (a sum leaves ZZ ZZZ < 2 q; anything below 2^12 q must do), the extremes of the Euclidean rounds
+    for x in [2, Q - 2, (Q - 1) // 2, (Q + 1) // 2, 1 << 380, (1 << 380) - 1, 3]:
+        for k in (0, 1, 100, 4000):
+            a = x * RQ % Q + k * Q
+            got = value(fq(lib, 9, limbs(a)))
+            assert got % Q == pow(x, -1, Q) * RQ % Q and got < 2 * Q, (x, k)
 
 
 def _pt(p):
@@ -165,6 +173,55 @@ def test_point_formulas_every_branch(lib):
         assert _g1(lib, 3, p, E.neg(p)) is None and _g1(lib, 3, p, None) == E.add(p, p) and _g1(lib, 3, None, q) == E.add(q, q)
         assert _g1(lib, 2, p, E.neg(p)) is None and _g1(lib, 2, p, p) == E.mul(p, 4) and _g1(lib, 2, None, q) == E.add(q, q)
     assert _g1(lib, 1, None) is None and _g1(lib, 5, None) is None
+
+
+def test_scalar_multiplication_on_four_lanes(lib):
+    """frw_quad.h: k P, k = k0 + lambda k1, by the level programmes run for four lanes one after the other -- against the oracle's
+    double-and-add; incl. the scalars that leave the point as one of the three addends, that make the running point meet the
+    addend (the complete one-lane formula takes over) or its negative, zero, and a point that arrives with ZZ != 1."""
+    rng = random.Random(59)
+    lam = E.Z_BLS ** 2 - 1
+    degenerate = [0]
+
+    def run(p, pre, k0, k1):
+        out = (C.c_uint32 * 24)()
+        k = (C.c_uint32 * 8)(*([(k0 >> (32 * i)) & 0xFFFFFFFF for i in range(4)] + [(k1 >> (32 * i)) & 0xFFFFFFFF for i in range(4)]))
+        rc = lib.t_g1_quad_scale(_pt(p), pre, k, out)
+        assert rc & 0xFF <= 32
+        degenerate[0] += rc >> 8
+        return E.from_limbs([out[2 * i] | out[2 * i + 1] << 32 for i in range(12)])
+
+    p = E.mul(E.G1, rng.randrange(1, E.R))
+    cases = [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (3, 0), (0, 2), (3, 3), (2, 3), (5, 4), ((1 << 128) - 1, (1 << 128) - 1), (lam - 1, lam + 1)]
+    cases += [(rng.randrange(1 << 128), rng.randrange(1 << 128)) for _ in range(6)]
+    cases += [(rng.randrange(1 << 20), 0), (0, rng.randrange(1 << 20)), (1 << 127, 0), (0, 1 << 127)]
+    for k0, k1 in cases:
+        for pre in (0, 2):
+            base = E.mul(p, 1 << pre)
+            assert run(p, pre, k0, k1) == E.mul(base, (k0 + lam * k1) % E.R), (hex(k0), hex(k1), pre)
+    for k0 in range(8):
+        for k1 in range(8):
+            assert run(p, 1, k0, k1) == E.mul(E.mul(p, 2), (k0 + lam * k1) % E.R)
+    assert degenerate[0] == 0
+    # the running point meets the addend (or its negative) when 2 v = +-a mod r for the prefix v and a in {1, lambda, 1 + lambda}:
+    # v = +-a / 2 mod r, split like any scalar, then one more bit pair that selects a
+    met = 0
+    for a_sel, a in ((1, 1), (2, lam), (3, 1 + lam)):
+        for sign in (1, -1):
+            v = sign * a * pow(2, -1, E.R) % E.R
+            v0, v1 = v % lam, v // lam
+            if v0 >> 127 or v1 >> 127:
+                continue
+            k0, k1 = v0 << 1 | (a_sel & 1), v1 << 1 | (a_sel >> 1)
+            before = degenerate[0]
+            assert run(p, 1, k0, k1) == (E.mul(E.mul(p, 2), 2 * a % E.R) if sign == 1 else None), (a_sel, sign)
+            assert degenerate[0] == before + 1
+            # and the chain goes on from there: two more bit pairs
+            if not (k0 >> 126 or k1 >> 126):
+                assert run(p, 0, k0 << 2 | 1, k1 << 2 | 2) == E.mul(p, (((k0 << 2) | 1) + lam * ((k1 << 2) | 2)) % E.R)
+            met += 1
+    assert met >= 2
+    assert run(None, 0, 5, 7) is None
 
 
 def limbs2(v):
