@@ -297,65 +297,89 @@ __host__ __device__ inline Fq29 fq_inv_fermat(const Fq29 &a)
 // coordinates is the tail of every sum and of a proof (one inversion on the critical path of a proof made alone), and
 // Fermat's 610 dependent products are 0.6 ms of one lane.  Invariant u = x1 A, v = x2 A (mod q), v odd: if u is odd
 // make it the larger of the two and subtract (u -= v, x1 -= x2), then halve u and x1; u reaches 0 in at most 2 x 382 rounds of
-// ~170 plain integer instructions, v is then 1 and x2 = 1 / A.  A = a 2^406 comes in, (1 / a) 2^406 = x2 2^(3 x 406) / 2^406 goes out.
+// ~200 plain integer instructions, v is then 1 and x2 = 1 / A.  A = a 2^406 comes in, (1 / a) 2^406 = x2 2^(3 x 406) / 2^406 goes out.
 // 2^1218 mod q; tests/test_fq29_host.py re-derives it
 constexpr LimbsQ FQ29_R3 = {{0x09217d6au, 0x1d6118bau, 0x1114b11cu, 0x0126aee7u, 0x0a55e2c4u, 0x04d63ce0u, 0x154ff87du,
                              0x14555478u, 0x1d1bdc0du, 0x161f98d4u, 0x1d74e921u, 0x09b4345au, 0x1e5ecfb8u, 0x0000000au}};
-__host__ __device__ __forceinline__ uint32_t w12_sub(uint32_t (&r)[12], const uint32_t (&a)[12], const uint32_t (&b)[12])   // -> borrow
+// 32-bit addition / subtraction with carry: the device has them as single instructions (v_addc_co / v_subb_co); written
+// through 64 bits the compiler emitted 64-bit adds and register shuffles, three times the instructions
+__host__ __device__ __forceinline__ uint32_t add_c(uint32_t a, uint32_t b, uint32_t &carry)
 {
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-        const uint64_t d = (uint64_t)a[k] - b[k] - borrow;
-        r[k] = (uint32_t)d;
-        borrow = (uint32_t)(d >> 32) & 1u;
-    }
-    return borrow;
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned out;
+    const uint32_t r = __builtin_addc(a, b, carry, &out);
+    carry = out;
+    return r;
+#else
+    const uint64_t t = (uint64_t)a + b + carry;
+    carry = (uint32_t)(t >> 32);
+    return (uint32_t)t;
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t sub_b(uint32_t a, uint32_t b, uint32_t &borrow)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned out;
+    const uint32_t r = __builtin_subc(a, b, borrow, &out);
+    borrow = out;
+    return r;
+#else
+    const uint64_t t = (uint64_t)a - b - borrow;
+    borrow = (uint32_t)(t >> 32) & 1u;
+    return (uint32_t)t;
+#endif
 }
 __host__ __device__ inline Fq29 fq_inv(const Fq29 &a)
 {
-    uint32_t u[12], v[12], x1[12], x2[12], d[12];
+    uint32_t u[12], v[12], x1[12], x2[12];
     fq_pack(fq_reduce(a), u);
 #pragma unroll
     for (int k = 0; k < 12; k++) { v[k] = Q32_[k]; x1[k] = k == 0 ? 1u : 0u; x2[k] = 0u; }
+#pragma nounroll
     for (int round = 0; round < 2 * 382; round++) {
         uint32_t any = 0;
 #pragma unroll
         for (int k = 0; k < 12; k++) any |= u[k];
+        // a lane whose u has reached 0 changes neither v nor x2 any more (u is even, nothing is exchanged): the loop may run on for
+        // the other lanes of its wavefront -- and a wave-uniform exit costs no copies of the live values, a per-lane one did
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__builtin_amdgcn_ballot_w64(any != 0) == 0) break;
+#else
         if (any == 0) break;
-        const bool odd = (u[0] & 1u) != 0;
-        const bool swap = odd && w12_sub(d, u, v) != 0;                  // u odd and u < v: exchange the two pairs
+#endif
+        // Everything below is mask arithmetic ((m & a) | (~m & b) is one v_bfi_b32): written with ?: the compiler made the exchange
+        // a chain of predicated branches.  x1, x2 live in [0, q] (q itself stands for 0: the range is closed under the steps).
+        const uint32_t odd = 0u - (u[0] & 1u);                           // all ones when u is odd
+        uint32_t d[12], e[12], f[12];
+        uint32_t borrow = 0;
 #pragma unroll
-        for (int k = 0; k < 12; k++) {
-            const uint32_t tu = u[k], tx = x1[k];
-            u[k] = swap ? v[k] : tu;   v[k] = swap ? tu : v[k];
-            x1[k] = swap ? x2[k] : tx; x2[k] = swap ? tx : x2[k];
-        }
-        // u -= v, x1 -= x2 mod q  (if u is odd)
-        (void)w12_sub(d, u, v);
+        for (int k = 0; k < 12; k++) d[k] = sub_b(u[k], v[k], borrow);   // u - v
+        const uint32_t less = 0u - borrow, take = odd & less;            // u < v;  u odd and u < v: the pairs change roles
+        borrow = 0;
 #pragma unroll
-        for (int k = 0; k < 12; k++) u[k] = odd ? d[k] : u[k];
-        const uint32_t below = w12_sub(d, x1, x2);
-        {
-            uint32_t carry = 0;
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const uint64_t t = (uint64_t)d[k] + (below ? Q32_[k] : 0u) + carry;
-                d[k] = (uint32_t)t;
-                carry = (uint32_t)(t >> 32);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 12; k++) x1[k] = odd ? d[k] : x1[k];
-        // u /= 2 (even now), x1 /= 2 mod q: (x1 + q) / 2 when x1 is odd; x1 + q < 2^382
-        const bool xodd = (x1[0] & 1u) != 0;
+        for (int k = 0; k < 12; k++) e[k] = sub_b(x1[k], x2[k], borrow); // x1 - x2 (+ q if negative)
+        const uint32_t below = 0u - borrow;
         uint32_t carry = 0;
 #pragma unroll
+        for (int k = 0; k < 12; k++) e[k] = add_c(e[k], Q32_[k] & below, carry);
+        borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) f[k] = sub_b(Q32_[k], e[k], borrow); // x2 - x1 = q - (x1 - x2)
+        borrow = 0;
+#pragma unroll
         for (int k = 0; k < 12; k++) {
-            const uint64_t t = (uint64_t)x1[k] + (xodd ? Q32_[k] : 0u) + carry;
-            x1[k] = (uint32_t)t;
-            carry = (uint32_t)(t >> 32);
+            const uint32_t neg = sub_b(d[k] ^ less, less, borrow);        // |u - v|: the two's complement when u < v
+            const uint32_t tu = u[k], tx = x1[k];
+            u[k] = (odd & neg) | (~odd & tu);
+            v[k] = (take & tu) | (~take & v[k]);
+            x1[k] = (odd & ((less & f[k]) | (~less & e[k]))) | (~odd & tx);
+            x2[k] = (take & tx) | (~take & x2[k]);
         }
+        // u /= 2 (even now), x1 /= 2 mod q: (x1 + q) / 2 when x1 is odd; x1 + q < 2^382
+        const uint32_t xodd = 0u - (x1[0] & 1u);
+        carry = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) x1[k] = add_c(x1[k], Q32_[k] & xodd, carry);
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             u[k] = (u[k] >> 1) | (k + 1 < 12 ? u[k + 1] << 31 : 0u);

@@ -449,6 +449,7 @@ __global__ __launch_bounds__(64, 2) void msm_combine_kernel(const uint32_t *__re
                                                             const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
                                                             uint32_t *__restrict__ buckets, uint32_t finer, uint32_t max_items)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int BW = Grp<F>::BK_WORDS;
     const size_t sig = blockIdx.y;
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(64, 2) void msm_ones_kernel(MsmDev m, const uint32_
 template <class F, int LOG_CHUNK>
 __global__ __launch_bounds__(64, 2) void msm_fold1_kernel(const uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int BW = Grp<F>::BK_WORDS, CHUNK = 1 << LOG_CHUNK;
     const size_t sig = blockIdx.y;
     const int g = blockIdx.x * 64 + threadIdx.x;
@@ -511,6 +513,7 @@ template <class F>
 __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint32_t *__restrict__ partial, int each,
                                                                      uint32_t *__restrict__ out /* [batch][ARK_WORDS], or [batch][BK_WORDS] */, int xyzz_out)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS;
     __shared__ uint32_t lds[MSM_FOLD_THREADS / 2 * SLOT];            // 58 KB (G1) / 116 KB (G2): the upper half of a tree level parks here
     const size_t sig = blockIdx.x;
@@ -675,6 +678,7 @@ __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(NmsmTables tables, c
                                                             const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items,
                                                             uint32_t target, uint32_t max_items)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int PW = Grp<F>::PT_WORDS;
     const size_t slot = blockIdx.y;
     size_t sig;
@@ -716,6 +720,7 @@ template <class F>
 __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(NmsmTables tables, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
                                                           uint32_t *__restrict__ partial_ones /* [slot][groups_stride][BK_WORDS] */, uint32_t groups_stride)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int SLOT = 4 * F::WORDS + 1, PER = 64 / F::LANES;                 // PER chains per workgroup (F::LANES lanes each)
     __shared__ uint32_t lds[32 * SLOT];
     const size_t slot = blockIdx.y;
@@ -755,6 +760,7 @@ template <class F>
 __global__ __launch_bounds__(64, 2) void nmsm_ones_fold_kernel(const uint32_t *__restrict__ partial_ones, uint32_t groups, uint32_t groups_stride,
                                                                uint32_t *__restrict__ folded /* [sig][64][BK_WORDS] */)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES;   // one wavefront: PER chains of F::LANES lanes
     __shared__ uint32_t lds[32 * SLOT];
     const size_t sig = blockIdx.y;
@@ -778,6 +784,7 @@ __global__ __launch_bounds__(64, 2) void nmsm_combine_kernel(const uint32_t *__r
                                                              uint32_t *__restrict__ buckets /* [slot][128][BK_WORDS] */, uint32_t target, uint32_t max_items,
                                                              uint32_t sigs)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES;
     __shared__ uint32_t lds[32 * SLOT];
     const size_t slot = blockIdx.y, sig = slot % sigs;
@@ -818,6 +825,7 @@ __global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restr
                                                          uint32_t *__restrict__ out /* [slot][ARK_WORDS], or [slot][BK_WORDS] */, int xyzz_out,
                                                          uint32_t sigs)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES, NB = NMSM_BUCKETS / PER;
     constexpr int LOG_PER = PER == 64 ? 6 : 5, LOG_NB = NB == 2 ? 1 : 2;
     static_assert(PER * NB == NMSM_BUCKETS && (1 << LOG_PER) == PER && (1 << LOG_NB) == NB, "64 or 32 chains of 2 or 4 buckets");
@@ -1107,6 +1115,7 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts, slices);
         hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
         // (four at a time: 12.6 ms with the finer split, 12.1 without); beyond 2^18 points: see MSM_MAX_ITEMS_LARGE
+        // (a lone Falcon-1024 proof with 2 / 3 / 4: 4.72 / 4.27 / 4.05 ms -- the finer cut shares the chip better with the proof's other sums)
         const uint32_t finer = cnt <= 2 ? (n > (1u << 18) ? 24u : 4u) : 1u;
         hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count, finer, max_items);
         hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
@@ -1176,10 +1185,15 @@ hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *
 // `sorted`: whose sort arrays to read; `own`: where the tables' partial sums go -- carved for `tables * cnt` signatures when there is
 // more than one table (the same carve as `sorted` for a sum on its own); d_out: [tables][cnt] results.  Every kernel here is a grid of
 // single wavefronts: none of them can be kept waiting by a kernel that fills the chip.
+// ones_stream / ones_done: the sums of the scalars that are one need nothing of the work items' sums and the other way round -- as two
+// launches on one stream the second waited for the first.  A caller with a second stream that is ordered after the sort (and an event
+// to spare) gives it here: the ones are summed there, `st` waits for them before the fold (a quarter of a millisecond off the chain of
+// a proof made alone).
 template <class F, bool PREFETCH>
 hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs &sorted, const NmsmBufs &own, size_t cnt, uint32_t *d_out, bool ones_as_mask,
-                           hipStream_t st, bool xyzz_out = false)
+                           hipStream_t st, bool xyzz_out = false, bool ones_elsewhere = false, hipStream_t ones_stream = nullptr, hipEvent_t ones_done = nullptr)
 {
+    if (!ones_elsewhere) ones_stream = st;                          // (a caller's stream may be the null stream: the flag says whether it was given)
     const uint32_t n = ms[0]->dev.n;
     frw::NmsmTables dev;
     dev.n = n; dev.sigs = (uint32_t)cnt;
@@ -1194,15 +1208,19 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
     // the ones' partial sums: enough threads to occupy the chip (~2^16 over the batch), between 256 and 4,096 per signature
     int ones_threads = 256;
     while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * rows < 65536) ones_threads <<= 1;
-    hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, rows), dim3(64), 0, st, dev, sorted.ones_count, sorted.ones_list,
+    hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, rows), dim3(64), 0, ones_stream, dev, sorted.ones_count, sorted.ones_list,
                        own.partial_ones, own.ones_stride);
     const uint32_t *ones_for_finish = own.partial_ones;
     uint32_t ones_groups = (uint32_t)ones_threads / 64, ones_finish_stride = own.ones_stride;
     if (ones_groups > 64) {
-        hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<FB>, dim3(64, rows), dim3(64), 0, st, own.partial_ones, ones_groups, own.ones_stride, own.folded_ones);
+        hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<FB>, dim3(64, rows), dim3(64), 0, ones_stream, own.partial_ones, ones_groups, own.ones_stride, own.folded_ones);
         ones_for_finish = own.folded_ones;
         ones_groups = 64;
         ones_finish_stride = 64;
+    }
+    if (ones_elsewhere) {
+        const hipError_t e = hipEventRecord(ones_done, ones_stream);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((sorted.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
                        sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items);
@@ -1212,6 +1230,10 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
     if (combine)
         hipLaunchKernelGGL(frw::nmsm_combine_kernel<FB>, dim3(frw::NMSM_BUCKETS, rows), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first,
                            own.partial_items, own.bucket_sums, sorted.target, sorted.max_items, (uint32_t)cnt);
+    if (ones_elsewhere) {
+        const hipError_t e = hipStreamWaitEvent(st, ones_done, 0);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(frw::nmsm_finish_kernel<FB>, dim3(rows), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first, own.partial_items,
                        combine ? own.bucket_sums : (uint32_t *)nullptr, ones_for_finish, (int)ones_groups, ones_finish_stride, sorted.target, sorted.max_items,
                        d_out, xyzz_out ? 1 : 0, (uint32_t)cnt);
@@ -1432,6 +1454,7 @@ __global__ __launch_bounds__(4) void groth16_scale_quad_kernel(size_t batch, con
                                                                const uint32_t *__restrict__ pts /* [2][batch][BK_WORDS] */,
                                                                uint32_t *__restrict__ out /* [2][batch][BK_WORDS] */)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     typedef FqField F;
     constexpr int BW = Grp<F>::BK_WORDS;
     __shared__ __attribute__((aligned(16))) uint32_t file[quad::NSLOTS * quad::SLOT_WORDS];
@@ -1467,6 +1490,7 @@ __global__ __launch_bounds__(64) void groth16_finish_kernel(size_t batch, const 
                                                             const uint32_t *__restrict__ b2_pts /* [batch][48], affine */,
                                                             uint32_t *__restrict__ proofs /* [batch][96] */)
 {
+    __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     typedef FqField F;
     constexpr int BW = Grp<F>::BK_WORDS;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x, sig = t >> 1;
@@ -1501,7 +1525,7 @@ struct frw_groth16_pk {
     // kernel ends -- two wavefronts of 240 registers per SIMD leave no CU with room for such a workgroup -- so every sum must be
     // on a stream where nothing delays its first kernels.
     hipStream_t main, side[3];
-    hipEvent_t fork, sorted, join[4];   // fork: the call's inputs are in place; sorted: the digits of its scalars too; join[3]: main
+    hipEvent_t fork, sorted, ones_done, join[4];   // fork: the call's inputs are in place; sorted: the digits of its scalars too; join[3]: main
     std::mutex enqueue;         // the side streams and events are the key's: one call at a time puts its work on them
 };
 
@@ -1517,6 +1541,7 @@ extern "C" void frw_groth16_pk_free(frw_groth16_pk *pk)
     if (pk->main) (void)hipStreamDestroy(pk->main);
     if (pk->fork) (void)hipEventDestroy(pk->fork);
     if (pk->sorted) (void)hipEventDestroy(pk->sorted);
+    if (pk->ones_done) (void)hipEventDestroy(pk->ones_done);
     delete pk;
 }
 
@@ -1531,7 +1556,7 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
     pk->device = device;
     pk->num_instance = d->num_instance; pk->num_witness = d->num_witness; pk->domain_size = d->domain_size;
     pk->h = pk->a = pk->b1 = pk->l = pk->b2 = nullptr;
-    pk->fork = pk->sorted = nullptr;
+    pk->fork = pk->sorted = pk->ones_done = nullptr;
     pk->main = nullptr;
     for (int i = 0; i < 4; i++) { if (i < 3) pk->side[i] = nullptr; pk->join[i] = nullptr; }
     const size_t nv = (size_t)(d->num_instance + d->num_witness);
@@ -1540,6 +1565,7 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->sorted, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->ones_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&pk->main, hipStreamNonBlocking);
         for (int i = 0; i < 4 && e == hipSuccess; i++) {
             if (i < 3) e = hipStreamCreateWithFlags(&pk->side[i], hipStreamNonBlocking);
@@ -1700,18 +1726,27 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
                            (uint32_t *)zext, stride * 8, nv);
-        // the witness map and the sum over h_query -- the longest chain of a proof made alone -- need nothing of what follows:
-        // they start now
+        // Four chains of small kernels, and ONE host thread that enqueues them at 15 - 35 us a launch (some 45 launches: a chain
+        // enqueued last starts a millisecond late; profiles/r04_groth16_batch1_latency.txt) -- so the longest chain goes first: for a
+        // few proofs at a time all of it; for a batch only its head, and the sum over h_query -- whose bucket kernel then fills the
+        // chip for tens of milliseconds -- after everything that has workgroups of several wavefronts (they would not start under it).
+        //   main      the witness map (a dozen launches, 0.7 ms; needs nothing of the sort) and the sum over h_query
+        //   caller's  the sort of the digits of z ++ [1, r, s]: ONE counting sort for all four witness-side sums (its arrays live in
+        //             b_g2_query's workspace; the workspaces of a_query, b_g1_query and l_query, one after the other, are the three G1
+        //             sums' as one); for a few proofs at a time also the G1 sums' ones
+        //   side[0]   the three G1 sums (A, B1' and L land one after the other) as ONE chain of kernels, then both scalar
+        //             multiplications as soon as their points exist
+        //   side[2]   G2
+        // (side[1] shares its hardware queue with the caller's stream on a default HIP runtime of four queues: it stays empty.)
+        const bool lone = cnt <= 4;                                        // latency counts, not throughput
         e = hipEventRecord(pk->fork, st);
         forked = true;
         if (e == hipSuccess) e = hipStreamWaitEvent(pk->main, pk->fork, 0);
         if (e != hipSuccess) break;
         rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
         // (h_query has n - 1 points and the dense pipeline: frw_groth16_pk_load; the scalars are h's coefficients 0 .. n - 2)
-        if (rc == FRW_OK) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
+        if (rc == FRW_OK && lone) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
         if (rc != FRW_OK) break;
-        // ONE counting sort of the digits of z ++ [1, r, s] for all four witness-side sums (its arrays live in b_g2_query's workspace;
-        // the workspaces of a_query, b_g1_query and l_query, one after the other, are the three G1 sums' as one)
         const NmsmBufs sorted = nmsm_carve<Fq2Field>(msm_ws[4], cnt, (uint32_t)stride);
         const bool ones_as_mask = pk->a->ones_table && pk->b1->ones_table && pk->l->ones_table && pk->b2->ones_table;
         e = nmsm_sort(sorted, (uint32_t)stride, cnt, (const uint32_t *)zext, stride * 8, 1, ones_as_mask, st);
@@ -1719,16 +1754,16 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         e = hipEventRecord(pk->sorted, st);
         for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
         if (e != hipSuccess) break;
-        // the three G1 sums (A, B1' and L land one after the other) as ONE chain of kernels, then both scalar multiplications, as
-        // soon as their points exist, on the same stream; G2 on another.  (side[1] shares its hardware queue with the caller's
-        // stream on a default HIP runtime of four queues: it stays empty.)
         const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
-        e = nmsm_accumulate<FqField, true>(g1s, 3, sorted, nmsm_carve<FqField>(msm_ws[1], 3 * cnt, (uint32_t)stride), cnt, pA, ones_as_mask, pk->side[0], true);
-        if (e == hipSuccess)
-            e = nmsm_accumulate<Fq2Field, false>(&pk->b2, 1, sorted, sorted, cnt, (uint32_t *)pB2, ones_as_mask, pk->side[2]);
+        e = nmsm_accumulate<FqField, true>(g1s, 3, sorted, nmsm_carve<FqField>(msm_ws[1], 3 * cnt, (uint32_t)stride), cnt, pA, ones_as_mask, pk->side[0], true,
+                                           lone, st, pk->ones_done);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_scale_quad_kernel, dim3((unsigned)(2 * cnt)), dim3(4), 0, pk->side[0], cnt, (const uint32_t *)d_split,
                            (const uint32_t *)pA, pSA);
+        e = nmsm_accumulate<Fq2Field, false>(&pk->b2, 1, sorted, sorted, cnt, (uint32_t *)pB2, ones_as_mask, pk->side[2]);
+        if (e != hipSuccess) break;
+        if (!lone) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
+        if (rc != FRW_OK) break;
         for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
         if (e == hipSuccess) e = hipEventRecord(pk->join[3], pk->main);
         if (e != hipSuccess) break;

@@ -409,9 +409,10 @@ int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, si
  *     d_proofs  uint64_t[batch][48]: A (G1Affine limbs, 12), B (G2Affine limbs, 24), C (12)
  *     d_num_unsatisfied  optional uint32_t[batch]: constraint rows the witness violates (the proof is then worthless)
  *     d_workspace  frw_groth16_workspace_bytes(pk, r, in_flight) bytes, 256-byte aligned; the batch runs in chunks that fit
- * d_witness / d_instance: what the witness entry points wrote (FRW_ENC_MONTGOMERY).  Ordered on `stream` -- the work itself runs
- * on four streams of the key's own (the witness map and the sum over h_query on one, the witness-side sums on three), forked from
- * and joined back into `stream` by events -- except for the upload of `rs`, which is waited for before the call goes on (the array
+ * d_witness / d_instance: what the witness entry points wrote (FRW_ENC_MONTGOMERY).  Ordered on `stream` -- the sort of the
+ * scalars' digits runs there, the rest on streams of the key's own (the witness map and the sum over h_query on one, the three G1
+ * witness-side sums as one chain of kernels followed by both scalar multiplications on another, G2 on a third), forked from and
+ * joined back into `stream` by events -- except for the upload of `rs`, which is waited for before the call goes on (the array
  * may be short-lived).
  * Calls with one key may come from several host threads: they take turns putting their work on the key's streams (each with a
  * workspace of its own).  A call that returns an error has waited for whatever it had already started.
