@@ -226,7 +226,7 @@ __device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomer
 // per second is what the L2 gives, and a signature has 4 x 10^6 pairs to place twice.)
 // 32 slices per signature for a batch (their histograms live in the buckets' memory until the first bucket is stored: room for 60);
 // a call with ONE signature (an aggregate statement's sum over 2^22 points) would keep 32 of the 256 CUs busy with them, so it cuts
-// 224, and parks their histograms in the work items' partial sums instead (131,072 x 240 bytes and more: room for 240), which
+// 224, and parks their histograms in the work items' partial sums instead (163,840 x 240 bytes and more: room for 300), which
 // nothing writes before the bucket kernel.
 constexpr int MSM_SLICES = 32, MSM_SLICES_LONE = 224;
 __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uin
 // size (a counting sort), so the 64 lanes of a wavefront run equally long; a bucket's items are neighbours, and
 // msm_combine_kernel adds them up.  At most 32,768 + 21,845 items whatever the scalars (sum of ceil(c_b / split)).
 constexpr int MSM_SIZE_CLASSES = 1024;         // sizes >= this share the first class
-constexpr int MSM_MAX_ITEMS = 131072;          // >= 32,768 + 32,768 / (1.5 / 4): the finest split (a lone signature), a multiple of 64
+constexpr int MSM_MAX_ITEMS = 163840;          // >= 32,768 + 32,768 finer / 1.5 for finer <= 6: the finest split (a lone signature), a multiple of 64
 // Sums over more than 2^18 points (an aggregate statement's h_query: ONE signature, 2^22 points, buckets of 2,048 entries) are cut
 // finer still: `finer` = 24 makes a bucket of the mean size 16 items of 128 entries -- 524,288 items, four rounds of the chip's
 // 131,072 thread slots at two wavefronts per SIMD (with 4 it was 98,304 items: a quarter of the slots idle and half the SIMDs with a
@@ -334,7 +334,7 @@ constexpr int MSM_MAX_ITEMS = 131072;          // >= 32,768 + 32,768 / (1.5 / 4)
 // combine's extra additions included).  Bound: 32,768 + 32,768 finer / 1.5.
 constexpr int MSM_MAX_ITEMS_LARGE = 32768 + 32768 * 24 * 2 / 3;     // 557,056
 __host__ __device__ constexpr uint32_t msm_max_items(uint32_t n) { return n > (1u << 18) ? (uint32_t)MSM_MAX_ITEMS_LARGE : (uint32_t)MSM_MAX_ITEMS; }
-// `finer`: 1 for a batch, 4 for one or two signatures at a time -- a bucket of the mean size is then three items instead of one
+// `finer`: 1 for a batch, 5 for one or two signatures at a time -- a bucket of the mean size is then four items instead of one
 // (a lone proof waits for ~128 dependent additions otherwise), and msm_combine_kernel adds them up
 __device__ __forceinline__ uint32_t msm_split_of(uint32_t total, uint32_t finer)
 {
@@ -1115,8 +1115,10 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts, slices);
         hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
         // (four at a time: 12.6 ms with the finer split, 12.1 without); beyond 2^18 points: see MSM_MAX_ITEMS_LARGE
-        // (a lone Falcon-1024 proof with 2 / 3 / 4: 4.72 / 4.27 / 4.05 ms -- the finer cut shares the chip better with the proof's other sums)
-        const uint32_t finer = cnt <= 2 ? (n > (1u << 18) ? 24u : 4u) : 1u;
+        // (a lone Falcon-1024 proof with 2 / 3 / 4: 4.72 / 4.27 / 4.05 ms -- the finer cut shares the chip better with the proof's other
+        // sums; 5 makes a bucket of the mean size four items: ~128,000 items = the chip's 131,072 thread slots at two wavefronts per
+        // SIMD once, where 4 left a quarter of the slots idle and half the SIMDs with one wavefront -- as in the note on MSM_MAX_ITEMS_LARGE)
+        const uint32_t finer = cnt <= 2 ? (n > (1u << 18) ? 24u : 5u) : 1u;
         hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count, finer, max_items);
         hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
         hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(max_items / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
@@ -1727,9 +1729,9 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
                            (uint32_t *)zext, stride * 8, nv);
         // Four chains of small kernels, and ONE host thread that enqueues them at 15 - 35 us a launch (some 45 launches: a chain
-        // enqueued last starts a millisecond late; profiles/r04_groth16_batch1_latency.txt) -- so the longest chain goes first: for a
-        // few proofs at a time all of it; for a batch only its head, and the sum over h_query -- whose bucket kernel then fills the
-        // chip for tens of milliseconds -- after everything that has workgroups of several wavefronts (they would not start under it).
+        // enqueued last starts a millisecond late; profiles/r04_groth16_batch1_latency.txt) -- so after the short sort the longest
+        // chain goes first: for a few proofs at a time all of it; for a batch only its head, and the sum over h_query -- whose bucket
+        // kernel then fills the chip for tens of milliseconds -- last.
         //   main      the witness map (a dozen launches, 0.7 ms; needs nothing of the sort) and the sum over h_query
         //   caller's  the sort of the digits of z ++ [1, r, s]: ONE counting sort for all four witness-side sums (its arrays live in
         //             b_g2_query's workspace; the workspaces of a_query, b_g1_query and l_query, one after the other, are the three G1
@@ -1743,10 +1745,8 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         forked = true;
         if (e == hipSuccess) e = hipStreamWaitEvent(pk->main, pk->fork, 0);
         if (e != hipSuccess) break;
-        rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
-        // (h_query has n - 1 points and the dense pipeline: frw_groth16_pk_load; the scalars are h's coefficients 0 .. n - 2)
-        if (rc == FRW_OK && lone) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
-        if (rc != FRW_OK) break;
+        // the sort first: its kernels are workgroups of 1,024 threads, which do not start under the sum over h_query's bucket kernel
+        // (0.8 ms late in a trace where the host was slow to get to them)
         const NmsmBufs sorted = nmsm_carve<Fq2Field>(msm_ws[4], cnt, (uint32_t)stride);
         const bool ones_as_mask = pk->a->ones_table && pk->b1->ones_table && pk->l->ones_table && pk->b2->ones_table;
         e = nmsm_sort(sorted, (uint32_t)stride, cnt, (const uint32_t *)zext, stride * 8, 1, ones_as_mask, st);
@@ -1754,6 +1754,10 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         e = hipEventRecord(pk->sorted, st);
         for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
         if (e != hipSuccess) break;
+        rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
+        // (h_query has n - 1 points and the dense pipeline: frw_groth16_pk_load; the scalars are h's coefficients 0 .. n - 2)
+        if (rc == FRW_OK && lone) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
+        if (rc != FRW_OK) break;
         const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
         e = nmsm_accumulate<FqField, true>(g1s, 3, sorted, nmsm_carve<FqField>(msm_ws[1], 3 * cnt, (uint32_t)stride), cnt, pA, ones_as_mask, pk->side[0], true,
                                            lone, st, pk->ones_done);

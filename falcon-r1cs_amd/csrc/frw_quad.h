@@ -212,7 +212,10 @@ __host__ __device__ inline XyzzT<FqField> running_point(const uint32_t *lds, boo
     m.inf = inf;
     return m;
 }
-// the addition whose operands are equal or opposite (P = 0 in the formulas above): the complete one-lane formula, by one lane
+// the addition whose operands are equal or opposite (P = 0 in the formulas above): the complete one-lane formula, by one lane.
+// (With the canonical split of a scalar below the group order -- k0 < lambda, what frw_msm.hip's glv_split hands over -- the running
+// point never meets an addend: 2 v = +-a mod r has no solution among the prefixes of such a pair.  The halves that do reach this
+// branch, tests/test_fq29_host.py, are non-canonical; it is here so that the kernel is complete for ANY pair of 128-bit halves.)
 __host__ __device__ inline bool add_degenerate(uint32_t *lds, uint32_t qx, uint32_t qy)
 {
     XyzzT<FqField> q;
