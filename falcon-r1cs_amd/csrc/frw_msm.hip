@@ -226,7 +226,7 @@ __device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomer
 // per second is what the L2 gives, and a signature has 4 x 10^6 pairs to place twice.)
 // 32 slices per signature for a batch (their histograms live in the buckets' memory until the first bucket is stored: room for 60);
 // a call with ONE signature (an aggregate statement's sum over 2^22 points) would keep 32 of the 256 CUs busy with them, so it cuts
-// 224, and parks their histograms in the work items' partial sums instead (163,840 x 240 bytes and more: room for 300), which
+// 224, and parks their histograms in the work items' partial sums instead (131,072 x 240 bytes and more: room for 240), which
 // nothing writes before the bucket kernel.
 constexpr int MSM_SLICES = 32, MSM_SLICES_LONE = 224;
 __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uin
 // size (a counting sort), so the 64 lanes of a wavefront run equally long; a bucket's items are neighbours, and
 // msm_combine_kernel adds them up.  At most 32,768 + 21,845 items whatever the scalars (sum of ceil(c_b / split)).
 constexpr int MSM_SIZE_CLASSES = 1024;         // sizes >= this share the first class
-constexpr int MSM_MAX_ITEMS = 163840;          // >= 32,768 + 32,768 finer / 1.5 for finer <= 6: the finest split (a lone signature), a multiple of 64
+constexpr int MSM_MAX_ITEMS = 131072;          // >= 32,768 + 32,768 / (1.5 / 4): the finest split (a lone signature), a multiple of 64
 // Sums over more than 2^18 points (an aggregate statement's h_query: ONE signature, 2^22 points, buckets of 2,048 entries) are cut
 // finer still: `finer` = 24 makes a bucket of the mean size 16 items of 128 entries -- 524,288 items, four rounds of the chip's
 // 131,072 thread slots at two wavefronts per SIMD (with 4 it was 98,304 items: a quarter of the slots idle and half the SIMDs with a
@@ -334,7 +334,7 @@ constexpr int MSM_MAX_ITEMS = 163840;          // >= 32,768 + 32,768 finer / 1.5
 // combine's extra additions included).  Bound: 32,768 + 32,768 finer / 1.5.
 constexpr int MSM_MAX_ITEMS_LARGE = 32768 + 32768 * 24 * 2 / 3;     // 557,056
 __host__ __device__ constexpr uint32_t msm_max_items(uint32_t n) { return n > (1u << 18) ? (uint32_t)MSM_MAX_ITEMS_LARGE : (uint32_t)MSM_MAX_ITEMS; }
-// `finer`: 1 for a batch, 5 for one or two signatures at a time -- a bucket of the mean size is then four items instead of one
+// `finer`: 1 for a batch, 4 for one or two signatures at a time -- a bucket of the mean size is then three items instead of one
 // (a lone proof waits for ~128 dependent additions otherwise), and msm_combine_kernel adds them up
 __device__ __forceinline__ uint32_t msm_split_of(uint32_t total, uint32_t finer)
 {
@@ -1116,9 +1116,8 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
         // (four at a time: 12.6 ms with the finer split, 12.1 without); beyond 2^18 points: see MSM_MAX_ITEMS_LARGE
         // (a lone Falcon-1024 proof with 2 / 3 / 4: 4.72 / 4.27 / 4.05 ms -- the finer cut shares the chip better with the proof's other
-        // sums; 5 makes a bucket of the mean size four items: ~128,000 items = the chip's 131,072 thread slots at two wavefronts per
-        // SIMD once, where 4 left a quarter of the slots idle and half the SIMDs with one wavefront -- as in the note on MSM_MAX_ITEMS_LARGE)
-        const uint32_t finer = cnt <= 2 ? (n > (1u << 18) ? 24u : 5u) : 1u;
+        // sums; 5, with a longer item list, changes nothing any more: 3.86 - 3.91 against 3.90 ms, the sums overlap either way)
+        const uint32_t finer = cnt <= 2 ? (n > (1u << 18) ? 24u : 4u) : 1u;
         hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count, finer, max_items);
         hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
         hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(max_items / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
@@ -1369,46 +1368,15 @@ __global__ __launch_bounds__(64) void groth16_tails_kernel(size_t batch, const u
     for (int j = 0; j < 2; j++)
         fr_store(dst + 8 * (j + 1), f29_pack(f29_canonical(f29_mul(f29_unpack(fr_load(rs + (sig * 2 + j) * 8)), c))));
 }
-// k P for one point per signature (s g_a and r (g1_b - s delta1) of g_c); runs on the side stream that made P.  One thread
-// per signature and a point that exists only now: the chain of doublings is the latency of a proof made alone, so the scalar
-// comes split by the endomorphism (k = k0 + lambda k1, done on the host where r and s arrive: glv_split) and the two 128-bit
-// halves share their doublings: 128 doublings and ~96 additions of P, phi(P) or P + phi(P) instead of 256 and ~128.
-// P arrives in XYZZ coordinates as its sum left it and k P leaves the same way (an inversion is a fifth of this kernel, and
-// the proof needs one at the very end only: groth16_finish_kernel).  phi(P) and P + phi(P) come for free in the same
-// denominators -- phi(x, y) = (beta x, y), and since the two have the same y their chord is horizontal:
-// P + phi(P) = (-(1 + beta) x, -y) -- so the loop is ONE doubling and ONE addition whose operand is selected: the same
-// instructions for every lane of the wavefront whatever its bits, and a loop small enough for the instruction cache (the
-// three-way branch over two mixed additions and a full one was 0.4 ms slower for a proof made alone).
-__global__ __launch_bounds__(64) void groth16_scale_kernel(size_t batch, const uint32_t *__restrict__ split /* [batch][2][8]: k0 | k1, 128 bits each */,
-                                                           int which, const uint32_t *__restrict__ pts /* [batch][BK_WORDS] */,
-                                                           uint32_t *__restrict__ out /* [batch][BK_WORDS] */)
-{
-    typedef FqField F;
-    constexpr int BW = Grp<F>::BK_WORDS;
-    const size_t sig = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (sig >= batch) return;
-    const XyzzT<F> base = load_bucket<F>(pts + sig * BW);                                  // X < 10 q, Y < 6 q
-    const Fq29 endo_x = fq_mul(base.x, fq_const(G1_ENDO_BETA29));                         // < 2 q
-    const Fq29 both_x = fq_neg<16>(fq_add(base.x, endo_x)), neg_y = fq_neg<16>(base.y);   // <= 16 q: operands of products only
-    const uint32_t *k = split + (sig * 2 + which) * 8;
-    uint32_t k0[4], k1[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { k0[i] = k[i]; k1[i] = k[4 + i]; }
-    XyzzT<F> m = pt_identity<F>();
-#pragma nounroll
-    for (int bit = 127; bit >= 0; bit--) {
-        m = pt_double(m);
-        const uint32_t sel = ((k0[bit >> 5] >> (bit & 31)) & 1u) | (((k1[bit >> 5] >> (bit & 31)) & 1u) << 1);
-        if (sel) {
-            XyzzT<F> q = base;
-            q.x = fq_select(sel == 1, base.x, fq_select(sel == 2, endo_x, both_x));
-            q.y = fq_select(sel == 3, neg_y, base.y);
-            m = pt_add(m, q);
-        }
-    }
-    store_bucket<F>(out + sig * BW, m);
-}
-// The same k P on FOUR lanes (frw_quad.h): the formulas' independent products side by side -- three dependent levels per
+// k P for one point per signature (s g_a and r (g1_b - s delta1) of g_c); runs on the side stream that made P.  A point that exists
+// only now: the chain of doublings is the latency of a proof made alone, so the scalar comes split by the endomorphism
+// (k = k0 + lambda k1, done on the host where r and s arrive: glv_split) and the two 128-bit halves share their doublings: 128
+// doublings and ~96 additions of P, phi(P) or P + phi(P) instead of 256 and ~128.  P arrives in XYZZ coordinates as its sum left it
+// and k P leaves the same way (the proof needs one inversion, at the very end: groth16_finish_kernel).  phi(P) and P + phi(P) come
+// for free in the same denominators -- phi(x, y) = (beta x, y), and since the two have the same y their chord is horizontal:
+// P + phi(P) = (-(1 + beta) x, -y) -- so a step is ONE doubling and ONE addition whose operand is selected.  (Until late in round 4
+// one thread per scalar multiplication ran this loop with the one-lane formulas of frw_fq29.h: 3.1 ms of a lone proof's 5.6.)
+// On FOUR lanes (frw_quad.h): the formulas' independent products side by side -- three dependent levels per
 // doubling instead of nine products, four per addition instead of fourteen -- with the results in a register file in LDS.  One
 // quad per workgroup: its lanes take the same branches (they depend on the scalar's bits and on zero tests every lane sees
 // alike), so nothing diverges, and a batch of scalar multiplications spreads over as many SIMDs.

@@ -91,7 +91,7 @@ def prove_leg_bytes(n, num_witness, num_instance, proofs_in_flight=64):
     queries -- and as much again for their ones tables --, 1,792 per point of h_query), the constraint matrices and transform tables of frw_r1cs_load (~1.3 KB per
     constraint), and frw_groth16_workspace_bytes for `proofs_in_flight` proofs (per proof: the products, h and working
     arrays of the witness map ~ 5 x 32 x domain + 96 C, the sort keys of the five sums ~ 64 x domain + 4 x 132 x (I + W), the
-    buckets, work items and partial sums of the 16-bit pipeline ~ 200,000 x 240).  Falcon-1024: 6.2 + 0.3 + 64 x 0.2 = 19.8 GB."""
+    buckets, work items and partial sums of the 16-bit pipeline ~ 168,000 x 240).  Falcon-1024: 6.2 + 0.3 + 64 x 0.2 = 19.3 GB."""
     nv = num_witness + num_instance
     constraints = num_witness + 6 * n + 2
     domain = 1
@@ -99,7 +99,7 @@ def prove_leg_bytes(n, num_witness, num_instance, proofs_in_flight=64):
         domain *= 2
     key = 2 * (3 * 3584 + 7168) * (nv + 3) + 1792 * domain          # window tables + the subset sums of every group of eight, as many bytes again
     matrices = 1300 * constraints + 9 * 32 * domain
-    per_proof = 5 * 32 * domain + 96 * constraints + 64 * domain + 4 * 132 * nv + (32768 + 163840 + 4096) * 240 + (1 << 20)
+    per_proof = 5 * 32 * domain + 96 * constraints + 64 * domain + 4 * 132 * nv + (32768 + 131072 + 4096) * 240 + (1 << 20)
     return int(key + matrices + proofs_in_flight * per_proof)
 
 

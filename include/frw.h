@@ -371,7 +371,7 @@ typedef struct {
     uint64_t table_bytes;                      /* 16 x num_points x 112 (G2: 224); a _narrow handle: 32 x num_points x 112, and for up to 2^18
                                                 * points as much again for the sums of the 255 non-empty subsets of every group of eight points */
     uint64_t workspace_bytes_per_signature;    /* sort keys (64 num_points bytes), the list of scalars equal to one (4 num_points),
-                                                * 32,768 buckets + 163,840 work items + 4,096 partial sums x 240 bytes (G2: 464),
+                                                * 32,768 buckets + 131,072 work items + 4,096 partial sums x 240 bytes (G2: 464),
                                                 * counters; a _narrow handle: 128 + 4 num_points bytes of keys and list, the partial
                                                 * sums of its work items and of the ones */
 } frw_msm_info_t;

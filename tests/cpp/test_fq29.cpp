@@ -178,3 +178,22 @@ extern "C" int t_g1_quad_scale(const uint32_t *pw, int pre, const uint32_t *k, u
     store_point(r, out);
     return quad::NSLOTS | ex.degenerate_calls << 8;
 }
+// the level programmes as data, for the structural checks of tests/test_fq29_host.py: out[step][lane][12] =
+// ap[4] am[3] bp[2] bm dst kind; returns the number of steps
+extern "C" int t_quad_programmes(uint8_t *out)
+{
+    const quad::Step *steps[] = {&quad::D1, &quad::D2, &quad::D3, &quad::A1, &quad::A2, &quad::A3, &quad::A4, &quad::COPY};
+    int n = 0;
+    for (const quad::Step *s : steps) {
+        for (int l = 0; l < 4; l++) {
+            const quad::Lane &L = s->l[l];
+            uint8_t *o = out + (n * 4 + l) * 12;
+            for (int k = 0; k < 4; k++) o[k] = L.ap[k];
+            for (int k = 0; k < 3; k++) o[4 + k] = L.am[k];
+            for (int k = 0; k < 2; k++) o[7 + k] = L.bp[k];
+            o[9] = L.bm; o[10] = L.dst; o[11] = L.kind;
+        }
+        n++;
+    }
+    return n;
+}

@@ -224,6 +224,47 @@ def test_scalar_multiplication_on_four_lanes(lib):
     assert run(None, 0, 5, 7) is None
 
 
+def test_level_programmes_are_well_formed(lib):
+    """frw_quad.h's level programmes as data: no two lanes of a level write the same slot (but the dump), a level never writes a
+    constant or the addend, a temporary is written before it is read within its operation, and the bounds the header states hold
+    when every slot carries the bound of what was last written to it (a difference must never subtract more than the K q it adds)."""
+    buf = (C.c_uint8 * (8 * 4 * 12))()
+    assert lib.t_quad_programmes(buf) == 8
+    names = ["ZERO", "K4", "K8", "X", "AY", "BY", "ZZ", "ZZZ", "PX", "PEX", "PBX", "PY", "PNY", "PZZ", "PZZZ"] + ["T%d" % i for i in range(11)] + ["DUMP", "FLAGS"]
+    idx = {n: i for i, n in enumerate(names)}
+    QX, QY = 62, 63
+    steps = [[dict(ap=list(buf[(s * 4 + l) * 12:(s * 4 + l) * 12 + 4]), am=list(buf[(s * 4 + l) * 12 + 4:(s * 4 + l) * 12 + 7]),
+                   bp=list(buf[(s * 4 + l) * 12 + 7:(s * 4 + l) * 12 + 9]), bm=buf[(s * 4 + l) * 12 + 9], dst=buf[(s * 4 + l) * 12 + 10],
+                   kind=buf[(s * 4 + l) * 12 + 11]) for l in range(4)] for s in range(8)]
+    state = {idx[n] for n in ("X", "AY", "BY", "ZZ", "ZZZ")}
+    constant = {idx[n] for n in ("ZERO", "K4", "K8", "PX", "PEX", "PBX", "PY", "PNY", "PZZ", "PZZZ")}
+    # bounds in units of q: what setup() and the programmes leave in the slots
+    for first, last in ((0, 3), (3, 7), (7, 8)):                 # doubling, addition, copy
+        bound = {idx["ZERO"]: 0, idx["K4"]: 4, idx["K8"]: 8, idx["X"]: 10, idx["AY"]: 2, idx["BY"]: 2, idx["ZZ"]: 2, idx["ZZZ"]: 2,
+                 idx["PX"]: 10, idx["PEX"]: 2, idx["PBX"]: 2, idx["PY"]: 2, idx["PNY"]: 2, idx["PZZ"]: 2, idx["PZZZ"]: 2, QX: 10, QY: 2}
+        written = set()
+        for step in steps[first:last]:
+            dsts = [l["dst"] for l in step if l["dst"] != idx["DUMP"]]
+            assert len(dsts) == len(set(dsts)) and not (set(dsts) & constant)
+            new_bounds = {}
+            for l in step:
+                reads = [x for x in l["ap"] + l["am"] + l["bp"] + [l["bm"]] if x != idx["ZERO"]]
+                for x in reads:
+                    assert x in bound, "slot %s is read before anything wrote it" % (names[x] if x < len(names) else x)
+                plus_a, minus_a = sum(bound[x] for x in l["ap"]), sum(bound[x] for x in l["am"])
+                plus_b, minus_b = sum(bound[x] for x in l["bp"]), bound[l["bm"]]
+                k_a = sum(bound[x] for x in l["ap"] if x in (idx["K4"], idx["K8"]))
+                k_b = sum(bound[x] for x in l["bp"] if x in (idx["K4"], idx["K8"]))
+                assert minus_a <= k_a and minus_b <= k_b, "a difference may go negative"
+                assert plus_a < 4096 and plus_b < 4096                          # operands of a product: anything below 2^12 q
+                if l["dst"] != idx["DUMP"]:
+                    new_bounds[l["dst"]] = plus_a if l["kind"] == 1 else 2       # a linear form keeps its bound, a product returns < 2 q
+            bound.update(new_bounds)
+            written |= set(new_bounds)
+        assert state <= written | {idx["BY"]}                                   # (the copy leaves BY as it is: zero for the identity)
+        assert bound[idx["X"]] <= 10 and bound[idx["AY"]] <= 2 and bound[idx["BY"]] <= 2 and bound[idx["ZZ"]] <= 2 and bound[idx["ZZZ"]] <= 2
+
+
 def limbs2(v):
     return (C.c_uint32 * 28)(*(list(limbs(v[0])) + list(limbs(v[1]))))
 
