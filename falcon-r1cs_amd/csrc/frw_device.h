@@ -112,7 +112,18 @@ struct R1csDev {
     const uint32_t *long_vars;  // [num_long_vars] column
     const uint32_t *long_cidx;  // [chunks][64] index into long_vars
     uint32_t k_rrp[9];          // R R' mod p (R = 2^256, R' = 2^261) as an integer, 29-bit limbs
+    // The short rows once more, flattened for r1cs_eval_flat_kernel: position i (rows by decreasing length, as `order`) has ONE
+    // header -- the row, how many terms it has in A, B, C (0 where it is long), the long mask -- and its terms of all three matrices
+    // one after the other, a word each: column | coefficient index << 24 (0: +1, 1: -1, else into flat_coef, c R' packed like
+    // val29: a Falcon circuit has 16 distinct coefficients).  A thread then needs three dependent loads for a row (header, terms,
+    // variables) where the CSR walk needed a dozen -- and a third of the memory instructions, which is what the kernel waits for.  flat_term is null when a circuit does not fit (> 254 coefficients, a column
+    // >= 2^24): r1cs_eval_kernel does the work then.
+    const uint32_t *flat_head;  // [num_constraints][4]: row | (nA | nB << 8 | nC << 16 | long mask << 24) | first term / 4 | 0
+    const uint32_t *flat_term;  // a row's terms start at a multiple of four words: a thread fetches them four at a time, as one 16-byte load
+    const uint32_t *flat_coef;  // [flat_num_coefs][8]
+    uint32_t flat_num_coefs;
 };
+constexpr uint32_t R1CS_FLAT_COEFS = 256;
 // Where one launch of the evaluation kernels finds the statements ("signatures") of its batch and where their products go,
 // in 32-bit words unless said otherwise.  The plain batch of the witness entry points and a run of statements inside an
 // aggregate assignment differ in nothing else:

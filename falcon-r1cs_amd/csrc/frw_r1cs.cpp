@@ -270,6 +270,49 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
             return m.a[x].size() + m.b[x].size() + m.c[x].size() > m.a[y].size() + m.b[y].size() + m.c[y].size();
         });
         r->dev.order = (const uint32_t *)upload(order.data(), order.size() * 4);
+        // the short rows flattened (frw_device.h: flat_*): one header and one run of term words per row, coefficients by index
+        {
+            const std::vector<frw::host::ConstraintMatrices::Row> *ms[3] = {&m.a, &m.b, &m.c};
+            const Fr one = Fr::one(), minus_one = -Fr::one(), two5 = Fr::from(32);
+            std::vector<Fr> coefs{one, minus_one};
+            std::vector<uint32_t> fhead, fterm;
+            bool fits = true;
+            for (size_t i = 0; i < m.num_constraints && fits; i++) {
+                const uint32_t row = order[i];               // (rows in their own order instead: stores coalesce, lengths diverge -- 1,727 us against 618)
+                const size_t first_term = fterm.size();
+                uint32_t counts = 0;
+                for (uint32_t mi = 0; mi < 3 && fits; mi++) {
+                    const auto &terms = (*ms[mi])[row];
+                    if (terms.size() >= frw::R1CS_LONG_ROW) { counts |= 1u << (24 + mi); continue; }
+                    counts |= (uint32_t)terms.size() << (8 * mi);
+                    for (const auto &t : terms) {
+                        size_t idx = 0;
+                        while (idx < coefs.size() && !(coefs[idx] == t.first)) idx++;
+                        if (idx == coefs.size()) coefs.push_back(t.first);
+                        if (idx >= frw::R1CS_FLAT_COEFS || (t.second >> 24)) { fits = false; break; }
+                        fterm.push_back(t.second | (uint32_t)idx << 24);
+                    }
+                }
+                fhead.push_back(row);
+                fhead.push_back(counts);
+                fhead.push_back((uint32_t)(first_term / 4));
+                fhead.push_back(0u);
+                while (fterm.size() % 4) fterm.push_back(0u);            // (0: the constant one with coefficient +1 -- beyond the row's count, never added)
+            }
+            r->dev.flat_term = nullptr;
+            r->dev.flat_num_coefs = 0;
+            if (fits) {
+                std::vector<uint32_t> fcoef;
+                for (const Fr &c : coefs) {
+                    const Fr c29 = c * two5;                             // Montgomery limbs of 32 c = c R' mod p, as val29
+                    for (int k = 0; k < 4; k++) { fcoef.push_back((uint32_t)c29.l[k]); fcoef.push_back((uint32_t)(c29.l[k] >> 32)); }
+                }
+                r->dev.flat_head = (const uint32_t *)upload(fhead.data(), fhead.size() * 4);
+                r->dev.flat_coef = (const uint32_t *)upload(fcoef.data(), fcoef.size() * 4);
+                r->dev.flat_num_coefs = (uint32_t)coefs.size();
+                r->dev.flat_term = (const uint32_t *)upload(fterm.data(), fterm.size() * 4);
+            }
+        }
         // long rows: chunked, coefficient planes (see frw_device.h)
         std::vector<frw::R1csLongRow> lrows;
         std::vector<uint32_t> lcol, lcoef;

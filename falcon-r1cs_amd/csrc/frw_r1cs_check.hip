@@ -77,6 +77,26 @@ __device__ __forceinline__ F29 row_dot29(const R1csMatrixDev &m, uint32_t row, c
     return acc;                                    // < 2 p
 }
 
+// (A z)(B z) = C z for one row, all three canonical in the form x R: (32 Az R)(Bz R) / R' = Az Bz R against Cz R -- ONE product
+// (with both sides brought to the form x R / 32 it was two, a fifth of the evaluation kernels' instructions).  32 x a canonical
+// value is below 2^260: a left operand f29_mul takes as it is once its limbs are carried.
+__device__ __forceinline__ bool row_holds(const F29 (&v)[3])
+{
+    F29 a32;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL29; k++) {
+        const uint32_t x = v[0].l[k];
+        a32.l[k] = k + 1 < NL29 ? ((x << 5) & M29) | carry : (x << 5) | carry;
+        carry = x >> 24;
+    }
+    const F29 ab = f29_canonical(f29_mul(a32, v[1]));
+    bool eq = true;
+#pragma unroll
+    for (int k = 0; k < NL29; k++) eq &= ab.l[k] == v[2].l[k];
+    return eq;
+}
+
 // STORE: write A z, B z, C z to abc (and read the long rows' products from there).  !STORE: check only -- nothing is
 // written; the long rows' products are read from `long_out` ([signature][long row], r.long_slot maps (matrix, row) to it).
 #ifndef FRW_EVAL_WAVES
@@ -90,11 +110,6 @@ __global__ __launch_bounds__(BLOCK, FRW_EVAL_WAVES) void r1cs_eval_kernel(R1csDe
     if (sig >= batch) return;
     const StatementVars z_of = statement_vars(r, view, sig);
     const uint32_t *lo = STORE ? nullptr : long_out + sig * (size_t)r.num_long * 8;
-    constexpr uint32_t R32[8] = FRW_R32;
-    Fr8 one_r;
-#pragma unroll
-    for (int k = 0; k < 8; k++) one_r.l[k] = R32[k];
-    const F29 one29 = f29_unpack(one_r);          // R as an integer: f29_mul(x R, R) = x R / 32
     unsigned bad = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < r.num_constraints; i += gridDim.x * BLOCK) {
         const uint32_t row = r.order[i], mask = r.long_mask[row];
@@ -110,12 +125,95 @@ __global__ __launch_bounds__(BLOCK, FRW_EVAL_WAVES) void r1cs_eval_kernel(R1csDe
                 if (STORE) fr_store(om, f29_pack(v[m]));
             }
         }
-        // (Az R)(Bz R) / R' = Az Bz R / 32  against  (Cz R) R / R' = Cz R / 32
-        const F29 ab = f29_canonical(f29_mul(v[0], v[1])), c32 = f29_canonical(f29_mul(v[2], one29));
-        bool eq = true;
+        bad += row_holds(v) ? 0u : 1u;
+    }
 #pragma unroll
-        for (int k = 0; k < NL29; k++) eq &= ab.l[k] == c32.l[k];
-        bad += eq ? 0u : 1u;
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && bad && view.flags) atomicAdd(&view.flags[sig * view.flag_stride], bad);
+}
+
+// The same work from the flattened rows (frw_device.h flat_*; r.flat_term != null).  r1cs_eval_kernel walks three CSR
+// matrices per row -- order -> long_mask -> row_ptr x 2 -> col_class -> variable (-> coefficient), three times over: a dozen
+// dependent loads for a row of three terms, and its waves spend two thirds of their cycles parked on them
+// (profiles/r03_qap_counters.txt).  Here a row is ONE header (coalesced), its term words four at a time (independent loads),
+// then their variables (independent again): three dependent loads for the 100,000 three-term rows of a Falcon-1024 system, five
+// for the six-term ones; the 16 distinct coefficients of a Falcon circuit wait in LDS, and a wavefront whose rows have none but
+// +1 / -1 (the boolean gates) skips the field product altogether.  Every (M z)_row is stored canonical, so the order of
+// summation cannot show: bit for bit what r1cs_eval_kernel writes.
+template <bool STORE>
+__global__ __launch_bounds__(BLOCK, FRW_EVAL_WAVES) void r1cs_eval_flat_kernel(R1csDev r, size_t batch, const R1csView view,
+                                                                               const uint32_t *__restrict__ long_out)
+{
+    __shared__ uint32_t coef[R1CS_FLAT_COEFS * 8];
+    for (uint32_t k = threadIdx.x; k < r.flat_num_coefs * 8; k += BLOCK) coef[k] = r.flat_coef[k];
+    __syncthreads();
+    const size_t sig = blockIdx.y;
+    if (sig >= batch) return;
+    const StatementVars z_of = statement_vars(r, view, sig);
+    const uint32_t *lo = STORE ? nullptr : long_out + sig * (size_t)r.num_long * 8;
+    unsigned bad = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < r.num_constraints; i += gridDim.x * BLOCK) {
+        const uint4 head = ((const uint4 *)r.flat_head)[i];
+        const uint4 *terms = (const uint4 *)r.flat_term + head.z;
+        const uint32_t row = head.x, n_a = head.y & 0xffu, n_ab = n_a + ((head.y >> 8) & 0xffu), n = n_ab + ((head.y >> 16) & 0xffu),
+                       mask = head.y >> 24;
+        // ONE running sum: the terms come A first, then B, then C, so the sum is parked (and restarted) where t reaches nA and nA + nB
+        F29 acc[3], run;
+#pragma unroll
+        for (int k = 0; k < NL29; k++) run.l[k] = acc[0].l[k] = acc[1].l[k] = acc[2].l[k] = 0;
+        for (uint32_t t0 = 0; t0 < n; t0 += 4) {
+            const uint4 w4 = terms[t0 >> 2];                                                      // (padded with 0: the constant one -- not added)
+            const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+            Fr8 zw[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (__any(t0 + k < n)) zw[k] = fr_load(z_of.at(w[k] & 0x00ffffffu));
+                else zw[k] = zw[0];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t t = t0 + k, idx = w[k] >> 24;
+                const bool live = t < n;
+                if (!__any(live)) break;
+                const bool at_b = live && t == n_a, at_c = live && t == n_ab;                      // (both when B is empty: A's sum parks, B's stays zero)
+#pragma unroll
+                for (int j = 0; j < NL29; j++) {
+                    acc[0].l[j] = at_b ? run.l[j] : acc[0].l[j];
+                    acc[1].l[j] = at_c && !at_b ? run.l[j] : acc[1].l[j];
+                    run.l[j] = at_b || at_c ? 0u : run.l[j];
+                }
+                F29 c = f29_unpack(zw[k]);
+                if (__any(live && idx >= 2u)) {                                                    // some row of the wavefront has a general coefficient here
+                    const F29 prod = f29_mul(c, f29_unpack(fr_load(coef + (idx < 2u ? 0u : idx) * 8)));
+#pragma unroll
+                    for (int j = 0; j < NL29; j++) c.l[j] = idx >= 2u ? prod.l[j] : c.l[j];
+                }
+                const F29 next = idx == 1u ? f29_reduce_4p(f29_sub_2p(run, c)) : f29_reduce_4p(f29_add(run, c));
+#pragma unroll
+                for (int j = 0; j < NL29; j++) run.l[j] = live ? next.l[j] : run.l[j];
+            }
+        }
+        // what is still running belongs to the last matrix that has terms
+        {
+            const bool to_a = n_a == n, to_b = !to_a && n_ab == n;
+#pragma unroll
+            for (int j = 0; j < NL29; j++) {
+                acc[0].l[j] = to_a ? run.l[j] : acc[0].l[j];
+                acc[1].l[j] = to_b ? run.l[j] : acc[1].l[j];
+                acc[2].l[j] = !to_a && !to_b ? run.l[j] : acc[2].l[j];
+            }
+        }
+        F29 v[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            uint32_t *om = STORE ? product_ptr(view, sig, m, row) : nullptr;
+            if (mask & (1u << m)) {
+                v[m] = f29_unpack(fr_load(STORE ? om : lo + (size_t)r.long_slot[(size_t)m * r.num_constraints + row] * 8));
+            } else {
+                v[m] = f29_canonical(acc[m]);
+                if (STORE) fr_store(om, f29_pack(v[m]));
+            }
+        }
+        bad += row_holds(v) ? 0u : 1u;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, WAVE);
@@ -316,6 +414,10 @@ __global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, s
     }
 }
 
+// (A/B, negative, round 4: a workgroup of four wavefronts taking one long row for 16 signatures, the row's coefficients -- 36 bytes a
+// term, which every group of four signatures fetches again -- coming through LDS once per workgroup, double-buffered with one barrier
+// per 64 terms: 725 us per 64 signatures against 469.  The refetches hit in cache; the barrier and two waves per SIMD cost more.)
+
 // Scratch of the evaluation: the small values of the long rows' variables (batch x num_long_vars x 4 bytes) and, when
 // the products are not kept (abc == nullptr), the long rows' results (batch x num_long x 32 bytes).  An aggregate's runs
 // are evaluated one after the other on one stream: they share the scratch of the largest.
@@ -366,7 +468,10 @@ hipError_t launch_view(const R1csDev &r, size_t batch, const R1csView &view, hip
                 hipLaunchKernelGGL(r1cs_long_rows_kernel, grid, dim3(WAVE), 0, st, r, batch, view, long_out);
             }
         }
-        if (abc) hipLaunchKernelGGL(r1cs_eval_kernel<true>, egrid, dim3(BLOCK), 0, st, r, batch, view, long_out);
+        if (r.flat_term) {
+            if (abc) hipLaunchKernelGGL(r1cs_eval_flat_kernel<true>, egrid, dim3(BLOCK), 0, st, r, batch, view, long_out);
+            else hipLaunchKernelGGL(r1cs_eval_flat_kernel<false>, egrid, dim3(BLOCK), 0, st, r, batch, view, long_out);
+        } else if (abc) hipLaunchKernelGGL(r1cs_eval_kernel<true>, egrid, dim3(BLOCK), 0, st, r, batch, view, long_out);
         else hipLaunchKernelGGL(r1cs_eval_kernel<false>, egrid, dim3(BLOCK), 0, st, r, batch, view, long_out);
     } else {
         hipLaunchKernelGGL(r1cs_check_kernel, egrid, dim3(BLOCK), 0, st, r, batch, view);
