@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <stdexcept>
@@ -276,7 +277,7 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
             const Fr one = Fr::one(), minus_one = -Fr::one(), two5 = Fr::from(32);
             std::vector<Fr> coefs{one, minus_one};
             std::vector<uint32_t> fhead, fterm;
-            bool fits = true;
+            bool fits = std::getenv("FRW_R1CS_NO_FLAT") == nullptr;     // (diagnostics: tests run the CSR walk, the route of a circuit that does not fit)
             for (size_t i = 0; i < m.num_constraints && fits; i++) {
                 const uint32_t row = order[i];               // (rows in their own order instead: stores coalesce, lengths diverge -- 1,727 us against 618)
                 const size_t first_term = fterm.size();

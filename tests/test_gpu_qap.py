@@ -143,9 +143,14 @@ def test_witness_map_full_batch_identity_and_chunking(engine, oracle, tmp_path):
     assert lhs == rhs
 
 
-def test_witness_map_matches_committed_golden(engine):
+@pytest.mark.parametrize("walk", ["flattened rows", "CSR walk"])
+def test_witness_map_matches_committed_golden(engine, walk, monkeypatch):
     """tests/golden/qap.json: the digest of h (ark-ff's Montgomery bytes, as frw_qap_witness_map_dev writes them) for the
-    committed witness fixtures, Falcon-512 and Falcon-1024."""
+    committed witness fixtures, Falcon-512 and Falcon-1024 -- through the flattened short rows (r1cs_eval_flat_kernel) and
+    through the CSR walk a circuit that does not fit them takes (r1cs_eval_kernel; FRW_R1CS_NO_FLAT at load time), incl. a
+    tampered witness, which both must flag."""
+    if walk == "CSR walk":
+        monkeypatch.setenv("FRW_R1CS_NO_FLAT", "1")
     import hashlib
     import json
     import os
@@ -173,10 +178,17 @@ def test_witness_map_matches_committed_golden(engine):
             bad = torch.empty(1, dtype=torch.int32, device=dev)
             engine.qap_witness_map_dev(r, 1, wit, inst, h, ws, per, bad, 0)
             torch.cuda.synchronize()
+            assert bad.tolist() == [0]
+            assert hashlib.sha256(h[0].cpu().numpy().tobytes()).hexdigest() == fx["h_sha256"]["montgomery"]
+            # one boolean of a range proof flipped: rows of the flattened / CSR evaluation no longer hold, and the count says so
+            wbad = wit.clone()
+            wbad[0, 2 * L.n + 5, 0] ^= 1
+            h2 = torch.empty_like(h)
+            engine.qap_witness_map_dev(r, 1, wbad, inst, h2, ws, per, bad, 0)
+            torch.cuda.synchronize()
+            assert int(bad[0]) > 0
         finally:
             engine.r1cs_free(r)
-        assert bad.tolist() == [0]
-        assert hashlib.sha256(h[0].cpu().numpy().tobytes()).hexdigest() == fx["h_sha256"]["montgomery"]
 
 
 def test_host_entry_point_equals_device_entry_point(engine):
