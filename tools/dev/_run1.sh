@@ -1,6 +1,4 @@
 set -e
-R=$(pwd); O=$R/gpurun_out/s4a; mkdir -p $O
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/gputests.txt 2>&1 || { tail -40 $O/gputests.txt; exit 1; }
-tail -3 $O/gputests.txt
-python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.log; tail -c 400 $O/bench_n1.json
-python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -n 1 $O/smoke.txt
+bash tools/profile_round.sh r04 > gpurun_out/profile_round_r04.log 2>&1 || { tail -30 gpurun_out/profile_round_r04.log; exit 1; }
+tail -3 gpurun_out/profile_round_r04.log | cut -c1-300
+python3 bench.py > gpurun_out/profiles_r04/r04_bench_n1.json 2> gpurun_out/bench_n1.log; tail -c 300 gpurun_out/profiles_r04/r04_bench_n1.json
