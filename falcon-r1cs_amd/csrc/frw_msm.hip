@@ -1125,6 +1125,7 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
         hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, offsets, counts, item_first,
                            partial_items, buckets, finer, max_items);
         // first stage of the fold: enough threads to occupy the chip (~2^16), as few as that allows
+        // (64 per call with 16 / 32 / 64 buckets per thread: 927 - 929 / 927 - 930 / 919 proofs/s -- the fold is 3 of a call's 69 ms)
         const int log_chunk = cnt >= 128 ? 6 : cnt >= 32 ? 5 : 3;
         const unsigned t1 = (unsigned)frw::MSM_BUCKETS >> log_chunk;
         hipLaunchKernelGGL(frw::msm_ones_kernel<F>, dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list, partial);
