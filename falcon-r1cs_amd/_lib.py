@@ -104,6 +104,8 @@ PROTOTYPES = {
     "frw_groth16_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "frw_groth16_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frw_groth16_prove_rs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_void_p]),
     "frw_groth16_vk_load": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "frw_groth16_vk_free": (None, [C.c_void_p]),
     "frw_groth16_verify": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -1369,6 +1369,45 @@ __global__ __launch_bounds__(64) void groth16_tails_kernel(size_t batch, const u
     for (int j = 0; j < 2; j++)
         fr_store(dst + 8 * (j + 1), f29_pack(f29_canonical(f29_mul(f29_unpack(fr_load(rs + (sig * 2 + j) * 8)), c))));
 }
+// k (any 256-bit value; taken mod the group order r) = k0 + lambda k1, lambda = z^2 - 1 = 0xac45a4010001a40200000000ffffffff,
+// r = lambda^2 + lambda + 1: k0 = k mod lambda, k1 = k div lambda <= lambda + 1 < 2^128 -- for both blinding factors of every proof,
+// one thread each (plain schoolbook division, a bit at a time: two scalars per proof).  out: [batch][2][k0 (2 x u64) | k1 (2 x u64)].
+// On the device so that a call with its blinding factors in device memory never waits on the host (frw_groth16_prove_rs_dev).
+__global__ __launch_bounds__(64) void groth16_split_kernel(size_t count, const uint64_t *__restrict__ rs /* [count][4] */, uint64_t *__restrict__ out /* [count][4] */)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t R[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    const uint64_t L0 = 0x00000000ffffffffULL, L1 = 0xac45a4010001a402ULL;
+    uint64_t k[4] = {rs[i * 4], rs[i * 4 + 1], rs[i * 4 + 2], rs[i * 4 + 3]};
+    for (int round = 0; round < 2; round++) {                       // 2^256 < 3 r: at most two subtractions
+        bool ge = true;
+        for (int j = 3; j >= 0; j--)
+            if (k[j] != R[j]) { ge = k[j] > R[j]; break; }
+        if (!ge) break;
+        uint64_t borrow = 0;
+        for (int j = 0; j < 4; j++) {
+            const uint64_t d = k[j] - R[j], d2 = d - borrow;
+            borrow = (k[j] < R[j]) | (d < borrow);
+            k[j] = d2;
+        }
+    }
+    uint64_t r0 = 0, r1 = 0, q0 = 0, q1 = 0;
+    for (int bit = 255; bit >= 0; bit--) {
+        const uint64_t top = r1 >> 63;
+        r1 = (r1 << 1) | (r0 >> 63);
+        r0 = (r0 << 1) | ((k[bit >> 6] >> (bit & 63)) & 1ULL);
+        q1 = (q1 << 1) | (q0 >> 63);                                 // k < r: the quotient's bits above 127 are zero
+        q0 <<= 1;
+        if (top || r1 > L1 || (r1 == L1 && r0 >= L0)) {
+            const uint64_t b = r0 < L0;
+            r0 -= L0;
+            r1 = r1 - L1 - b;
+            q0 |= 1ULL;
+        }
+    }
+    out[i * 4] = r0; out[i * 4 + 1] = r1; out[i * 4 + 2] = q0; out[i * 4 + 3] = q1;
+}
 // k P for one point per signature (s g_a and r (g1_b - s delta1) of g_c); runs on the side stream that made P.  A point that exists
 // only now: the chain of doublings is the latency of a proof made alone, so the scalar comes split by the endomorphism
 // (k = k0 + lambda k1, done on the host where r and s arrive: glv_split) and the two 128-bit halves share their doublings: 128
@@ -1588,32 +1627,6 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
 }
 
 namespace {
-// k (any 256-bit value; taken mod the group order r) = k0 + lambda k1, lambda = z^2 - 1 = 0xac45a4010001a40200000000ffffffff,
-// r = lambda^2 + lambda + 1: k0 = k mod lambda, k1 = k div lambda <= lambda + 1 < 2^128.  out: k0 (2 words) | k1 (2 words).
-void glv_split(const uint64_t k_in[4], uint64_t out[4])
-{
-    typedef unsigned __int128 u128;
-    static const uint64_t R[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
-    const u128 lambda = ((u128)0xac45a4010001a402ULL << 64) | 0x00000000ffffffffULL;
-    uint64_t k[4] = {k_in[0], k_in[1], k_in[2], k_in[3]};
-    for (int round = 0; round < 3; round++) {                       // 2^256 < 3 r: at most two subtractions
-        bool ge = true;
-        for (int i = 3; i >= 0; i--)
-            if (k[i] != R[i]) { ge = k[i] > R[i]; break; }
-        if (!ge) break;
-        u128 borrow = 0;
-        for (int i = 0; i < 4; i++) { const u128 d = (u128)k[i] - R[i] - borrow; k[i] = (uint64_t)d; borrow = (d >> 64) & 1; }
-    }
-    u128 rem = 0, quo = 0;
-    for (int bit = 255; bit >= 0; bit--) {                          // schoolbook, one bit at a time: two scalars per proof
-        const bool top = (rem >> 127) & 1;
-        rem = (rem << 1) | ((k[bit >> 6] >> (bit & 63)) & 1);
-        quo <<= 1;                                                  // k < r: the quotient's bits above 127 are zero
-        if (top || rem >= lambda) { rem -= lambda; quo |= 1; }
-    }
-    out[0] = (uint64_t)rem; out[1] = (uint64_t)(rem >> 64);
-    out[2] = (uint64_t)quo; out[3] = (uint64_t)(quo >> 64);
-}
 struct Groth16Sizes { size_t qap, h, zext, msm[5], msm_all, pts, per; };
 Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
 {
@@ -1644,10 +1657,13 @@ extern "C" size_t frw_groth16_workspace_bytes(const frw_groth16_pk *pk, const fr
     return groth16_sizes(pk, r).per * batch_in_flight;
 }
 
-extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, const uint64_t *d_witness,
-                                     const uint64_t *d_instance, const uint64_t *rs, uint64_t *d_proofs, uint32_t *d_num_unsatisfied,
-                                     void *d_workspace, size_t workspace_bytes, void *stream)
+namespace {
+// rs_host: the blinding factors in host memory (uploaded, and waited for: the array may be short-lived); rs_dev: in device memory
+int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                  const uint64_t *rs_host, const uint64_t *rs_dev, uint64_t *d_proofs, uint32_t *d_num_unsatisfied, void *d_workspace,
+                  size_t workspace_bytes, void *stream)
 {
+    const uint64_t *rs = rs_host ? rs_host : rs_dev;
     if (!pk || !r1cs || (batch && (!d_witness || !d_instance || !rs || !d_proofs || !d_workspace))) return FRW_E_INVALID_ARG;
     if (batch == 0) return FRW_OK;
     frw_qap_info_t q;
@@ -1677,25 +1693,21 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         (void)pB1;                                                       // [A | B1' | L] is what the three G1 sums write, [s A | r B1'] the scalar multiplications
         uint64_t *pB2 = (uint64_t *)(pRB1 + cnt * XW), *d_rs = pB2 + cnt * 24, *d_split = d_rs + cnt * 8;
         const uint64_t *wit = d_witness + lo * W * 4, *inst = d_instance + lo * I * 4;
-        // the blinding factors: a host array (the prover draws them), uploaded before anything reads them
-        e = hipMemcpyAsync(d_rs, rs + lo * 8, cnt * 64, hipMemcpyHostToDevice, st);
-        std::vector<uint64_t> halves;
-        try {
-            halves.resize(cnt * 8);
-        } catch (const std::exception &) {
-            rc = FRW_E_OUT_OF_MEMORY;
-            break;
+        // the blinding factors: a host array (the prover draws them) is uploaded before anything reads them -- and waited for, the
+        // array may be pageable and short-lived; factors that are in device memory already cost no wait (and the call is capturable)
+        const uint64_t *rs_now = rs_dev ? rs_dev + lo * 8 : d_rs;
+        if (rs_host) {
+            e = hipMemcpyAsync(d_rs, rs_host + lo * 8, cnt * 64, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) break;
         }
-        for (size_t i = 0; i < cnt * 2; i++) glv_split(rs + (lo * 2 + i) * 4, &halves[i * 4]);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_split, halves.data(), cnt * 64, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);                                  // `rs` may be pageable and short-lived; `halves` is
-        if (e != hipSuccess) break;
         lock.lock();
+        hipLaunchKernelGGL(frw::groth16_split_kernel, dim3((unsigned)((2 * cnt + 63) / 64)), dim3(64), 0, st, 2 * cnt, rs_now, d_split);
         // z ++ [1, r, s] per signature, then the witness-side sums on their own streams ...
         e = hipMemcpy2DAsync(zext, stride * 32, inst, I * 32, I * 32, cnt, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipMemcpy2DAsync(zext + I * 4, stride * 32, wit, W * 32, W * 32, cnt, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)d_rs,
+        hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)rs_now,
                            (uint32_t *)zext, stride * 8, nv);
         // Four chains of small kernels, and ONE host thread that enqueues them at 15 - 35 us a launch (some 45 launches: a chain
         // enqueued last starts a millisecond late; profiles/r04_groth16_batch1_latency.txt) -- so after the short sort the longest
@@ -1737,10 +1749,13 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         if (e != hipSuccess) break;
         if (!lone) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
         if (rc != FRW_OK) break;
-        for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
+        // (side[1] carries nothing: it is neither recorded nor waited for -- inside a stream capture an event of a stream that is
+        // not part of the capture could not be waited for)
+        for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipEventRecord(pk->join[i], pk->side[i]);
         if (e == hipSuccess) e = hipEventRecord(pk->join[3], pk->main);
         if (e != hipSuccess) break;
-        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st, pk->join[i], 0);
+        for (int i = 0; i < 4 && e == hipSuccess; i++)
+            if (i != 1) e = hipStreamWaitEvent(st, pk->join[i], 0);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3((unsigned)((2 * cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)pA,
                            (const uint32_t *)pSA, (const uint32_t *)pRB1, (const uint32_t *)pL, (const uint32_t *)pH, (const uint32_t *)pB2,
@@ -1754,4 +1769,20 @@ extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r
         return e != hipSuccess ? frw::record_hip_error(e, "frw_groth16_prove_dev") : rc;
     }
     return FRW_OK;
+}
+}  // namespace
+
+extern "C" int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, const uint64_t *d_witness,
+                                     const uint64_t *d_instance, const uint64_t *rs, uint64_t *d_proofs, uint32_t *d_num_unsatisfied,
+                                     void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (!rs && batch) return FRW_E_INVALID_ARG;
+    return groth16_prove(pk, r1cs, batch, d_witness, d_instance, rs, nullptr, d_proofs, d_num_unsatisfied, d_workspace, workspace_bytes, stream);
+}
+extern "C" int frw_groth16_prove_rs_dev(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, const uint64_t *d_witness,
+                                        const uint64_t *d_instance, const uint64_t *d_rs, uint64_t *d_proofs, uint32_t *d_num_unsatisfied,
+                                        void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (!d_rs && batch) return FRW_E_INVALID_ARG;
+    return groth16_prove(pk, r1cs, batch, d_witness, d_instance, nullptr, d_rs, d_proofs, d_num_unsatisfied, d_workspace, workspace_bytes, stream);
 }

@@ -526,6 +526,12 @@ class WitnessEngine:
                                               self._ptr(d_proofs), self._ptr(d_num_unsatisfied) if d_num_unsatisfied is not None else None,
                                               self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)), "frw_groth16_prove_dev")
 
+    def groth16_prove_rs_dev(self, pk, r1cs, batch, d_wit, d_inst, d_rs, d_proofs, d_workspace, workspace_bytes, d_num_unsatisfied=None, stream=0):
+        """The same with the blinding factors in device memory (d_rs: int64[batch, 2, 4]): stream-ordered throughout, capturable."""
+        check(self._lib.frw_groth16_prove_rs_dev(pk, r1cs, batch, self._ptr(d_wit), self._ptr(d_inst), self._ptr(d_rs),
+                                                 self._ptr(d_proofs), self._ptr(d_num_unsatisfied) if d_num_unsatisfied is not None else None,
+                                                 self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)), "frw_groth16_prove_rs_dev")
+
     def qap_info(self, handle):
         """Domain of the QAP witness map for the loaded matrices: (log n, n, C, I, workspace bytes per signature)."""
         from ._lib import QapInfoStruct

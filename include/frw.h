@@ -416,8 +416,8 @@ int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, si
  * may be short-lived).
  * Calls with one key may come from several host threads: they take turns putting their work on the key's streams (each with a
  * workspace of its own).  A call that returns an error has waited for whatever it had already started.
- * NOT stream-capture safe, unlike the witness map it wraps: once per chunk the call waits on the host (hipStreamSynchronize on
- * `stream`) for the upload of r, s and their split halves -- i.e. also for whatever `stream` held before -- and only then takes the
+ * NOT stream-capture safe (frw_groth16_prove_rs_dev is): once per chunk the call waits on the host (hipStreamSynchronize on
+ * `stream`) for the upload of r, s -- i.e. also for whatever `stream` held before -- and only then takes the
  * key's lock, so concurrent provers do not wait for each other's streams. */
 typedef struct frw_groth16_pk frw_groth16_pk;
 typedef struct {
@@ -447,6 +447,14 @@ size_t frw_groth16_workspace_bytes(const frw_groth16_pk *pk, const frw_r1cs *r, 
 int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch, const uint64_t *d_witness,
                           const uint64_t *d_instance, const uint64_t *rs, uint64_t *d_proofs, uint32_t *d_num_unsatisfied,
                           void *d_workspace, size_t workspace_bytes, void *stream);
+/* The same with the blinding factors in DEVICE memory (d_rs: uint64_t[batch][2][4], any 256-bit values: taken modulo the group
+ * order; their split by the curve's endomorphism, done on the host for the call above until round 4, happens on the device for
+ * both).  Nothing waits on the host: the call is ordered on `stream` throughout and MAY be captured into a HIP graph and replayed
+ * (one capture = one chunk: give it the workspace of the whole batch; the key's streams join the capture through its events and
+ * leave it before the call returns).  A replay reads the factors that are in d_rs THEN: refresh them between replays. */
+int frw_groth16_prove_rs_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch, const uint64_t *d_witness,
+                             const uint64_t *d_instance, const uint64_t *d_rs, uint64_t *d_proofs, uint32_t *d_num_unsatisfied,
+                             void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Groth16 verification (examples/pok_sig.rs:34-47: Groth16::verify(&vk, &public_inputs, &proof)) --------------------------------
  * ark-groth16 0.3.0 verifier.rs: prepare_verifying_key (e(alpha_g1, beta_g2), -gamma_g2, -delta_g2), prepare_inputs

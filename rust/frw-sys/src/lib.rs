@@ -223,6 +223,9 @@ extern "C" {
     pub fn frw_groth16_prove_dev(pk: *const frw_groth16_pk, r: *const frw_r1cs, batch: usize, d_witness: *const u64,
                                  d_instance: *const u64, rs: *const u64, d_proofs: *mut u64, d_num_unsatisfied: *mut u32,
                                  d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn frw_groth16_prove_rs_dev(pk: *const frw_groth16_pk, r: *const frw_r1cs, batch: usize, d_witness: *const u64,
+                                    d_instance: *const u64, d_rs: *const u64, d_proofs: *mut u64, d_num_unsatisfied: *mut u32,
+                                    d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_groth16_vk_load(vk: *const u64, num_instance: usize, out: *mut *mut frw_groth16_vk) -> c_int;
     pub fn frw_groth16_vk_free(vk: *mut frw_groth16_vk);
     pub fn frw_groth16_verify(vk: *const frw_groth16_vk, batch: usize, instance: *const u64, encoding: c_int, proofs: *const u64,

@@ -253,3 +253,66 @@ def test_setup_prove_verify_with_nothing_known_in_the_exponent(engine, circuit, 
     finally:
         engine.r1cs_free(r1cs)
         engine.groth16_pk_free(key)
+
+
+@pytest.mark.gpu
+def test_blinding_factors_in_device_memory_and_a_captured_call(engine):
+    """frw_groth16_prove_rs_dev: the blinding factors in device memory, split by the endomorphism on the device -- the same proofs,
+    byte for byte, as frw_groth16_prove_dev with the same factors in host memory (incl. factors beyond the group order and the
+    extremes of the split); and the call captured into a HIP graph (torch.cuda.CUDAGraph on a stream of its own: the key's streams
+    join the capture through the call's events) replays to the same proofs, and to the right ones after the factors in d_rs change."""
+    import torch
+    import falcon_r1cs_amd as frw
+    dev = torch.device("cuda:0")
+    logn, batch = 9, 3
+    L = frw.layout(logn)
+    rng = random.Random(811)
+    key, vk = engine.groth16_setup(0, logn, *(rng.randrange(2, E.R) for _ in range(5)))
+    r1cs = engine.r1cs_load(0, logn)
+    try:
+        sig, pk_, hm = frw.synth_triples(logn, batch, seed=99)
+        dd = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk_, hm)]
+        wit = torch.empty((batch, L.num_witness, 4), dtype=torch.int64, device=dev)
+        inst = torch.empty((batch, L.num_instance, 4), dtype=torch.int64, device=dev)
+        st = torch.empty(batch, dtype=torch.int32, device=dev)
+        engine.witness_ntt_verify_dev(logn, batch, dd[0], dd[1], dd[2], wit, inst, st, 1, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        lam = E.Z_BLS ** 2 - 1
+        lim = lambda pairs: np.array([T.ints_to_limbs([a % (1 << 256), b % (1 << 256)]) for a, b in pairs])
+        sets = [[(E.R - 1, lam), (E.R + 12345, (1 << 256) - 1), (rng.randrange(E.R), 0)],
+                [(rng.randrange(E.R), rng.randrange(E.R)) for _ in range(batch)]]
+        ws_bytes = engine.groth16_workspace_bytes(key, r1cs, batch)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        want = []
+        for pairs in sets:
+            p = torch.empty((batch, 48), dtype=torch.int64, device=dev)
+            engine.groth16_prove_dev(key, r1cs, batch, wit, inst, lim(pairs), p, ws, ws_bytes, None, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            want.append(p)
+        ver = frw.Groth16Verifier(vk)
+        assert ver.verify(inst.cpu().numpy().view(np.uint64), want[1].cpu().numpy().view(np.uint64)).tolist() == [1] * batch
+        ver.close()
+        d_rs = torch.from_numpy(lim(sets[0]).view(np.int64)).to(dev)
+        got = torch.zeros((batch, 48), dtype=torch.int64, device=dev)
+        engine.groth16_prove_rs_dev(key, r1cs, batch, wit, inst, d_rs, got, ws, ws_bytes, None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want[0])
+        # captured once, replayed with either set of factors
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        got.zero_()
+        with torch.cuda.stream(side):
+            engine.groth16_prove_rs_dev(key, r1cs, batch, wit, inst, d_rs, got, ws, ws_bytes, None, side.cuda_stream)      # warm the capture stream
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                engine.groth16_prove_rs_dev(key, r1cs, batch, wit, inst, d_rs, got, ws, ws_bytes, None, torch.cuda.current_stream().cuda_stream)
+        for k in (0, 1, 0):
+            d_rs.copy_(torch.from_numpy(lim(sets[k]).view(np.int64)).to(dev))
+            got.zero_()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(got, want[k]), "replay %d" % k
+    finally:
+        engine.r1cs_free(r1cs)
+        engine.groth16_pk_free(key)

@@ -10,6 +10,7 @@ R=$(pwd)
 O="$R/gpurun_out/profiles_$TAG"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
+export FRW_TIME_GRAPH=0      # the traces are of plain stream launches; the graph replay of a lone proof is timed below, without the profiler
 trace() {   # trace <name> <program and arguments...>: kernel trace + stats as CSV, the program's own output beside it
     local name=$1; shift
     rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/p_${TAG}_$name" -o "$name" --output-format csv -- python3 "$@" > "$O/${TAG}_${name}_timing.txt" 2>&1
@@ -28,6 +29,6 @@ python3 "$R/tools/kernel_timeline.py" "$(find "$R/gpurun_out/p_${TAG}_aggregate1
     python3 "$R/tools/time_groth16.py" 9 64 5
     python3 "$R/tools/time_groth16.py" 10 16 5
     python3 "$R/tools/time_groth16.py" 10 128 3
-    python3 "$R/tools/time_groth16.py" 10 1 10
+    FRW_TIME_GRAPH=1 python3 "$R/tools/time_groth16.py" 10 1 20
     python3 "$R/bench.py" --workload aggregate --aggregate 10x1,9x1,10x2 --steps 5
 } > "$O/${TAG}_prover_other_sizes.txt" 2>&1

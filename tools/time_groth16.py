@@ -57,6 +57,39 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print("Falcon-%d, %d proofs per call: %.2f ms/call = %.2f ms/proof = %.1f proofs/s" % (1 << logn, batch, ms, ms / batch, batch / ms * 1e3))
+    if batch <= 4 and os.environ.get("FRW_TIME_GRAPH", "1") != "0":
+        # the same call with the blinding factors in device memory (frw_groth16_prove_rs_dev: nothing waits on the host), on a
+        # stream and as a captured HIP graph replayed
+        d_rs = torch.from_numpy(rs.view(np.int64)).to(dev)
+        proofs2 = torch.empty_like(proofs)
+        run_dev = lambda s: eng.groth16_prove_rs_dev(key, r1cs, batch, wit, inst, d_rs, proofs2, ws, ws_bytes, None, s)
+        run_dev(s0)
+        torch.cuda.synchronize()
+        assert torch.equal(proofs2, proofs)
+        e0.record()
+        for _ in range(reps):
+            run_dev(s0)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_dev = e0.elapsed_time(e1) / reps
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            run_dev(side.cuda_stream)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                run_dev(torch.cuda.current_stream().cuda_stream)
+        proofs2.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(proofs2, proofs)
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_graph = e0.elapsed_time(e1) / reps
+        print("  blinding factors in device memory: %.2f ms/call on a stream, %.2f ms/call as a captured HIP graph replayed (same proofs)" % (ms_dev, ms_graph))
 
 
 if __name__ == "__main__":
