@@ -1346,7 +1346,7 @@ extern "C" int frw_groth16_msm_h_dev(const frw_msm *m, size_t batch, const uint6
 //     g2_b = s delta_g2 + b_g2_query[0] + MSM(b_g2_query[1..], ...) + beta_g2        one sum over  b_g2_query ++ [beta2, O, delta2]  with z ++ [1, r, s]
 //     g_c  = s g_a + r g1_b - r s delta_g1 + MSM(l_query, aux) + MSM(h_query, h)  =  L + H + s g_a + r (g1_b - s delta1)
 // z = instance_assignment ++ witness_assignment (z[0] = 1 is the scalar of query[0]); the blinding terms ride in the sums as
-// extra points, the two scalar multiplications of g_c are done by one thread per signature at the end.
+// extra points, the two scalar multiplications of g_c are done by four lanes each at the end (frw_quad.h).
 namespace frw {
 // 2^517 mod p in nine 29-bit limbs: f29_mul(x, 2^517) = x 2^256, the Montgomery form of a canonical scalar
 __device__ const uint32_t FR_TO_MONT[NL29] = {0x1e538d9eu, 0x19e99103u, 0x13b31eccu, 0x04e2d5e4u, 0x181dac62u, 0x115f1ba1u,
@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(64) void groth16_split_kernel(size_t count, const u
 }
 // k P for one point per signature (s g_a and r (g1_b - s delta1) of g_c); runs on the side stream that made P.  A point that exists
 // only now: the chain of doublings is the latency of a proof made alone, so the scalar comes split by the endomorphism
-// (k = k0 + lambda k1, done on the host where r and s arrive: glv_split) and the two 128-bit halves share their doublings: 128
+// (k = k0 + lambda k1: groth16_split_kernel) and the two 128-bit halves share their doublings: 128
 // doublings and ~96 additions of P, phi(P) or P + phi(P) instead of 256 and ~128.  P arrives in XYZZ coordinates as its sum left it
 // and k P leaves the same way (the proof needs one inversion, at the very end: groth16_finish_kernel).  phi(P) and P + phi(P) come
 // for free in the same denominators -- phi(x, y) = (beta x, y), and since the two have the same y their chord is horizontal:
@@ -1523,17 +1523,16 @@ struct frw_groth16_pk {
     int device;
     uint64_t num_instance, num_witness, domain_size;
     frw_msm *h, *a, *b1, *l, *b2;
-    // FOUR streams of the key's own, created one after the other -- as many as the device has hardware queues (HIP's default),
-    // so that no two of them wait in line for the same queue: the witness map + the sum over h_query on `main`, the sums over
-    // a_query, b_g1_query and b_g2_query on the three `side` streams; their folds and the sorting of a few ten thousand pairs are
-    // latency, not throughput, and hide behind the 2^18-point sum.  The caller's stream forks into them, carries the shortest
-    // chain itself (the sum over l_query, enqueued FIRST: whichever of the key's streams shares a hardware queue with the caller's
-    // waits for that one short chain and nothing else) and joins them again.  Two things learnt from timelines
-    // (profiles/r03_groth16_timeline_64.txt, r04_groth16_timeline_64.txt, r04_aggregate16_timeline.txt): when the caller's stream
-    // carried the witness map it sat behind a side stream's whole chain on a shared queue (a quarter of the call); and a sum whose
-    // sorting kernels (workgroups of 1,024 threads) are issued once the 2^18-point bucket kernel runs does not start before that
-    // kernel ends -- two wavefronts of 240 registers per SIMD leave no CU with room for such a workgroup -- so every sum must be
-    // on a stream where nothing delays its first kernels.
+    // FOUR streams of the key's own, created one after the other -- as many as the device has hardware queues (HIP's default), so
+    // that no two of them wait in line for the same queue.  `main`: the witness map + the sum over h_query; side[0]: the three G1
+    // witness-side sums as one chain of kernels, then both scalar multiplications; side[2]: the sum over b_g2_query; side[1] shares
+    // its hardware queue with the caller's stream (the fifth stream on four queues) and carries nothing.  The caller's stream sorts
+    // the scalars' digits, forks into the others by events and joins them again (frw_groth16_prove_dev has the order things are
+    // enqueued in, and why).  Two things learnt from timelines (profiles/r03_groth16_timeline_64.txt, r04_groth16_timeline_64.txt,
+    // r04_aggregate16_timeline.txt): when the caller's stream carried the witness map it sat behind a side stream's whole chain on a
+    // shared queue (a quarter of the call); and a kernel whose workgroups have several wavefronts (the sorts' 1,024 threads) does not
+    // start once the 2^18-point bucket kernel runs -- two wavefronts of 240 registers per SIMD leave no CU with room for such a
+    // workgroup -- so the sort goes first and everything after it is grids of single wavefronts.
     hipStream_t main, side[3];
     hipEvent_t fork, sorted, ones_done, join[4];   // fork: the call's inputs are in place; sorted: the digits of its scalars too; join[3]: main
     std::mutex enqueue;         // the side streams and events are the key's: one call at a time puts its work on them

@@ -213,7 +213,7 @@ __host__ __device__ inline XyzzT<FqField> running_point(const uint32_t *lds, boo
     return m;
 }
 // the addition whose operands are equal or opposite (P = 0 in the formulas above): the complete one-lane formula, by one lane.
-// (With the canonical split of a scalar below the group order -- k0 < lambda, what frw_msm.hip's glv_split hands over -- the running
+// (With the canonical split of a scalar below the group order -- k0 < lambda, what frw_msm.hip's groth16_split_kernel hands over -- the running
 // point never meets an addend: 2 v = +-a mod r has no solution among the prefixes of such a pair.  The halves that do reach this
 // branch, tests/test_fq29_host.py, are non-canonical; it is here so that the kernel is complete for ANY pair of 128-bit halves.)
 __host__ __device__ inline bool add_degenerate(uint32_t *lds, uint32_t qx, uint32_t qy)
@@ -227,7 +227,7 @@ __host__ __device__ inline bool add_degenerate(uint32_t *lds, uint32_t qx, uint3
     return r.inf;
 }
 
-// k P, k = k0 + lambda k1 (128 bits each; frw_msm.hip glv_split), on an executor that runs a level for the four lanes of a quad:
+// k P, k = k0 + lambda k1 (128 bits each; frw_msm.hip groth16_split_kernel), on an executor that runs a level for the four lanes of a quad:
 //   ex.template step<S>(qx, qy)            one level
 //   ex.template step_test<S>(qx, qy, pz)   one level; pz = lane 0's first operand is zero (mod q)
 //   ex.degenerate(qx, qy) -> inf           add_degenerate by one lane, its answer to all
