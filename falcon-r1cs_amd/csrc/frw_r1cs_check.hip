@@ -335,7 +335,12 @@ __global__ __launch_bounds__(BLOCK) void r1cs_zsmall_kernel(R1csDev r, size_t ba
 // limb instead of a field product.  A term whose variable is not small takes the field product and enters the same
 // columns as 32 z c R.  At the end the 64 lanes' columns are carried into 29-bit limbs, added across the wavefront, and
 // X = 32 R sum(c z) becomes sum(c z) R through one Montgomery reduction (X / R') and one product with R R' mod p.
-__global__ __launch_bounds__(WAVE) void r1cs_long_rows_small_kernel(R1csDev r, size_t batch, const R1csView view,
+// (occupancy A/B, tools/ab_qap.py, profiles/r04_qap_long_rows_occupancy_ab.txt: asking for three waves per SIMD -- 168 registers, 128 bytes
+// of scratch -- changes nothing, 1.136 against 1.139 ms of sparse products per 64 signatures; four -- 304 bytes of scratch -- doubles them)
+#ifndef FRW_LONG_WAVES
+#define FRW_LONG_WAVES 2
+#endif
+__global__ __launch_bounds__(WAVE, FRW_LONG_WAVES) void r1cs_long_rows_small_kernel(R1csDev r, size_t batch, const R1csView view,
                                                                     const uint32_t *__restrict__ zs, uint32_t *__restrict__ long_out)
 {
     const R1csLongRow d = r.long_rows[blockIdx.x];
