@@ -27,7 +27,7 @@ enum : uint32_t {
     X, AY, BY, ZZ, ZZZ,                        // the running point
     PX, PEX, PBX, PY, PNY, PZZ, PZZZ,          // P, phi(P), P + phi(P): x | beta x | -(1 + beta) x;  y | -y;  ZZ, ZZZ shared
     T0, T1, T2, T3, T4, T5, T6, T7, T8, T9, T10,
-    DUMP, FLAGS, NSLOTS,
+    DUMP, NSLOTS,
     QX = 62, QY = 63                           // the addend's x and y: resolved per bit to PX / PEX / PBX and PY / PNY
 };
 enum : uint8_t { MUL = 0, LIN = 1, SQR = 2 };  // result = A B | A | A A

@@ -230,7 +230,9 @@ int frw_r1cs_export(int circuit, int logn, const char *path, uint64_t *counts);
  * signature of an HBM-resident batch, against the matrices above (emitted from the gadget definitions, independently
  * of the witness kernels' closed form).  frw_r1cs_load builds them on the host (seconds) and uploads them once;
  * d_witness / d_instance are the buffers of the witness entry points with encoding FRW_ENC_MONTGOMERY;
- * d_num_unsatisfied[i] = number of constraint rows signature i violates (0 = satisfied). */
+ * d_num_unsatisfied[i] = number of constraint rows signature i violates (0 = satisfied).
+ * (Diagnostics: with FRW_R1CS_NO_FLAT set in the environment at load time the handle's short rows are evaluated by the CSR walk
+ * instead of from their flattened form -- the route of a circuit with more than 254 distinct coefficients; the tests run both.) */
 typedef struct frw_r1cs frw_r1cs;
 int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out);
 void frw_r1cs_free(frw_r1cs *r);

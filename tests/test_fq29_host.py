@@ -230,7 +230,7 @@ def test_level_programmes_are_well_formed(lib):
     when every slot carries the bound of what was last written to it (a difference must never subtract more than the K q it adds)."""
     buf = (C.c_uint8 * (8 * 4 * 12))()
     assert lib.t_quad_programmes(buf) == 8
-    names = ["ZERO", "K4", "K8", "X", "AY", "BY", "ZZ", "ZZZ", "PX", "PEX", "PBX", "PY", "PNY", "PZZ", "PZZZ"] + ["T%d" % i for i in range(11)] + ["DUMP", "FLAGS"]
+    names = ["ZERO", "K4", "K8", "X", "AY", "BY", "ZZ", "ZZZ", "PX", "PEX", "PBX", "PY", "PNY", "PZZ", "PZZZ"] + ["T%d" % i for i in range(11)] + ["DUMP"]
     idx = {n: i for i, n in enumerate(names)}
     QX, QY = 62, 63
     steps = [[dict(ap=list(buf[(s * 4 + l) * 12:(s * 4 + l) * 12 + 4]), am=list(buf[(s * 4 + l) * 12 + 4:(s * 4 + l) * 12 + 7]),
