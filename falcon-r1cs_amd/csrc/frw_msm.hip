@@ -1525,9 +1525,9 @@ struct frw_groth16_pk {
     frw_msm *h, *a, *b1, *l, *b2;
     // FOUR streams of the key's own, created one after the other -- as many as the device has hardware queues (HIP's default), so
     // that no two of them wait in line for the same queue.  `main`: the witness map + the sum over h_query; side[0]: the three G1
-    // witness-side sums as one chain of kernels, then both scalar multiplications; side[2]: the sum over b_g2_query; side[1] shares
-    // its hardware queue with the caller's stream (the fifth stream on four queues) and carries nothing.  The caller's stream sorts
-    // the scalars' digits, forks into the others by events and joins them again (frw_groth16_prove_dev has the order things are
+    // witness-side sums as one chain of kernels, then both scalar multiplications; side[2]: the sum over b_g2_query; side[1]: the G1
+    // sums' ones when latency counts.  The caller's stream (a fifth stream on four queues: it shares one, which one is not ours to know)
+    // sorts the scalars' digits, forks into the others by events and joins them again (frw_groth16_prove_dev has the order things are
     // enqueued in, and why).  Two things learnt from timelines (profiles/r03_groth16_timeline_64.txt, r04_groth16_timeline_64.txt,
     // r04_aggregate16_timeline.txt): when the caller's stream carried the witness map it sat behind a side stream's whole chain on a
     // shared queue (a quarter of the call); and a kernel whose workgroups have several wavefronts (the sorts' 1,024 threads) does not
@@ -1715,11 +1715,16 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
         //   main      the witness map (a dozen launches, 0.7 ms; needs nothing of the sort) and the sum over h_query
         //   caller's  the sort of the digits of z ++ [1, r, s]: ONE counting sort for all four witness-side sums (its arrays live in
         //             b_g2_query's workspace; the workspaces of a_query, b_g1_query and l_query, one after the other, are the three G1
-        //             sums' as one); for a few proofs at a time also the G1 sums' ones
+        //             sums' as one)
         //   side[0]   the three G1 sums (A, B1' and L land one after the other) as ONE chain of kernels, then both scalar
         //             multiplications as soon as their points exist
+        //   side[1]   for a few proofs at a time the G1 sums' ones, beside their work items; nothing otherwise
         //   side[2]   G2
-        // (side[1] shares its hardware queue with the caller's stream on a default HIP runtime of four queues: it stays empty.)
+        // The key's four streams were created one after the other and sit on four different hardware queues (HIP's default); the
+        // caller's stream shares a queue with ONE of them, which one depends on how many streams its process made before.  So nothing
+        // but the short sort (first) and the assembly (last) runs on the caller's stream: the ones' sums, put there at first, waited
+        // behind the whole witness-map chain in a process whose stream shared `main`'s queue (profiles/r04_aggregate16_timeline.txt of
+        // that build: 3 ms of a 26 ms proof).
         const bool lone = cnt <= 4;                                        // latency counts, not throughput
         e = hipEventRecord(pk->fork, st);
         forked = true;
@@ -1732,7 +1737,8 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
         e = nmsm_sort(sorted, (uint32_t)stride, cnt, (const uint32_t *)zext, stride * 8, 1, ones_as_mask, st);
         if (e != hipSuccess) break;
         e = hipEventRecord(pk->sorted, st);
-        for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
+        for (int i = 0; i < 3 && e == hipSuccess; i++)
+            if (i != 1 || lone) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
         if (e != hipSuccess) break;
         rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
         // (h_query has n - 1 points and the dense pipeline: frw_groth16_pk_load; the scalars are h's coefficients 0 .. n - 2)
@@ -1740,7 +1746,7 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
         if (rc != FRW_OK) break;
         const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
         e = nmsm_accumulate<FqField, true>(g1s, 3, sorted, nmsm_carve<FqField>(msm_ws[1], 3 * cnt, (uint32_t)stride), cnt, pA, ones_as_mask, pk->side[0], true,
-                                           lone, st, pk->ones_done);
+                                           lone, pk->side[1], pk->ones_done);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_scale_quad_kernel, dim3((unsigned)(2 * cnt)), dim3(4), 0, pk->side[0], cnt, (const uint32_t *)d_split,
                            (const uint32_t *)pA, pSA);
@@ -1748,8 +1754,8 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
         if (e != hipSuccess) break;
         if (!lone) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
         if (rc != FRW_OK) break;
-        // (side[1] carries nothing: it is neither recorded nor waited for -- inside a stream capture an event of a stream that is
-        // not part of the capture could not be waited for)
+        // (side[1] is neither recorded nor waited for: what it carries, if anything, side[0] has waited for -- and inside a stream
+        // capture an event of a stream that is not part of the capture could not be waited for)
         for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipEventRecord(pk->join[i], pk->side[i]);
         if (e == hipSuccess) e = hipEventRecord(pk->join[3], pk->main);
         if (e != hipSuccess) break;
