@@ -1723,8 +1723,8 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
         // The key's four streams were created one after the other and sit on four different hardware queues (HIP's default); the
         // caller's stream shares a queue with ONE of them, which one depends on how many streams its process made before.  So nothing
         // but the short sort (first) and the assembly (last) runs on the caller's stream: the ones' sums, put there at first, waited
-        // behind the whole witness-map chain in a process whose stream shared `main`'s queue (profiles/r04_aggregate16_timeline.txt of
-        // that build: 3 ms of a 26 ms proof).
+        // behind the whole witness-map chain in a process whose stream shared `main`'s queue (the sixteen-statement aggregate under the
+        // profiler: 26.6 ms with them there, 22.8 ms with them on side[1]).
         const bool lone = cnt <= 4;                                        // latency counts, not throughput
         e = hipEventRecord(pk->fork, st);
         forked = true;
