@@ -1709,9 +1709,9 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
         hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, cnt, (const uint32_t *)rs_now,
                            (uint32_t *)zext, stride * 8, nv);
         // Four chains of small kernels, and ONE host thread that enqueues them at 15 - 35 us a launch (some 45 launches: a chain
-        // enqueued last starts a millisecond late; profiles/r04_groth16_batch1_latency.txt) -- so after the short sort the longest
-        // chain goes first: for a few proofs at a time all of it; for a batch only its head, and the sum over h_query -- whose bucket
-        // kernel then fills the chip for tens of milliseconds -- last.
+        // enqueued last starts a millisecond late; profiles/r04_groth16_batch1_latency.txt) -- so after the short sort the head of
+        // the longest chain goes first, and the sum over h_query -- which cannot start before the witness map is through, and whose
+        // bucket kernel then fills the chip -- last (for a lone proof, enqueued right behind the map instead: the same 3.92 - 3.97 ms).
         //   main      the witness map (a dozen launches, 0.7 ms; needs nothing of the sort) and the sum over h_query
         //   caller's  the sort of the digits of z ++ [1, r, s]: ONE counting sort for all four witness-side sums (its arrays live in
         //             b_g2_query's workspace; the workspaces of a_query, b_g1_query and l_query, one after the other, are the three G1
@@ -1741,8 +1741,6 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
             if (i != 1 || lone) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
         if (e != hipSuccess) break;
         rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
-        // (h_query has n - 1 points and the dense pipeline: frw_groth16_pk_load; the scalars are h's coefficients 0 .. n - 2)
-        if (rc == FRW_OK && lone) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
         if (rc != FRW_OK) break;
         const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
         e = nmsm_accumulate<FqField, true>(g1s, 3, sorted, nmsm_carve<FqField>(msm_ws[1], 3 * cnt, (uint32_t)stride), cnt, pA, ones_as_mask, pk->side[0], true,
@@ -1752,7 +1750,8 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
                            (const uint32_t *)pA, pSA);
         e = nmsm_accumulate<Fq2Field, false>(&pk->b2, 1, sorted, sorted, cnt, (uint32_t *)pB2, ones_as_mask, pk->side[2]);
         if (e != hipSuccess) break;
-        if (!lone) rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
+        // (h_query has n - 1 points and the dense pipeline: frw_groth16_pk_load; the scalars are h's coefficients 0 .. n - 2)
+        rc = msm_run<FqField, true>(pk->h, cnt, h, n, 1, (uint64_t *)pH, msm_ws[0], cnt * sz.msm[0], pk->main, true);
         if (rc != FRW_OK) break;
         // (side[1] is neither recorded nor waited for: what it carries, if anything, side[0] has waited for -- and inside a stream
         // capture an event of a stream that is not part of the capture could not be waited for)
