@@ -53,6 +53,15 @@ class Groth16PkDesc(C.Structure):
                 ("h_query", C.c_void_p), ("l_query", C.c_void_p)]
 
 
+class Groth16KeyOpts(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("rank", C.c_uint32), ("world", C.c_uint32)]
+
+
+class Groth16PkInfoStruct(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("rank", C.c_uint32), ("world", C.c_uint32), ("z_lo", C.c_uint64), ("z_hi", C.c_uint64),
+                ("h_lo", C.c_uint64), ("h_hi", C.c_uint64), ("key_bytes", C.c_uint64)]
+
+
 class R1csInfoStruct(C.Structure):
     _fields_ = [("num_statements", C.c_uint64), ("count_logn9", C.c_uint64), ("count_logn10", C.c_uint64),
                 ("num_instance", C.c_uint64), ("num_witness", C.c_uint64), ("num_constraints", C.c_uint64),
@@ -91,6 +100,16 @@ PROTOTYPES = {
     "frw_msm_g2_load": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
     "frw_msm_g1_load_narrow": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
     "frw_msm_g2_load_narrow": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "frw_msm_g1_load_bare": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "frw_msm_g2_load_bare": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "frw_groth16_pk_load_opts": (C.c_int, [C.c_int, C.POINTER(Groth16PkDesc), C.POINTER(Groth16KeyOpts), C.POINTER(C.c_void_p)]),
+    "frw_groth16_pk_info": (C.c_int, [C.c_void_p, C.POINTER(Groth16PkInfoStruct)]),
+    "frw_groth16_setup_r1cs_opts": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Groth16KeyOpts), C.POINTER(C.c_void_p), C.c_void_p]),
+    "frw_groth16_prove_partial_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frw_groth16_prove_combine_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frw_groth16_vk_load_opts": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "frw_diag_poly_eval_dev": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frw_msm_g2_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),
     "frw_msm_info": (C.c_int, [C.c_void_p, C.POINTER(MsmInfoStruct)]),

@@ -4,6 +4,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+struct frw_msm;
+struct frw_groth16_pk;
+
 namespace frw {
 
 constexpr uint32_t Q = 12289;          // falcon-rust MODULUS (gadgets/arithmetics.rs:5)
@@ -196,6 +199,41 @@ struct QapDev {
     uint32_t sixteen_over_n[9];   // 16 / n, x R' in nine limbs
 };
 size_t qap_workspace_bytes_per_signature(const R1csDev &r, const QapDev &q);
+// ---- setup on the device (frw_setup.hip): transform tables, the QAP at the toxic point, the queries' scalars ------------------------
+// a field constant x R' (R' = 2^261) in nine 29-bit limbs, as a kernel argument
+struct SetupConst { uint32_t l[9]; };
+// base^e for any e below the domain size from two small tables: lo[k] = base^k (k < 2^14), hi[k] = base^(k 2^14) (k < 2^(L - 14)); x R' packed
+constexpr int SETUP_POW_LO_BITS = 14;
+constexpr uint64_t SETUP_POW_LO = (uint64_t)1 << SETUP_POW_LO_BITS;
+struct SetupPowTab { const uint32_t *lo, *hi; };
+// a per-signature matrix by columns: the non-zeros of variable c are [col_ptr[c], col_ptr[c + 1]): their rows and coefficients (c R' packed)
+struct SetupCsc { const uint32_t *col_ptr, *row, *val; };
+// a run of consecutive statements of one parameter set inside an aggregate (R1csAggRun), or a single circuit (count 1, offsets 0)
+struct SetupRun {
+    SetupCsc m[3];
+    uint32_t num_vars, num_inst, num_constraints;    // of the per-signature system: I + W, I (with the constant one), C
+    uint32_t first, count;                           // statements [first, first + count)
+    uint64_t wit_off, pub_off, row_off;
+};
+hipError_t launch_qap_table(uint64_t n, const SetupPowTab &t, int mode, int sh, int ts, int L, const SetupConst *first, uint32_t *out, hipStream_t st);
+hipError_t launch_setup_lagrange(uint64_t n, const SetupPowTab &wt, const SetupConst &t, const SetupConst &c, const SetupConst &one, uint32_t *lag, hipStream_t st);
+hipError_t launch_setup_columns(const SetupRun *runs, size_t num_runs, uint32_t statements, uint64_t num_instance_all, uint64_t num_constraints_all,
+                                size_t num_vars_all, const uint32_t *lag, uint32_t *uvw, uint32_t *col0, hipStream_t st);
+hipError_t launch_setup_var_scalars(int kind, uint64_t first, uint64_t count, uint64_t num_instance_all, size_t num_vars_all, const uint32_t *uvw, int which,
+                                    const SetupConst &alpha, const SetupConst &beta, const SetupConst &ginv, const SetupConst &dinv, uint32_t *out, hipStream_t st);
+hipError_t launch_setup_h_scalars(uint64_t first, uint64_t count, const SetupPowTab &tt, const SetupConst &c, uint32_t *out, hipStream_t st);
+// the multi-scalar multiplication side of a device-made key (frw_msm.hip): bare handles filled in place by fixed-base kernels
+struct FixedBaseGen { uint32_t *g1, *g2; };        // [32][256] multiples of the published generators, as table rows
+int fixed_base_gen_create(int device, FixedBaseGen *g);
+void fixed_base_gen_free(FixedBaseGen *g);
+int msm_alloc_bare(int device, int group /* 1: G1, 2: G2 */, int window_bits, size_t rows, uint64_t row_lo, ::frw_msm **out);
+hipError_t msm_fill_fixed_base(::frw_msm *m, const FixedBaseGen &g, size_t first_row, size_t count, const uint32_t *d_scalars, hipStream_t st);
+hipError_t fixed_base_ark_dev(const FixedBaseGen &g, int group, size_t count, const uint32_t *d_scalars, uint32_t *d_out, hipStream_t st);
+void groth16_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi);
+int groth16_pk_assemble(int device, uint64_t ni, uint64_t nw, uint64_t n, uint32_t rank, uint32_t world, ::frw_msm *h, ::frw_msm *a, ::frw_msm *b1,
+                        ::frw_msm *l, ::frw_msm *b2, ::frw_groth16_pk **out);
+hipError_t launch_poly_eval(uint64_t n, const uint32_t *coeffs, const SetupConst &t, const SetupPowTab &tt, uint32_t *part, uint32_t *out, hipStream_t st);
+size_t poly_eval_scratch_bytes(uint64_t n);
 hipError_t diag_valu_rates(int num_cu, void *scratch, double out[4], hipStream_t st);
 hipError_t launch_qap_quotient(const R1csDev &r, const QapDev &q, size_t batch, const uint64_t *witness,
                                const uint64_t *instance, uint64_t *h, uint32_t *num_unsatisfied, void *workspace,

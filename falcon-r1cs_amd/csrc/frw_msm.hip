@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <mutex>
 #include <vector>
@@ -204,10 +205,11 @@ __device__ __forceinline__ Fr8 scalar_canonical(const uint32_t *src, int montgom
     }
     return w;
 }
-__device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomery, int (&d)[MSM_W])
+// detect_one == false (a bare handle, below): the scalar one is digit 1 of window 0 like any other value
+__device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomery, int (&d)[MSM_W], bool detect_one = true)
 {
     const Fr8 w = scalar_canonical(src, montgomery);
-    if (w.l[0] == 1u && !(w.l[1] | w.l[2] | w.l[3] | w.l[4] | w.l[5] | w.l[6] | w.l[7])) return true;
+    if (detect_one && w.l[0] == 1u && !(w.l[1] | w.l[2] | w.l[3] | w.l[4] | w.l[5] | w.l[6] | w.l[7])) return true;
     int carry = 0;
 #pragma unroll
     for (int j = 0; j < MSM_W; j++) {
@@ -229,20 +231,39 @@ __device__ __forceinline__ bool scalar_digits(const uint32_t *src, int montgomer
 // 224, and parks their histograms in the work items' partial sums instead (131,072 x 240 bytes and more: room for 240), which
 // nothing writes before the bucket kernel.
 constexpr int MSM_SLICES = 32, MSM_SLICES_LONE = 224;
+// A BARE handle (round 5) holds the points themselves and nothing else -- 112 bytes a point instead of 1,792: the key of a
+// 1,024-statement aggregate is 2^27 points of h_query alone, whose window tables would be 240 GB.  The sum is then sixteen bucket
+// accumulations, one per 16-bit window, over the SAME rows: grid row y of every kernel below is window y of ONE scalar vector
+// (instead of signature y with all its windows), a row's entries are point indices, and msm_horner_kernel puts the sixteen window
+// sums together (15 x 16 doublings).  The number of bucket additions is the table path's: one per (point, non-zero digit).
+// the digit of window `win` (a register array indexed at run time would live in scratch: sixteen selects)
+__device__ __forceinline__ int msm_digit_of(const int (&d)[MSM_W], uint32_t win)
+{
+    int v = 0;
+#pragma unroll
+    for (int j = 0; j < MSM_W; j++) v = (uint32_t)j == win ? d[j] : v;
+    return v;
+}
 __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
-                                                        int montgomery, uint32_t *__restrict__ slice_hist /* [sig][slice][buckets] */,
-                                                        uint32_t *__restrict__ ones_count /* [sig] */, uint32_t *__restrict__ ones_list /* [sig][n] */)
+                                                        int montgomery, uint32_t *__restrict__ slice_hist /* [row][slice][buckets] */,
+                                                        uint32_t *__restrict__ ones_count /* [sig] */, uint32_t *__restrict__ ones_list /* [sig][n] */,
+                                                        int bare)
 {
     __shared__ uint32_t hist[MSM_BUCKETS];
-    const size_t sig = blockIdx.y;
+    const size_t row = blockIdx.y, sig = bare ? 0 : row;
     const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
     const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
     for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) hist[b] = 0;
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
         int d[MSM_W];
-        if (scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d)) {
+        if (scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d, !bare)) {
             ones_list[sig * n + atomicAdd(&ones_count[sig], 1u)] = i;
+            continue;
+        }
+        if (bare) {
+            const int v = msm_digit_of(d, (uint32_t)row);
+            if (v) atomicAdd(&hist[(v < 0 ? -v : v) - 1], 1u);
             continue;
         }
 #pragma unroll
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32
             if (d[j]) atomicAdd(&hist[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
     }
     __syncthreads();
-    uint32_t *out = slice_hist + (sig * slices + slice) * MSM_BUCKETS;
+    uint32_t *out = slice_hist + (row * slices + slice) * MSM_BUCKETS;
     for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) out[b] = hist[b];
 }
 
@@ -296,19 +317,24 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *__restri
 
 __global__ __launch_bounds__(1024) void msm_scatter_kernel(uint32_t n, const uint32_t *__restrict__ scalars, size_t sig_stride_words,
                                                            int montgomery, const uint32_t *__restrict__ offsets,
-                                                           const uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ entries)
+                                                           const uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ entries, int bare)
 {
     __shared__ uint32_t cursor[MSM_BUCKETS];
-    const size_t sig = blockIdx.y;
+    const size_t row = blockIdx.y, sig = bare ? 0 : row;
     const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
     const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
-    const uint32_t *first = slice_hist + (sig * slices + slice) * MSM_BUCKETS, *off = offsets + sig * MSM_BUCKETS;
+    const uint32_t *first = slice_hist + (row * slices + slice) * MSM_BUCKETS, *off = offsets + row * MSM_BUCKETS;
     for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) cursor[b] = off[b] + first[b];
     __syncthreads();
-    uint32_t *ent = entries + sig * (size_t)MSM_W * n;
+    uint32_t *ent = entries + row * (bare ? (size_t)n : (size_t)MSM_W * n);      // a bare row: one window, entries = point indices
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
         int d[MSM_W];
-        if (scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d)) continue;
+        if (scalar_digits(scalars + sig * sig_stride_words + (size_t)i * 8, montgomery, d, !bare)) continue;
+        if (bare) {
+            const int v = msm_digit_of(d, (uint32_t)row);
+            if (v) ent[atomicAdd(&cursor[(uint32_t)(v < 0 ? -v : v) - 1u], 1u)] = i | (v < 0 ? 0x80000000u : 0u);
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < MSM_W; j++) {
             if (!d[j]) continue;
@@ -332,8 +358,16 @@ constexpr int MSM_MAX_ITEMS = 131072;          // >= 32,768 + 32,768 / (1.5 / 4)
 // 131,072 thread slots at two wavefronts per SIMD (with 4 it was 98,304 items: a quarter of the slots idle and half the SIMDs with a
 // single wavefront, 1.55 x the time per addition of a 64-signature call: 16.7 ms; with 12, two rounds: 14.4 ms; with 24: 13.4 ms, the
 // combine's extra additions included).  Bound: 32,768 + 32,768 finer / 1.5.
-constexpr int MSM_MAX_ITEMS_LARGE = 32768 + 32768 * 24 * 2 / 3;     // 557,056
-__host__ __device__ constexpr uint32_t msm_max_items(uint32_t n) { return n > (1u << 18) ? (uint32_t)MSM_MAX_ITEMS_LARGE : (uint32_t)MSM_MAX_ITEMS; }
+// (msm_split_of rounds the split DOWN, by less than one entry in at least 32: 33 / 32 of that bound is what the list must hold; an item is
+// two words, bucket and part -- packed into one, `part << 15` overflowed for a bucket cut into more than 2^17 parts, which one digit repeated
+// in all the scalars of a 2^22-point sum produces: round 4's ADVICE)
+constexpr int MSM_MAX_ITEMS_LARGE = 32768 + (32768 * 24 * 2 / 3) / 32 * 33 + 64;     // 573,504
+static_assert(MSM_MAX_ITEMS_LARGE % 64 == 0 && MSM_MAX_ITEMS >= 32768 + (32768 * 4 * 2 / 3) / 32 * 33 + 64, "whole wavefronts; the finest split fits");
+// a bare handle's rows are windows of one sum: sixteen of them fill the chip with items of the buckets' own size (finer = 1)
+__host__ __device__ constexpr uint32_t msm_max_items(uint32_t n, bool bare = false)
+{
+    return !bare && n > (1u << 18) ? (uint32_t)MSM_MAX_ITEMS_LARGE : (uint32_t)MSM_MAX_ITEMS;
+}
 // `finer`: 1 for a batch, 4 for one or two signatures at a time -- a bucket of the mean size is then three items instead of one
 // (a lone proof waits for ~128 dependent additions otherwise), and msm_combine_kernel adds them up
 __device__ __forceinline__ uint32_t msm_split_of(uint32_t total, uint32_t finer)
@@ -343,7 +377,7 @@ __device__ __forceinline__ uint32_t msm_split_of(uint32_t total, uint32_t finer)
 }
 __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
                                                          uint32_t *__restrict__ order, uint32_t *__restrict__ item_first /* [sig][buckets] */,
-                                                         uint32_t *__restrict__ items /* [sig][max_items]: bucket | chunk << 15 */,
+                                                         uint32_t *__restrict__ items /* [sig][max_items][2]: bucket, part */,
                                                          uint32_t *__restrict__ item_count /* [sig] */, uint32_t finer, uint32_t max_items)
 {
     __shared__ uint32_t hist[MSM_SIZE_CLASSES];
@@ -391,12 +425,16 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t *__restr
         __syncthreads();
     }
     uint32_t pos = hist[t] - local;
-    if (t == 1023) item_count[sig] = hist[t];
+    if (t == 1023) item_count[sig] = hist[t] < max_items ? hist[t] : max_items;     // (the bound above holds; a list is never overrun if it did not)
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         const uint32_t b = ord[t * PER + j];
         item_first[sig * MSM_BUCKETS + b] = pos;
-        for (uint32_t c = 0; c < k[j]; c++) items[sig * (size_t)max_items + pos + c] = b | (c << 15);
+        for (uint32_t c = 0; c < k[j] && pos + c < max_items; c++) {
+            uint32_t *it = items + (sig * (size_t)max_items + pos + c) * 2;
+            it[0] = b;
+            it[1] = c;
+        }
         pos += k[j];
     }
 }
@@ -408,18 +446,19 @@ template <class F, bool PREFETCH>
 __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
                                                            const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items, uint32_t finer,
-                                                           uint32_t max_items)
+                                                           uint32_t max_items, size_t ent_stride /* entries per row: 16 n, a bare handle's: n */)
 {
     constexpr int PW = Grp<F>::PT_WORDS;
     const size_t sig = blockIdx.y;
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     if (it >= item_count[sig]) return;
-    const uint32_t item = items[sig * (size_t)max_items + it], b = item & (MSM_BUCKETS - 1), chunk = item >> 15;
+    const uint2 item = *(const uint2 *)(items + (sig * (size_t)max_items + it) * 2);
+    const uint32_t b = item.x, chunk = item.y;
     const uint32_t c = counts[sig * MSM_BUCKETS + b];
     const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total, finer);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
     const uint32_t lo = (uint32_t)((uint64_t)c * chunk / k), cnt = (uint32_t)((uint64_t)c * (chunk + 1) / k) - lo;     // equal parts
-    const uint32_t *ent = entries + sig * (size_t)MSM_W * m.n + offsets[sig * MSM_BUCKETS + b] + lo;
+    const uint32_t *ent = entries + sig * ent_stride + offsets[sig * MSM_BUCKETS + b] + lo;
     XyzzT<F> acc = pt_identity<F>();
     if (PREFETCH) {
         uint32_t e = cnt ? ent[0] : 0u;
@@ -441,6 +480,26 @@ __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint3
         }
     }
     store_bucket<F>(partial_items + (sig * (size_t)max_items + it) * (size_t)Grp<F>::BK_WORDS, acc);
+}
+
+// sum_j 2^(window_bits j) S_j for the window sums S_j of a bare handle (Horner: window_bits doublings and one addition per window:
+// 255 point operations of ONE chain -- F::LANES lanes -- whatever the size of the sum: 5 ms beside the 10^9 additions it crowns).
+// Grid: one workgroup per sum (the three G1 tables of a proof side by side); sums: [sum][windows][BK_WORDS].
+template <class F>
+__global__ __launch_bounds__(64) void msm_horner_kernel(const uint32_t *__restrict__ sums, int windows, int window_bits,
+                                                        uint32_t *__restrict__ out /* [sum][ARK_WORDS], or [sum][BK_WORDS] */, int xyzz_out)
+{
+    __builtin_amdgcn_s_setprio(2);
+    constexpr int BW = Grp<F>::BK_WORDS;
+    if (threadIdx.x >= (unsigned)F::LANES) return;
+    const uint32_t *src = sums + (size_t)blockIdx.x * windows * BW;
+    XyzzT<F> acc = load_bucket<F>(src + (size_t)(windows - 1) * BW);
+    for (int j = windows - 2; j >= 0; j--) {
+        for (int k = 0; k < window_bits; k++) acc = pt_double(acc);
+        acc = pt_add(acc, load_bucket<F>(src + (size_t)j * BW));
+    }
+    if (xyzz_out) store_bucket<F>(out + (size_t)blockIdx.x * BW, acc);
+    else store_ark_point<F>(out + (size_t)blockIdx.x * Grp<F>::ARK_WORDS, pt_to_affine(acc));
 }
 
 // bucket b = the sum of its items (one for almost every bucket: a copy)
@@ -671,12 +730,78 @@ __global__ __launch_bounds__(1024) void nmsm_scatter_kernel(uint32_t n, const ui
         }
     }
 }
+// ---- the narrow sums of a BARE handle (round 5: a key whose window tables would not fit; the points only) ------------------------------
+// One scalar vector, thirty-two 8-bit windows: the counting sort is over (window, digit) -- 4,096 counters in 16 KB of LDS, ONE pass over
+// the scalars for all the windows -- and from there on window w is what signature w is to the kernels above: its own 128 buckets, its own
+// work items, its own fold; an entry is a point index (a table row: the tables have no other), a window's entries start at
+// entry_base[w] (the windows' totals differ by orders of magnitude: the low two hold every 14-bit value of a witness, the upper
+// thirteen nothing), and msm_horner_kernel puts the thirty-two window sums of every table together.  Scalars equal to one: a list,
+// summed with window 0.
+__global__ __launch_bounds__(1024) void nmsm_hist_bare_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery,
+                                                              uint32_t *__restrict__ slice_hist /* [window][slice][128] */,
+                                                              uint32_t *__restrict__ ones_count /* [0] */, uint32_t *__restrict__ ones_list /* [n] */)
+{
+    __shared__ uint32_t hist[NMSM_W * NMSM_BUCKETS];
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    for (int b = threadIdx.x; b < NMSM_W * NMSM_BUCKETS; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int d[NMSM_W];
+        if (scalar_digits8(scalars + (size_t)i * 8, montgomery, d)) {
+            ones_list[atomicAdd(&ones_count[0], 1u)] = i;
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < NMSM_W; j++)
+            if (d[j]) atomicAdd(&hist[j * NMSM_BUCKETS + (d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NMSM_W * NMSM_BUCKETS; b += 1024)
+        slice_hist[((size_t)(b / NMSM_BUCKETS) * slices + slice) * NMSM_BUCKETS + (b % NMSM_BUCKETS)] = hist[b];
+}
+// where each window's entries start: the running total of the windows before it (64 bits: thirty-two windows of 2^27 scalars can be 2^32 entries)
+__global__ __launch_bounds__(64) void nmsm_entry_base_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+                                                             unsigned long long *__restrict__ entry_base /* [32] */)
+{
+    if (threadIdx.x) return;
+    unsigned long long run = 0;
+    for (int w = 0; w < NMSM_W; w++) {
+        entry_base[w] = run;
+        run += (unsigned long long)offsets[w * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[w * NMSM_BUCKETS + NMSM_BUCKETS - 1];
+    }
+}
+__global__ __launch_bounds__(1024) void nmsm_scatter_bare_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery,
+                                                                 const uint32_t *__restrict__ offsets /* [window][128] */,
+                                                                 const uint32_t *__restrict__ slice_hist,
+                                                                 const unsigned long long *__restrict__ entry_base, uint32_t *__restrict__ entries)
+{
+    __shared__ uint32_t cursor[NMSM_W * NMSM_BUCKETS];
+    __shared__ unsigned long long base[NMSM_W];
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    for (int b = threadIdx.x; b < NMSM_W * NMSM_BUCKETS; b += 1024)
+        cursor[b] = offsets[b] + slice_hist[((size_t)(b / NMSM_BUCKETS) * slices + slice) * NMSM_BUCKETS + (b % NMSM_BUCKETS)];
+    if (threadIdx.x < NMSM_W) base[threadIdx.x] = entry_base[threadIdx.x];
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int d[NMSM_W];
+        if (scalar_digits8(scalars + (size_t)i * 8, montgomery, d)) continue;
+#pragma unroll
+        for (int j = 0; j < NMSM_W; j++) {
+            if (!d[j]) continue;
+            const uint32_t b = (uint32_t)(d[j] < 0 ? -d[j] : d[j]) - 1u;
+            entries[base[j] + atomicAdd(&cursor[j * NMSM_BUCKETS + b], 1u)] = i | (d[j] < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
 // one thread per (signature, item): the sum of the item's table rows
 template <class F, bool PREFETCH>
 __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(NmsmTables tables, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                             const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
                                                             const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items,
-                                                            uint32_t target, uint32_t max_items)
+                                                            uint32_t target, uint32_t max_items,
+                                                            const unsigned long long *__restrict__ entry_base /* a bare handle's windows; else null */)
 {
     __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int PW = Grp<F>::PT_WORDS;
@@ -690,7 +815,7 @@ __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(NmsmTables tables, c
     const uint32_t total = offsets[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1] + counts[sig * NMSM_BUCKETS + NMSM_BUCKETS - 1], split = nmsm_split_of(total, target);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
     const uint32_t lo = (uint32_t)((uint64_t)c * part / k), cnt = (uint32_t)((uint64_t)c * (part + 1) / k) - lo;     // equal parts
-    const uint32_t *ent = entries + sig * (size_t)NMSM_W * m.n + offsets[sig * NMSM_BUCKETS + b] + lo;
+    const uint32_t *ent = entries + (entry_base ? (size_t)entry_base[sig] : sig * (size_t)NMSM_W * m.n) + offsets[sig * NMSM_BUCKETS + b] + lo;
     XyzzT<F> acc = pt_identity<F>();
     if (PREFETCH) {
         uint32_t e = cnt ? ent[0] : 0u;
@@ -718,14 +843,15 @@ __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(NmsmTables tables, c
 // partial sum per workgroup goes out: gridDim.x <= 64 of them per signature
 template <class F>
 __global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(NmsmTables tables, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
-                                                          uint32_t *__restrict__ partial_ones /* [slot][groups_stride][BK_WORDS] */, uint32_t groups_stride)
+                                                          uint32_t *__restrict__ partial_ones /* [blockIdx.y][groups_stride][BK_WORDS] */, uint32_t groups_stride,
+                                                          uint32_t row_step /* 1; a bare handle's tables: 32 -- grid row y is (table y, window 0), the only window with ones */)
 {
     __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int SLOT = 4 * F::WORDS + 1, PER = 64 / F::LANES;                 // PER chains per workgroup (F::LANES lanes each)
     __shared__ uint32_t lds[32 * SLOT];
     const size_t slot = blockIdx.y;
     size_t sig;
-    const MsmDev m = tables.of(blockIdx.y, sig);
+    const MsmDev m = tables.of(blockIdx.y * row_step, sig);
     const uint32_t nthreads = gridDim.x * PER, t = blockIdx.x * PER + threadIdx.x / F::LANES;
     const uint32_t *list = ones_list + sig * m.n;
     XyzzT<F> acc = pt_identity<F>();
@@ -823,7 +949,7 @@ __global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restr
                                                          const uint32_t *__restrict__ partial_ones /* [sig][ones_stride][BK_WORDS] */,
                                                          int ones_groups, uint32_t ones_stride, uint32_t target, uint32_t max_items,
                                                          uint32_t *__restrict__ out /* [slot][ARK_WORDS], or [slot][BK_WORDS] */, int xyzz_out,
-                                                         uint32_t sigs)
+                                                         uint32_t sigs, int ones_window0 /* a bare handle: rows are (table, window); the ones' sums are [table] and go with window 0 */)
 {
     __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int SLOT = 4 * F::WORDS + 1, BW = Grp<F>::BK_WORDS, PER = 64 / F::LANES, NB = NMSM_BUCKETS / PER;
@@ -896,7 +1022,8 @@ __global__ __launch_bounds__(64) void nmsm_finish_kernel(const uint32_t *__restr
             add = true; p = lds + (i * NB + 1) * SLOT;
         } else if (step < at_tree) {
             const int g = i + PER * (int)(step - at_ones);
-            add = g < ones_groups; p = partial_ones + (slot * (size_t)ones_stride + (size_t)g) * BW;
+            const size_t ones_row = ones_window0 ? slot / sigs : slot;
+            add = g < ones_groups && !(ones_window0 && sig != 0); p = partial_ones + (ones_row * (size_t)ones_stride + (size_t)g) * BW;
         } else {
             const int stride = PER >> (step - at_tree + 1);
             if (i >= stride && i < 2 * stride) store_slot = (i - stride) * NB;
@@ -959,6 +1086,22 @@ __global__ __launch_bounds__(64) void fixed_base_kernel(size_t count, const uint
     }
     store_ark_point<F>(out + i * Grp<F>::ARK_WORDS, pt_to_affine(acc));
 }
+// the same multiples written as table rows (29-bit limbs, what load_row reads): a bare handle's query made in place on the device
+// (frw_groth16_setup_r1cs_opts: a 2^27-point h_query never exists as ark-ff bytes anywhere)
+template <class F>
+__global__ __launch_bounds__(64) void fixed_base_rows_kernel(size_t count, const uint32_t *__restrict__ scalars /* [count][8], canonical */,
+                                                             const uint32_t *__restrict__ table, uint32_t *__restrict__ rows /* [count][PT_WORDS] */)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    const Fr8 k = fr_load(scalars + i * 8);
+    XyzzT<F> acc = pt_identity<F>();
+    for (int w = 0; w < FB_WINDOWS; w++) {
+        const uint32_t d = (k.l[w >> 2] >> (8 * (w & 3))) & 255u;
+        if (d) acc = pt_add_affine(acc, load_row<F>(table + ((size_t)w * FB_DIGITS + d) * Grp<F>::PT_WORDS));
+    }
+    store_row<F>(rows + i * Grp<F>::PT_WORDS, pt_to_affine(acc));
+}
 
 }  // namespace frw
 
@@ -967,6 +1110,8 @@ struct frw_msm {
     int device;
     int group;                  // 1: G1, 2: G2
     int window_bits;            // 16: the dense pipeline (32,768 buckets), 8: the narrow one (128 buckets)
+    bool bare = false;          // the table is the points themselves (one row each): the sums run window by window (round 5)
+    uint64_t row_lo = 0;        // a slice of a sharded key: the index of row 0 in the whole query (the caller offsets the scalars by it)
     frw::MsmDev dev;
     void *table;
     void *ones_table;           // narrow handles of up to 2^18 points (MsmDev::ones_table), else null
@@ -975,33 +1120,129 @@ struct frw_msm {
 namespace {
 using frw::FqField;
 using frw::Fq2Field;
-template <class F> size_t msm_workspace_per_signature(uint32_t n)
+// ---- the dense pipeline's workspace: per grid row (a signature; a bare handle: a window), every array but the last two a multiple of
+// four words per row, so that whatever the number of points everything before them is 16-byte aligned (the items are read two words at a time)
+template <class F> struct MsmBufs {
+    uint32_t *counts, *offsets, *order, *item_first, *item_count, *ones_count, *items, *buckets, *partial, *partial_items, *entries, *ones_list, *end;
+    uint32_t max_items;
+    size_t ent_stride, ones_stride;
+};
+template <class F> MsmBufs<F> msm_carve(void *ws, size_t rows, uint32_t n, bool bare)
 {
-    // counts, offsets, order (3 x 32,768 x 4 B), entries (16 n x 4 B), buckets (32,768 buckets; the sort's per-slice
-    // histograms, 32 x 32,768 x 4 B, live there before the buckets are written), the list of scalars that are one (n x 4 B +
-    // a counter) and their 512 partial sums
-    static_assert((size_t)frw::MSM_SLICES * 4 <= (size_t)frw::Grp<F>::BK_WORDS * 4, "the slice histograms borrow the buckets' memory");
-    static_assert((size_t)frw::MSM_SLICES_LONE * frw::MSM_BUCKETS <= (size_t)frw::MSM_MAX_ITEMS * frw::Grp<F>::BK_WORDS, "... or, for a lone signature, the work items'");
-    // + the work items: first item of every bucket, the item list, a counter, and the items' partial sums
-    const size_t items = frw::msm_max_items(n);
-    return 4 * (size_t)frw::MSM_BUCKETS * 4 + (size_t)frw::MSM_W * n * 4 + (size_t)frw::MSM_BUCKETS * frw::Grp<F>::BK_WORDS * 4 +
-           ((size_t)n + 4) * 4 + (size_t)frw::MSM_FOLD1_THREADS * frw::Grp<F>::BK_WORDS * 4 +
-           (items + 4) * 4 + items * frw::Grp<F>::BK_WORDS * 4;
+    constexpr size_t BW = frw::Grp<F>::BK_WORDS;
+    static_assert((size_t)frw::MSM_SLICES * 4 <= BW * 4, "the slice histograms borrow the buckets' memory");
+    static_assert((size_t)frw::MSM_SLICES_LONE * frw::MSM_BUCKETS <= (size_t)frw::MSM_MAX_ITEMS * BW, "... or, for a lone signature, the work items'");
+    MsmBufs<F> b;
+    b.max_items = frw::msm_max_items(n, bare);
+    b.ent_stride = bare ? (size_t)n : (size_t)frw::MSM_W * n;
+    b.ones_stride = bare ? 0 : (size_t)n;                               // a bare handle's ones are digits like any other
+    b.counts = (uint32_t *)ws;
+    b.offsets = b.counts + rows * frw::MSM_BUCKETS;
+    b.order = b.offsets + rows * frw::MSM_BUCKETS;
+    b.item_first = b.order + rows * frw::MSM_BUCKETS;
+    b.item_count = b.item_first + rows * frw::MSM_BUCKETS;             // [rows], four words each
+    b.ones_count = b.item_count + rows * 4;                            // likewise
+    b.items = b.ones_count + rows * 4;                                 // [rows][max_items][2]
+    b.buckets = b.items + rows * (size_t)b.max_items * 2;              // the sort's per-slice histograms live here before the buckets are written
+    b.partial = b.buckets + rows * (size_t)frw::MSM_BUCKETS * BW;
+    b.partial_items = b.partial + rows * (size_t)frw::MSM_FOLD1_THREADS * BW;
+    b.entries = b.partial_items + rows * (size_t)b.max_items * BW;
+    b.ones_list = b.entries + rows * b.ent_stride;
+    b.end = b.ones_list + rows * b.ones_stride;
+    return b;
+}
+// a bare handle: sixteen rows (windows) and their sixteen sums
+template <class F> size_t msm_workspace_per_signature(uint32_t n, bool bare = false)
+{
+    const size_t rows = bare ? frw::MSM_W : 1;
+    char *const base = (char *)(uintptr_t)4096;                       // (a carve of nothing: only the distance to its end is used)
+    const size_t bytes = (size_t)((char *)msm_carve<F>(base, rows, n, bare).end - base) + (bare ? (size_t)frw::MSM_W * frw::Grp<F>::BK_WORDS * 4 : 0);
+    return (bytes + 15) & ~(size_t)15;
 }
 
-template <class F> size_t nmsm_workspace_per_signature(uint32_t n)
+// ---- the narrow pipeline's workspace -----------------------------------------------------------------------------------------------
+struct NmsmBufs {
+    uint32_t *slice_hist, *counts, *offsets, *item_first, *items, *item_count, *ones_count, *ones_list, *entries;      // the sort's
+    uint32_t *partial_items, *partial_ones, *folded_ones, *bucket_sums;                                              // a table's own
+    uint32_t target, max_items, ones_stride;
+    // a bare handle's sort (rows = the thirty-two windows of one scalar vector): where every window's entries start, and its tables'
+    // window sums [table][32]
+    unsigned long long *entry_base = nullptr;
+    uint32_t *window_sums = nullptr;
+    uint32_t *end = nullptr;
+};
+template <class F> NmsmBufs nmsm_carve(void *d_workspace, size_t cnt, uint32_t n)
+{
+    constexpr int BW = frw::Grp<F>::BK_WORDS;
+    NmsmBufs b;
+    b.target = frw::nmsm_target_items(n); b.max_items = frw::nmsm_max_items(n); b.ones_stride = frw::nmsm_ones_max(n) / 64;
+    b.slice_hist = (uint32_t *)d_workspace;
+    b.counts = b.slice_hist + cnt * (size_t)frw::nmsm_slices(n) * frw::NMSM_BUCKETS;
+    b.offsets = b.counts + cnt * frw::NMSM_BUCKETS;
+    b.item_first = b.offsets + cnt * frw::NMSM_BUCKETS;
+    b.items = b.item_first + cnt * frw::NMSM_BUCKETS;
+    b.item_count = b.items + cnt * (size_t)b.max_items;                    // [cnt], padded to four words per signature in the budget
+    b.ones_count = b.item_count + cnt * 4;                                 // likewise
+    b.ones_list = b.ones_count + cnt * 4;
+    b.entries = b.ones_list + cnt * (size_t)n;
+    b.partial_items = b.entries + cnt * (size_t)frw::NMSM_W * n;           // 16-byte aligned: every term above is a multiple of 4 words per signature but n
+    b.partial_items += (4 - ((uintptr_t)b.partial_items >> 2 & 3)) & 3;    // ... at most three words, out of the four the budget adds to the list for it
+    b.partial_ones = b.partial_items + cnt * (size_t)b.max_items * BW;
+    b.folded_ones = b.partial_ones + cnt * (size_t)b.ones_stride * BW;     // second stage, only when ones_stride > 64
+    b.bucket_sums = b.folded_ones + (b.ones_stride > 64 ? cnt * (size_t)64 * BW : 0);
+    b.end = b.bucket_sums + cnt * (size_t)frw::NMSM_BUCKETS * BW;
+    return b;
+}
+// ... of a bare handle: ONE sort (thirty-two window rows) and the own arrays of `tables` tables.  The entries are budgeted for the worst
+// case, every digit of every scalar non-zero (32 n words); a witness fills a seventieth of that.
+// `sorted`: another carve whose sort this one reads (the G2 sum of a proof reads the G1 sums' sort): only the own arrays are carved then.
+template <class F> NmsmBufs nmsm_carve_bare(void *d_workspace, size_t tables, uint32_t n, const NmsmBufs *sorted = nullptr)
+{
+    constexpr int BW = frw::Grp<F>::BK_WORDS;
+    constexpr size_t WIN = frw::NMSM_W;
+    NmsmBufs b;
+    uint32_t *p = (uint32_t *)d_workspace;
+    if (sorted) {
+        b = *sorted;
+    } else {
+        b.target = frw::nmsm_target_items(n); b.max_items = frw::nmsm_max_items(n); b.ones_stride = frw::nmsm_ones_max(n) / 64;
+        b.entry_base = (unsigned long long *)d_workspace;                  // [32]
+        b.slice_hist = (uint32_t *)(b.entry_base + WIN);
+        b.counts = b.slice_hist + WIN * (size_t)frw::nmsm_slices(n) * frw::NMSM_BUCKETS;
+        b.offsets = b.counts + WIN * frw::NMSM_BUCKETS;
+        b.item_first = b.offsets + WIN * frw::NMSM_BUCKETS;
+        b.items = b.item_first + WIN * frw::NMSM_BUCKETS;
+        b.item_count = b.items + WIN * (size_t)b.max_items;
+        b.ones_count = b.item_count + WIN * 4;                             // [0] is the one in use
+        p = b.ones_count + 4;                                              // (every term so far a multiple of four words: 16-byte aligned)
+    }
+    b.partial_items = p;
+    b.partial_ones = b.partial_items + tables * WIN * (size_t)b.max_items * BW;
+    b.folded_ones = b.partial_ones + tables * (size_t)b.ones_stride * BW;
+    b.bucket_sums = b.folded_ones + tables * (size_t)64 * BW;
+    b.window_sums = b.bucket_sums + tables * WIN * (size_t)frw::NMSM_BUCKETS * BW;
+    b.end = b.window_sums + tables * WIN * BW;
+    if (!sorted) {
+        b.ones_list = b.end;
+        b.entries = b.ones_list + (size_t)n;
+        b.end = b.entries + WIN * (size_t)n;
+    }
+    return b;
+}
+template <class F> size_t nmsm_workspace_per_signature(uint32_t n, bool bare = false)
 {
     // slice histograms, counts, offsets, first item of every bucket (all x 128), the item list + counter, the ones' list + counter,
     // the entries (32 n x 4 B), the items' and the ones' partial sums
-    // (n + 8 words for the list: the four after it are the alignment pad of what follows, budgeted here rather than borrowed)
-    const size_t items = frw::nmsm_max_items(n), ones_groups = frw::nmsm_ones_max(n) / 64;
-    return ((size_t)frw::nmsm_slices(n) + 3) * frw::NMSM_BUCKETS * 4 + (items + 4) * 4 + ((size_t)n + 8) * 4 +
-           (size_t)frw::NMSM_W * n * 4 + (items + ones_groups + (ones_groups > 64 ? 64 : 0) + frw::NMSM_BUCKETS) * frw::Grp<F>::BK_WORDS * 4;
+    // (four words more than the carve: the alignment pad after the list, budgeted here rather than borrowed)
+    char *const base = (char *)(uintptr_t)4096;
+    const NmsmBufs b = bare ? nmsm_carve_bare<F>(base, 1, n) : nmsm_carve<F>(base, 1, n);
+    return (((size_t)((char *)b.end - base) + 16) + 15) & ~(size_t)15;
 }
 
-template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, int window_bits, frw_msm **out)
+template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, int window_bits, bool bare, frw_msm **out)
 {
-    if (!out || !bases || num_points == 0 || num_points > ((size_t)1 << (window_bits == 8 ? 25 : 26))) return FRW_E_INVALID_ARG;
+    // (a table row index and its window share 31 bits of an entry: 2^26 points x 16 windows, 2^25 x 32; a bare handle's entries are point indices)
+    if (!out || !bases || num_points == 0 || num_points > (bare ? ((size_t)1 << 31) - 1 : (size_t)1 << (window_bits == 8 ? 25 : 26))) return FRW_E_INVALID_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
@@ -1012,18 +1253,19 @@ template <class F> int msm_load(int device, int group, size_t num_points, const 
     m->device = device;
     m->group = group;
     m->window_bits = window_bits;
+    m->bare = bare;
     m->table = nullptr;
     m->ones_table = nullptr;
     m->dev.ones_table = nullptr;
     m->dev.n = (uint32_t)num_points;
     void *d_bases = nullptr;
-    const size_t table_bytes = (size_t)(256 / window_bits) * num_points * frw::Grp<F>::PT_WORDS * 4, ark_bytes = (size_t)frw::Grp<F>::ARK_WORDS * 4;
+    const size_t table_bytes = (size_t)(bare ? 1 : 256 / window_bits) * num_points * frw::Grp<F>::PT_WORDS * 4, ark_bytes = (size_t)frw::Grp<F>::ARK_WORDS * 4;
     e = hipMalloc(&m->table, table_bytes);
     if (e == hipSuccess) e = hipMalloc(&d_bases, num_points * ark_bytes);
     if (e == hipSuccess) e = hipMemcpy(d_bases, bases, num_points * ark_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(frw::msm_precompute_kernel<F>, dim3((unsigned)((num_points + 63) / 64)), dim3(64), 0, nullptr,
-                           (uint32_t)num_points, (const uint32_t *)d_bases, (uint32_t *)m->table, window_bits);
+                           (uint32_t)num_points, (const uint32_t *)d_bases, (uint32_t *)m->table, bare ? 256 : window_bits);     // (256-bit "windows": one row per point)
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1031,7 +1273,7 @@ template <class F> int msm_load(int device, int group, size_t num_points, const 
     d_bases = nullptr;
     // the subset sums of every group of eight points, for the scalars equal to one (narrow handles of per-signature size: an aggregate
     // statement's tables are tens of gigabytes as it is, and its ones go through the list)
-    if (e == hipSuccess && window_bits == 8 && num_points <= ((size_t)1 << 18)) {
+    if (e == hipSuccess && !bare && window_bits == 8 && num_points <= ((size_t)1 << 18)) {
         const size_t entries = (num_points + 7) / 8 * 255;
         e = hipMalloc(&m->ones_table, entries * frw::Grp<F>::PT_WORDS * 4);
         if (e == hipSuccess) {
@@ -1076,65 +1318,78 @@ template <class F> int fixed_base(int device, size_t count, const uint64_t *scal
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_fixed_base");
 }
 
+// One chunk of the dense pipeline: `rows` grid rows -- signatures with all their windows, or (a bare handle) the sixteen windows of ONE
+// scalar vector -- to `rows` sums in `out` (XYZZ buckets or ark-ff's affine bytes).
+template <class F, bool PREFETCH>
+hipError_t msm_rows(const frw_msm *m, size_t rows, const uint32_t *sc, size_t stride_words, int montgomery, uint32_t *out, bool xyzz_out,
+                    void *d_workspace, hipStream_t st)
+{
+    const uint32_t n = m->dev.n;
+    const bool bare = m->bare;
+    const MsmBufs<F> b = msm_carve<F>(d_workspace, rows, n, bare);
+    uint32_t *slice_hist = b.buckets;                                // [rows][32][32,768], dead before the first bucket is stored (rows == 1: see below)
+    const int slices = rows == 1 ? frw::MSM_SLICES_LONE : frw::MSM_SLICES;
+    if (rows == 1) slice_hist = b.partial_items;                     // [224][32,768], dead before the first work item's sum is stored
+    const dim3 sgrid((unsigned)slices, (unsigned)rows);
+    hipError_t e = hipMemsetAsync(b.ones_count, 0, rows * 16, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, b.ones_count, b.ones_list, bare ? 1 : 0);
+    hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)rows), dim3(256), 0, st, slice_hist, b.counts, slices);
+    hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)rows), dim3(1024), 0, st, b.counts, b.offsets);
+    // (four at a time: 12.6 ms with the finer split, 12.1 without); beyond 2^18 points: see MSM_MAX_ITEMS_LARGE
+    // (a lone Falcon-1024 proof with 2 / 3 / 4: 4.72 / 4.27 / 4.05 ms -- the finer cut shares the chip better with the proof's other
+    // sums; 5, with a longer item list, changes nothing any more: 3.86 - 3.91 against 3.90 ms, the sums overlap either way)
+    // (a bare handle's sixteen windows are sixteen rows of equal buckets: 524,288 items as they are)
+    const uint32_t finer = bare ? 1u : rows <= 2 ? (n > (1u << 18) ? 24u : 4u) : 1u;
+    hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)rows), dim3(1024), 0, st, b.counts, b.offsets, b.order, b.item_first, b.items, b.item_count, finer,
+                       b.max_items);
+    hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.offsets, slice_hist, b.entries, bare ? 1 : 0);
+    hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(b.max_items / 64, (unsigned)rows), dim3(64), 0, st, m->dev, b.offsets,
+                       b.counts, b.items, b.item_count, b.entries, b.partial_items, finer, b.max_items, b.ent_stride);
+    hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, (unsigned)rows), dim3(64), 0, st, b.offsets, b.counts, b.item_first,
+                       b.partial_items, b.buckets, finer, b.max_items);
+    // first stage of the fold: enough threads to occupy the chip (~2^16), as few as that allows
+    // (64 per call with 16 / 32 / 64 buckets per thread: 927 - 929 / 927 - 930 / 919 proofs/s -- the fold is 3 of a call's 69 ms)
+    const int log_chunk = rows >= 128 ? 6 : rows >= 32 ? 5 : 3;
+    const unsigned t1 = (unsigned)frw::MSM_BUCKETS >> log_chunk;
+    frw::MsmDev ones_dev = m->dev;
+    if (bare) ones_dev.n = 0;                                        // (no list: every row's count is zero and its slice of the list the same empty one)
+    hipLaunchKernelGGL(frw::msm_ones_kernel<F>, dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, ones_dev, b.ones_count, b.ones_list, b.partial);
+    if (log_chunk == 6) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 6>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial);
+    else if (log_chunk == 5) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 5>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial);
+    else hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 3>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial);
+    hipLaunchKernelGGL(frw::msm_fold2_kernel<F>, dim3((unsigned)rows), dim3(frw::MSM_FOLD_THREADS), 0, st, b.partial,
+                       (int)(t1 / frw::MSM_FOLD_THREADS), out, xyzz_out ? 1 : 0);
+    return hipGetLastError();
+}
 // the whole call for one group; `d_out` rows are ARK_WORDS / 2 uint64_t
 template <class F, bool PREFETCH>
 int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery, uint64_t *d_out,
             void *d_workspace, size_t workspace_bytes, hipStream_t st, bool xyzz_out = false)
 {
     const uint32_t n = m->dev.n;
-    const size_t per = msm_workspace_per_signature<F>(n);
+    const size_t per = msm_workspace_per_signature<F>(n, m->bare);
     size_t chunk = workspace_bytes / per;
     if (chunk == 0 || ((uintptr_t)d_workspace & 15)) return FRW_E_INVALID_ARG;
     if (chunk > 32768) chunk = 32768;                                  // grid.y
     constexpr int BW = frw::Grp<F>::BK_WORDS;
     hipError_t e = hipSetDevice(m->device);
+    if (m->bare) {
+        // one scalar vector at a time: its sixteen windows fill the grid; the window sums wait at the end of the workspace for Horner's rule
+        uint32_t *window_sums = (uint32_t *)((char *)d_workspace + per) - (size_t)frw::MSM_W * BW;
+        for (size_t sig = 0; e == hipSuccess && sig < batch; sig++) {
+            e = msm_rows<F, PREFETCH>(m, frw::MSM_W, (const uint32_t *)(d_scalars + sig * scalar_stride * 4), 0, montgomery, window_sums, true, d_workspace, st);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(frw::msm_horner_kernel<F>, dim3(1), dim3(64), 0, st, window_sums, frw::MSM_W, frw::MSM_C,
+                               (uint32_t *)d_out + sig * (xyzz_out ? BW : frw::Grp<F>::ARK_WORDS), xyzz_out ? 1 : 0);
+            e = hipGetLastError();
+        }
+        return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
+    }
     for (size_t lo = 0; e == hipSuccess && lo < batch; lo += chunk) {
         const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
-        uint32_t *counts = (uint32_t *)d_workspace;
-        uint32_t *offsets = counts + cnt * frw::MSM_BUCKETS;
-        uint32_t *order = offsets + cnt * frw::MSM_BUCKETS;
-        uint32_t *entries = order + cnt * frw::MSM_BUCKETS;
-        uint32_t *buckets = entries + cnt * (size_t)frw::MSM_W * n;
-        uint32_t *slice_hist = buckets;                                  // [cnt][32][32,768], dead before the first bucket is stored (cnt == 1: see below)
-        uint32_t *partial = buckets + cnt * (size_t)frw::MSM_BUCKETS * BW;
-        uint32_t *ones_list = partial + cnt * (size_t)frw::MSM_FOLD1_THREADS * BW;
-        uint32_t *ones_count = ones_list + cnt * (size_t)n;             // [cnt], padded to four words per signature in the budget
-        uint32_t *item_first = ones_count + cnt * 4;
-        uint32_t *items = item_first + cnt * (size_t)frw::MSM_BUCKETS;
-        const uint32_t max_items = frw::msm_max_items(n);
-        uint32_t *item_count = items + cnt * (size_t)max_items;          // [cnt], padded likewise
-        uint32_t *partial_items = item_count + cnt * 4;
-        const uint32_t *sc = (const uint32_t *)(d_scalars + lo * scalar_stride * 4);
-        const size_t stride_words = scalar_stride * 8;
-        const int slices = cnt == 1 ? frw::MSM_SLICES_LONE : frw::MSM_SLICES;
-        if (cnt == 1) slice_hist = partial_items;                        // [224][32,768], dead before the first work item's sum is stored
-        const dim3 sgrid((unsigned)slices, (unsigned)cnt);
-        e = hipMemsetAsync(ones_count, 0, cnt * 4, st);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, ones_count, ones_list);
-        hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)cnt), dim3(256), 0, st, slice_hist, counts, slices);
-        hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets);
-        // (four at a time: 12.6 ms with the finer split, 12.1 without); beyond 2^18 points: see MSM_MAX_ITEMS_LARGE
-        // (a lone Falcon-1024 proof with 2 / 3 / 4: 4.72 / 4.27 / 4.05 ms -- the finer cut shares the chip better with the proof's other
-        // sums; 5, with a longer item list, changes nothing any more: 3.86 - 3.91 against 3.90 ms, the sums overlap either way)
-        const uint32_t finer = cnt <= 2 ? (n > (1u << 18) ? 24u : 4u) : 1u;
-        hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)cnt), dim3(1024), 0, st, counts, offsets, order, item_first, items, item_count, finer, max_items);
-        hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, offsets, slice_hist, entries);
-        hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(max_items / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, offsets,
-                           counts, items, item_count, entries, partial_items, finer, max_items);
-        hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, (unsigned)cnt), dim3(64), 0, st, offsets, counts, item_first,
-                           partial_items, buckets, finer, max_items);
-        // first stage of the fold: enough threads to occupy the chip (~2^16), as few as that allows
-        // (64 per call with 16 / 32 / 64 buckets per thread: 927 - 929 / 927 - 930 / 919 proofs/s -- the fold is 3 of a call's 69 ms)
-        const int log_chunk = cnt >= 128 ? 6 : cnt >= 32 ? 5 : 3;
-        const unsigned t1 = (unsigned)frw::MSM_BUCKETS >> log_chunk;
-        hipLaunchKernelGGL(frw::msm_ones_kernel<F>, dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, m->dev, ones_count, ones_list, partial);
-        if (log_chunk == 6) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 6>), dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, buckets, partial);
-        else if (log_chunk == 5) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 5>), dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, buckets, partial);
-        else hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 3>), dim3(t1 / 64, (unsigned)cnt), dim3(64), 0, st, buckets, partial);
-        hipLaunchKernelGGL(frw::msm_fold2_kernel<F>, dim3((unsigned)cnt), dim3(frw::MSM_FOLD_THREADS), 0, st, partial,
-                           (int)(t1 / frw::MSM_FOLD_THREADS), (uint32_t *)d_out + lo * (xyzz_out ? BW : frw::Grp<F>::ARK_WORDS), xyzz_out ? 1 : 0);
-        e = hipGetLastError();
+        e = msm_rows<F, PREFETCH>(m, cnt, (const uint32_t *)(d_scalars + lo * scalar_stride * 4), scalar_stride * 8, montgomery,
+                                  (uint32_t *)d_out + lo * (xyzz_out ? BW : frw::Grp<F>::ARK_WORDS), xyzz_out, d_workspace, st);
     }
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
 }
@@ -1142,32 +1397,6 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
 // over one window table with a sort's result.  The four witness-side sums of a proof take the SAME scalars -- z ++ [1, r, s] against
 // a_query, b_g1_query, b_g2_query and l_query, each table padded to the same length with points at infinity -- so a proof sorts once
 // (frw_groth16_prove_dev); frw_msm_g1_dev / _g2_dev on a narrow handle are one sort and one sum.
-struct NmsmBufs {
-    uint32_t *slice_hist, *counts, *offsets, *item_first, *items, *item_count, *ones_count, *ones_list, *entries;      // the sort's
-    uint32_t *partial_items, *partial_ones, *folded_ones, *bucket_sums;                                              // a table's own
-    uint32_t target, max_items, ones_stride;
-};
-template <class F> NmsmBufs nmsm_carve(void *d_workspace, size_t cnt, uint32_t n)
-{
-    constexpr int BW = frw::Grp<F>::BK_WORDS;
-    NmsmBufs b;
-    b.target = frw::nmsm_target_items(n); b.max_items = frw::nmsm_max_items(n); b.ones_stride = frw::nmsm_ones_max(n) / 64;
-    b.slice_hist = (uint32_t *)d_workspace;
-    b.counts = b.slice_hist + cnt * (size_t)frw::nmsm_slices(n) * frw::NMSM_BUCKETS;
-    b.offsets = b.counts + cnt * frw::NMSM_BUCKETS;
-    b.item_first = b.offsets + cnt * frw::NMSM_BUCKETS;
-    b.items = b.item_first + cnt * frw::NMSM_BUCKETS;
-    b.item_count = b.items + cnt * (size_t)b.max_items;                    // [cnt], padded to four words per signature in the budget
-    b.ones_count = b.item_count + cnt * 4;                                 // likewise
-    b.ones_list = b.ones_count + cnt * 4;
-    b.entries = b.ones_list + cnt * (size_t)n;
-    b.partial_items = b.entries + cnt * (size_t)frw::NMSM_W * n;           // 16-byte aligned: every term above is a multiple of 4 words per signature but n
-    b.partial_items += (4 - ((uintptr_t)b.partial_items >> 2 & 3)) & 3;    // ... at most three words, out of the four the budget adds to the list for it
-    b.partial_ones = b.partial_items + cnt * (size_t)b.max_items * BW;
-    b.folded_ones = b.partial_ones + cnt * (size_t)b.ones_stride * BW;     // second stage, only when ones_stride > 64
-    b.bucket_sums = b.folded_ones + (b.ones_stride > 64 ? cnt * (size_t)64 * BW : 0);
-    return b;
-}
 // ones_as_mask: every table that will be summed with this sort has the subset sums of its groups of eight (MsmDev::ones_table): the
 // scalars equal to one are then recorded as a bit mask (the first n / 32 words of each signature's list) instead of a list
 hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *sc, size_t stride_words, int montgomery, bool ones_as_mask, hipStream_t st)
@@ -1182,6 +1411,19 @@ hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *
     hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3((unsigned)cnt), dim3(frw::NMSM_BUCKETS), 0, st, b.slice_hist, b.counts, b.offsets, b.item_first, b.items,
                        b.item_count, b.target, b.max_items, slices);
     hipLaunchKernelGGL(frw::nmsm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.offsets, b.slice_hist, b.entries);
+    return hipGetLastError();
+}
+// ... of ONE scalar vector for bare handles: all thirty-two windows in one pass (`b` from nmsm_carve_bare)
+hipError_t nmsm_sort_bare(const NmsmBufs &b, uint32_t n, const uint32_t *sc, int montgomery, hipStream_t st)
+{
+    const uint32_t slices = frw::nmsm_slices(n);
+    hipError_t e = hipMemsetAsync(b.ones_count, 0, 16, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(frw::nmsm_hist_bare_kernel, dim3(slices), dim3(1024), 0, st, n, sc, montgomery, b.slice_hist, b.ones_count, b.ones_list);
+    hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3(frw::NMSM_W), dim3(frw::NMSM_BUCKETS), 0, st, b.slice_hist, b.counts, b.offsets, b.item_first, b.items,
+                       b.item_count, b.target, b.max_items, slices);
+    hipLaunchKernelGGL(frw::nmsm_entry_base_kernel, dim3(1), dim3(64), 0, st, b.counts, b.offsets, b.entry_base);
+    hipLaunchKernelGGL(frw::nmsm_scatter_bare_kernel, dim3(slices), dim3(1024), 0, st, n, sc, montgomery, b.offsets, b.slice_hist, b.entry_base, b.entries);
     return hipGetLastError();
 }
 // `sorted`: whose sort arrays to read; `own`: where the tables' partial sums go -- carved for `tables * cnt` signatures when there is
@@ -1211,7 +1453,7 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
     int ones_threads = 256;
     while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * rows < 65536) ones_threads <<= 1;
     hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, rows), dim3(64), 0, ones_stream, dev, sorted.ones_count, sorted.ones_list,
-                       own.partial_ones, own.ones_stride);
+                       own.partial_ones, own.ones_stride, 1u);
     const uint32_t *ones_for_finish = own.partial_ones;
     uint32_t ones_groups = (uint32_t)ones_threads / 64, ones_finish_stride = own.ones_stride;
     if (ones_groups > 64) {
@@ -1225,7 +1467,8 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((sorted.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
-                       sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items);
+                       sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items,
+                       (const unsigned long long *)nullptr);
     // the items of a bucket: added up by a workgroup per bucket where latency counts (a lone proof: 12 ms -> 8.6), by the fold's own
     // thread where throughput does (the combine is nine times the wave-level additions: 3 % of a 64-proof call)
     const bool combine = cnt <= 16;
@@ -1238,7 +1481,46 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
     }
     hipLaunchKernelGGL(frw::nmsm_finish_kernel<FB>, dim3(rows), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first, own.partial_items,
                        combine ? own.bucket_sums : (uint32_t *)nullptr, ones_for_finish, (int)ones_groups, ones_finish_stride, sorted.target, sorted.max_items,
-                       d_out, xyzz_out ? 1 : 0, (uint32_t)cnt);
+                       d_out, xyzz_out ? 1 : 0, (uint32_t)cnt, 0);
+    return hipGetLastError();
+}
+// The sums of ONE scalar vector over `tables` bare handles that share its sort (`b` from nmsm_carve_bare<F>(.., tables, n): the sort's
+// arrays and the tables' own): grid row = (table, window); a window's buckets are cut into work items, combined by a workgroup per bucket
+// (the low windows hold every small value of a witness: a bucket of 250,000 entries is a thousand items), folded by one wavefront per
+// (table, window); the scalars equal to one -- a list -- are summed by up to 65,536 threads per table and join window 0; Horner's rule
+// over the thirty-two window sums.  d_out: [tables] results.
+template <class F, bool PREFETCH>
+hipError_t nmsm_accumulate_bare(const frw_msm *const *ms, int tables, const NmsmBufs &b, uint32_t *d_out, hipStream_t st, bool xyzz_out)
+{
+    const uint32_t n = ms[0]->dev.n;
+    frw::NmsmTables dev;
+    dev.n = n; dev.sigs = frw::NMSM_W;
+    for (int t = 0; t < 3; t++) {
+        dev.table[t] = ms[t < tables ? t : 0]->dev.table;
+        dev.ones_table[t] = nullptr;
+    }
+    const unsigned rows = (unsigned)tables * frw::NMSM_W;
+    typedef typename frw::BulkPolicy<F>::type FB;
+    constexpr bool BULK_PREFETCH = PREFETCH || FB::LANES > 1;
+    const uint32_t ones_threads = frw::nmsm_ones_max(n);             // 4,096, or 65,536 beyond 2^18 points
+    hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3(ones_threads / 64, (unsigned)tables), dim3(64), 0, st, dev, b.ones_count, b.ones_list, b.partial_ones,
+                       b.ones_stride, (uint32_t)frw::NMSM_W);
+    const uint32_t *ones_for_finish = b.partial_ones;
+    uint32_t ones_groups = ones_threads / 64, ones_finish_stride = b.ones_stride;
+    if (ones_groups > 64) {
+        hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<FB>, dim3(64, (unsigned)tables), dim3(64), 0, st, b.partial_ones, ones_groups, b.ones_stride, b.folded_ones);
+        ones_for_finish = b.folded_ones;
+        ones_groups = 64;
+        ones_finish_stride = 64;
+    }
+    hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((b.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
+                       b.offsets, b.counts, b.items, b.item_count, b.entries, b.partial_items, b.target, b.max_items, (const unsigned long long *)b.entry_base);
+    hipLaunchKernelGGL(frw::nmsm_combine_kernel<FB>, dim3(frw::NMSM_BUCKETS, rows), dim3(64), 0, st, b.counts, b.offsets, b.item_first,
+                       b.partial_items, b.bucket_sums, b.target, b.max_items, (uint32_t)frw::NMSM_W);
+    hipLaunchKernelGGL(frw::nmsm_finish_kernel<FB>, dim3(rows), dim3(64), 0, st, b.counts, b.offsets, b.item_first, b.partial_items,
+                       b.bucket_sums, ones_for_finish, (int)ones_groups, ones_finish_stride, b.target, b.max_items,
+                       b.window_sums, 1, (uint32_t)frw::NMSM_W, 1);
+    hipLaunchKernelGGL(frw::msm_horner_kernel<FB>, dim3((unsigned)tables), dim3(64), 0, st, b.window_sums, frw::NMSM_W, frw::NMSM_C, d_out, xyzz_out ? 1 : 0);
     return hipGetLastError();
 }
 // the narrow pipeline for one group
@@ -1247,11 +1529,19 @@ int nmsm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t s
              void *d_workspace, size_t workspace_bytes, hipStream_t st)
 {
     const uint32_t n = m->dev.n;
-    const size_t per = nmsm_workspace_per_signature<F>(n);
+    const size_t per = nmsm_workspace_per_signature<F>(n, m->bare);
     size_t chunk = workspace_bytes / per;
     if (chunk == 0 || ((uintptr_t)d_workspace & 15)) return FRW_E_INVALID_ARG;
     if (chunk > 32768) chunk = 32768;                                  // grid.y
     hipError_t e = hipSetDevice(m->device);
+    if (m->bare) {
+        const NmsmBufs b = nmsm_carve_bare<F>(d_workspace, 1, n);
+        for (size_t sig = 0; e == hipSuccess && sig < batch; sig++) {
+            e = nmsm_sort_bare(b, n, (const uint32_t *)(d_scalars + sig * scalar_stride * 4), montgomery, st);
+            if (e == hipSuccess) e = nmsm_accumulate_bare<F, PREFETCH>(&m, 1, b, (uint32_t *)(d_out + sig * (frw::Grp<F>::ARK_WORDS / 2)), st, false);
+        }
+        return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
+    }
     for (size_t lo = 0; e == hipSuccess && lo < batch; lo += chunk) {
         const size_t cnt = batch - lo < chunk ? batch - lo : chunk;
         const NmsmBufs b = nmsm_carve<F>(d_workspace, cnt, n);
@@ -1274,19 +1564,27 @@ extern "C" void frw_msm_free(frw_msm *m)
 
 extern "C" int frw_msm_g1_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
 {
-    return msm_load<FqField>(device, 1, num_points, bases, 16, out);
+    return msm_load<FqField>(device, 1, num_points, bases, 16, false, out);
 }
 extern "C" int frw_msm_g1_load_narrow(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
 {
-    return msm_load<FqField>(device, 1, num_points, bases, 8, out);
+    return msm_load<FqField>(device, 1, num_points, bases, 8, false, out);
 }
 extern "C" int frw_msm_g2_load_narrow(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
 {
-    return msm_load<Fq2Field>(device, 2, num_points, bases, 8, out);
+    return msm_load<Fq2Field>(device, 2, num_points, bases, 8, false, out);
 }
 extern "C" int frw_msm_g2_load(int device, size_t num_points, const uint64_t *bases, frw_msm **out)
 {
-    return msm_load<Fq2Field>(device, 2, num_points, bases, 16, out);
+    return msm_load<Fq2Field>(device, 2, num_points, bases, 16, false, out);
+}
+extern "C" int frw_msm_g1_load_bare(int device, size_t num_points, const uint64_t *bases, int narrow, frw_msm **out)
+{
+    return msm_load<FqField>(device, 1, num_points, bases, narrow ? 8 : 16, true, out);
+}
+extern "C" int frw_msm_g2_load_bare(int device, size_t num_points, const uint64_t *bases, int narrow, frw_msm **out)
+{
+    return msm_load<Fq2Field>(device, 2, num_points, bases, narrow ? 8 : 16, true, out);
 }
 extern "C" int frw_g1_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out)
 {
@@ -1305,10 +1603,12 @@ extern "C" int frw_msm_info(const frw_msm *m, frw_msm_info_t *out)
     const bool narrow = m->window_bits == 8;
     out->window_bits = m->window_bits;
     out->num_windows = 256 / m->window_bits;
-    out->table_bytes = (uint64_t)out->num_windows * m->dev.n * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
+    out->table_bytes = (uint64_t)(m->bare ? 1 : out->num_windows) * m->dev.n * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
     if (m->ones_table) out->table_bytes += (uint64_t)((m->dev.n + 7) / 8) * 255 * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
-    out->workspace_bytes_per_signature = narrow ? (g2 ? nmsm_workspace_per_signature<Fq2Field>(m->dev.n) : nmsm_workspace_per_signature<FqField>(m->dev.n))
-                                                : (g2 ? msm_workspace_per_signature<Fq2Field>(m->dev.n) : msm_workspace_per_signature<FqField>(m->dev.n));
+    const uint32_t n = m->dev.n;
+    const bool bare = m->bare;
+    out->workspace_bytes_per_signature = narrow ? (g2 ? nmsm_workspace_per_signature<Fq2Field>(n, bare) : nmsm_workspace_per_signature<FqField>(n, bare))
+                                                : (g2 ? msm_workspace_per_signature<Fq2Field>(n, bare) : msm_workspace_per_signature<FqField>(n, bare));
     return FRW_OK;
 }
 
@@ -1517,12 +1817,40 @@ __global__ __launch_bounds__(64) void groth16_finish_kernel(size_t batch, const 
         for (int k = 0; k < 48; k++) o[24 + k] = b2_pts[sig * 48 + k];
     store_ark_point<F>(o + (holds_a ? 0 : 72), pt_to_affine(acc));
 }
+// ---- a key in slices (round 5): every rank sums its slice of every query; the five partial sums of a rank leave as ark-ff's affine
+// bytes -- A | B1' | L | H (G1, 12 u64 each) | B (G2, 24) -- and any rank puts `world` of them together
+__global__ __launch_bounds__(64) void groth16_partial_kernel(const uint32_t *__restrict__ g1_pts /* [4][BK_WORDS]: A, B1', L, H */,
+                                                             const uint32_t *__restrict__ b2_ark /* [48] */, uint32_t *__restrict__ out /* [144] */)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < 4) store_ark_point<FqField>(out + t * 24, pt_to_affine(load_bucket<FqField>(g1_pts + t * Grp<FqField>::BK_WORDS)));
+    else if (t < 4 + 48) out[96 + (t - 4)] = b2_ark[t - 4];
+}
+__global__ __launch_bounds__(64) void groth16_combine_kernel(uint32_t world, const uint32_t *__restrict__ partials /* [world][144] */,
+                                                             uint32_t *__restrict__ g1_pts /* [4][BK_WORDS] */, uint32_t *__restrict__ b2_ark /* [48] */)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < 4) {
+        XyzzT<FqField> acc = pt_identity<FqField>();
+        for (uint32_t r = 0; r < world; r++) acc = pt_add_affine(acc, load_ark_point<FqField>(partials + (size_t)r * 144 + t * 24));
+        store_bucket<FqField>(g1_pts + t * Grp<FqField>::BK_WORDS, acc);
+    } else if (t == 4) {
+        XyzzT<Fq2Field> acc = pt_identity<Fq2Field>();
+        for (uint32_t r = 0; r < world; r++) acc = pt_add_affine(acc, load_ark_point<Fq2Field>(partials + (size_t)r * 144 + 96));
+        store_ark_point<Fq2Field>(b2_ark, pt_to_affine(acc));
+    }
+}
 }  // namespace frw
 
 struct frw_groth16_pk {
     int device;
     uint64_t num_instance, num_witness, domain_size;
     frw_msm *h, *a, *b1, *l, *b2;
+    // round 5: a key of bare handles (the points only: 83 GB for the 1,024-statement aggregate instead of 3.6 KB per variable), and a
+    // key in slices: this handle holds rows [z_lo, z_hi) of the nv + 3 rows of the four witness-side tables and [h_lo, h_hi) of h_query
+    bool bare = false;
+    uint32_t rank = 0, world = 1;
+    uint64_t z_lo = 0, z_hi = 0, h_lo = 0, h_hi = 0;
     // FOUR streams of the key's own, created one after the other -- as many as the device has hardware queues (HIP's default), so
     // that no two of them wait in line for the same queue.  `main`: the witness map + the sum over h_query; side[0]: the three G1
     // witness-side sums as one chain of kernels, then both scalar multiplications; side[2]: the sum over b_g2_query; side[1]: the G1
@@ -1554,37 +1882,215 @@ extern "C" void frw_groth16_pk_free(frw_groth16_pk *pk)
     delete pk;
 }
 
-extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, frw_groth16_pk **out)
+namespace {
+// the key's own streams and events (see the struct)
+int pk_create(int device, uint64_t ni, uint64_t nw, uint64_t n, frw_groth16_pk **out)
+{
+    frw_groth16_pk *pk = new (std::nothrow) frw_groth16_pk;
+    if (!pk) return FRW_E_OUT_OF_MEMORY;
+    pk->device = device;
+    pk->num_instance = ni; pk->num_witness = nw; pk->domain_size = n;
+    pk->h = pk->a = pk->b1 = pk->l = pk->b2 = nullptr;
+    pk->fork = pk->sorted = pk->ones_done = nullptr;
+    pk->main = nullptr;
+    for (int i = 0; i < 4; i++) { if (i < 3) pk->side[i] = nullptr; pk->join[i] = nullptr; }
+    pk->z_lo = 0; pk->z_hi = ni + nw + 3; pk->h_lo = 0; pk->h_hi = n - 1;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->sorted, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->ones_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&pk->main, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) {
+        if (i < 3) e = hipStreamCreateWithFlags(&pk->side[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->join[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        frw_groth16_pk_free(pk);
+        return frw::record_hip_error(e, "frw_groth16_pk_load");
+    }
+    *out = pk;
+    return FRW_OK;
+}
+// a bare handle with room for `rows` rows and nothing in them yet
+template <class F> int msm_alloc_bare_t(int device, int group, int window_bits, size_t rows, uint64_t row_lo, frw_msm **out)
+{
+    if (!out || rows == 0 || rows >= ((size_t)1 << 31)) return FRW_E_INVALID_ARG;
+    *out = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return frw::record_hip_error(e, "hipSetDevice");
+    frw_msm *m = new (std::nothrow) frw_msm;
+    if (!m) return FRW_E_OUT_OF_MEMORY;
+    m->device = device; m->group = group; m->window_bits = window_bits; m->bare = true; m->row_lo = row_lo;
+    m->table = nullptr; m->ones_table = nullptr;
+    m->dev.n = (uint32_t)rows; m->dev.ones_table = nullptr;
+    e = hipMalloc(&m->table, rows * frw::Grp<F>::PT_WORDS * 4);
+    if (e != hipSuccess) { delete m; return frw::record_hip_error(e, "frw_msm: the key's rows"); }
+    m->dev.table = (const uint32_t *)m->table;
+    *out = m;
+    return FRW_OK;
+}
+// rows [first, first + count) of a bare handle from `count` ark-ff points in HOST memory, a few megabytes at a time
+template <class F> int msm_upload_rows(frw_msm *m, size_t first, size_t count, const std::function<const uint64_t *(size_t)> &point_of /* null: infinity */)
+{
+    constexpr size_t AW = frw::Grp<F>::ARK_WORDS / 2, CHUNK = (size_t)1 << 18;
+    std::vector<uint64_t> stage(std::min(count, CHUNK) * AW);
+    void *d_stage = nullptr;
+    hipError_t e = hipSetDevice(m->device);
+    if (e == hipSuccess) e = hipMalloc(&d_stage, stage.size() * 8);
+    for (size_t lo = 0; e == hipSuccess && lo < count; lo += CHUNK) {
+        const size_t cnt = std::min(CHUNK, count - lo);
+        for (size_t i = 0; i < cnt; i++) {
+            const uint64_t *src = point_of(lo + i);
+            if (src) std::memcpy(&stage[i * AW], src, AW * 8);
+            else std::memset(&stage[i * AW], 0, AW * 8);
+        }
+        e = hipMemcpy(d_stage, stage.data(), cnt * AW * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(frw::msm_precompute_kernel<F>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)cnt, (const uint32_t *)d_stage,
+                           (uint32_t *)m->table + (first + lo) * frw::Grp<F>::PT_WORDS, 256);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (d_stage) (void)hipFree(d_stage);
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_groth16_pk_load: rows");
+}
+}  // namespace
+
+namespace frw {
+// slice `rank` of `world` of `total` rows
+void groth16_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi)
+{
+    if (world <= 1) { *lo = 0; *hi = total; return; }
+    *lo = total / world * rank + std::min<uint64_t>(rank, total % world);
+    *hi = *lo + total / world + (rank < total % world ? 1 : 0);
+}
+int msm_alloc_bare(int device, int group, int window_bits, size_t rows, uint64_t row_lo, frw_msm **out)
+{
+    return group == 1 ? msm_alloc_bare_t<FqField>(device, 1, window_bits, rows, row_lo, out)
+                      : msm_alloc_bare_t<Fq2Field>(device, 2, window_bits, rows, row_lo, out);
+}
+int fixed_base_gen_create(int device, FixedBaseGen *g)
+{
+    g->g1 = g->g2 = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->g1, (size_t)FB_WINDOWS * FB_DIGITS * Grp<FqField>::PT_WORDS * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->g2, (size_t)FB_WINDOWS * FB_DIGITS * Grp<Fq2Field>::PT_WORDS * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fixed_base_table_kernel<FqField>, dim3(FB_WINDOWS * FB_DIGITS / 64), dim3(64), 0, nullptr, g->g1);
+        hipLaunchKernelGGL(fixed_base_table_kernel<Fq2Field>, dim3(FB_WINDOWS * FB_DIGITS / 64), dim3(64), 0, nullptr, g->g2);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { fixed_base_gen_free(g); return record_hip_error(e, "fixed-base tables"); }
+    return FRW_OK;
+}
+void fixed_base_gen_free(FixedBaseGen *g)
+{
+    if (g->g1) (void)hipFree(g->g1);
+    if (g->g2) (void)hipFree(g->g2);
+    g->g1 = g->g2 = nullptr;
+}
+// rows [first_row, first_row + count) of a bare handle = d_scalars[i] x the group's generator (canonical scalars in device memory)
+hipError_t msm_fill_fixed_base(frw_msm *m, const FixedBaseGen &g, size_t first_row, size_t count, const uint32_t *d_scalars, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    if (!m->bare || first_row + count > m->dev.n) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((count + 63) / 64));
+    if (m->group == 1)
+        hipLaunchKernelGGL(fixed_base_rows_kernel<FqField>, grid, dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g1,
+                           (uint32_t *)m->table + first_row * Grp<FqField>::PT_WORDS);
+    else
+        hipLaunchKernelGGL(fixed_base_rows_kernel<Fq2Field>, grid, dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g2,
+                           (uint32_t *)m->table + first_row * Grp<Fq2Field>::PT_WORDS);
+    return hipGetLastError();
+}
+// ... as ark-ff's affine bytes in device memory (the verifying key's points)
+hipError_t fixed_base_ark_dev(const FixedBaseGen &g, int group, size_t count, const uint32_t *d_scalars, uint32_t *d_out, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    const dim3 grid((unsigned)((count + 63) / 64));
+    if (group == 1) hipLaunchKernelGGL(fixed_base_kernel<FqField>, grid, dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g1, d_out);
+    else hipLaunchKernelGGL(fixed_base_kernel<Fq2Field>, grid, dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g2, d_out);
+    return hipGetLastError();
+}
+// a key of bare handles from its five tables (ownership passes to the key, also on failure)
+int groth16_pk_assemble(int device, uint64_t ni, uint64_t nw, uint64_t n, uint32_t rank, uint32_t world, frw_msm *h, frw_msm *a, frw_msm *b1, frw_msm *l,
+                        frw_msm *b2, frw_groth16_pk **out)
+{
+    frw_groth16_pk *pk = nullptr;
+    const int rc = pk_create(device, ni, nw, n, &pk);
+    if (rc != FRW_OK) {
+        for (frw_msm *m : {h, a, b1, l, b2}) frw_msm_free(m);
+        return rc;
+    }
+    pk->h = h; pk->a = a; pk->b1 = b1; pk->l = l; pk->b2 = b2;
+    pk->bare = true;
+    pk->rank = rank; pk->world = world < 1 ? 1 : world;
+    groth16_shard_range(ni + nw + 3, rank, pk->world, &pk->z_lo, &pk->z_hi);
+    groth16_shard_range(n - 1, rank, pk->world, &pk->h_lo, &pk->h_hi);
+    *out = pk;
+    return FRW_OK;
+}
+}  // namespace frw
+
+extern "C" int frw_groth16_pk_load_opts(int device, const frw_groth16_pk_desc_t *d, const frw_groth16_key_opts_t *opts, frw_groth16_pk **out)
 {
     if (!out || !d || !d->alpha_g1 || !d->beta_g1 || !d->delta_g1 || !d->beta_g2 || !d->delta_g2 || !d->a_query || !d->b_g1_query ||
         !d->b_g2_query || !d->h_query || !d->l_query || d->num_instance == 0 || d->domain_size < 2)
         return FRW_E_INVALID_ARG;
     *out = nullptr;
-    frw_groth16_pk *pk = new (std::nothrow) frw_groth16_pk;
-    if (!pk) return FRW_E_OUT_OF_MEMORY;
-    pk->device = device;
-    pk->num_instance = d->num_instance; pk->num_witness = d->num_witness; pk->domain_size = d->domain_size;
-    pk->h = pk->a = pk->b1 = pk->l = pk->b2 = nullptr;
-    pk->fork = pk->sorted = pk->ones_done = nullptr;
-    pk->main = nullptr;
-    for (int i = 0; i < 4; i++) { if (i < 3) pk->side[i] = nullptr; pk->join[i] = nullptr; }
-    const size_t nv = (size_t)(d->num_instance + d->num_witness);
-    int rc = FRW_OK;
-    {
-        hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->sorted, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->ones_done, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&pk->main, hipStreamNonBlocking);
-        for (int i = 0; i < 4 && e == hipSuccess; i++) {
-            if (i < 3) e = hipStreamCreateWithFlags(&pk->side[i], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&pk->join[i], hipEventDisableTiming);
+    const size_t ni = (size_t)d->num_instance, nv = (size_t)(d->num_instance + d->num_witness);
+    int mode = opts ? opts->mode : FRW_KEY_AUTO;
+    const uint32_t world = opts && opts->world > 1 ? opts->world : 1, rank = opts ? opts->rank : 0;
+    if ((mode != FRW_KEY_AUTO && mode != FRW_KEY_TABLES && mode != FRW_KEY_BARE) || rank >= world) return FRW_E_INVALID_ARG;
+    if (mode == FRW_KEY_AUTO) mode = world > 1 || nv > FRW_KEY_AUTO_TABLE_VARIABLES ? FRW_KEY_BARE : FRW_KEY_TABLES;
+    if (mode == FRW_KEY_TABLES && world > 1) return FRW_E_INVALID_ARG;          // a key in slices is a key of bare handles
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
+    if (mode == FRW_KEY_BARE) {
+        // rows [z_lo, z_hi) of the four witness-side tables (a_query ++ [alpha, delta, O], b_g1_query ++ [beta, O, O],
+        // O x I ++ l_query ++ [O, O, O], b_g2_query ++ [beta2, O, delta2]) and [h_lo, h_hi) of h_query, as they are
+        uint64_t z_lo, z_hi, h_lo, h_hi;
+        frw::groth16_shard_range(nv + 3, rank, world, &z_lo, &z_hi);
+        frw::groth16_shard_range((uint64_t)d->domain_size - 1, rank, world, &h_lo, &h_hi);
+        if (z_hi == z_lo || h_hi == h_lo) return FRW_E_INVALID_ARG;             // more ranks than rows
+        frw_msm *t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // h, a, b1, l, b2
+        int rc = frw::msm_alloc_bare(device, 1, 16, h_hi - h_lo, h_lo, &t[0]);
+        for (int k = 1; k < 5 && rc == FRW_OK; k++) rc = frw::msm_alloc_bare(device, k == 4 ? 2 : 1, 8, z_hi - z_lo, z_lo, &t[k]);
+        try {
+            if (rc == FRW_OK) rc = msm_upload_rows<FqField>(t[0], 0, h_hi - h_lo, [&](size_t i) { return d->h_query + 12 * (h_lo + i); });
+            if (rc == FRW_OK)
+                rc = msm_upload_rows<FqField>(t[1], 0, z_hi - z_lo, [&](size_t i) -> const uint64_t * {
+                    const size_t g = z_lo + i;
+                    return g < nv ? d->a_query + 12 * g : g == nv ? d->alpha_g1 : g == nv + 1 ? d->delta_g1 : nullptr;
+                });
+            if (rc == FRW_OK)
+                rc = msm_upload_rows<FqField>(t[2], 0, z_hi - z_lo, [&](size_t i) -> const uint64_t * {
+                    const size_t g = z_lo + i;
+                    return g < nv ? d->b_g1_query + 12 * g : g == nv ? d->beta_g1 : nullptr;
+                });
+            if (rc == FRW_OK)
+                rc = msm_upload_rows<FqField>(t[3], 0, z_hi - z_lo, [&](size_t i) -> const uint64_t * {
+                    const size_t g = z_lo + i;
+                    return g >= ni && g < nv ? d->l_query + 12 * (g - ni) : nullptr;
+                });
+            if (rc == FRW_OK)
+                rc = msm_upload_rows<Fq2Field>(t[4], 0, z_hi - z_lo, [&](size_t i) -> const uint64_t * {
+                    const size_t g = z_lo + i;
+                    return g < nv ? d->b_g2_query + 24 * g : g == nv ? d->beta_g2 : g == nv + 2 ? d->delta_g2 : nullptr;
+                });
+        } catch (const std::exception &) {
+            rc = FRW_E_OUT_OF_MEMORY;
         }
-        if (e != hipSuccess) {
-            frw_groth16_pk_free(pk);
-            return frw::record_hip_error(e, "frw_groth16_pk_load");
+        if (rc != FRW_OK) {
+            for (frw_msm *m : t) frw_msm_free(m);
+            return rc;
         }
+        return frw::groth16_pk_assemble(device, d->num_instance, d->num_witness, d->domain_size, rank, world, t[0], t[1], t[2], t[3], t[4], out);
     }
+    frw_groth16_pk *pk = nullptr;
+    int rc = pk_create(device, d->num_instance, d->num_witness, d->domain_size, &pk);
+    if (rc != FRW_OK) return rc;
     try {
         // The four witness-side sums take the same scalars, z ++ [1, r, s] (nv + 3 of them), and so ONE sort of their digits: every
         // table has nv + 3 rows, the points that a sum does not have being the point at infinity (all-zero rows, which cost an
@@ -1624,6 +2130,23 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
     *out = pk;
     return FRW_OK;
 }
+extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, frw_groth16_pk **out)
+{
+    const frw_groth16_key_opts_t opts = {FRW_KEY_TABLES, 0, 1};                // (as before round 5: window tables, whatever the size)
+    return frw_groth16_pk_load_opts(device, d, &opts, out);
+}
+extern "C" int frw_groth16_pk_info(const frw_groth16_pk *pk, frw_groth16_pk_info_t *out)
+{
+    if (!pk || !out) return FRW_E_INVALID_ARG;
+    out->mode = pk->bare ? FRW_KEY_BARE : FRW_KEY_TABLES;
+    out->rank = pk->rank; out->world = pk->world;
+    out->z_lo = pk->z_lo; out->z_hi = pk->z_hi; out->h_lo = pk->h_lo; out->h_hi = pk->h_hi;
+    out->key_bytes = 0;
+    frw_msm_info_t mi;
+    for (const frw_msm *m : {pk->h, pk->a, pk->b1, pk->l, pk->b2})
+        if (frw_msm_info(m, &mi) == FRW_OK) out->key_bytes += mi.table_bytes;
+    return FRW_OK;
+}
 
 namespace {
 struct Groth16Sizes { size_t qap, h, zext, msm[5], msm_all, pts, per; };
@@ -1637,6 +2160,22 @@ Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
     s.qap = q.workspace_bytes_per_signature;
     s.h = (size_t)pk->domain_size * 32;
     s.zext = (nv + 3) * 32;
+    if (pk->bare) {
+        // msm[0]: the sum over h_query (sixteen window rows); msm[1]: ONE sort of the slice's scalars and the three G1 tables' own
+        // arrays; msm[4]: the G2 table's own arrays (it reads msm[1]'s sort)
+        const uint32_t nz = pk->a->dev.n;
+        char *const base = (char *)(uintptr_t)4096;
+        frw_msm_info(pk->h, &mi);
+        s.msm[0] = (mi.workspace_bytes_per_signature + 255) & ~(size_t)255;
+        const NmsmBufs g1 = nmsm_carve_bare<FqField>(base, 3, nz);
+        s.msm[1] = ((size_t)((char *)g1.end - base) + 255) & ~(size_t)255;
+        const NmsmBufs g2 = nmsm_carve_bare<Fq2Field>(base, 1, nz, &g1);
+        s.msm[4] = ((size_t)((char *)g2.end - base) + 255) & ~(size_t)255;
+        s.msm_all = s.msm[0] + s.msm[1] + s.msm[4];
+        s.pts = 6 * (size_t)frw::Grp<FqField>::BK_WORDS * 4 + 192 + 64 + 64;
+        s.per = ((s.qap + s.h + s.zext + s.msm_all + s.pts) + 255) & ~(size_t)255;
+        return s;
+    }
     int i = 0;
     for (const frw_msm *m : {pk->h, pk->a, pk->b1, pk->l, pk->b2}) {                // each sum has a workspace of its own: they overlap in time
         frw_msm_info(m, &mi);
@@ -1653,10 +2192,97 @@ Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
 extern "C" size_t frw_groth16_workspace_bytes(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch_in_flight)
 {
     if (!pk || !r) return 0;
-    return groth16_sizes(pk, r).per * batch_in_flight;
+    return groth16_sizes(pk, r).per * (pk->bare ? (batch_in_flight ? 1 : 0) : batch_in_flight);     // a bare key proves one statement at a time
 }
 
 namespace {
+// A key of bare handles: one statement at a time (its sums fill the chip by themselves: 2 x 10^9 bucket additions for the 1,024-statement
+// aggregate).  The same five sums, the same streams; the sort of the scalars' digits is the bare handles' (thirty-two windows, one pass),
+// shared by the three G1 tables -- one chain of kernels -- and the G2 table; the sum over h_query runs window by window.
+// d_proofs: [batch][48] (a whole key), or d_partial: [batch][72] (a slice: the five partial sums, frw.h FRW_GROTH16_PARTIAL_WORDS).
+int groth16_prove_bare(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
+                       const uint64_t *rs_host, const uint64_t *rs_dev, uint64_t *d_proofs, uint64_t *d_partial, uint32_t *d_num_unsatisfied,
+                       void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    const Groth16Sizes sz = groth16_sizes(pk, r1cs);
+    if (workspace_bytes < sz.per || ((uintptr_t)d_workspace & 255)) return FRW_E_INVALID_ARG;
+    const size_t I = (size_t)pk->num_instance, W = (size_t)pk->num_witness, nv = I + W, n = (size_t)pk->domain_size, stride = nv + 3;
+    const uint32_t nz = pk->a->dev.n;                                    // rows of this slice of the witness-side tables
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(pk->device);
+    int rc = FRW_OK;
+    bool forked = false;
+    std::unique_lock<std::mutex> lock(const_cast<frw_groth16_pk *>(pk)->enqueue, std::defer_lock);
+    for (size_t b = 0; e == hipSuccess && rc == FRW_OK && b < batch; b++) {
+        if (lock.owns_lock()) lock.unlock();
+        char *base = (char *)d_workspace;
+        void *qap_ws = base;                          base += sz.qap;
+        uint64_t *h = (uint64_t *)base;               base += sz.h;
+        uint64_t *zext = (uint64_t *)base;            base += sz.zext;
+        char *h_ws = base;                            base += sz.msm[0];
+        char *g1_ws = base;                           base += sz.msm[1];
+        char *g2_ws = base;                           base += sz.msm[4];
+        constexpr size_t XW = frw::Grp<FqField>::BK_WORDS;
+        uint32_t *pA = (uint32_t *)base, *pH = pA + 3 * XW, *pSA = pH + XW, *pRB1 = pSA + XW;      // [A | B1' | L] [H] [s A | r B1']
+        uint64_t *pB2 = (uint64_t *)(pRB1 + XW), *d_rs = pB2 + 24, *d_split = d_rs + 8;
+        const uint64_t *wit = d_witness + b * W * 4, *inst = d_instance + b * I * 4;
+        const uint64_t *rs_now = rs_dev ? rs_dev + b * 8 : d_rs;
+        if (rs_host) {
+            e = hipMemcpyAsync(d_rs, rs_host + b * 8, 64, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) break;
+        }
+        lock.lock();
+        hipLaunchKernelGGL(frw::groth16_split_kernel, dim3(1), dim3(64), 0, st, (size_t)2, rs_now, d_split);
+        e = hipMemcpyAsync(zext, inst, I * 32, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(zext + I * 4, wit, W * 32, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(frw::groth16_tails_kernel, dim3(1), dim3(64), 0, st, (size_t)1, (const uint32_t *)rs_now, (uint32_t *)zext, stride * 8, nv);
+        e = hipEventRecord(pk->fork, st);
+        forked = true;
+        if (e == hipSuccess) e = hipStreamWaitEvent(pk->main, pk->fork, 0);
+        if (e != hipSuccess) break;
+        // the sort first, on the caller's stream (workgroups of 1,024 threads: they would not start under the bucket kernels)
+        const NmsmBufs g1 = nmsm_carve_bare<FqField>(g1_ws, 3, nz);
+        const NmsmBufs g2 = nmsm_carve_bare<Fq2Field>(g2_ws, 1, nz, &g1);
+        e = nmsm_sort_bare(g1, nz, (const uint32_t *)(zext + pk->z_lo * 4), 1, st);
+        if (e != hipSuccess) break;
+        e = hipEventRecord(pk->sorted, st);
+        for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
+        if (e != hipSuccess) break;
+        rc = frw_qap_witness_map_dev(r1cs, 1, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + b : nullptr, qap_ws, sz.qap, pk->main);
+        if (rc != FRW_OK) break;
+        const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
+        e = nmsm_accumulate_bare<FqField, true>(g1s, 3, g1, pA, pk->side[0], true);
+        if (e != hipSuccess) break;
+        e = nmsm_accumulate_bare<Fq2Field, false>(&pk->b2, 1, g2, (uint32_t *)pB2, pk->side[2], false);
+        if (e != hipSuccess) break;
+        // h's coefficients [h_lo, h_hi) against this slice of h_query
+        rc = msm_run<FqField, true>(pk->h, 1, h + pk->h_lo * 4, n, 1, (uint64_t *)pH, h_ws, sz.msm[0], pk->main, true);
+        if (rc != FRW_OK) break;
+        for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipEventRecord(pk->join[i], pk->side[i]);
+        if (e == hipSuccess) e = hipEventRecord(pk->join[3], pk->main);
+        for (int i = 0; i < 4 && e == hipSuccess; i++)
+            if (i != 1) e = hipStreamWaitEvent(st, pk->join[i], 0);
+        if (e != hipSuccess) break;
+        if (d_partial) {
+            hipLaunchKernelGGL(frw::groth16_partial_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)pA, (const uint32_t *)pB2,
+                               (uint32_t *)(d_partial + b * FRW_GROTH16_PARTIAL_WORDS));
+        } else {
+            hipLaunchKernelGGL(frw::groth16_scale_quad_kernel, dim3(2), dim3(4), 0, st, (size_t)1, (const uint32_t *)d_split, (const uint32_t *)pA, pSA);
+            hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3(1), dim3(64), 0, st, (size_t)1, (const uint32_t *)pA, (const uint32_t *)pSA,
+                               (const uint32_t *)pRB1, (const uint32_t *)(pA + 2 * XW), (const uint32_t *)pH, (const uint32_t *)pB2,
+                               (uint32_t *)(d_proofs + b * 48));
+        }
+        e = hipGetLastError();
+        // the next statement reuses the workspace: everything of this one must be through (the streams are ordered by `st` from here on)
+    }
+    if (e != hipSuccess || rc != FRW_OK) {
+        if (forked) (void)hipDeviceSynchronize();
+        return e != hipSuccess ? frw::record_hip_error(e, "frw_groth16_prove_dev") : rc;
+    }
+    return FRW_OK;
+}
 // rs_host: the blinding factors in host memory (uploaded, and waited for: the array may be short-lived); rs_dev: in device memory
 int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, const uint64_t *d_witness, const uint64_t *d_instance,
                   const uint64_t *rs_host, const uint64_t *rs_dev, uint64_t *d_proofs, uint32_t *d_num_unsatisfied, void *d_workspace,
@@ -1667,6 +2293,10 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
     if (batch == 0) return FRW_OK;
     frw_qap_info_t q;
     if (frw_qap_info(r1cs, &q) != FRW_OK || q.domain_size != pk->domain_size || q.num_instance != pk->num_instance) return FRW_E_INVALID_ARG;
+    if (pk->bare) {
+        if (pk->world > 1) return FRW_E_INVALID_ARG;                        // a slice makes partial sums: frw_groth16_prove_partial_dev
+        return groth16_prove_bare(pk, r1cs, batch, d_witness, d_instance, rs_host, rs_dev, d_proofs, nullptr, d_num_unsatisfied, d_workspace, workspace_bytes, stream);
+    }
     const Groth16Sizes sz = groth16_sizes(pk, r1cs);
     const size_t chunk = std::min<size_t>(workspace_bytes / sz.per, 4096);
     if (chunk == 0 || ((uintptr_t)d_workspace & 255)) return FRW_E_INVALID_ARG;
@@ -1789,4 +2419,40 @@ extern "C" int frw_groth16_prove_rs_dev(const frw_groth16_pk *pk, const frw_r1cs
 {
     if (!d_rs && batch) return FRW_E_INVALID_ARG;
     return groth16_prove(pk, r1cs, batch, d_witness, d_instance, nullptr, d_rs, d_proofs, d_num_unsatisfied, d_workspace, workspace_bytes, stream);
+}
+
+// ---- a key in slices: the partial sums of one rank, and their combination ---------------------------------------------------------------
+extern "C" int frw_groth16_prove_partial_dev(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, const uint64_t *d_witness,
+                                             const uint64_t *d_instance, const uint64_t *rs, uint64_t *d_partial, uint32_t *d_num_unsatisfied,
+                                             void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (!pk || !pk->bare || !r1cs || (batch && (!d_witness || !d_instance || !rs || !d_partial || !d_workspace))) return FRW_E_INVALID_ARG;
+    if (batch == 0) return FRW_OK;
+    frw_qap_info_t q;
+    if (frw_qap_info(r1cs, &q) != FRW_OK || q.domain_size != pk->domain_size || q.num_instance != pk->num_instance) return FRW_E_INVALID_ARG;
+    return groth16_prove_bare(pk, r1cs, batch, d_witness, d_instance, rs, nullptr, nullptr, d_partial, d_num_unsatisfied, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int frw_groth16_prove_combine_dev(const frw_groth16_pk *pk, size_t world, const uint64_t *d_partials, const uint64_t *rs, uint64_t *d_proof,
+                                             void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    constexpr size_t XW = frw::Grp<FqField>::BK_WORDS;
+    if (!pk || world == 0 || world > 65536 || !d_partials || !rs || !d_proof || !d_workspace || workspace_bytes < FRW_GROTH16_COMBINE_WORKSPACE ||
+        ((uintptr_t)d_workspace & 255))
+        return FRW_E_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(pk->device);
+    uint32_t *pA = (uint32_t *)d_workspace, *pH = pA + 3 * XW, *pSA = pH + XW, *pRB1 = pSA + XW;
+    uint64_t *pB2 = (uint64_t *)(pRB1 + XW), *d_rs = pB2 + 24, *d_split = d_rs + 8;
+    static_assert(6 * XW * 4 + 192 + 64 + 64 <= FRW_GROTH16_COMBINE_WORKSPACE, "the combine step's points fit its workspace");
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rs, rs, 64, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);                     // (the array may be short-lived)
+    if (e != hipSuccess) return frw::record_hip_error(e, "frw_groth16_prove_combine_dev");
+    hipLaunchKernelGGL(frw::groth16_split_kernel, dim3(1), dim3(64), 0, st, (size_t)2, (const uint64_t *)d_rs, d_split);
+    hipLaunchKernelGGL(frw::groth16_combine_kernel, dim3(1), dim3(64), 0, st, (uint32_t)world, (const uint32_t *)d_partials, pA, (uint32_t *)pB2);
+    hipLaunchKernelGGL(frw::groth16_scale_quad_kernel, dim3(2), dim3(4), 0, st, (size_t)1, (const uint32_t *)d_split, (const uint32_t *)pA, pSA);
+    hipLaunchKernelGGL(frw::groth16_finish_kernel, dim3(1), dim3(64), 0, st, (size_t)1, (const uint32_t *)pA, (const uint32_t *)pSA, (const uint32_t *)pRB1,
+                       (const uint32_t *)(pA + 2 * XW), (const uint32_t *)pH, (const uint32_t *)pB2, (uint32_t *)d_proof);
+    e = hipGetLastError();
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_groth16_prove_combine_dev");
 }

@@ -8,8 +8,11 @@
 #include <array>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <thread>
 #include <stdexcept>
+#include <system_error>
 #include <exception>
 #include <numeric>
 #include <vector>
@@ -40,6 +43,9 @@ struct frw_r1cs {
     frw::R1csDev dev;
     frw::QapDev qap;
     std::vector<void *> allocs;
+    // a per-signature handle keeps its matrices on the host too (100 MB): frw_groth16_setup_r1cs(_opts) needs them again -- by rows for
+    // the host-made keys, by columns for the device-made ones -- and arkworks' finalize() inlining takes seconds
+    std::shared_ptr<const frw::host::ConstraintMatrices> host_matrices;
     mutable frw::HostArena arena;     // working memory of frw_qap_witness_map (host buffers in, host buffers out)
     // an aggregate (frw_r1cs_load_aggregate): the per-signature systems it is made of (owned), its statements and its runs
     frw_r1cs *base[2] = {nullptr, nullptr};             // Falcon-512, Falcon-1024
@@ -100,77 +106,29 @@ void packed29(const Fr &v, uint32_t out[8])
     const Fr x = v * Fr::from(32);
     for (int k = 0; k < 4; k++) { out[2 * k] = (uint32_t)x.l[k]; out[2 * k + 1] = (uint32_t)(x.l[k] >> 32); }
 }
-uint32_t bitrev(uint32_t x, int bits)
+// ---- the tables of the witness map's transforms, made on the device (round 5) --------------------------------------------------------
+// Every table is first x base^(e(i)) over the whole domain -- thirteen tables of 32 n bytes for a five-pass domain: 56 GB at 2^27, which the
+// host built one sequential product at a time until round 4 (and held twice).  The host now supplies, per base, two small power tables
+// (base^k for k < 2^14 and base^(k 2^14)) and the constants; qap_table_kernel (frw_setup.hip) does the rest: 2 products per entry.
+struct PowTabHost { std::vector<uint32_t> lo, hi; };
+PowTabHost pow_tab_host(const Fr &base, int L)
 {
-    uint32_t r = 0;
-    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
-    return r;
-}
-struct QapTables {
-    int log_n, num_passes = 0, pass_t[frw::QAP_MAX_PASSES], pass_sh[frw::QAP_MAX_PASSES];
-    std::vector<uint32_t> roots_fwd, roots_inv, twist_fwd[frw::QAP_MAX_PASSES - 1], twist_inv[frw::QAP_MAX_PASSES - 1], scale_in, scale_in_a,
-        scale_out, scale_psi_in, scale_psi_out;
-    uint32_t sixteen_over_n[9];
-};
-QapTables build_qap_tables(uint64_t num_constraints, uint64_t num_instance)
-{
-    QapTables t;
-    t.log_n = domain_log(num_constraints + num_instance);
-    if (t.log_n > 32) throw std::runtime_error("PolynomialDegreeTooLarge");
-    t.num_passes = frw::qap_pass_schedule(t.log_n, t.pass_t, t.pass_sh);
-    if (!t.num_passes) return t;                                // no device witness map for such a domain (frw_qap.hip)
-    const int L = t.log_n;
-    const size_t n = (size_t)1 << L;
-    const uint64_t root_limbs[4] = {0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL};
-    Fr w = Fr::from_montgomery(root_limbs);
-    for (int i = L; i < 32; i++) w = w * w;
-    const Fr winv = inverse(w), g = Fr::from(7), ginv = inverse(g), ninv = inverse(Fr::from(n)), two5 = Fr::from(32);
-    const Fr zinv = inverse(g.pow(n) - Fr::one());             // divide_by_vanishing_poly_on_coset
-    // first, first * step, ... packed
-    auto fill = [&](std::vector<uint32_t> &v, size_t count, Fr first, const Fr &step) {
-        v.resize(count * 8);
-        for (size_t k = 0; k < count; k++) { packed29(first, &v[8 * k]); first = first * step; }
-    };
-    fill(t.scale_in, n, ninv, g);
-    fill(t.scale_in_a, n, ninv * two5, g);
-    fill(t.scale_out, n, ninv * zinv, ginv);
-    {
-        // psi: the primitive 2n-th root of unity whose square is w (get_root_of_unity(2 n))
-        Fr psi = Fr::from_montgomery(root_limbs);
-        for (int i = L + 1; i < 32; i++) psi = psi * psi;
-        const Fr sixteen_n = Fr::from(16) * ninv;
-        fill(t.scale_psi_in, n, ninv, psi);
-        fill(t.scale_psi_out, n, -sixteen_n, inverse(psi));
-        limbs29(sixteen_n, t.sixteen_over_n);
-    }
-    // powers of w and w^-1, then the twist tables: a pass on the index bits [sh, sh + T) goes with the factor
-    // root^((i mod 2^sh) * bitrev_T((i >> sh) mod 2^T) * 2^(L - sh - T)) on index i (tools/dev/qap_fourstep_model.py)
-    std::vector<uint32_t> pw_fwd, pw_inv;
-    fill(pw_fwd, n, Fr::one(), w);
-    fill(pw_inv, n, Fr::one(), winv);
-    // table k goes with pass k + 1: the inverse transform's pass k leaves it for the next pass, the forward transform's pass
-    // k + 1 applies it on its way out
-    for (int k = 0; k + 1 < t.num_passes; k++) {
-        const int sh = t.pass_sh[k + 1], ts = t.pass_t[k + 1];
-        t.twist_fwd[k].resize(n * 8);
-        t.twist_inv[k].resize(n * 8);
-        for (size_t i = 0; i < n; i++) {
-            const uint64_t low = i & (((uint64_t)1 << sh) - 1), r = (i >> sh) & (((uint64_t)1 << ts) - 1);
-            const size_t e = (size_t)((low * bitrev((uint32_t)r, ts)) << (L - sh - ts));
-            std::memcpy(&t.twist_fwd[k][8 * i], &pw_fwd[8 * e], 32);
-            std::memcpy(&t.twist_inv[k][8 * i], &pw_inv[8 * e], 32);
-        }
-    }
-    // 64-th roots, nine 29-bit limbs, 12 words apart
-    auto roots = [&](std::vector<uint32_t> &v, const Fr &root) {
-        v.assign(32 * 12, 0u);
-        const Fr step = root.pow(n >> 6);
-        Fr x = Fr::one();
-        for (int k = 0; k < 32; k++) { limbs29(x, &v[12 * k]); x = x * step; }
-    };
-    roots(t.roots_fwd, w);
-    roots(t.roots_inv, winv);
+    PowTabHost t;
+    const size_t nlo = (size_t)frw::SETUP_POW_LO, nhi = L > frw::SETUP_POW_LO_BITS ? (size_t)1 << (L - frw::SETUP_POW_LO_BITS) : 1;
+    t.lo.resize(nlo * 8);
+    t.hi.resize(nhi * 8);
+    Fr x = Fr::one();
+    for (size_t k = 0; k < nlo; k++) { packed29(x, &t.lo[8 * k]); x = x * base; }
+    const Fr step = x;                                           // base^(2^14)
+    x = Fr::one();
+    for (size_t k = 0; k < nhi; k++) { packed29(x, &t.hi[8 * k]); x = x * step; }
     return t;
+}
+frw::SetupConst setup_const(const Fr &v)
+{
+    frw::SetupConst c;
+    limbs29(v, c.l);
+    return c;
 }
 }  // namespace
 
@@ -187,6 +145,10 @@ extern "C" void frw_r1cs_free(frw_r1cs *r)
 namespace {
 // the transform tables of the domain of (num_constraints + num_instance) coefficients, uploaded; r->qap.num_passes == 0 if the
 // device has no pass schedule for that domain
+// Tables of Radix2EvaluationDomain::new(num_constraints + num_instance) (ark-poly 0.3.0), Montgomery limbs as the
+// device reads them.  group_gen = two_adic_root_of_unity^(2^(32 - log n)) (ark-ff 0.3.0 get_root_of_unity); the root is
+// ark-bls12-381 0.3.0's TWO_ADIC_ROOT_OF_UNITY = 7^((p-1)/2^32) (tests/test_qap.py derives these limbs from the formula).
+const uint64_t TWO_ADIC_ROOT_LIMBS[4] = {0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL};
 void upload_qap_tables(frw_r1cs *r, uint64_t num_constraints, uint64_t num_instance)
 {
     auto upload = [&](const void *src, size_t bytes) -> void * {
@@ -196,22 +158,74 @@ void upload_qap_tables(frw_r1cs *r, uint64_t num_constraints, uint64_t num_insta
         if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy");
         return d;
     };
-    const QapTables qt = build_qap_tables(num_constraints, num_instance);
     r->qap = frw::QapDev{};
-    r->qap.log_n = qt.log_n;
-    r->qap.num_passes = qt.num_passes;
-    if (!qt.num_passes) return;
-    for (int k = 0; k < qt.num_passes; k++) { r->qap.pass_t[k] = qt.pass_t[k]; r->qap.pass_sh[k] = qt.pass_sh[k]; }
-    auto up = [&](const std::vector<uint32_t> &v) { return (const uint32_t *)upload(v.data(), v.size() * 4); };
-    r->qap.roots_fwd = up(qt.roots_fwd);
-    r->qap.roots_inv = up(qt.roots_inv);
-    for (int k = 0; k + 1 < qt.num_passes; k++) { r->qap.twist_fwd[k] = up(qt.twist_fwd[k]); r->qap.twist_inv[k] = up(qt.twist_inv[k]); }
-    r->qap.scale_in = up(qt.scale_in);
-    r->qap.scale_in_a = up(qt.scale_in_a);
-    r->qap.scale_out = up(qt.scale_out);
-    r->qap.scale_psi_in = up(qt.scale_psi_in);
-    r->qap.scale_psi_out = up(qt.scale_psi_out);
-    std::memcpy(r->qap.sixteen_over_n, qt.sixteen_over_n, sizeof(qt.sixteen_over_n));
+    const int L = domain_log(num_constraints + num_instance);
+    if (L > 32) throw std::runtime_error("PolynomialDegreeTooLarge");
+    r->qap.log_n = L;
+    r->qap.num_passes = frw::qap_pass_schedule(L, r->qap.pass_t, r->qap.pass_sh);
+    if (!r->qap.num_passes) return;                                 // no device witness map for such a domain (frw_qap.hip)
+    const size_t n = (size_t)1 << L;
+    // what the tables take: 2 (K - 1) twists + 5 scale tables of 32 n bytes -- asked of the device before anything is allocated
+    {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)(2 * (r->qap.num_passes - 1) + 5) * n * 32;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + (need >> 4) > free_b) throw std::bad_alloc();
+    }
+    Fr w = Fr::from_montgomery(TWO_ADIC_ROOT_LIMBS);
+    for (int i = L; i < 32; i++) w = w * w;
+    // psi: the primitive 2n-th root of unity whose square is w (get_root_of_unity(2 n))
+    Fr psi = Fr::from_montgomery(TWO_ADIC_ROOT_LIMBS);
+    for (int i = L + 1; i < 32; i++) psi = psi * psi;
+    const Fr winv = inverse(w), g = Fr::from(7), ginv = inverse(g), ninv = inverse(Fr::from(n)), two5 = Fr::from(32);
+    const Fr zinv = inverse(g.pow(n) - Fr::one());             // divide_by_vanishing_poly_on_coset
+    const Fr sixteen_n = Fr::from(16) * ninv;
+    // one table: its base's power tables go up, the kernel runs, the power tables go again
+    auto make = [&](const Fr &base, int mode, int sh, int ts, const Fr *first) -> const uint32_t * {
+        const PowTabHost pt = pow_tab_host(base, L);
+        void *d_lo = nullptr, *d_hi = nullptr, *d_out = nullptr;
+        hipError_t e = hipMalloc(&d_out, n * 32);
+        if (e == hipSuccess) r->allocs.push_back(d_out);
+        if (e == hipSuccess) e = hipMalloc(&d_lo, pt.lo.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(&d_hi, pt.hi.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(d_lo, pt.lo.data(), pt.lo.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_hi, pt.hi.data(), pt.hi.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            const frw::SetupPowTab t{(const uint32_t *)d_lo, (const uint32_t *)d_hi};
+            frw::SetupConst c{};
+            if (first) c = setup_const(*first);
+            e = frw::launch_qap_table(n, t, mode, sh, ts, L, first ? &c : nullptr, (uint32_t *)d_out, nullptr);
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (d_lo) (void)hipFree(d_lo);
+        if (d_hi) (void)hipFree(d_hi);
+        if (e != hipSuccess) throw std::runtime_error("transform table");
+        return (const uint32_t *)d_out;
+    };
+    const Fr in_a = ninv * two5, out_f = ninv * zinv, psi_out = -sixteen_n;
+    r->qap.scale_in = make(g, 0, 0, 0, &ninv);                      // g^k / n
+    r->qap.scale_in_a = make(g, 0, 0, 0, &in_a);                    // 2^5 g^k / n
+    r->qap.scale_out = make(ginv, 0, 0, 0, &out_f);                 // g^-k / (n (g^n - 1))
+    r->qap.scale_psi_in = make(psi, 0, 0, 0, &ninv);                // psi^k / n
+    r->qap.scale_psi_out = make(inverse(psi), 0, 0, 0, &psi_out);   // -16 psi^-k / n
+    limbs29(sixteen_n, r->qap.sixteen_over_n);
+    // the twist tables: a pass on the index bits [sh, sh + T) goes with the factor
+    // root^((i mod 2^sh) * bitrev_T((i >> sh) mod 2^T) * 2^(L - sh - T)) on index i (tools/dev/qap_fourstep_model.py).
+    // table k goes with pass k + 1: the inverse transform's pass k leaves it for the next pass, the forward transform's pass
+    // k + 1 applies it on its way out
+    for (int k = 0; k + 1 < r->qap.num_passes; k++) {
+        r->qap.twist_fwd[k] = make(w, 1, r->qap.pass_sh[k + 1], r->qap.pass_t[k + 1], nullptr);
+        r->qap.twist_inv[k] = make(winv, 1, r->qap.pass_sh[k + 1], r->qap.pass_t[k + 1], nullptr);
+    }
+    // 64-th roots, nine 29-bit limbs, 12 words apart
+    auto roots = [&](const Fr &root) {
+        std::vector<uint32_t> v(32 * 12, 0u);
+        const Fr step = root.pow(n >> 6);
+        Fr x = Fr::one();
+        for (int k = 0; k < 32; k++) { limbs29(x, &v[12 * k]); x = x * step; }
+        return (const uint32_t *)upload(v.data(), v.size() * 4);
+    };
+    r->qap.roots_fwd = roots(w);
+    r->qap.roots_inv = roots(winv);
 }
 }  // namespace
 
@@ -224,8 +238,10 @@ extern "C" int frw_r1cs_load(int device, int circuit, int logn, frw_r1cs **out)
     if (hipSetDevice(device) != hipSuccess) return FRW_E_HIP;
     frw_r1cs *r = nullptr;
     try {
-        const frw::host::ConstraintMatrices m = build_matrices(circuit, logn);
+        auto matrices = std::make_shared<const frw::host::ConstraintMatrices>(build_matrices(circuit, logn));
+        const frw::host::ConstraintMatrices &m = *matrices;
         r = new frw_r1cs;
+        r->host_matrices = matrices;
         r->device = device;
         r->circuit = circuit;
         r->logn = logn;
@@ -405,7 +421,7 @@ extern "C" int frw_r1cs_load_aggregate(int device, size_t count, const int32_t *
                 rows += (uint64_t)(j - i) * b.num_constraints;
                 i = j;
             }
-            if (wit + pub + 1 >= ((uint64_t)1 << 30) || rows >= ((uint64_t)1 << 31)) throw std::runtime_error("aggregate too large");
+            if (wit + pub + 1 >= ((uint64_t)1 << 30) || rows >= ((uint64_t)1 << 31)) throw std::invalid_argument("aggregate too large");
             r->agg.num_statements = (uint32_t)count;
             r->agg.num_runs = (uint32_t)r->runs.size();
             r->agg.runs = r->runs.data();
@@ -415,6 +431,8 @@ extern "C" int frw_r1cs_load_aggregate(int device, size_t count, const int32_t *
             r->dev.num_constraints = (uint32_t)rows;
             upload_qap_tables(r, rows, pub + 1);
         }
+    } catch (const std::invalid_argument &) {
+        rc = FRW_E_INVALID_ARG;                                      // a statement beyond the 2^30 variables / 2^31 rows the kernels index
     } catch (const std::exception &) {
         rc = FRW_E_OUT_OF_MEMORY;
     }
@@ -688,10 +706,19 @@ int groth16_setup_blocks(int device, const std::vector<SetupBlock> &blocks, size
         }
     };
     {
-        std::vector<std::thread> th;
-        for (size_t tid = 1; tid < nthreads; tid++) th.emplace_back(work, tid);
+        // (a thread that cannot be started must not take the process down with the ones that were: they are joined whatever happens)
+        struct Joiner {
+            std::vector<std::thread> th;
+            ~Joiner() { for (auto &x : th) if (x.joinable()) x.join(); }
+        } pool;
+        size_t started = 1;
+        try {
+            for (size_t tid = 1; tid < nthreads; tid++, started++) pool.th.emplace_back(work, tid);
+        } catch (const std::system_error &) {
+            // no more threads to be had: this one does the rest
+        }
         work(0);
-        for (auto &x : th) x.join();
+        for (size_t tid = started; tid < nthreads; tid++) work(tid);
     }
     for (size_t tid = 0; tid < nthreads; tid++) { u[0] = u[0] + col0[tid][0]; v[0] = v[0] + col0[tid][1]; ww[0] = ww[0] + col0[tid][2]; }
     std::vector<Fr>().swap(lag);
@@ -732,6 +759,184 @@ int groth16_setup_blocks(int device, const std::vector<SetupBlock> &blocks, size
     }
     return rc;
 }
+
+// ---- the same on the device, into a key of bare handles (round 5) -----------------------------------------------------------------------
+// Nothing of the statement's size is made on the host: L_i(t) for the whole domain, the transposed sparse products, the queries' scalars
+// and the query points themselves (written straight into their table rows) are kernels of frw_setup.hip / frw_msm.hip.  The host supplies
+// the per-signature matrices by columns (once per parameter set), two power tables each for w and t, and a dozen constants.
+struct DeviceRun { const frw::host::ConstraintMatrices *m; uint32_t first, count; uint64_t wit_off, pub_off, row_off; };
+struct DeviceBuffers {
+    std::vector<void *> all;
+    ~DeviceBuffers() { for (void *p : all) if (p) (void)hipFree(p); }
+    void *get(size_t bytes)
+    {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) throw std::bad_alloc();
+        all.push_back(d);
+        return d;
+    }
+    void *put(const void *src, size_t bytes)
+    {
+        void *d = get(bytes);
+        if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy");
+        return d;
+    }
+    void drop(void *p)
+    {
+        for (void *&q : all)
+            if (q == p) { (void)hipFree(q); q = nullptr; }
+    }
+};
+void hip_ok(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) { frw::record_hip_error(e, what); throw std::runtime_error(what); }
+}
+
+int groth16_setup_device(int device, const std::vector<DeviceRun> &runs, uint32_t statements, size_t ni, size_t nw, size_t nc, const uint64_t *toxic,
+                         uint32_t rank, uint32_t world, frw_groth16_pk **pk_out, uint64_t *vk_out)
+{
+    using namespace frw::host;
+    const size_t nv = ni + nw;
+    const int L = domain_log(nc + ni);
+    if (L > 30 || L < frw::SETUP_POW_LO_BITS || rank >= world) return FRW_E_INVALID_ARG;
+    const size_t n = (size_t)1 << L;
+    const Fr alpha = Fr::from_canonical(toxic), beta = Fr::from_canonical(toxic + 4), gamma = Fr::from_canonical(toxic + 8),
+             delta = Fr::from_canonical(toxic + 12), t = Fr::from_canonical(toxic + 16);
+    Fr w = Fr::from_montgomery(TWO_ADIC_ROOT_LIMBS);
+    for (int i = L; i < 32; i++) w = w * w;
+    const Fr zt = t.pow(n) - Fr::one();
+    if (zt.is_zero() || gamma.is_zero() || delta.is_zero()) return FRW_E_INVALID_ARG;       // t must lie outside the domain
+    const Fr dinv = inverse(delta), ginv = inverse(gamma);
+    uint64_t z_lo, z_hi, h_lo, h_hi;
+    frw::groth16_shard_range(nv + 3, rank, world, &z_lo, &z_hi);
+    frw::groth16_shard_range(n - 1, rank, world, &h_lo, &h_hi);
+    if (z_hi == z_lo || h_hi == h_lo) return FRW_E_INVALID_ARG;                              // more ranks than rows
+    if (hipSetDevice(device) != hipSuccess) return FRW_E_NO_DEVICE;
+    frw_msm *tab[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};                         // h, a, b1, l, b2
+    frw::FixedBaseGen gen{nullptr, nullptr};
+    int rc = FRW_OK;
+    try {
+        DeviceBuffers dev;
+        auto pow_tab = [&](const Fr &base) {
+            const PowTabHost pt = pow_tab_host(base, L);
+            return frw::SetupPowTab{(const uint32_t *)dev.put(pt.lo.data(), pt.lo.size() * 4), (const uint32_t *)dev.put(pt.hi.data(), pt.hi.size() * 4)};
+        };
+        // (1) L_i(t) = zt w^i / (n (t - w^i)) for the whole domain
+        uint32_t *lag = (uint32_t *)dev.get(n * 32);
+        const frw::SetupPowTab wt = pow_tab(w);
+        hip_ok(frw::launch_setup_lagrange(n, wt, setup_const(t), setup_const(zt * inverse(Fr::from(n))), setup_const(Fr::one()), lag, nullptr), "setup: Lagrange coefficients");
+        // (2) u, v, w: the per-signature matrices by columns, a run of statements per launch
+        std::vector<const ConstraintMatrices *> distinct;
+        std::vector<std::array<frw::SetupCsc, 3>> csc;
+        std::vector<void *> csc_bufs;
+        for (const DeviceRun &run : runs) {
+            if (std::find(distinct.begin(), distinct.end(), run.m) != distinct.end()) continue;
+            distinct.push_back(run.m);
+            std::array<frw::SetupCsc, 3> three;
+            const std::vector<ConstraintMatrices::Row> *mats[3] = {&run.m->a, &run.m->b, &run.m->c};
+            const size_t V = run.m->num_instance_variables + run.m->num_witness_variables;
+            for (int k = 0; k < 3; k++) {
+                std::vector<uint32_t> ptr(V + 1, 0u);
+                for (const auto &row : *mats[k])
+                    for (const auto &e : row) ptr[e.second + 1]++;
+                for (size_t c = 0; c < V; c++) ptr[c + 1] += ptr[c];
+                std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1), rows(ptr[V]), val((size_t)ptr[V] * 8);
+                for (size_t r = 0; r < mats[k]->size(); r++)
+                    for (const auto &e : (*mats[k])[r]) {
+                        const uint32_t at = fill[e.second]++;
+                        rows[at] = (uint32_t)r;
+                        packed29(e.first, &val[(size_t)at * 8]);
+                    }
+                void *b0 = dev.put(ptr.data(), ptr.size() * 4), *b1 = dev.put(rows.data(), rows.size() * 4), *b2 = dev.put(val.data(), val.size() * 4);
+                csc_bufs.insert(csc_bufs.end(), {b0, b1, b2});
+                three[k] = frw::SetupCsc{(const uint32_t *)b0, (const uint32_t *)b1, (const uint32_t *)b2};
+            }
+            csc.push_back(three);
+        }
+        std::vector<frw::SetupRun> druns;
+        for (const DeviceRun &run : runs) {
+            const size_t which = std::find(distinct.begin(), distinct.end(), run.m) - distinct.begin();
+            frw::SetupRun d{};
+            for (int k = 0; k < 3; k++) d.m[k] = csc[which][k];
+            d.num_inst = (uint32_t)run.m->num_instance_variables;
+            d.num_vars = (uint32_t)(run.m->num_instance_variables + run.m->num_witness_variables);
+            d.num_constraints = (uint32_t)run.m->num_constraints;
+            d.first = run.first; d.count = run.count;
+            d.wit_off = run.wit_off; d.pub_off = run.pub_off; d.row_off = run.row_off;
+            druns.push_back(d);
+        }
+        uint32_t *uvw = (uint32_t *)dev.get(3 * nv * 32), *col0 = (uint32_t *)dev.get((size_t)statements * 3 * 32);
+        hip_ok(frw::launch_setup_columns(druns.data(), druns.size(), statements, ni, nc, nv, lag, uvw, col0, nullptr), "setup: the QAP at t");
+        hip_ok(hipDeviceSynchronize(), "setup: the QAP at t");
+        dev.drop(lag);
+        for (void *p : csc_bufs) dev.drop(p);
+        // (3) the five tables, row by row in place
+        rc = frw::msm_alloc_bare(device, 1, 16, h_hi - h_lo, h_lo, &tab[0]);
+        for (int k = 1; k < 5 && rc == FRW_OK; k++) rc = frw::msm_alloc_bare(device, k == 4 ? 2 : 1, 8, z_hi - z_lo, z_lo, &tab[k]);
+        if (rc == FRW_OK) rc = frw::fixed_base_gen_create(device, &gen);
+        if (rc != FRW_OK) throw std::runtime_error("tables");
+        const size_t zrows = z_hi - z_lo, hrows = h_hi - h_lo;
+        uint32_t *scal = (uint32_t *)dev.get(std::max(std::max(zrows, hrows), ni) * 32);
+        const frw::SetupConst ca = setup_const(alpha), cb = setup_const(beta), cg = setup_const(ginv), cd = setup_const(dinv);
+        // rows [z_lo, z_hi) of a witness-side table: variables [from, nv) by the kernel (kind, which), then the three tail rows
+        auto tails = [&](const Fr *tail) {
+            for (size_t j = 0; j < 3; j++) {
+                const size_t g = nv + j;
+                if (g < z_lo || g >= z_hi || !tail) continue;
+                uint64_t canon[4];
+                tail[j].to_canonical(canon);
+                hip_ok(hipMemcpy(scal + (g - z_lo) * 8, canon, 32, hipMemcpyHostToDevice), "setup: scalars");
+            }
+        };
+        auto var_scalars = [&](int kind, int which, size_t from) {
+            hip_ok(hipMemset(scal, 0, zrows * 32), "setup: scalars");
+            const size_t lo = std::max<size_t>(z_lo, from), hi = std::min<size_t>(z_hi, nv);
+            if (lo < hi) hip_ok(frw::launch_setup_var_scalars(kind, lo, hi - lo, ni, nv, uvw, which, ca, cb, cg, cd, scal + (lo - z_lo) * 8, nullptr), "setup: scalars");
+        };
+        const Fr zero = Fr::zero();
+        const Fr tail_a[3] = {alpha, delta, zero}, tail_b1[3] = {beta, zero, zero}, tail_b2[3] = {beta, zero, delta};
+        var_scalars(0, 0, 0);
+        tails(tail_a);
+        hip_ok(frw::msm_fill_fixed_base(tab[1], gen, 0, zrows, scal, nullptr), "setup: a_query");
+        var_scalars(0, 1, 0);
+        tails(tail_b1);
+        hip_ok(frw::msm_fill_fixed_base(tab[2], gen, 0, zrows, scal, nullptr), "setup: b_g1_query");
+        tails(tail_b2);                                             // the same scalars but for the tail: b_g2_query ++ [beta2, O, delta2]
+        hip_ok(frw::msm_fill_fixed_base(tab[4], gen, 0, zrows, scal, nullptr), "setup: b_g2_query");
+        var_scalars(1, 0, ni);                                      // l_query: the witness variables; the instance rows stay the point at infinity
+        hip_ok(frw::msm_fill_fixed_base(tab[3], gen, 0, zrows, scal, nullptr), "setup: l_query");
+        {
+            const frw::SetupPowTab tt = pow_tab(t);
+            hip_ok(frw::launch_setup_h_scalars(h_lo, hrows, tt, setup_const(zt * dinv), scal, nullptr), "setup: scalars");
+            hip_ok(frw::msm_fill_fixed_base(tab[0], gen, 0, hrows, scal, nullptr), "setup: h_query");
+        }
+        // (4) the verifying key: alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | gamma_abc_g1 [ni]
+        if (vk_out) {
+            uint32_t *pts = (uint32_t *)dev.get(std::max<size_t>(ni * 96, 4 * 192));
+            hip_ok(frw::launch_setup_var_scalars(1, 0, ni, ni, nv, uvw, 0, ca, cb, cg, cd, scal, nullptr), "setup: scalars");
+            hip_ok(frw::fixed_base_ark_dev(gen, 1, ni, scal, pts, nullptr), "setup: gamma_abc_g1");
+            hip_ok(hipMemcpy(vk_out + 84, pts, ni * 96, hipMemcpyDeviceToHost), "setup: gamma_abc_g1");
+            uint64_t fixed[16];
+            alpha.to_canonical(fixed); beta.to_canonical(fixed + 4); gamma.to_canonical(fixed + 8); delta.to_canonical(fixed + 12);
+            hip_ok(hipMemcpy(scal, fixed, sizeof(fixed), hipMemcpyHostToDevice), "setup: scalars");
+            hip_ok(frw::fixed_base_ark_dev(gen, 1, 1, scal, pts, nullptr), "setup: alpha_g1");
+            hip_ok(hipMemcpy(vk_out, pts, 96, hipMemcpyDeviceToHost), "setup: alpha_g1");
+            hip_ok(frw::fixed_base_ark_dev(gen, 2, 3, scal + 8, pts, nullptr), "setup: the verifying key's G2 points");
+            hip_ok(hipMemcpy(vk_out + 12, pts, 3 * 192, hipMemcpyDeviceToHost), "setup: the verifying key's G2 points");
+        }
+        hip_ok(hipDeviceSynchronize(), "setup");
+    } catch (const std::bad_alloc &) {
+        rc = FRW_E_OUT_OF_MEMORY;
+    } catch (const std::exception &) {
+        if (rc == FRW_OK) rc = FRW_E_HIP;
+    }
+    frw::fixed_base_gen_free(&gen);
+    if (rc != FRW_OK) {
+        for (frw_msm *m : tab) frw_msm_free(m);
+        return rc;
+    }
+    return frw::groth16_pk_assemble(device, ni, nw, n, rank, world, tab[0], tab[1], tab[2], tab[3], tab[4], pk_out);
+}
 }  // namespace
 
 extern "C" int frw_groth16_setup(int device, int circuit, int logn, const uint64_t *toxic /* [5][4]: alpha, beta, gamma, delta, t; canonical */,
@@ -752,20 +957,43 @@ extern "C" int frw_groth16_setup(int device, int circuit, int logn, const uint64
 // The same for the system behind any handle -- in particular an aggregate statement (frw_r1cs_load_aggregate): the QAP at t is
 // evaluated block by block from the per-signature matrices, the key has one query point per variable of the WHOLE statement
 // (a_query, b_g1_query, b_g2_query: 1 + sum (2 N_i + W_i) points; h_query: domain - 1), and vk_out takes 84 + 12 (1 + sum 2 N_i)
-// uint64_t.
-extern "C" int frw_groth16_setup_r1cs(const frw_r1cs *r, const uint64_t *toxic, frw_groth16_pk **pk_out, uint64_t *vk_out)
+// uint64_t.  opts (null: FRW_KEY_AUTO, the whole key): window tables made through the host (as until round 4), or bare handles made on
+// the device end to end (groth16_setup_device), whole or one rank's slices.
+extern "C" int frw_groth16_setup_r1cs_opts(const frw_r1cs *r, const uint64_t *toxic, const frw_groth16_key_opts_t *opts, frw_groth16_pk **pk_out,
+                                           uint64_t *vk_out)
 {
     using namespace frw::host;
     if (!r || !toxic || !pk_out) return FRW_E_INVALID_ARG;
-    if (!r->dev.agg) return frw_groth16_setup(r->device, r->circuit, r->logn, toxic, pk_out, vk_out);
     *pk_out = nullptr;
+    int mode = opts ? opts->mode : FRW_KEY_AUTO;
+    const uint32_t world = opts && opts->world > 1 ? opts->world : 1, rank = opts ? opts->rank : 0;
+    if ((mode != FRW_KEY_AUTO && mode != FRW_KEY_TABLES && mode != FRW_KEY_BARE) || rank >= world) return FRW_E_INVALID_ARG;
+    const size_t nv = (size_t)r->dev.num_instance + r->dev.num_witness;
+    if (mode == FRW_KEY_AUTO) mode = world > 1 || nv > FRW_KEY_AUTO_TABLE_VARIABLES ? FRW_KEY_BARE : FRW_KEY_TABLES;
+    if (mode == FRW_KEY_TABLES && world > 1) return FRW_E_INVALID_ARG;
     try {
-        ConstraintMatrices mats[2];
+        if (!r->dev.agg) {
+            if (!r->host_matrices) return FRW_E_INVALID_ARG;
+            const ConstraintMatrices &m = *r->host_matrices;
+            if (mode == FRW_KEY_TABLES)
+                return groth16_setup_blocks(r->device, {SetupBlock{&m, 0, 0, 0}}, m.num_instance_variables, m.num_witness_variables, m.num_constraints,
+                                            toxic, pk_out, vk_out);
+            return groth16_setup_device(r->device, {DeviceRun{&m, 0, 1, 0, 0, 0}}, 1, m.num_instance_variables, m.num_witness_variables,
+                                        m.num_constraints, toxic, rank, world, pk_out, vk_out);
+        }
+        const ConstraintMatrices *mats[2] = {nullptr, nullptr};
         for (int g = 0; g < 2; g++)
-            if (r->base[g]) mats[g] = build_matrices(FRW_CIRCUIT_NTT, 9 + g);
+            if (r->base[g]) mats[g] = r->base[g]->host_matrices.get();
+        if (mode == FRW_KEY_BARE) {
+            std::vector<DeviceRun> runs;
+            for (const frw::R1csAggRun &run : r->runs)
+                runs.push_back(DeviceRun{mats[r->statement_logn[run.first] - 9], run.first, run.count, run.wit_off, run.pub_off, run.row_off});
+            return groth16_setup_device(r->device, runs, r->agg.num_statements, r->dev.num_instance, r->dev.num_witness, r->dev.num_constraints, toxic,
+                                        rank, world, pk_out, vk_out);
+        }
         std::vector<SetupBlock> blocks;
         for (const frw::R1csAggRun &run : r->runs) {
-            const ConstraintMatrices &m = mats[r->statement_logn[run.first] - 9];
+            const ConstraintMatrices &m = *mats[r->statement_logn[run.first] - 9];
             for (uint32_t k = 0; k < run.count; k++)
                 blocks.push_back(SetupBlock{&m, (size_t)(run.row_off + (uint64_t)k * m.num_constraints),
                                             (size_t)(run.pub_off + (uint64_t)k * (m.num_instance_variables - 1)),
@@ -774,5 +1002,37 @@ extern "C" int frw_groth16_setup_r1cs(const frw_r1cs *r, const uint64_t *toxic, 
         return groth16_setup_blocks(r->device, blocks, r->dev.num_instance, r->dev.num_witness, r->dev.num_constraints, toxic, pk_out, vk_out);
     } catch (const std::exception &) {
         return FRW_E_OUT_OF_MEMORY;
+    }
+}
+extern "C" int frw_groth16_setup_r1cs(const frw_r1cs *r, const uint64_t *toxic, frw_groth16_pk **pk_out, uint64_t *vk_out)
+{
+    return frw_groth16_setup_r1cs_opts(r, toxic, nullptr, pk_out, vk_out);
+}
+
+// ---- diagnostics: p(t) on the device for a polynomial whose coefficients no host arithmetic could visit (2^27 of them) --------------------
+// d_coeffs: uint64_t[n][4], ark-ff's Montgomery form, coefficient k at index k (what frw_qap_witness_map_dev writes); t: host, canonical;
+// out: host, p(t) as a canonical integer.  Synchronous; allocates its own scratch (32 bytes per 4,096 coefficients + two small tables).
+extern "C" int frw_diag_poly_eval_dev(int device, uint64_t n, const uint64_t *d_coeffs, const uint64_t *t, uint64_t *out)
+{
+    if (!d_coeffs || !t || !out || n == 0 || n > ((uint64_t)1 << 30)) return FRW_E_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRW_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FRW_E_HIP;
+    try {
+        const Fr tv = Fr::from_canonical(t);
+        const int L = std::max(domain_log(n), (int)frw::SETUP_POW_LO_BITS);
+        const PowTabHost pt = pow_tab_host(tv, L);
+        DeviceBuffers dev;
+        const frw::SetupPowTab tt{(const uint32_t *)dev.put(pt.lo.data(), pt.lo.size() * 4), (const uint32_t *)dev.put(pt.hi.data(), pt.hi.size() * 4)};
+        uint32_t *part = (uint32_t *)dev.get(frw::poly_eval_scratch_bytes(n)), *res = (uint32_t *)dev.get(32);
+        hip_ok(frw::launch_poly_eval(n, (const uint32_t *)d_coeffs, setup_const(tv), tt, part, res, nullptr), "frw_diag_poly_eval_dev");
+        uint64_t limbs[4];
+        hip_ok(hipMemcpy(limbs, res, 32, hipMemcpyDeviceToHost), "frw_diag_poly_eval_dev");
+        Fr::from_montgomery(limbs).to_canonical(out);
+        return FRW_OK;
+    } catch (const std::bad_alloc &) {
+        return FRW_E_OUT_OF_MEMORY;
+    } catch (const std::exception &) {
+        return FRW_E_HIP;
     }
 }

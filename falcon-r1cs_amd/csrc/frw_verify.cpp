@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstring>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -106,6 +107,10 @@ struct frw_groth16_vk {
 
 extern "C" int frw_groth16_vk_load(const uint64_t *vk, size_t num_instance, frw_groth16_vk **out)
 {
+    return frw_groth16_vk_load_opts(vk, num_instance, 0, out);
+}
+extern "C" int frw_groth16_vk_load_opts(const uint64_t *vk, size_t num_instance, int flags, frw_groth16_vk **out)
+{
     if (!vk || !out || num_instance == 0) return FRW_E_INVALID_ARG;
     *out = nullptr;
     frw_groth16_vk *k = new (std::nothrow) frw_groth16_vk();
@@ -123,14 +128,15 @@ extern "C" int frw_groth16_vk_load(const uint64_t *vk, size_t num_instance, frw_
         // reads (a ladder per point: a few host threads for the 32,769 points of a sixteen-statement aggregate's key)
         if (ok) {
             const size_t hw = std::max(1u, std::thread::hardware_concurrency());
-            const size_t threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(num_instance / 256, hw), 32));
+            const bool vouched = (flags & FRW_VK_POINTS_ARE_CHECKED) != 0;
+            const size_t threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(num_instance / 256, hw), 64));
             std::atomic<bool> good{true};
             auto work = [&](size_t tid) {
                 for (size_t i = tid; i < num_instance && good; i += threads) {
                     const uint64_t *w = vk + 84 + 12 * i;
                     if (!coordinates_canonical(w, 2)) { good = false; break; }
                     k->gamma_abc[i] = g1_lazy_from_ark(w);
-                    if (!g1_on_curve(g1_strict(k->gamma_abc[i])) || !in_subgroup(k->gamma_abc[i])) good = false;
+                    if (!vouched && (!g1_on_curve(g1_strict(k->gamma_abc[i])) || !in_subgroup(k->gamma_abc[i]))) good = false;
                 }
             };
             std::vector<std::thread> pool;
@@ -156,25 +162,49 @@ extern "C" void frw_groth16_vk_free(frw_groth16_vk *vk) { delete vk; }
 
 namespace {
 // sum_i x_i gamma_abc[i]: buckets of 8-bit windows, as many windows as the longest input needs (Falcon's are below 2^14)
+// (an aggregate of 1,024 statements has 1.57 M inputs: the points are dealt to a few host threads, each with buckets of its own)
 G1Xyzz prepare_inputs(const frw_groth16_vk &vk, const std::vector<uint64_t> &canon)
 {
     const size_t n = vk.num_instance;
     int bits = 1;
     for (size_t i = 0; i < n; i++) bits = std::max(bits, bit_length(&canon[4 * i]));
     const int windows = (bits + 7) / 8;
-    G1Xyzz total = g1_identity();
-    std::vector<G1Xyzz> bucket(255);
-    for (int w = windows - 1; w >= 0; w--) {
-        for (int s = 0; s < 8; s++) total = g1_double(total);
-        for (auto &b : bucket) b = g1_identity();
-        for (size_t i = 0; i < n; i++) {
-            const unsigned d = (unsigned)(canon[4 * i + (w >> 3)] >> (8 * (w & 7))) & 0xffu;
-            if (d && !vk.gamma_abc[i].inf) bucket[d - 1] = g1_add_affine(bucket[d - 1], vk.gamma_abc[i]);
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t parts = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n / 16384, hw), 64));
+    std::vector<G1Xyzz> partial(parts, g1_identity());
+    auto work = [&](size_t part) {
+        const size_t lo = n * part / parts, hi = n * (part + 1) / parts;
+        G1Xyzz total = g1_identity();
+        std::vector<G1Xyzz> bucket(255);
+        for (int w = windows - 1; w >= 0; w--) {
+            for (int s = 0; s < 8; s++) total = g1_double(total);
+            for (auto &b : bucket) b = g1_identity();
+            for (size_t i = lo; i < hi; i++) {
+                const unsigned d = (unsigned)(canon[4 * i + (w >> 3)] >> (8 * (w & 7))) & 0xffu;
+                if (d && !vk.gamma_abc[i].inf) bucket[d - 1] = g1_add_affine(bucket[d - 1], vk.gamma_abc[i]);
+            }
+            G1Xyzz run = g1_identity(), sum = g1_identity();
+            for (int d = 254; d >= 0; d--) { run = g1_add(run, bucket[d]); sum = g1_add(sum, run); }
+            total = g1_add(total, sum);
         }
-        G1Xyzz run = g1_identity(), sum = g1_identity();
-        for (int d = 254; d >= 0; d--) { run = g1_add(run, bucket[d]); sum = g1_add(sum, run); }
-        total = g1_add(total, sum);
+        partial[part] = total;
+    };
+    {
+        struct Joiner {
+            std::vector<std::thread> th;
+            ~Joiner() { for (auto &x : th) if (x.joinable()) x.join(); }
+        } pool;
+        size_t started = 1;
+        try {
+            for (size_t part = 1; part < parts; part++, started++) pool.th.emplace_back(work, part);
+        } catch (const std::system_error &) {
+            // no more threads to be had: this one does the rest
+        }
+        work(0);
+        for (size_t part = started; part < parts; part++) work(part);
     }
+    G1Xyzz total = partial[0];
+    for (size_t part = 1; part < parts; part++) total = g1_add(total, partial[part]);
     return total;
 }
 

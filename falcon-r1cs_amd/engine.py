@@ -89,6 +89,10 @@ def synth_triples(logn, batch, seed=0x46414C434F4E, first_index=0):
 
 
 VERIFY_POINTS_ARE_CHECKED = 1
+VK_POINTS_ARE_CHECKED = 1
+KEY_AUTO, KEY_TABLES, KEY_BARE = 0, 1, 2           # frw.h FRW_KEY_*: window tables, or the points only (keys that would not fit)
+GROTH16_PARTIAL_WORDS = 72
+GROTH16_COMBINE_WORKSPACE = 4096
 
 
 class Groth16Verifier:
@@ -96,7 +100,7 @@ class Groth16Verifier:
 
     vk: the dict WitnessEngine.groth16_setup returns, or one flat uint64 array in frw_groth16_setup's vk_out layout."""
 
-    def __init__(self, vk):
+    def __init__(self, vk, points_are_checked=False):
         self._lib = load_library()
         if isinstance(vk, dict):
             vk = np.concatenate([np.asarray(vk[k], dtype=np.uint64).reshape(-1) for k in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1")])
@@ -105,7 +109,8 @@ class Groth16Verifier:
             raise FrwError("verifying key: expected 84 + 12 x num_instance uint64 values")
         self.num_instance = (vk.size - 84) // 12
         self._h = C.c_void_p()
-        check(self._lib.frw_groth16_vk_load(vk.ctypes.data_as(C.c_void_p), self.num_instance, C.byref(self._h)), "frw_groth16_vk_load")
+        check(self._lib.frw_groth16_vk_load_opts(vk.ctypes.data_as(C.c_void_p), self.num_instance, VK_POINTS_ARE_CHECKED if points_are_checked else 0,
+                                                 C.byref(self._h)), "frw_groth16_vk_load")
 
     def verify(self, instance, proofs, encoding=ENC_MONTGOMERY, flags=0):
         """instance: uint64[batch, num_instance, 4] as the witness entry points write it (the constant one first);
@@ -401,14 +406,20 @@ class WitnessEngine:
         check(self._lib.frw_aggregate_assign_dev(handle, P(d_wit512), P(d_inst512), P(d_wit1024), P(d_inst1024), self._ptr(d_wit),
                                                  self._ptr(d_inst), C.c_void_p(stream)), "frw_aggregate_assign_dev")
 
-    def groth16_setup_r1cs(self, handle, alpha, beta, gamma, delta, t):
-        """groth16_setup for the system behind an r1cs handle (a per-signature circuit or an aggregate statement)."""
+    def groth16_setup_r1cs(self, handle, alpha, beta, gamma, delta, t, mode=KEY_AUTO, rank=0, world=1, want_vk=True):
+        """groth16_setup for the system behind an r1cs handle (a per-signature circuit or an aggregate statement).
+        mode: KEY_TABLES (window tables), KEY_BARE (the points only, made on the device end to end), KEY_AUTO by size;
+        rank / world: one slice of a key in slices (bare)."""
+        from ._lib import Groth16KeyOpts
         tox = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in (alpha, beta, gamma, delta, t)), dtype=np.uint64).copy()
         ni = int(self.r1cs_info(handle).num_instance)
         vk = np.zeros(84 + 12 * ni, dtype=np.uint64)
         h = C.c_void_p()
-        check(self._lib.frw_groth16_setup_r1cs(handle, tox.ctypes.data_as(C.c_void_p), C.byref(h), vk.ctypes.data_as(C.c_void_p)),
-              "frw_groth16_setup_r1cs")
+        opts = Groth16KeyOpts(int(mode), int(rank), int(world))
+        check(self._lib.frw_groth16_setup_r1cs_opts(handle, tox.ctypes.data_as(C.c_void_p), C.byref(opts), C.byref(h),
+                                                    vk.ctypes.data_as(C.c_void_p) if want_vk else None), "frw_groth16_setup_r1cs")
+        if not want_vk:
+            return h, None
         return h, {"alpha_g1": vk[:12], "beta_g2": vk[12:36], "gamma_g2": vk[36:60], "delta_g2": vk[60:84],
                    "gamma_abc_g1": vk[84:].reshape(-1, 12)}
 
@@ -433,11 +444,16 @@ class WitnessEngine:
                                                   C.c_void_p(stream)), "frw_r1cs_eval_scratch_dev")
 
     # ---- multi-scalar multiplication over BLS12-381 G1 (frw_msm.hip) --------------------------------------------------
-    def msm_g1_load(self, bases, narrow=False):
+    def msm_g1_load(self, bases, narrow=False, bare=False):
         """bases: uint64[n, 12] (ark-ff's bytes of n affine points, zeros = infinity) -> handle; free with msm_free.
-        narrow: 8-bit windows (128 buckets) instead of 16-bit ones: for scalars that are mostly zero, one or small."""
+        narrow: 8-bit windows (128 buckets) instead of 16-bit ones: for scalars that are mostly zero, one or small.
+        bare: the points only, no window table (the sums run window by window)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 12)
         h = C.c_void_p()
+        if bare:
+            check(self._lib.frw_msm_g1_load_bare(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), 1 if narrow else 0, C.byref(h)),
+                  "frw_msm_g1_load_bare")
+            return h
         fn = self._lib.frw_msm_g1_load_narrow if narrow else self._lib.frw_msm_g1_load
         check(fn(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_msm_g1_load")
         return h
@@ -458,9 +474,13 @@ class WitnessEngine:
                                           out.ctypes.data_as(C.c_void_p)), "frw_g2_fixed_base")
         return out
 
-    def msm_g2_load(self, bases, narrow=False):
+    def msm_g2_load(self, bases, narrow=False, bare=False):
         bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 24)
         h = C.c_void_p()
+        if bare:
+            check(self._lib.frw_msm_g2_load_bare(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), 1 if narrow else 0, C.byref(h)),
+                  "frw_msm_g2_load_bare")
+            return h
         fn = self._lib.frw_msm_g2_load_narrow if narrow else self._lib.frw_msm_g2_load
         check(fn(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), C.byref(h)), "frw_msm_g2_load")
         return h
@@ -488,9 +508,10 @@ class WitnessEngine:
 
     # ---- a whole Groth16 proof per signature ---------------------------------------------------------------------------
     def groth16_pk_load(self, num_instance, num_witness, domain_size, alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query,
-                        b_g1_query, b_g2_query, h_query, l_query):
-        """The proving key's elements as uint64 arrays in ark-ff's bytes (G1 rows of 12, G2 rows of 24) -> handle."""
-        from ._lib import Groth16PkDesc
+                        b_g1_query, b_g2_query, h_query, l_query, mode=KEY_TABLES, rank=0, world=1):
+        """The proving key's elements as uint64 arrays in ark-ff's bytes (G1 rows of 12, G2 rows of 24) -> handle.
+        mode / rank / world: as groth16_setup_r1cs (every rank passes the WHOLE key and keeps its slice)."""
+        from ._lib import Groth16PkDesc, Groth16KeyOpts
         arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query, b_g1_query,
                                                                    b_g2_query, h_query, l_query)]
         nv = num_instance + num_witness
@@ -499,8 +520,36 @@ class WitnessEngine:
             raise ValueError("proving key: wrong array sizes")
         d = Groth16PkDesc(num_instance, num_witness, domain_size, *[a.ctypes.data_as(C.c_void_p) for a in arrs])
         h = C.c_void_p()
-        check(self._lib.frw_groth16_pk_load(self.device, C.byref(d), C.byref(h)), "frw_groth16_pk_load")
+        opts = Groth16KeyOpts(int(mode), int(rank), int(world))
+        check(self._lib.frw_groth16_pk_load_opts(self.device, C.byref(d), C.byref(opts), C.byref(h)), "frw_groth16_pk_load")
         return h
+
+    def groth16_pk_info(self, pk):
+        from ._lib import Groth16PkInfoStruct
+        info = Groth16PkInfoStruct()
+        check(self._lib.frw_groth16_pk_info(pk, C.byref(info)), "frw_groth16_pk_info")
+        return info
+
+    def groth16_prove_partial_dev(self, pk, r1cs, batch, d_wit, d_inst, rs, d_partial, d_workspace, workspace_bytes, d_num_unsatisfied=None, stream=0):
+        """One rank's partial sums of a key in slices: d_partial int64[batch, 72] = A | B1' | L | H | B (ark-ff's affine bytes)."""
+        rs = np.ascontiguousarray(rs, dtype=np.uint64).reshape(batch, 2, 4)
+        check(self._lib.frw_groth16_prove_partial_dev(pk, r1cs, batch, self._ptr(d_wit), self._ptr(d_inst), rs.ctypes.data_as(C.c_void_p),
+                                                      self._ptr(d_partial), self._ptr(d_num_unsatisfied) if d_num_unsatisfied is not None else None,
+                                                      self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)), "frw_groth16_prove_partial_dev")
+
+    def groth16_prove_combine_dev(self, pk, world, d_partials, rs, d_proof, d_workspace, workspace_bytes, stream=0):
+        """All ranks' partial sums (int64[world, 72], rank order) -> the proof int64[48]."""
+        rs = np.ascontiguousarray(rs, dtype=np.uint64).reshape(2, 4)
+        check(self._lib.frw_groth16_prove_combine_dev(pk, world, self._ptr(d_partials), rs.ctypes.data_as(C.c_void_p), self._ptr(d_proof),
+                                                      self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)), "frw_groth16_prove_combine_dev")
+
+    def diag_poly_eval_dev(self, d_coeffs, n, t):
+        """p(t) for the polynomial whose n coefficients (ark-ff's Montgomery form) are in device memory; t, result: Python integers."""
+        tt = np.frombuffer(int(t).to_bytes(32, "little"), dtype=np.uint64).copy()
+        out = np.zeros(4, dtype=np.uint64)
+        check(self._lib.frw_diag_poly_eval_dev(self.device, n, self._ptr(d_coeffs), tt.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)),
+              "frw_diag_poly_eval_dev")
+        return int.from_bytes(out.tobytes(), "little")
 
     def groth16_setup(self, circuit, logn, alpha, beta, gamma, delta, t):
         """generate_parameters with the given toxic waste (Python integers) -> (proving-key handle, verifying key dict of uint64 arrays)."""

@@ -400,6 +400,13 @@ int frw_msm_g1_load_narrow(int device, size_t num_points, const uint64_t *bases,
 int frw_msm_g2_load_narrow(int device, size_t num_points, const uint64_t *bases, frw_msm **out);
 int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t scalar_stride, int montgomery,
                    uint64_t *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
+/* BARE handles (round 5): the points themselves and no window table -- 112 (G2: 224) bytes a point, up to 2^31 - 1 of them.  A sum then
+ * runs window by window over the same rows (narrow == 0: sixteen 16-bit windows, the dense pipeline -- for uniform scalars such as h;
+ * narrow != 0: thirty-two 8-bit windows sorted in one pass -- for a witness as scalars), the window sums put together by Horner's rule:
+ * the bucket additions of the table path, one per point and non-zero digit, plus 255 point operations.  Results are the same affine
+ * points, bit for bit.  frw_msm_info: table_bytes = num_points x 112 (224); one scalar vector is summed at a time, whatever the workspace. */
+int frw_msm_g1_load_bare(int device, size_t num_points, const uint64_t *bases, int narrow, frw_msm **out);
+int frw_msm_g2_load_bare(int device, size_t num_points, const uint64_t *bases, int narrow, frw_msm **out);
 
 /* ---- a whole Groth16 proof per signature (the rest of examples/pok_sig.rs:30-47) ---------------------------------------------------
  * ark-groth16 0.3.0 prover.rs, create_proof_with_reduction_and_matrices, for every signature of a resident batch of witnesses:
@@ -432,6 +439,39 @@ typedef struct {
     const uint64_t *l_query;                               /* [W][12] */
 } frw_groth16_pk_desc_t;
 int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *desc, frw_groth16_pk **out);
+/* ---- keys beyond what window tables can hold, and keys in slices (round 5; BASELINE configs[4]: ONE proof for 1,024 statements) -------
+ * The window tables above are a speed-up, not a requirement: 3.6 KB per variable and 1.8 KB per domain point make a sixteen-statement key
+ * 53 GB.  A key of BARE handles keeps the points only (112 bytes a G1 point, 224 a G2 point: 83 GB for the 1,024-statement aggregate --
+ * 513 Falcon-512 + 511 Falcon-1024, 121.9 M variables, the 2^27 domain) and its sums run window by window over the same rows: the same
+ * number of bucket additions (one per point and non-zero digit), plus 255 point operations per sum to put the windows together.
+ *   FRW_KEY_TABLES  window tables (the fastest proofs; what frw_groth16_pk_load and frw_groth16_setup make)
+ *   FRW_KEY_BARE    the points only
+ *   FRW_KEY_AUTO    tables up to FRW_KEY_AUTO_TABLE_VARIABLES variables (some sixteen Falcon-1024 statements: 50 GB), bare beyond
+ * rank / world: a key in slices (bare handles only) -- this handle holds slice `rank` of `world` of every query: rows [z_lo, z_hi) of the
+ * nv + 3 rows of a_query ++ [alpha, delta, O] and of the three tables laid out like it, and [h_lo, h_hi) of h_query (frw_groth16_pk_info;
+ * the split is by equal counts, the first `total mod world` slices one longer).  A slice proves nothing by itself: every rank runs
+ * frw_groth16_prove_partial_dev on the WHOLE witness (the witness map is recomputed by every rank: a tenth of the sums' time) with the SAME
+ * blinding factors, which sums its slices of the five queries into FRW_GROTH16_PARTIAL_WORDS uint64_t -- A | B1' | L | H as G1Affine limbs (12
+ * each) | B as G2Affine limbs (24), partial sums all, the blinding terms r delta_1, alpha_1, beta, s delta_2 inside those of the last rank;
+ * the partial sums of all ranks in rank order (one all-gather of 576 bytes per rank) go to frw_groth16_prove_combine_dev on any rank, which
+ * adds them up, applies s A + r B1' and writes the proof A | B | C -- byte for byte the proof of the whole key. */
+#define FRW_KEY_AUTO    0
+#define FRW_KEY_TABLES  1
+#define FRW_KEY_BARE    2
+#define FRW_KEY_AUTO_TABLE_VARIABLES 3000000
+typedef struct {
+    int32_t mode;               /* FRW_KEY_* */
+    uint32_t rank, world;       /* world <= 1: the whole key */
+} frw_groth16_key_opts_t;
+typedef struct {
+    int32_t mode;               /* FRW_KEY_TABLES or FRW_KEY_BARE */
+    uint32_t rank, world;
+    uint64_t z_lo, z_hi;        /* rows of the witness-side tables this handle holds, of num_instance + num_witness + 3 */
+    uint64_t h_lo, h_hi;        /* rows of h_query, of domain_size - 1 */
+    uint64_t key_bytes;         /* device memory of the five tables */
+} frw_groth16_pk_info_t;
+int frw_groth16_pk_load_opts(int device, const frw_groth16_pk_desc_t *desc, const frw_groth16_key_opts_t *opts, frw_groth16_pk **out);
+int frw_groth16_pk_info(const frw_groth16_pk *pk, frw_groth16_pk_info_t *out);
 /* ark-groth16 0.3.0 generator.rs generate_parameters for one of the Falcon circuits, with the toxic waste GIVEN:
  * toxic = uint64_t[5][4], canonical: alpha, beta, gamma, delta and the evaluation point t (circuit_specific_setup draws them
  * from its rng, and random generators of G1 / G2; here the published generators are used).  The QAP is evaluated at t on the
@@ -444,6 +484,14 @@ int frw_groth16_setup(int device, int circuit, int logn, const uint64_t *toxic, 
 /* the same for the system behind a handle (a per-signature circuit or an aggregate statement), on the handle's device;
  * vk_out: 84 + 12 x num_instance uint64_t */
 int frw_groth16_setup_r1cs(const frw_r1cs *r, const uint64_t *toxic, frw_groth16_pk **pk_out, uint64_t *vk_out);
+/* The same with the kind of key chosen (frw_groth16_setup_r1cs is FRW_KEY_AUTO, whole).  A key of bare handles is made ON THE DEVICE end to
+ * end: the Lagrange coefficients of the whole domain at t, the QAP's polynomials at t as transposed sparse products over the per-signature
+ * matrices (block by block, in place), the queries' scalars, and every query point written straight into its table row by the fixed-base
+ * kernels -- nothing of the statement's size exists in host memory but the verifying key's gamma_abc_g1 (the 1,024-statement key: 83 GB of
+ * rows, 1.57 M points of gamma_abc_g1).  With world > 1 only this rank's slices are made (vk_out, if given, is the whole verifying key on
+ * every rank). */
+int frw_groth16_setup_r1cs_opts(const frw_r1cs *r, const uint64_t *toxic, const frw_groth16_key_opts_t *opts, frw_groth16_pk **pk_out,
+                                uint64_t *vk_out);
 void frw_groth16_pk_free(frw_groth16_pk *pk);
 size_t frw_groth16_workspace_bytes(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch_in_flight);
 int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch, const uint64_t *d_witness,
@@ -457,6 +505,19 @@ int frw_groth16_prove_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t ba
 int frw_groth16_prove_rs_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch, const uint64_t *d_witness,
                              const uint64_t *d_instance, const uint64_t *d_rs, uint64_t *d_proofs, uint32_t *d_num_unsatisfied,
                              void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* A key in slices (see frw_groth16_key_opts_t).  d_witness / d_instance: the WHOLE statement's vectors, on every rank; rs: host,
+ * uint64_t[batch][2][4], the same on every rank; d_partial: uint64_t[batch][FRW_GROTH16_PARTIAL_WORDS]; workspace as frw_groth16_prove_dev
+ * (frw_groth16_workspace_bytes).  A whole key (world == 1) may be used too: its "partial" sums are the sums. */
+#define FRW_GROTH16_PARTIAL_WORDS 72
+#define FRW_GROTH16_COMBINE_WORKSPACE 4096
+int frw_groth16_prove_partial_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t batch, const uint64_t *d_witness,
+                                  const uint64_t *d_instance, const uint64_t *rs, uint64_t *d_partial, uint32_t *d_num_unsatisfied,
+                                  void *d_workspace, size_t workspace_bytes, void *stream);
+/* d_partials: uint64_t[world][FRW_GROTH16_PARTIAL_WORDS] in rank order (device memory); rs: host, uint64_t[2][4]; d_proof: uint64_t[48];
+ * d_workspace: FRW_GROTH16_COMBINE_WORKSPACE bytes, 256-byte aligned.  `pk` names the device (any rank's handle). */
+int frw_groth16_prove_combine_dev(const frw_groth16_pk *pk, size_t world, const uint64_t *d_partials, const uint64_t *rs, uint64_t *d_proof,
+                                  void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Groth16 verification (examples/pok_sig.rs:34-47: Groth16::verify(&vk, &public_inputs, &proof)) --------------------------------
  * ark-groth16 0.3.0 verifier.rs: prepare_verifying_key (e(alpha_g1, beta_g2), -gamma_g2, -delta_g2), prepare_inputs
@@ -478,6 +539,11 @@ int frw_groth16_prove_rs_dev(const frw_groth16_pk *pk, const frw_r1cs *r, size_t
 #define FRW_VERIFY_POINTS_ARE_CHECKED 1
 typedef struct frw_groth16_vk frw_groth16_vk;
 int frw_groth16_vk_load(const uint64_t *vk, size_t num_instance, frw_groth16_vk **out);
+/* flags: FRW_VK_POINTS_ARE_CHECKED -- the caller vouches for gamma_abc_g1 being on the curve and in the subgroup (a key it made itself a
+ * moment ago: the 1,024-statement aggregate has 1.57 M of these points, a 255-bit ladder each); canonical limbs are still required and the
+ * four fixed points are still checked. */
+#define FRW_VK_POINTS_ARE_CHECKED 1
+int frw_groth16_vk_load_opts(const uint64_t *vk, size_t num_instance, int flags, frw_groth16_vk **out);
 void frw_groth16_vk_free(frw_groth16_vk *vk);
 int frw_groth16_verify(const frw_groth16_vk *vk, size_t batch, const uint64_t *instance, int encoding, const uint64_t *proofs,
                        int flags, int32_t *accepted);
@@ -572,6 +638,11 @@ int frw_synth_triples(int logn, size_t batch, uint64_t seed, uint64_t first_inde
  * per SIMD per microsecond with four waves per SIMD; out[2] = field products per second of the bare multiplier loop
  * (frw_fr29.h f29_mul, no loads, no butterflies) over the whole chip; out[3] = number of SIMDs.  Synchronous, ~10 ms. */
 int frw_diag_valu_rates(frw_ctx *ctx, double out[4]);
+
+/* p(t) on the device for a polynomial in device memory: d_coeffs uint64_t[n][4] (ark-ff's Montgomery form, coefficient k at index k -- an
+ * h of frw_qap_witness_map_dev), t host, canonical; out: host uint64_t[4], canonical.  For checks such as h_acc == (h(t) zt / delta) G1 on
+ * domains of 2^27 coefficients.  Synchronous; allocates its own small scratch. */
+int frw_diag_poly_eval_dev(int device, uint64_t n, const uint64_t *d_coeffs, const uint64_t *t, uint64_t *out);
 
 /* Page-locked host memory.  Output buffers of the host-buffer entry points allocated here are filled by
  * asynchronous DMA that overlaps with the kernels of the next chunk (pageable buffers work too, slower). */

@@ -137,6 +137,32 @@ pub struct frw_groth16_pk_desc_t {
     pub h_query: *const u64,
     pub l_query: *const u64,
 }
+/// round 5: keys beyond what window tables can hold (the points only), and keys in slices (frw.h FRW_KEY_*)
+pub const FRW_KEY_AUTO: i32 = 0;
+pub const FRW_KEY_TABLES: i32 = 1;
+pub const FRW_KEY_BARE: i32 = 2;
+pub const FRW_GROTH16_PARTIAL_WORDS: usize = 72;
+pub const FRW_GROTH16_COMBINE_WORKSPACE: usize = 4096;
+pub const FRW_VK_POINTS_ARE_CHECKED: c_int = 1;
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct frw_groth16_key_opts_t {
+    pub mode: i32,
+    pub rank: u32,
+    pub world: u32,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct frw_groth16_pk_info_t {
+    pub mode: i32,
+    pub rank: u32,
+    pub world: u32,
+    pub z_lo: u64,
+    pub z_hi: u64,
+    pub h_lo: u64,
+    pub h_hi: u64,
+    pub key_bytes: u64,
+}
 
 extern "C" {
     pub fn frw_layout(logn: c_int, out: *mut frw_layout_t) -> c_int;
@@ -216,6 +242,19 @@ extern "C" {
     pub fn frw_groth16_msm_h_dev(m: *const frw_msm, batch: usize, d_h: *const u64, domain_size: usize, d_out: *mut u64,
                                  d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_groth16_pk_load(device: c_int, desc: *const frw_groth16_pk_desc_t, out: *mut *mut frw_groth16_pk) -> c_int;
+    pub fn frw_groth16_pk_load_opts(device: c_int, desc: *const frw_groth16_pk_desc_t, opts: *const frw_groth16_key_opts_t,
+                                    out: *mut *mut frw_groth16_pk) -> c_int;
+    pub fn frw_groth16_pk_info(pk: *const frw_groth16_pk, out: *mut frw_groth16_pk_info_t) -> c_int;
+    pub fn frw_groth16_setup_r1cs_opts(r: *const frw_r1cs, toxic: *const u64, opts: *const frw_groth16_key_opts_t,
+                                       pk_out: *mut *mut frw_groth16_pk, vk_out: *mut u64) -> c_int;
+    pub fn frw_groth16_prove_partial_dev(pk: *const frw_groth16_pk, r: *const frw_r1cs, batch: usize, d_witness: *const u64,
+                                         d_instance: *const u64, rs: *const u64, d_partial: *mut u64, d_num_unsatisfied: *mut u32,
+                                         d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn frw_groth16_prove_combine_dev(pk: *const frw_groth16_pk, world: usize, d_partials: *const u64, rs: *const u64,
+                                         d_proof: *mut u64, d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn frw_msm_g1_load_bare(device: c_int, num_points: usize, bases: *const u64, narrow: c_int, out: *mut *mut frw_msm) -> c_int;
+    pub fn frw_msm_g2_load_bare(device: c_int, num_points: usize, bases: *const u64, narrow: c_int, out: *mut *mut frw_msm) -> c_int;
+    pub fn frw_diag_poly_eval_dev(device: c_int, n: u64, d_coeffs: *const u64, t: *const u64, out: *mut u64) -> c_int;
     pub fn frw_groth16_pk_free(pk: *mut frw_groth16_pk);
     pub fn frw_groth16_setup(device: c_int, circuit: c_int, logn: c_int, toxic: *const u64, pk_out: *mut *mut frw_groth16_pk,
                              vk_out: *mut u64) -> c_int;
@@ -227,6 +266,7 @@ extern "C" {
                                     d_instance: *const u64, d_rs: *const u64, d_proofs: *mut u64, d_num_unsatisfied: *mut u32,
                                     d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn frw_groth16_vk_load(vk: *const u64, num_instance: usize, out: *mut *mut frw_groth16_vk) -> c_int;
+    pub fn frw_groth16_vk_load_opts(vk: *const u64, num_instance: usize, flags: c_int, out: *mut *mut frw_groth16_vk) -> c_int;
     pub fn frw_groth16_vk_free(vk: *mut frw_groth16_vk);
     pub fn frw_groth16_verify(vk: *const frw_groth16_vk, batch: usize, instance: *const u64, encoding: c_int, proofs: *const u64,
                               flags: c_int, accepted: *mut i32) -> c_int;

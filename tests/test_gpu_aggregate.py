@@ -237,15 +237,84 @@ def test_witness_map_on_the_other_domains(engine, oracle, tmp_path, logns):
         agg.close()
 
 
-def _prove_and_check(engine, oracle, tmp_path, logns, seed, python_pairing):
+def _bare_and_sliced_keys_give_the_same_bytes(engine, agg, toxic, vk, r, s, want_proof, slices):
+    """The key of BARE handles (the points only, made on the device end to end: frw_groth16_setup_r1cs_opts) must give the proof of the
+    window tables byte for byte -- and so must a key in slices: every rank's partial sums over its slices of the five queries, put
+    together by frw_groth16_prove_combine_dev (here the ranks are handles on one card, one after the other)."""
     import torch
     import falcon_r1cs_amd as frw
+    from falcon_r1cs_amd import engine as EN
+    dev, s0 = agg.dev, agg.s0
+    lim = T.ints_to_limbs
+    tox = [toxic[k] for k in ("alpha", "beta", "gamma", "delta", "t")]
+    rs = np.array([lim([r, s])])
+    key, vk_bare = engine.groth16_setup_r1cs(agg.handle, *tox, mode=EN.KEY_BARE)
+    try:
+        info = engine.groth16_pk_info(key)
+        assert (info.mode, info.rank, info.world) == (EN.KEY_BARE, 0, 1) and (info.z_lo, info.z_hi) == (0, agg.ni + agg.nw + 3)
+        n = 1 << int(agg.info.log_domain_size)
+        assert (info.h_lo, info.h_hi) == (0, n - 1) and info.key_bytes == 3 * (agg.ni + agg.nw + 3) * 112 + (agg.ni + agg.nw + 3) * 224 + (n - 1) * 112
+        for k in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1"):
+            assert np.array_equal(vk_bare[k], vk[k]), "the device-made verifying key differs from the host-made one: " + k
+        ws_bytes = engine.groth16_workspace_bytes(key, agg.handle, 1)
+        pws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        proof = torch.full((1, 48), -1, dtype=torch.int64, device=dev)
+        bad = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        engine.groth16_prove_dev(key, agg.handle, 1, agg.wit, agg.inst, rs, proof, pws, ws_bytes, bad, s0)
+        torch.cuda.synchronize()
+        assert bad.tolist() == [0]
+        assert proof.cpu().numpy().view(np.uint64)[0].tolist() == want_proof.tolist(), "bare key: another proof than the window tables'"
+        # a whole key through the partial / combine pair
+        part = torch.full((1, EN.GROTH16_PARTIAL_WORDS), -1, dtype=torch.int64, device=dev)
+        cws = torch.empty(EN.GROTH16_COMBINE_WORKSPACE, dtype=torch.uint8, device=dev)
+        engine.groth16_prove_partial_dev(key, agg.handle, 1, agg.wit, agg.inst, rs, part, pws, ws_bytes, bad, s0)
+        engine.groth16_prove_combine_dev(key, 1, part, rs[0], proof, cws, cws.numel(), s0)
+        torch.cuda.synchronize()
+        assert proof.cpu().numpy().view(np.uint64)[0].tolist() == want_proof.tolist(), "partial + combine of a whole key"
+        del pws
+    finally:
+        engine.groth16_pk_free(key)
+    for world in slices:
+        parts = torch.full((world, EN.GROTH16_PARTIAL_WORDS), -1, dtype=torch.int64, device=dev)
+        covered_z, covered_h = 0, 0
+        last = None
+        for rank in range(world):
+            key, _ = engine.groth16_setup_r1cs(agg.handle, *tox, mode=EN.KEY_BARE, rank=rank, world=world, want_vk=False)
+            try:
+                info = engine.groth16_pk_info(key)
+                assert (info.rank, info.world) == (rank, world) and info.z_lo == covered_z and info.h_lo == covered_h
+                covered_z, covered_h = int(info.z_hi), int(info.h_hi)
+                ws_bytes = engine.groth16_workspace_bytes(key, agg.handle, 1)
+                pws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                bad = torch.full((1,), -1, dtype=torch.int32, device=dev)
+                with pytest.raises(frw.FrwError):                  # a slice proves nothing by itself
+                    engine.groth16_prove_dev(key, agg.handle, 1, agg.wit, agg.inst, rs, proof, pws, ws_bytes, bad, s0)
+                engine.groth16_prove_partial_dev(key, agg.handle, 1, agg.wit, agg.inst, rs, parts[rank:rank + 1], pws, ws_bytes, bad, s0)
+                torch.cuda.synchronize()
+                assert bad.tolist() == [0]
+                del pws
+                if rank == world - 1:
+                    proof = torch.full((1, 48), -1, dtype=torch.int64, device=dev)
+                    cws = torch.empty(EN.GROTH16_COMBINE_WORKSPACE, dtype=torch.uint8, device=dev)
+                    engine.groth16_prove_combine_dev(key, world, parts, rs[0], proof, cws, cws.numel(), s0)
+                    torch.cuda.synchronize()
+                    last = proof.cpu().numpy().view(np.uint64)[0].tolist()
+            finally:
+                engine.groth16_pk_free(key)
+        assert covered_z == agg.ni + agg.nw + 3 and covered_h == (1 << int(agg.info.log_domain_size)) - 1
+        assert last == want_proof.tolist(), "a key in %d slices: another proof than the whole key's" % world
+
+
+def _prove_and_check(engine, oracle, tmp_path, logns, seed, python_pairing, slices=()):
+    import torch
+    import falcon_r1cs_amd as frw
+    from falcon_r1cs_amd import engine as EN
     agg = Aggregate(engine, logns, seed=seed)
     try:
         dev, s0 = agg.dev, agg.s0
         rng = random.Random(seed)
         toxic = {k: rng.randrange(2, E.R) for k in ("alpha", "beta", "gamma", "delta", "t")}
-        key, vk = engine.groth16_setup_r1cs(agg.handle, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["t"])
+        key, vk = engine.groth16_setup_r1cs(agg.handle, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["t"], mode=EN.KEY_TABLES)
         try:
             q = engine.qap_info(agg.handle)
             n = int(q.domain_size)
@@ -295,15 +364,17 @@ def _prove_and_check(engine, oracle, tmp_path, logns, seed, python_pairing):
                 assert E.verify_proof(vk_pts, zi[1:], pr), "verify_proof rejects the aggregate proof"
         finally:
             engine.groth16_pk_free(key)
+        del pws, ws, h
+        _bare_and_sliced_keys_give_the_same_bytes(engine, agg, toxic, vk, r, s, got_p, slices)
     finally:
         agg.close()
 
 
 def test_one_proof_for_four_mixed_statements(engine, oracle, tmp_path):
     """(1024, 512, 1024, 1024): three runs, the 2^20 domain (6 + 5 + 5 + 4 stages)."""
-    _prove_and_check(engine, oracle, tmp_path, (10, 9, 10, 10), seed=20, python_pairing=True)
+    _prove_and_check(engine, oracle, tmp_path, (10, 9, 10, 10), seed=20, python_pairing=True, slices=(2, 3))
 
 
 def test_one_proof_for_sixteen_falcon1024_statements(engine, oracle, tmp_path):
     """The 2^22 domain (6 + 6 + 5 + 5 stages): 2.5 M variables, 4.2 M points of h_query, 53 GB of window tables."""
-    _prove_and_check(engine, oracle, tmp_path, (10,) * 16, seed=22, python_pairing=False)
+    _prove_and_check(engine, oracle, tmp_path, (10,) * 16, seed=22, python_pairing=False, slices=(4,))

@@ -34,9 +34,13 @@ def _run(engine, handle, scalars, montgomery, chunk=None):
     return out.cpu().numpy().view(np.uint64)
 
 
-@pytest.mark.parametrize("narrow", [False, True])
-def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle, narrow):
-    """Both pipelines (16-bit windows / 32,768 buckets; 8-bit windows / 128 buckets: frw_msm_g1_load_narrow)."""
+HANDLES = [(False, False), (True, False), (False, True), (True, True)]
+HANDLE_IDS = ["tables-16bit", "tables-8bit", "bare-16bit", "bare-8bit"]
+
+@pytest.mark.parametrize("narrow,bare", HANDLES, ids=HANDLE_IDS)
+def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle, narrow, bare):
+    """Both pipelines (16-bit windows / 32,768 buckets; 8-bit windows / 128 buckets: frw_msm_g1_load_narrow), over window tables and over
+    bare handles (the points only: frw_msm_g1_load_bare -- the sums then run window by window and end in Horner's rule)."""
     rng = random.Random(2026)
     n = 300
     ks = [rng.randrange(1, E.R) for _ in range(n)]
@@ -60,10 +64,11 @@ def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle
     ]
     vectors[0][3] = vectors[0][10]                                 # the duplicated base with the same scalar: doubling
     vectors[0][11] = vectors[0][4]                                 # the negated base with the same scalar: cancellation
-    handle = engine.msm_g1_load(bases, narrow=narrow)
+    handle = engine.msm_g1_load(bases, narrow=narrow, bare=bare)
     try:
         info = engine.msm_info(handle)
         assert info.num_points == n and (info.window_bits, info.num_windows) == ((8, 32) if narrow else (16, 16))
+        assert info.table_bytes == n * 112 * (1 if bare else info.num_windows) + (0 if bare or not narrow else (n + 7) // 8 * 255 * 112)
         canon = np.stack([T.ints_to_limbs(v) for v in vectors])
         mont = np.stack([T.ints_to_limbs([x * FR_R % E.R for x in v]) for v in vectors])
         want = [oracle.g1_msm(bases, T.ints_to_limbs([x % E.R for x in v]), 11).tolist() for v in vectors]
@@ -188,8 +193,8 @@ def test_fixed_base_multiples_of_the_generator_equal_the_oracle(engine, oracle):
     assert got[0].tolist() == [0] * 12 and got[1].tolist() == E.to_limbs(E.G1)
 
 
-@pytest.mark.parametrize("narrow", [False, True])
-def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine, oracle, narrow):
+@pytest.mark.parametrize("narrow,bare", HANDLES, ids=HANDLE_IDS)
+def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine, oracle, narrow, bare):
     """The witness-side sums of the prover (prover.rs calculate_coeff / l_aux_acc: MSM(a_query | b_g1_query | l_query,
     assignment)): the scalars are a Falcon-512 witness -- 91 % of them 0 or 1 -- over as many bases as the circuit has
     variables.  Ones are summed apart from the buckets; the result must be the CPU's, bit for bit, for genuine witnesses and
@@ -210,7 +215,7 @@ def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine,
     z = np.concatenate([z, np.zeros((2, n, 4), dtype=np.uint64)])
     z[batch, :, 0] = 1                                            # all ones
     z[batch + 1, 12345, 0] = 1                                    # a single one
-    handle = engine.msm_g1_load(bases, narrow=narrow)
+    handle = engine.msm_g1_load(bases, narrow=narrow, bare=bare)
     try:
         got = _run(engine, handle, z, 0)
         for i in range(z.shape[0]):
@@ -220,8 +225,8 @@ def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine,
         engine.msm_free(handle)
 
 
-@pytest.mark.parametrize("narrow", [False, True])
-def test_g2_fixed_base_and_msm_equal_python_integers(engine, narrow):
+@pytest.mark.parametrize("narrow,bare", HANDLES, ids=HANDLE_IDS)
+def test_g2_fixed_base_and_msm_equal_python_integers(engine, narrow, bare):
     """G2 (prover.rs: g2_b = MSM(b_g2_query, assignment) + ...): the generator's fixed-base multiples and a multi-scalar
     multiplication against oracle/bls12_381.py's Fq2 arithmetic in Python integers -- bases as multiples k_i G2 of the
     published generator, so that the expected sum is (sum s_i k_i) G2, one scalar multiplication; with the same degenerate
@@ -240,7 +245,7 @@ def test_g2_fixed_base_and_msm_equal_python_integers(engine, narrow):
                [rng.choice([0, 1, 1, rng.randrange(1 << 14), rng.randrange(1 << 146)]) for _ in range(n)]]
     vectors[0][3] = vectors[0][10]
     vectors[0][11] = vectors[0][4]
-    handle = engine.msm_g2_load(bases, narrow=narrow)
+    handle = engine.msm_g2_load(bases, narrow=narrow, bare=bare)
     try:
         import torch
         dev = torch.device("cuda:0")
@@ -259,5 +264,33 @@ def test_g2_fixed_base_and_msm_equal_python_integers(engine, narrow):
         import falcon_r1cs_amd as frw
         with pytest.raises(frw.FrwError):                          # a G2 table through the G1 entry point
             engine.msm_g1_dev(handle, 1, d_sc, n, 0, out, ws, ws.numel(), 0)
+    finally:
+        engine.msm_free(handle)
+
+
+@pytest.mark.parametrize("bare", [False, True], ids=["tables", "bare"])
+def test_one_digit_in_every_window_of_a_large_sum(engine, oracle, bare):
+    """More than 2^18 points (the finest split of the dense pipeline: a bucket of the mean size cut 16 ways) whose scalars are ALL the same
+    value with one digit in every window: ONE bucket takes all 16 n entries and is cut into 2^18 work items -- which a work item packed
+    as bucket | part << 15 could not number (round 4's ADVICE).  The bases are multiples k_i G of the generator, so the expected sum is
+    (k sum k_i) G: one scalar multiplication."""
+    rng = random.Random(99)
+    n = (1 << 18) + 1234
+    ks = [rng.randrange(1, E.R) for _ in range(n)]
+    bases = engine.g1_fixed_base(T.ints_to_limbs(ks))
+    for i in (0, 1, n - 1):
+        assert bases[i].tolist() == oracle.g1_scalar_mul(oracle.g1_generator(), ks[i]).tolist()
+    k = int("0002" * 16, 16)
+    ksum = sum(ks) % E.R
+    vectors = np.stack([T.ints_to_limbs([k] * n), T.ints_to_limbs([rng.randrange(E.R) if i % 4096 == 0 else k for i in range(n)])])
+    extra = sum((int.from_bytes(vectors[1][i].tobytes(), "little") - k) * ks[i] for i in range(0, n, 4096))
+    want = [oracle.g1_scalar_mul(oracle.g1_generator(), k * ksum % E.R).tolist(),
+            oracle.g1_scalar_mul(oracle.g1_generator(), (k * ksum + extra) % E.R).tolist()]
+    handle = engine.msm_g1_load(bases, bare=bare)
+    try:
+        # one signature at a time (the finest split: a chunk of one or two), then both in one chunk
+        got1 = [_run(engine, handle, vectors[i:i + 1], 0)[0].tolist() for i in range(2)]
+        assert got1 == want
+        assert [g.tolist() for g in _run(engine, handle, vectors, 0)] == want
     finally:
         engine.msm_free(handle)
