@@ -103,6 +103,7 @@ PROTOTYPES = {
     "frw_msm_g1_load_bare": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "frw_msm_g2_load_bare": (C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "frw_groth16_pk_load_opts": (C.c_int, [C.c_int, C.POINTER(Groth16PkDesc), C.POINTER(Groth16KeyOpts), C.POINTER(C.c_void_p)]),
+    "frw_groth16_pk_query": (C.c_void_p, [C.c_void_p, C.c_int]),
     "frw_groth16_pk_info": (C.c_int, [C.c_void_p, C.POINTER(Groth16PkInfoStruct)]),
     "frw_groth16_setup_r1cs_opts": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Groth16KeyOpts), C.POINTER(C.c_void_p), C.c_void_p]),
     "frw_groth16_prove_partial_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

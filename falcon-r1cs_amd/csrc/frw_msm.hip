@@ -2135,6 +2135,12 @@ extern "C" int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *d, f
     const frw_groth16_key_opts_t opts = {FRW_KEY_TABLES, 0, 1};                // (as before round 5: window tables, whatever the size)
     return frw_groth16_pk_load_opts(device, d, &opts, out);
 }
+extern "C" const frw_msm *frw_groth16_pk_query(const frw_groth16_pk *pk, int which)
+{
+    if (!pk) return nullptr;
+    return which == FRW_QUERY_H ? pk->h : which == FRW_QUERY_A ? pk->a : which == FRW_QUERY_B1 ? pk->b1 : which == FRW_QUERY_L ? pk->l
+         : which == FRW_QUERY_B2 ? pk->b2 : nullptr;
+}
 extern "C" int frw_groth16_pk_info(const frw_groth16_pk *pk, frw_groth16_pk_info_t *out)
 {
     if (!pk || !out) return FRW_E_INVALID_ARG;

@@ -530,6 +530,13 @@ class WitnessEngine:
         check(self._lib.frw_groth16_pk_info(pk, C.byref(info)), "frw_groth16_pk_info")
         return info
 
+    def groth16_pk_query(self, pk, which):
+        """One of the key's five tables (0: h_query, 1: a, 2: b_g1, 3: l, 4: b_g2) as a BORROWED msm handle (never msm_free it)."""
+        h = self._lib.frw_groth16_pk_query(pk, int(which))
+        if not h:
+            raise FrwError(-1, "frw_groth16_pk_query", "no such query")
+        return C.c_void_p(h)
+
     def groth16_prove_partial_dev(self, pk, r1cs, batch, d_wit, d_inst, rs, d_partial, d_workspace, workspace_bytes, d_num_unsatisfied=None, stream=0):
         """One rank's partial sums of a key in slices: d_partial int64[batch, 72] = A | B1' | L | H | B (ark-ff's affine bytes)."""
         rs = np.ascontiguousarray(rs, dtype=np.uint64).reshape(batch, 2, 4)

@@ -472,6 +472,15 @@ typedef struct {
 } frw_groth16_pk_info_t;
 int frw_groth16_pk_load_opts(int device, const frw_groth16_pk_desc_t *desc, const frw_groth16_key_opts_t *opts, frw_groth16_pk **out);
 int frw_groth16_pk_info(const frw_groth16_pk *pk, frw_groth16_pk_info_t *out);
+/* one of the key's five tables as the frw_msm handle it is (borrowed: it goes with the key; never frw_msm_free it) -- for sums over a
+ * single query, e.g. frw_groth16_msm_h_dev(frw_groth16_pk_query(pk, FRW_QUERY_H), ...) checked against (h(t) zt / delta) G1.  The
+ * witness-side tables have num_instance + num_witness + 3 rows (see frw_groth16_key_opts_t); a slice of a key is a slice here too. */
+#define FRW_QUERY_H   0
+#define FRW_QUERY_A   1
+#define FRW_QUERY_B1  2
+#define FRW_QUERY_L   3
+#define FRW_QUERY_B2  4
+const frw_msm *frw_groth16_pk_query(const frw_groth16_pk *pk, int which);
 /* ark-groth16 0.3.0 generator.rs generate_parameters for one of the Falcon circuits, with the toxic waste GIVEN:
  * toxic = uint64_t[5][4], canonical: alpha, beta, gamma, delta and the evaluation point t (circuit_specific_setup draws them
  * from its rng, and random generators of G1 / G2; here the published generators are used).  The QAP is evaluated at t on the

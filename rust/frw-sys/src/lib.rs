@@ -245,6 +245,7 @@ extern "C" {
     pub fn frw_groth16_pk_load_opts(device: c_int, desc: *const frw_groth16_pk_desc_t, opts: *const frw_groth16_key_opts_t,
                                     out: *mut *mut frw_groth16_pk) -> c_int;
     pub fn frw_groth16_pk_info(pk: *const frw_groth16_pk, out: *mut frw_groth16_pk_info_t) -> c_int;
+    pub fn frw_groth16_pk_query(pk: *const frw_groth16_pk, which: c_int) -> *const frw_msm;
     pub fn frw_groth16_setup_r1cs_opts(r: *const frw_r1cs, toxic: *const u64, opts: *const frw_groth16_key_opts_t,
                                        pk_out: *mut *mut frw_groth16_pk, vk_out: *mut u64) -> c_int;
     pub fn frw_groth16_prove_partial_dev(pk: *const frw_groth16_pk, r: *const frw_r1cs, batch: usize, d_witness: *const u64,

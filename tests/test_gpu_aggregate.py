@@ -378,3 +378,99 @@ def test_one_proof_for_four_mixed_statements(engine, oracle, tmp_path):
 def test_one_proof_for_sixteen_falcon1024_statements(engine, oracle, tmp_path):
     """The 2^22 domain (6 + 6 + 5 + 5 stages): 2.5 M variables, 4.2 M points of h_query, 53 GB of window tables."""
     _prove_and_check(engine, oracle, tmp_path, (10,) * 16, seed=22, python_pairing=False, slices=(4,))
+
+
+# ---- BASELINE configs[4] as written: ONE proof for 1,024 mixed statements (and the sizes on the way there) -------------------------------
+BENCH_SEED = 0x46414C434F4E31                                      # bench.py SEED: the mix its aggregate_1024_mixed line draws
+
+
+def configs4_mix(total=1024):
+    rng = random.Random(BENCH_SEED)
+    return [rng.choice([9, 10]) for _ in range(total)]
+
+
+def _prove_large_and_check_by_properties(engine, oracle, logns, seed, log_domain, vouch_for_vk):
+    """Statements whose vectors no Python integer arithmetic can visit (10^7 .. 10^8 elements): what the domain offers instead of an
+    element-by-element oracle --
+      * the witness satisfies the system row by row (0 violated rows, decided on the device) and deg h <= n - 2;
+      * h_acc = sum h_i h_query[i], the 2^24 / 2^27-point sum through the bare handle, equals (h(t) zt / delta) G1: ONE fixed-base
+        multiple of a field element -- h(t) by Horner's rule on the device (frw_diag_poly_eval_dev), the multiple by the oracle on the CPU;
+      * the proof is accepted by the product's pairing verifier for the statement's public inputs (e(A, B) = e(alpha, beta) e(x, gamma)
+        e(C, delta) holds only if ALL five sums are right) and rejected with one input of the LAST statement changed.
+    The same code paths are held to the exponent prover byte for byte at 2^20 and 2^22 above."""
+    import torch
+    import falcon_r1cs_amd as frw
+    from falcon_r1cs_amd import engine as EN
+    torch.cuda.empty_cache()
+    agg = Aggregate(engine, logns, seed=seed)
+    try:
+        dev, s0 = agg.dev, agg.s0
+        assert int(agg.info.log_domain_size) == log_domain and agg.info.witness_map_on_device
+        n = 1 << log_domain
+        assert n >= agg.nc + agg.ni > n // 2
+        rng = random.Random(seed)
+        toxic = {k: rng.randrange(2, E.R) for k in ("alpha", "beta", "gamma", "delta", "t")}
+        key, vk = engine.groth16_setup_r1cs(agg.handle, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["t"])
+        try:
+            info = engine.groth16_pk_info(key)
+            assert info.mode == EN.KEY_BARE, "FRW_KEY_AUTO keeps window tables for a statement of this size"
+            nv = agg.ni + agg.nw
+            assert info.key_bytes == 3 * (nv + 3) * 112 + (nv + 3) * 224 + (n - 1) * 112
+            r, s = rng.randrange(E.R), rng.randrange(E.R)
+            lim = T.ints_to_limbs
+            ws_bytes = engine.groth16_workspace_bytes(key, agg.handle, 1)
+            pws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            proof = torch.full((1, 48), -1, dtype=torch.int64, device=dev)
+            bad = torch.full((1,), -1, dtype=torch.int32, device=dev)
+            engine.groth16_prove_dev(key, agg.handle, 1, agg.wit, agg.inst, np.array([lim([r, s])]), proof, pws, ws_bytes, bad, s0)
+            torch.cuda.synchronize()
+            assert bad.tolist() == [0], "violated rows"
+            got_p = proof.cpu().numpy().view(np.uint64)[0]
+            # h on its own (the prover's workspace lends the memory), its top coefficient, h(t), and the sum over h_query
+            q = engine.qap_info(agg.handle)
+            assert int(q.domain_size) == n and int(q.workspace_bytes_per_signature) <= ws_bytes
+            h = torch.empty((1, n, 4), dtype=torch.int64, device=dev)
+            engine.qap_witness_map_dev(agg.handle, 1, agg.wit, agg.inst, h, pws, ws_bytes, bad, s0)
+            torch.cuda.synchronize()
+            assert bad.tolist() == [0] and int(h[0, -1].abs().sum()) == 0, "deg h must be <= n - 2"
+            h_t = engine.diag_poly_eval_dev(h, n, toxic["t"])
+            hq = engine.groth16_pk_query(key, 0)
+            mi = engine.msm_info(hq)
+            assert mi.num_points == n - 1 and mi.table_bytes == (n - 1) * 112
+            assert int(mi.workspace_bytes_per_signature) <= ws_bytes
+            hacc = torch.full((1, 12), -1, dtype=torch.int64, device=dev)
+            engine.groth16_msm_h_dev(hq, 1, h, n, hacc, pws, ws_bytes, s0)
+            torch.cuda.synchronize()
+            zt = (pow(toxic["t"], n, E.R) - 1) % E.R
+            want = oracle.g1_scalar_mul(oracle.g1_generator(), h_t * zt * pow(toxic["delta"], -1, E.R) % E.R)
+            assert hacc.cpu().numpy().view(np.uint64)[0].tolist() == want.tolist(), "h_acc differs from (h(t) zt / delta) G1"
+            del h, pws
+        finally:
+            engine.groth16_pk_free(key)
+        gen = oracle.g1_generator()
+        assert vk["alpha_g1"].tolist() == oracle.g1_scalar_mul(gen, toxic["alpha"]).tolist()
+        assert vk["delta_g2"].tolist() == E.g2_to_limbs(E.g2_mul(E.G2, toxic["delta"]))
+        ver = frw.Groth16Verifier(vk, points_are_checked=vouch_for_vk)
+        inst_h = agg.inst.cpu().numpy().view(np.uint64)
+        assert ver.verify(inst_h, got_p[None]).tolist() == [1], "frw_groth16_verify rejects the aggregate proof"
+        other = inst_h.copy()
+        other[0, agg.ni - 3, 0] ^= np.uint64(1)                          # a public input of the LAST statement
+        assert ver.verify(other, got_p[None]).tolist() == [0]
+        ver.close()
+    finally:
+        agg.close()
+        torch.cuda.empty_cache()
+
+
+def test_one_proof_for_sixty_four_falcon1024_statements(engine, oracle):
+    """The 2^24 domain (6 + 6 + 6 + 6 stages): 10.2 M variables -- past what window tables hold (FRW_KEY_AUTO: bare handles, 7 GB of points
+    instead of 200 GB of tables), the key made on the device end to end."""
+    _prove_large_and_check_by_properties(engine, oracle, (10,) * 64, seed=64, log_domain=24, vouch_for_vk=False)
+
+
+def test_configs4_one_proof_for_1024_mixed_statements(engine, oracle):
+    """BASELINE configs[4] as written: ONE Groth16 proof for 1,024 mixed statements -- the mix bench.py draws (513 Falcon-512 + 511
+    Falcon-1024), C + I = 126.6 M: the 2^27 domain (6 + 6 + 5 + 5 + 5 stages), 121.9 M variables, 83 GB of key."""
+    logns = configs4_mix()
+    assert (logns.count(9), logns.count(10)) == (513, 511)
+    _prove_large_and_check_by_properties(engine, oracle, logns, seed=1024, log_domain=27, vouch_for_vk=True)
