@@ -375,6 +375,32 @@ def qap_products_per_map(log_n):
     return int(n * (2 * ifft + 2 * fft + 2 * (ifft + 1)))
 
 
+def qap_pass_stages(log_n):
+    """frw_device.h qap_pass_schedule: the stages of the passes of a 2^log_n-point transform, lowest bits first."""
+    k = (log_n + 5) // 6
+    t = [6] * k
+    deficit = 6 * k - log_n
+    for _ in range(2):
+        for i in range(k - 1, 0, -1):
+            if deficit:
+                t[i] -= 1
+                deficit -= 1
+    assert deficit == 0
+    return t
+
+
+def qap_products_per_map_any(log_n):
+    """qap_products_per_map for any domain (aggregate statements: four or five passes of six, five or four stages): a pass of T stages
+    does 5 twiddle products per 8 elements in its three low stages and 4 per further stage (17 / 13 / 9 for T = 6 / 5 / 4), plus 8 by
+    the per-index factor unless it stores plainly (the last pass of a forward transform)."""
+    n = 1 << log_n
+    tw = {6: 17, 5: 13, 4: 9}
+    t = qap_pass_stages(log_n)
+    ifft = sum((tw[x] + 8) / 8.0 for x in t)
+    fft = sum((tw[x] + 8) / 8.0 for x in t[1:]) + tw[t[0]] / 8.0
+    return int(n * (2 * ifft + 2 * fft + 2 * (ifft + 1)))
+
+
 def qap_products_per_map_seven(log_n):
     """ark-groth16's schedule as written: seven transforms (3 + 3 + 1 arrays), plus a(X) b(X) - c(X) once per index."""
     n = 1 << log_n
@@ -669,27 +695,17 @@ def prove_leg(eng, handle, dev, cdev, d_wit, d_inst, held, L, logn, world, rank,
     return out
 
 
-def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True):
-    """BASELINE configs[4] as written: ONE Groth16 proof for an aggregate statement -- FalconNTTVerificationCircuit once per
-    (pk, msg, sig) on one constraint system (falcon_ntt.rs:26-123 per statement; the flow of examples/pok_sig.rs:30-47 on the
-    whole).  The statements' witnesses come from the witness kernel (one launch per parameter set), frw_aggregate_assign_dev lays
-    them out as the aggregate's assignment, frw_groth16_setup_r1cs makes the key, and what is timed is frw_groth16_prove_dev on
-    the aggregate handle: the witness map over the aggregate's domain, five sums, one proof.  The proof is verified
-    (frw_groth16_verify, host pairing; also against a statement with one public input of the LAST statement changed), and
-    h_acc is checked against the MSM-free value (h(t) zt / delta) G1.  `separate`: the per-signature prover's line
-    (time_groth16) for the break-even against k separate proofs."""
-    import random
-    rng = random.Random(SEED ^ len(logns))
-    stream = torch.cuda.current_stream()
-    s0 = stream.cuda_stream
+def aggregate_statements(eng, dev, logns, first_index=0):
+    """The statements of an aggregate on the device: per parameter set ONE launch of the witness kernel (synthetic triples, counter-based:
+    the same on every rank), then the aggregate's handle and its own assignment vectors (frw_aggregate_assign_dev)."""
+    s0 = torch.cuda.current_stream().cuda_stream
     batches = {}
-    t_wit = time.perf_counter()
     for g in (9, 10):
         cnt = list(logns).count(g)
         if not cnt:
             continue
         L = frw.layout(g)
-        sig, pk, hm = frw.synth_triples(g, cnt, SEED, (1 << 43) + (g << 20))
+        sig, pk, hm = frw.synth_triples(g, cnt, SEED, (1 << 43) + (g << 20) + first_index)
         d = [torch.from_numpy(a.view(np.int16)).to(dev) for a in (sig, pk, hm)]
         wit = torch.empty((cnt, L.num_witness, 4), dtype=torch.int64, device=dev)
         inst = torch.empty((cnt, L.num_instance, 4), dtype=torch.int64, device=dev)
@@ -698,6 +714,75 @@ def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True):
         torch.cuda.synchronize()
         assert not st.any()
         batches[g] = (wit, inst)
+    return batches
+
+
+def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s):
+    """groth16_roofline for one proof of an aggregate statement: the point additions of the four witness-side sums counted from ONE
+    statement of each parameter set (every statement of a set has the same structure: a few hundred additions either way) times the
+    number of such statements; a key of window tables sums the ones of eight points in one addition (byte-pattern tables) up to 2^18
+    points, a key of bare handles adds every one; the sum over h_query is 16 (n - 1) mixed additions either way, its buckets' folds
+    once per call (tables) or once per window (bare: 16 x), plus Horner's 255 operations per sum."""
+    rates = eng.valu_rates()
+    (mm, mo), (am, ao) = point_op_instructions(MADD_OPS), point_op_instructions(ADD_OPS)
+    n = 1 << log_n
+    g1_madds = g2_madds = 0
+    for g in (9, 10):
+        cnt = list(logns).count(g)
+        if not cnt:
+            continue
+        wit, inst = batches[g]
+        inst_row, wit_row = inst[0, 1:].cpu().numpy().view(np.uint64), wit[0].cpu().numpy().view(np.uint64)
+        ones, digits, _ = witness_side_additions(inst_row, wit_row)
+        ones_w, digits_w, _ = witness_side_additions(inst_row[:0], wit_row)
+        g1_madds += cnt * (2 * (ones + digits) + (ones_w + digits_w))
+        g2_madds += cnt * (ones + digits)
+    bare = key_mode == frw.KEY_BARE
+    windows_h, windows_w = (16, 32) if bare else (1, 1)
+    G2_FACTOR = 3
+    h_madds, h_adds = 16 * (n - 1), windows_h * 2 * 32768 + (255 if bare else 0)
+    g1_adds = 3 * (windows_w * (2 * 128 + 64) + (255 if bare else 0))
+    g2_adds = windows_w * (2 * 128 + 64) + (255 if bare else 0)
+    madds = h_madds + g1_madds + G2_FACTOR * g2_madds
+    adds = h_adds + g1_adds + G2_FACTOR * g2_adds
+    fq_products = madds * 10 + adds * 14
+    fr_products = qap_products_per_map_any(log_n)
+    wave_us = ((madds * mm + adds * am) / rates["v_mad_u64_u32"] + (madds * mo + adds * ao) / rates["v_add_u32"]
+               + fr_products * (F29_MUL_MAD64 / rates["v_mad_u64_u32"] + F29_MUL_OTHER / rates["v_add_u32"]))
+    peak_proofs = rates["simds"] * 64 / wave_us * 1e6
+    total = fq_products + fr_products
+    return {"bound": "valu_issue", "unit": "G field products/s (Fq products of the five sums + Fr products of the witness map)",
+            "achieved": round(total * proofs_per_s / 1e9, 2), "peak": round(total * peak_proofs / 1e9, 2),
+            "frac": round(proofs_per_s / peak_proofs, 4),
+            "per_proof": {"fq_products": fq_products, "fr_products": fr_products,
+                          "mixed_additions": {"h_query": h_madds, "a_query + b_g1_query + l_query": g1_madds, "b_g2_query (Fq2)": g2_madds},
+                          "g2_priced_as_g1_times": G2_FACTOR, "transform_passes": qap_pass_stages(log_n)},
+            "peak_is": "%d SIMDs x 64 lanes issuing only the instructions of these products (an Fq product %d multiplies + %d others, an Fr "
+                       "product %d + %d; multiplies at %.1f, the others at %.1f wave-instructions/SIMD/us, measured in this process)"
+                       % (rates["simds"], FQ_MUL_MULTIPLY, FQ_MUL_OTHER, F29_MUL_MAD64, F29_MUL_OTHER, rates["v_mad_u64_u32"], rates["v_add_u32"]),
+            "kernel": "frw_groth16_prove_dev on the aggregate handle: ntt_pass_kernel + r1cs_eval (witness map), msm_bucket_kernel (h_query, %s), "
+                      "nmsm_bucket_kernel / nmsm_ones_kernel (witness-side sums), folds" % ("sixteen window rows over the bare points" if bare else "window tables")}
+
+
+def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True, world=1, rank=0, cdev=None):
+    """BASELINE configs[4] as written: ONE Groth16 proof for an aggregate statement -- FalconNTTVerificationCircuit once per
+    (pk, msg, sig) on one constraint system (falcon_ntt.rs:26-123 per statement; the flow of examples/pok_sig.rs:30-47 on the
+    whole).  The statements' witnesses come from the witness kernel (one launch per parameter set), frw_aggregate_assign_dev lays
+    them out as the aggregate's assignment, frw_groth16_setup_r1cs_opts makes the key ON THE DEVICE (window tables while they fit,
+    bare handles -- the points only -- beyond: the 1,024 statements of configs[4] are 121.9 M variables on the 2^27 domain, 83 GB of
+    points), and what is timed is the proof: the witness map over the aggregate's domain, five sums, one proof.
+    world > 1: the key in `world` slices, one per rank -- every rank proves the WHOLE statement's witness map and its slices of the five
+    sums (frw_groth16_prove_partial_dev), ONE all-gather of 576 bytes per rank over the process group, frw_groth16_prove_combine_dev
+    on every rank; the time of a proof is then the slowest rank's (strong scaling: the statement is fixed).
+    The proof is verified (frw_groth16_verify, host pairing; also against a statement with one public input of the LAST statement
+    changed); h_acc is checked against the MSM-free value (h(t) zt / delta) G1 (h(t) by Horner's rule on the device).  `separate`: the
+    per-signature prover's line (time_groth16) for the break-even against k separate proofs."""
+    import random
+    rng = random.Random(SEED ^ len(logns))
+    stream = torch.cuda.current_stream()
+    s0 = stream.cuda_stream
+    t_wit = time.perf_counter()
+    batches = aggregate_statements(eng, dev, logns)
     handle = eng.r1cs_load_aggregate(list(logns))
     info = eng.r1cs_info(handle)
     ni, nw, nc, n = int(info.num_instance), int(info.num_witness), int(info.num_constraints), 1 << int(info.log_domain_size)
@@ -713,71 +798,128 @@ def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True):
     load_s = time.perf_counter() - t_wit
     toxic = [rng.randrange(2, R_FR) for _ in range(5)]
     t0 = time.perf_counter()
-    pk_h, vk = eng.groth16_setup_r1cs(handle, *toxic)
+    pk_h, vk = eng.groth16_setup_r1cs(handle, *toxic, mode=frw.KEY_BARE if world > 1 else frw.KEY_AUTO, rank=rank, world=world, want_vk=(rank == 0))
+    torch.cuda.synchronize()
     key_s = time.perf_counter() - t0
+    pinfo = eng.groth16_pk_info(pk_h)
+    key_mode = int(pinfo.mode)
     ws_bytes = eng.groth16_workspace_bytes(pk_h, handle, 1)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     proof = torch.empty((1, 48), dtype=torch.int64, device=dev)
     bad = torch.empty(1, dtype=torch.int32, device=dev)
     lim = lambda ks: np.frombuffer(b"".join(int(k).to_bytes(32, "little") for k in ks), dtype=np.uint64).reshape(-1, 4)
     rs = np.stack([lim([rng.randrange(R_FR), rng.randrange(R_FR)])])
-    run = lambda: eng.groth16_prove_dev(pk_h, handle, 1, d_wit, d_inst, rs, proof, ws, ws_bytes, bad, s0)
+    if world > 1:
+        part = torch.empty((1, frw.GROTH16_PARTIAL_WORDS), dtype=torch.int64, device=dev)
+        cws = torch.empty(frw.GROTH16_COMBINE_WORKSPACE, dtype=torch.uint8, device=dev)
+
+        def run():
+            eng.groth16_prove_partial_dev(pk_h, handle, 1, d_wit, d_inst, rs, part, ws, ws_bytes, bad, s0)
+            if dist.get_backend() != "nccl":
+                torch.cuda.synchronize()
+            parts = sharding.all_gather_bytes(part[0], world, rank)           # 576 bytes per rank: RCCL over xGMI (gloo in the rehearsals)
+            eng.groth16_prove_combine_dev(pk_h, world, parts, rs[0], proof, cws, cws.numel(), s0)
+    else:
+        run = lambda: eng.groth16_prove_dev(pk_h, handle, 1, d_wit, d_inst, rs, proof, ws, ws_bytes, bad, s0)
     run()
     torch.cuda.synchronize()
+    sharding.barrier()
+    t0 = time.perf_counter()
     e0.record(stream)
     for _ in range(reps):
         run()
     e1.record(stream)
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    sharding.barrier()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / reps
+    ms = e0.elapsed_time(e1) / reps if world == 1 else sharding.max_over_ranks(wall_ms, cdev)
     assert bad.tolist() == [0], "the aggregate's witness violates its constraint system"
     # the witness map on its own (timed), and h_acc against the value no MSM is needed for
     q = eng.qap_info(handle)
-    qws = torch.empty(int(q.workspace_bytes_per_signature), dtype=torch.uint8, device=dev)
+    assert int(q.workspace_bytes_per_signature) <= ws_bytes
     h = torch.empty((1, n, 4), dtype=torch.int64, device=dev)
-    eng.qap_witness_map_dev(handle, 1, d_wit, d_inst, h, qws, qws.numel(), None, s0)
+    eng.qap_witness_map_dev(handle, 1, d_wit, d_inst, h, ws, ws_bytes, None, s0)
     torch.cuda.synchronize()
+    map_reps = max(1, min(reps, 5))
     e0.record(stream)
-    for _ in range(reps):
-        eng.qap_witness_map_dev(handle, 1, d_wit, d_inst, h, qws, qws.numel(), None, s0)
+    for _ in range(map_reps):
+        eng.qap_witness_map_dev(handle, 1, d_wit, d_inst, h, ws, ws_bytes, None, s0)
     e1.record(stream)
     torch.cuda.synchronize()
-    map_ms = e0.elapsed_time(e1) / reps
+    map_ms = e0.elapsed_time(e1) / map_reps
     assert int(h[0, -1].abs().sum()) == 0, "deg h must be <= n - 2 for a satisfied system"
+    h_sum_ms = None
+    if check_h and world == 1:
+        hq = eng.groth16_pk_query(pk_h, 0)
+        assert int(eng.msm_info(hq).workspace_bytes_per_signature) <= ws_bytes
+        hacc = torch.empty((1, 12), dtype=torch.int64, device=dev)
+        eng.groth16_msm_h_dev(hq, 1, h, n, hacc, ws, ws_bytes, s0)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        eng.groth16_msm_h_dev(hq, 1, h, n, hacc, ws, ws_bytes, s0)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        h_sum_ms = e0.elapsed_time(e1)
+        t, delta = toxic[4], toxic[3]
+        h_t = eng.diag_poly_eval_dev(h, n, t)
+        c = (pow(t, n, R_FR) - 1) * pow(delta, -1, R_FR) % R_FR
+        want = eng.g1_fixed_base(np.frombuffer((h_t * c % R_FR).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4))[0]
+        assert np.array_equal(hacc[0].cpu().numpy().view(np.uint64), want), "h_acc differs from (h(t) zt / delta) G1"
+    rates = aggregate_roofline(eng, logns, int(info.log_domain_size), batches, key_mode, 1e3 / ms) if rank == 0 else None
+    hbm_in_use = torch.cuda.mem_get_info(dev)
     eng.groth16_pk_free(pk_h)
-    del ws, qws
+    del ws, h
     k = len(logns)
-    verifier = frw.Groth16Verifier(vk)
     inst_h = d_inst.cpu().numpy().view(np.uint64)
     proof_h = proof.cpu().numpy().view(np.uint64)
-    t0 = time.perf_counter()
-    ok = verifier.verify(inst_h, proof_h).tolist()
-    verify_s = time.perf_counter() - t0
-    assert ok == [1], "frw_groth16_verify rejects the aggregate proof"
-    other = inst_h.copy()
-    other[0, ni - 3, 0] ^= np.uint64(1)
-    assert verifier.verify(other, proof_h).tolist() == [0], "the aggregate proof verifies for another statement"
-    verifier.close()
+    verify_s = None
+    if world > 1:
+        # every rank must hold the same 384 bytes
+        dig = torch.from_numpy(proof_h.view(np.int64).copy()).reshape(-1).to(cdev)
+        every = sharding.gather_per_signature(dig, 48 * world, rank, world).reshape(world, 48)
+        assert bool((every == every[0]).all()), "the ranks' combined proofs differ"
+    if rank == 0:
+        verifier = frw.Groth16Verifier(vk, points_are_checked=key_mode == frw.KEY_BARE)      # (a key made here a moment ago: 1.57 M points of gamma_abc_g1 for 1,024 statements)
+        t0 = time.perf_counter()
+        ok = verifier.verify(inst_h, proof_h).tolist()
+        verify_s = time.perf_counter() - t0
+        assert ok == [1], "frw_groth16_verify rejects the aggregate proof"
+        other = inst_h.copy()
+        other[0, ni - 3, 0] ^= np.uint64(1)
+        assert verifier.verify(other, proof_h).tolist() == [0], "the aggregate proof verifies for another statement"
+        verifier.close()
     eng.r1cs_free(handle)
+    if rank != 0:
+        return {"ms_per_proof": round(ms, 3)}
+    plan = sharding.sharded_aggregate_plan(world, rank, list(logns))
     out = {"workload": "ONE Groth16 proof for %d Falcon statements (%d x Falcon-512, %d x Falcon-1024) on one constraint system: "
                        "I = %d, W = %d, C = %d, QAP domain 2^%d" % (k, list(logns).count(9), list(logns).count(10), ni, nw, nc,
                                                                   int(info.log_domain_size)),
            "ms_per_proof": round(ms, 3), "signatures_per_s": round(k / (ms * 1e-3), 1), "calls_timed": reps,
            "witness_map_ms": round(map_ms, 3), "assignment_ms": round(assign_ms, 3),
+           "h_query_sum_alone_ms": None if h_sum_ms is None else round(h_sum_ms, 3),
            "proof_bytes": {"this_aggregate": 48 * 8, "k_separate_proofs": k * 48 * 8,
                            "note": "uncompressed ark-ff limbs (A 96 B, B 192 B, C 96 B); 192 B compressed either way"},
-           "proving_key": {"points_g1": 3 * (ni + nw) - ni + n - 1 + 3, "points_g2": ni + nw + 2, "frw_groth16_setup_r1cs_s": round(key_s, 2)},
+           "proving_key": {"kind": "bare handles (the points only)" if key_mode == frw.KEY_BARE else "window tables",
+                           "made": "on the device (frw_groth16_setup_r1cs_opts)", "slices": world, "bytes_this_rank": int(pinfo.key_bytes),
+                           "rows_this_rank": {"witness_side_tables": [int(pinfo.z_lo), int(pinfo.z_hi)], "h_query": [int(pinfo.h_lo), int(pinfo.h_hi)]},
+                           "points_g1": 3 * (ni + nw) - ni + n - 1 + 3, "points_g2": ni + nw + 2, "setup_s": round(key_s, 2)},
+           "statements_and_handle_s": round(load_s, 2),
            "workspace_bytes": ws_bytes,
+           "hbm": {"plan_bytes_leg": plan["hbm_plan_bytes"] if key_mode == frw.KEY_BARE else None, "plan_limit_bytes": plan["hbm_limit_bytes"],
+                   "device_bytes_in_use_while_proving": int(hbm_in_use[1] - hbm_in_use[0])},
            "verify": {"seconds": round(verify_s, 4), "public_inputs": ni - 1, "pairings": 3,
-                      "what": "frw_groth16_verify, one host thread: prepare_inputs over %d public inputs + 3 Miller loops + 1 final "
-                              "exponentiation" % (ni - 1)},
-           "checked": "constraint system satisfied (0 violated rows of %d); deg h <= n - 2; proof accepted by frw_groth16_verify for its "
+                      "what": "frw_groth16_verify: prepare_inputs over %d public inputs (a few host threads beyond 16,384) + 3 Miller loops + "
+                              "1 final exponentiation" % (ni - 1)},
+           "roofline": rates,
+           "checked": "constraint system satisfied (0 violated rows of %d); deg h <= n - 2; %sproof accepted by frw_groth16_verify for its "
                       "%d public inputs and rejected with one input of the last statement changed; bit-exactness of (A, B, C) against the "
-                      "prover restated in the exponent: tests/test_gpu_aggregate.py" % (nc, ni - 1)}
-    out["configs4_on_one_gpu"] = {"signatures": 1024, "aggregates_of_%d" % k: -(-1024 // k), "seconds": round(-(-1024 // k) * ms * 1e-3, 3),
-                                  "note": "BASELINE configs[4]'s 1,024 signatures as aggregates of this size, one after the other on ONE GPU (the 2^28 "
-                                          "domain of a single 1,024-statement proof is not one GPU's: DESIGN 5.7); on a node the aggregates shard "
-                                          "over the GPUs (bench.py --gpus N: scaling_curves.prove.aggregate)"}
+                      "prover restated in the exponent (2^18 - 2^22, window tables == bare handles == keys in slices): tests/test_gpu_aggregate.py"
+                      % (nc, "h_acc == (h(t) zt / delta) G1; " if h_sum_ms is not None else "", ni - 1)}
+    if world > 1:
+        out["sharding"] = ("the key in %d slices by row range (every query); every rank: the whole witness map + its slices of the five sums; ONE "
+                           "all-gather of 576 bytes per rank (%s); the combination on every rank; all ranks' proofs byte-identical" % (world, dist.get_backend()))
+        out["scaling"] = "strong (one statement whatever the number of ranks)"
     if separate is not None and k and all(g == 10 for g in logns):
         per = separate["proofs_per_s"]
         out["against_k_separate_proofs"] = {
@@ -789,6 +931,92 @@ def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True):
             "break_even": "one proof instead of %d: %dx fewer proof bytes and pairings for %.2fx the proving time of %d separate proofs made 64 "
                           "per call" % (k, k, ms / (k / per * 1e3), k)}
     return out
+
+
+def time_configs4_as_aggregates_of_16(eng, dev):
+    """BASELINE configs[4]'s 1,024 mixed signatures proved FOR REAL as 64 proofs of 16 statements each, one after the other on one GPU --
+    what round 4's bench line gave as a multiplication.  The same mix as `aggregate_proof_1024_mixed` (513 Falcon-512 + 511 Falcon-1024),
+    grouped by parameter set so that three keys serve all 64 aggregates: 32 x (16 Falcon-512), 31 x (16 Falcon-1024) and the 16 left over
+    (1 Falcon-512 + 15 Falcon-1024).  Timed: assignment + proof of all 64, back to back (keys made before; witnesses resident); every
+    proof verified afterwards (frw_groth16_verify, one proof per host thread)."""
+    import random
+    rng = random.Random(SEED ^ 0xC4)
+    stream = torch.cuda.current_stream()
+    s0 = stream.cuda_stream
+    mix = sharding.aggregate_mix(1024)
+    n9, n10 = mix.count(9), mix.count(10)
+    batches = aggregate_statements(eng, dev, mix)
+    shapes = [((9,) * 16, n9 // 16), ((10,) * 16, n10 // 16), ((9,) * (n9 % 16) + (10,) * (n10 % 16), 1 if (n9 % 16 + n10 % 16) else 0)]
+    assert sum(len(l) * c for l, c in shapes) == 1024 and len(shapes[2][0]) in (0, 16)
+    lim = lambda ks: np.frombuffer(b"".join(int(k).to_bytes(32, "little") for k in ks), dtype=np.uint64).reshape(-1, 4)
+    keys, t_keys = [], time.perf_counter()
+    for logns, count in shapes:
+        if not count:
+            continue
+        handle = eng.r1cs_load_aggregate(list(logns))
+        info = eng.r1cs_info(handle)
+        pk_h, vk = eng.groth16_setup_r1cs(handle, *[rng.randrange(2, R_FR) for _ in range(5)])
+        ws_bytes = eng.groth16_workspace_bytes(pk_h, handle, 1)
+        keys.append({"logns": logns, "count": count, "handle": handle, "pk": pk_h, "vk": vk, "ws_bytes": ws_bytes,
+                     "ni": int(info.num_instance), "nw": int(info.num_witness)})
+    torch.cuda.synchronize()
+    key_s = time.perf_counter() - t_keys
+    ws = torch.empty(max(k["ws_bytes"] for k in keys), dtype=torch.uint8, device=dev)
+    total = sum(k["count"] for k in keys)
+    proofs = torch.empty((total, 48), dtype=torch.int64, device=dev)
+    bad = torch.full((total,), -1, dtype=torch.int32, device=dev)
+    d_wit = [torch.empty((k["count"], k["nw"], 4), dtype=torch.int64, device=dev) for k in keys]
+    d_inst = [torch.empty((k["count"], k["ni"], 4), dtype=torch.int64, device=dev) for k in keys]
+    rs = np.stack([lim([rng.randrange(R_FR), rng.randrange(R_FR)]) for _ in range(total)])
+    L9, L10 = frw.layout(9), frw.layout(10)
+
+    def all_of_them():
+        used, at = {9: 0, 10: 0}, 0
+        for ki, k in enumerate(keys):
+            c9, c10 = k["logns"].count(9), k["logns"].count(10)
+            for j in range(k["count"]):
+                w9 = batches[9][0][used[9]:] if c9 else None
+                i9 = batches[9][1][used[9]:] if c9 else None
+                w10 = batches[10][0][used[10]:] if c10 else None
+                i10 = batches[10][1][used[10]:] if c10 else None
+                eng.aggregate_assign_dev(k["handle"], w9, i9, w10, i10, d_wit[ki][j:j + 1], d_inst[ki][j:j + 1], s0)
+                eng.groth16_prove_dev(k["pk"], k["handle"], 1, d_wit[ki][j:j + 1], d_inst[ki][j:j + 1], rs[at:at + 1], proofs[at:at + 1], ws,
+                                      k["ws_bytes"], bad[at:at + 1], s0)
+                used[9] += c9
+                used[10] += c10
+                at += 1
+        assert used == {9: n9, 10: n10} and at == total
+    all_of_them()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    all_of_them()
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    assert bad.tolist() == [0] * total, "an aggregate's witness violates its constraint system"
+    proofs_h = proofs.cpu().numpy().view(np.uint64)
+    t0 = time.perf_counter()
+    at = 0
+    for ki, k in enumerate(keys):
+        ver = frw.Groth16Verifier(k["vk"])
+        inst_h = d_inst[ki].cpu().numpy().view(np.uint64)
+        ok = ver.verify(inst_h, proofs_h[at:at + k["count"]]).tolist()
+        assert ok == [1] * k["count"], "frw_groth16_verify rejects an aggregate proof"
+        other = inst_h.copy()
+        other[:, k["ni"] - 3, 0] ^= np.uint64(1)
+        assert ver.verify(other, proofs_h[at:at + k["count"]]).tolist() == [0] * k["count"]
+        ver.close()
+        at += k["count"]
+    verify_s = time.perf_counter() - t0
+    for k in keys:
+        eng.groth16_pk_free(k["pk"])
+        eng.r1cs_free(k["handle"])
+    return {"workload": "BASELINE configs[4]'s 1,024 mixed signatures (%d Falcon-512 + %d Falcon-1024) as %d proofs of 16 statements each, one after "
+                        "the other on ONE GPU: %s" % (n9, n10, total, ", ".join("%d x (%d Falcon-512 + %d Falcon-1024)" % (k["count"], k["logns"].count(9),
+                                                                                                                      k["logns"].count(10)) for k in keys)),
+            "run": "timed, not extrapolated: assignment + frw_groth16_prove_dev of all %d aggregates back to back (wall clock, second of two rounds)" % total,
+            "seconds": round(seconds, 3), "signatures_per_s": round(1024 / seconds, 1), "proofs": total, "ms_per_proof": round(seconds / total * 1e3, 3),
+            "keys": len(keys), "keys_setup_s": round(key_s, 2), "all_proofs_verified": True, "verify_s_all": round(verify_s, 3),
+            "against_one_proof_for_all_1024": "secondary.aggregate_proof_1024_mixed"}
 
 
 def aggregate_leg(eng, dev, cdev, k, world, rank, reps=5):
@@ -1298,6 +1526,9 @@ def main():
     ap.add_argument("--aggregate-leg", type=int, default=16, metavar="K",
                     help="N > 1 only (with the proof leg): every rank also makes ONE proof for an aggregate of K Falcon-1024 statements "
                          "(BASELINE configs[4] on the node: 1,024 signatures = 64 aggregates of 16, eight per GPU); 0 = skip")
+    ap.add_argument("--aggregate-sharded", type=int, default=1024, metavar="K",
+                    help="BASELINE configs[4] as written: ONE proof for K mixed statements (default 1,024: the 2^27 domain) -- N = 1: the last "
+                         "`secondary` line; N > 1: the key in N slices, one per rank (scaling_curves.aggregate_proof_sharded); 0: skip")
     ap.add_argument("--allgather-chunk", type=int, default=0, help="signatures per rank per all-gather (default 4,096)")
     ap.add_argument("--allgather-deadline", type=int, default=240,
                     help="seconds the N > 1 gather legs may take before the run reports `value` without them")
@@ -1550,6 +1781,40 @@ def main():
         elif "e" in box:
             gather_info["error"] = box["e"]
 
+    # ---- third curve (N > 1): BASELINE configs[4] as written -- ONE proof for the 1,024 mixed statements, its key in N slices ----------
+    # The witness buffer has served its purpose (digests, checks, gather legs): its 164 GB go back first -- the leg keeps the transform tables
+    # of the 2^27 domain, this rank's slices of the key and one proof's workspace (sharding.sharded_aggregate_plan).  One collective on its
+    # data path (an all-gather of 576 bytes per rank), so it runs under a deadline like the gather legs.
+    sharded_info = None
+    if use_pg and not dual and args.aggregate_sharded and logn == 10 and not legs_hung and not args.dump_digests:
+        import threading
+        mix = sharding.aggregate_mix(args.aggregate_sharded)
+        splan = sharding.sharded_aggregate_plan(world, rank, mix)
+        assert splan["fits"], "the sharded aggregate leg plans %.1f GB of HBM per GPU" % (splan["hbm_plan_bytes"] / 1e9)
+        d_wit = d_inst = None
+        torch.cuda.empty_cache()
+        sbox = {}
+
+        def sharded_leg():
+            torch.cuda.set_device(dev_index)
+            try:
+                sbox["r"] = time_aggregate_proof(eng, dev, mix, 3, None, check_h=False, world=world, rank=rank, cdev=cdev)
+            except Exception as ex:      # noqa: BLE001 -- the primary metric must not depend on this leg
+                import traceback
+                sbox["e"] = repr(ex)[:300]
+                sys.stderr.write("bench.py rank %d: the sharded aggregate leg raised %r\n%s" % (rank, ex, traceback.format_exc()))
+                sys.stderr.flush()
+        th = threading.Thread(target=sharded_leg, daemon=True)
+        th.start()
+        th.join(args.allgather_deadline)
+        sharded_info = dict(sbox.get("r") or {})
+        sharded_info["hbm_plan_bytes_leg"] = splan["hbm_plan_bytes"]
+        if th.is_alive():
+            legs_hung = True
+            sharded_info["error"] = "no result within %d s (a collective did not complete)" % args.allgather_deadline
+        elif "e" in sbox:
+            sharded_info["error"] = sbox["e"]
+
     if args.dump_digests:
         # one extra, untimed pass with every launch digested: per-signature (global index, status, digest) of this rank
         dd = torch.zeros(batch, dtype=torch.int64, device=dev)
@@ -1601,13 +1866,15 @@ def main():
         }
         if r1cs is not None:
             result["r1cs_check"] = r1cs
-        if gather_info is not None or prove_info is not None:
+        if gather_info is not None or prove_info is not None or sharded_info is not None:
             result["scaling_curves"] = {"generate_only_signatures_per_s": round(value, 1)}
             if gather_info is not None:
                 result["scaling_curves"]["generate_plus_allgather"] = gather_info
             if prove_info is not None:
                 result["scaling_curves"]["prove"] = prove_info
                 result["scaling_curves"]["prove_proofs_per_s"] = prove_info.get("proofs_per_s_all_gpus")
+            if sharded_info is not None:
+                result["scaling_curves"]["aggregate_proof_sharded"] = sharded_info
         if world == 1 and not args.no_secondary and not dual:
             # untimed w.r.t. `value`: the other two rooflines BASELINE / north_star name, measured in this process
             result["secondary"] = {
@@ -1624,17 +1891,29 @@ def main():
                 torch.cuda.empty_cache()
                 result["secondary"]["aggregate_proof_16_falcon1024"] = time_aggregate_proof(eng, dev, (10,) * 16, 10, groth16_result)
                 torch.cuda.empty_cache()
+                result["secondary"]["configs4_as_64_proofs_of_16"] = time_configs4_as_aggregates_of_16(eng, dev)
+                torch.cuda.empty_cache()
             if not args.no_aggregate:
                 result["secondary"]["host_call_one_signature_falcon%d" % n] = time_host_call(eng, logn)
                 result["secondary"]["aggregate_1024_mixed"] = time_aggregate(eng, dev, 1024, 50, threads)
                 result["secondary"]["input_preparation_falcon%d" % n] = time_prepare(eng, dev, logn, 65536, 5, 1)
+            if not args.no_aggregate and logn == 10 and args.aggregate_sharded:
+                # BASELINE configs[4] as written: ONE proof for the 1,024 mixed statements.  Last: the witness buffer (164 GB) goes back to
+                # the device first -- the proof keeps 208 GB of its own (sharding.sharded_aggregate_plan).
+                d_wit = d_inst = None
+                torch.cuda.empty_cache()
+                mix = sharding.aggregate_mix(args.aggregate_sharded)
+                assert sharding.sharded_aggregate_plan(1, 0, mix)["fits"]
+                result["secondary"]["aggregate_proof_%d_mixed" % len(mix)] = time_aggregate_proof(eng, dev, mix, 3, None)
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and not dual:
             slots = np.arange(0, held, max(1, held // 4096))[:4096]        # strided over the whole buffer
             digest_of = {int(slot_sig[j]): int(held_dig[j]) for j in slots}
             result["cpu_baseline"] = cpu_baseline(logn, sig, pk, hm, slot_sig[slots], lambda i: digest_of[int(i)])
         emit(result)
     if use_pg:
-        leave(legs_hung, bool((gather_info and "error" in gather_info) or (prove_info and ("error" in prove_info or "error" in prove_info.get("aggregate", {})))),
+        leave(legs_hung, bool((gather_info and "error" in gather_info) or (prove_info and ("error" in prove_info or "error" in prove_info.get("aggregate", {})))
+                               or (sharded_info and "error" in sharded_info)),
               rank)
 
 
@@ -1702,6 +1981,16 @@ def print_plans(args, only_this_world):
             "hbm_plan_bytes_per_rank": p0["hbm_plan_bytes"], "hbm_plan_GB_per_rank": round(p0["hbm_plan_bytes"] / 1e9, 2),
             "hbm_limit_bytes": p0["hbm_limit_bytes"], "fits": p0["fits"],
             "buffers_GB": {k: round(v / 1e9, 3) for k, v in p0["buffers"].items()}}
+        if args.aggregate_sharded and args.logn == 10 and args.circuit != "dual":
+            # the last leg, after the witness buffer has gone back to the device: ONE proof for K mixed statements, the key in `world` slices
+            sp = [sharding.sharded_aggregate_plan(world, r, sharding.aggregate_mix(args.aggregate_sharded)) for r in range(world)]
+            sharding.check_sharded_aggregate_plans(sp)
+            out["gpus_%d" % world]["aggregate_proof_sharded (held alone, the witness buffer released)"] = {
+                "statements": sp[0]["statements"], "log_domain_size": sp[0]["log_domain_size"],
+                "rows_of_the_witness_side_tables_per_rank": [[p["z_lo"], p["z_hi"]] for p in sp],
+                "rows_of_h_query_per_rank": [[p["h_lo"], p["h_hi"]] for p in sp],
+                "hbm_plan_GB_per_rank": [round(p["hbm_plan_bytes"] / 1e9, 2) for p in sp],
+                "buffers_GB_rank0": {k: round(v / 1e9, 3) for k, v in sp[0]["buffers"].items()}}
     emit(out)
 
 

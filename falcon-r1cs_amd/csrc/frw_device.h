@@ -208,12 +208,14 @@ constexpr uint64_t SETUP_POW_LO = (uint64_t)1 << SETUP_POW_LO_BITS;
 struct SetupPowTab { const uint32_t *lo, *hi; };
 // a per-signature matrix by columns: the non-zeros of variable c are [col_ptr[c], col_ptr[c + 1]): their rows and coefficients (c R' packed)
 struct SetupCsc { const uint32_t *col_ptr, *row, *val; };
-// a run of consecutive statements of one parameter set inside an aggregate (R1csAggRun), or a single circuit (count 1, offsets 0)
+// ALL the statements of one parameter set inside an aggregate, wherever they stand (or a single circuit: one statement at zero)
 struct SetupRun {
     SetupCsc m[3];
     uint32_t num_vars, num_inst, num_constraints;    // of the per-signature system: I + W, I (with the constant one), C
-    uint32_t first, count;                           // statements [first, first + count)
-    uint64_t wit_off, pub_off, row_off;
+    uint32_t count;                                  // statements of this launch
+    // [count][4], device memory: before statement s, the aggregate's witness variables, its public inputs (the statement's instance
+    // variable j >= 1 is aggregate variable pub + j), its constraint rows; and the statement's index in the aggregate
+    const uint64_t *offs;
 };
 hipError_t launch_qap_table(uint64_t n, const SetupPowTab &t, int mode, int sh, int ts, int L, const SetupConst *first, uint32_t *out, hipStream_t st);
 hipError_t launch_setup_lagrange(uint64_t n, const SetupPowTab &wt, const SetupConst &t, const SetupConst &c, const SetupConst &one, uint32_t *lag, hipStream_t st);
@@ -227,6 +229,7 @@ struct FixedBaseGen { uint32_t *g1, *g2; };        // [32][256] multiples of the
 int fixed_base_gen_create(int device, FixedBaseGen *g);
 void fixed_base_gen_free(FixedBaseGen *g);
 int msm_alloc_bare(int device, int group /* 1: G1, 2: G2 */, int window_bits, size_t rows, uint64_t row_lo, ::frw_msm **out);
+int msm_expand_tables(::frw_msm **m);       // a filled bare handle -> window tables over the same points (frees the bare one)
 hipError_t msm_fill_fixed_base(::frw_msm *m, const FixedBaseGen &g, size_t first_row, size_t count, const uint32_t *d_scalars, hipStream_t st);
 hipError_t fixed_base_ark_dev(const FixedBaseGen &g, int group, size_t count, const uint32_t *d_scalars, uint32_t *d_out, hipStream_t st);
 void groth16_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi);

@@ -119,6 +119,16 @@ template <class F> __device__ __forceinline__ void store_row(uint32_t *row, cons
 #pragma unroll
     for (int k = 0; k < Grp<F>::PT_WORDS; k++) row[k] = p.inf ? 0u : w[k];
 }
+// the two-lane Fq2: every lane writes its own component of x and of y
+template <> __device__ __forceinline__ void store_row<Fq2PairField>(uint32_t *row, const AffineT<Fq2PairField> &p)
+{
+    uint32_t *mine = row + (Fq2PairField::odd() ? NLQ : 0);
+#pragma unroll
+    for (int k = 0; k < NLQ; k++) {
+        mine[k] = p.inf ? 0u : p.x.v.l[k];
+        mine[2 * NLQ + k] = p.inf ? 0u : p.y.v.l[k];
+    }
+}
 template <class F> __device__ __forceinline__ void store_bucket(uint32_t *b, const XyzzT<F> &p)
 {
     F::store(p.x, b); F::store(p.y, b + F::WORDS); F::store(p.zz, b + 2 * F::WORDS); F::store(p.zzz, b + 3 * F::WORDS);
@@ -160,6 +170,24 @@ __global__ __launch_bounds__(64) void msm_precompute_kernel(uint32_t n, const ui
     if (i >= n) return;
     const int windows = 256 / window_bits;
     AffineT<F> p = load_ark_point<F>(bases + (size_t)i * Grp<F>::ARK_WORDS);
+    for (int j = 0; j < windows; j++) {
+        store_row<F>(table + ((size_t)j * n + i) * Grp<F>::PT_WORDS, p);
+        if (j + 1 == windows) break;
+        XyzzT<F> d = pt_from_affine(p);
+        for (int k = 0; k < window_bits; k++) d = pt_double(d);
+        p = pt_to_affine(d);
+    }
+}
+
+// the same from table ROWS (a bare handle's: what the device-side setup fills): a key made on the device grows its window tables here
+template <class F>
+__global__ __launch_bounds__(64) void msm_precompute_rows_kernel(uint32_t n, const uint32_t *__restrict__ rows /* [n][PT_WORDS] */,
+                                                                 uint32_t *__restrict__ table, int window_bits /* 16 or 8 */)
+{
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int windows = 256 / window_bits;
+    AffineT<F> p = load_row<F>(rows + (size_t)i * Grp<F>::PT_WORDS);
     for (int j = 0; j < windows; j++) {
         store_row<F>(table + ((size_t)j * n + i) * Grp<F>::PT_WORDS, p);
         if (j + 1 == windows) break;
@@ -1086,21 +1114,51 @@ __global__ __launch_bounds__(64) void fixed_base_kernel(size_t count, const uint
     }
     store_ark_point<F>(out + i * Grp<F>::ARK_WORDS, pt_to_affine(acc));
 }
-// the same multiples written as table rows (29-bit limbs, what load_row reads): a bare handle's query made in place on the device
-// (frw_groth16_setup_r1cs_opts: a 2^27-point h_query never exists as ark-ff bytes anywhere)
+// ---- the same for a key made on the device (frw_groth16_setup_r1cs_opts: 5 x 10^8 G1 and 1.2 x 10^8 G2 multiples for the 1,024-statement
+// aggregate): SIXTEEN-bit windows -- table[w][d] = d 2^(16 w) G, 2^20 rows (117 MB, G2 235 MB), sixteen mixed additions per scalar instead of
+// thirty-two -- G2 with two lanes per point (with one lane and 3.8 KB of scratch the 123 M rows of b_g2_query took 85 of the first version's
+// 94 seconds), and the multiples written as table rows (29-bit limbs, what load_row reads) straight into a bare handle: a 2^27-point
+// h_query never exists as ark-ff bytes anywhere.
+constexpr int FBW_WINDOWS = 16, FBW_DIGITS = 65536;
+// B_w = 2^(16 w) G, w < 16, one after the other (240 doublings of one chain)
 template <class F>
-__global__ __launch_bounds__(64) void fixed_base_rows_kernel(size_t count, const uint32_t *__restrict__ scalars /* [count][8], canonical */,
-                                                             const uint32_t *__restrict__ table, uint32_t *__restrict__ rows /* [count][PT_WORDS] */)
+__global__ __launch_bounds__(64) void fixed_base_window_gens_kernel(uint32_t *__restrict__ gens /* [16][PT_WORDS] */)
 {
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x || blockIdx.x) return;
+    XyzzT<F> acc = pt_from_affine(group_generator<F>());
+    for (int w = 0; w < FBW_WINDOWS; w++) {
+        store_row<F>(gens + (size_t)w * Grp<F>::PT_WORDS, pt_to_affine(acc));
+        for (int k = 0; k < 16; k++) acc = pt_double(acc);
+    }
+}
+template <class F>
+__global__ __launch_bounds__(64) void fixed_base_wide_table_kernel(const uint32_t *__restrict__ gens, uint32_t *__restrict__ table /* [16][65536][PT_WORDS] */)
+{
+    const uint32_t id = blockIdx.x * 64 + threadIdx.x, w = id >> 16, d = id & 65535u;
+    if (w >= (uint32_t)FBW_WINDOWS) return;
+    const AffineT<F> g = load_row<F>(gens + (size_t)w * Grp<F>::PT_WORDS);
+    XyzzT<F> acc = pt_identity<F>();
+    for (int bit = 15; bit >= 0; bit--) {
+        acc = pt_double(acc);
+        if ((d >> bit) & 1u) acc = pt_add_affine(acc, g);
+    }
+    store_row<F>(table + (size_t)id * Grp<F>::PT_WORDS, pt_to_affine(acc));
+}
+// F: FqField, or Fq2PairField (two adjacent lanes per scalar).  ARK_OUT: ark-ff's affine bytes (the verifying key's points) instead of rows.
+template <class F, bool ARK_OUT>
+__global__ __launch_bounds__(64) void fixed_base_wide_kernel(size_t count, const uint32_t *__restrict__ scalars /* [count][8], canonical */,
+                                                             const uint32_t *__restrict__ table, uint32_t *__restrict__ out)
+{
+    const size_t i = ((size_t)blockIdx.x * 64 + threadIdx.x) / F::LANES;
     if (i >= count) return;
     const Fr8 k = fr_load(scalars + i * 8);
     XyzzT<F> acc = pt_identity<F>();
-    for (int w = 0; w < FB_WINDOWS; w++) {
-        const uint32_t d = (k.l[w >> 2] >> (8 * (w & 3))) & 255u;
-        if (d) acc = pt_add_affine(acc, load_row<F>(table + ((size_t)w * FB_DIGITS + d) * Grp<F>::PT_WORDS));
+    for (int w = 0; w < FBW_WINDOWS; w++) {
+        const uint32_t d = (k.l[w >> 1] >> (16 * (w & 1))) & 65535u;
+        if (d) acc = pt_add_affine(acc, load_row<F>(table + ((size_t)w * FBW_DIGITS + d) * Grp<F>::PT_WORDS));
     }
-    store_row<F>(rows + i * Grp<F>::PT_WORDS, pt_to_affine(acc));
+    if (ARK_OUT) store_ark_point<F>(out + i * Grp<F>::ARK_WORDS, pt_to_affine(acc));
+    else store_row<F>(out + i * Grp<F>::PT_WORDS, pt_to_affine(acc));
 }
 
 }  // namespace frw
@@ -1956,7 +2014,48 @@ template <class F> int msm_upload_rows(frw_msm *m, size_t first, size_t count, c
 }
 }  // namespace
 
+namespace {
+// a bare handle -> the handle with window tables over the same points (the bare one is freed)
+template <class F> int msm_expand_tables_t(frw_msm **pm)
+{
+    frw_msm *b = *pm;
+    const size_t n = b->dev.n;
+    if (!b->bare || n > ((size_t)1 << (b->window_bits == 8 ? 25 : 26))) return FRW_E_INVALID_ARG;
+    hipError_t e = hipSetDevice(b->device);
+    frw_msm *m = new (std::nothrow) frw_msm;
+    if (!m) return FRW_E_OUT_OF_MEMORY;
+    m->device = b->device; m->group = b->group; m->window_bits = b->window_bits; m->bare = false; m->row_lo = 0;
+    m->table = nullptr; m->ones_table = nullptr; m->dev.n = (uint32_t)n; m->dev.ones_table = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&m->table, (size_t)(256 / b->window_bits) * n * frw::Grp<F>::PT_WORDS * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(frw::msm_precompute_rows_kernel<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)n, (const uint32_t *)b->table,
+                           (uint32_t *)m->table, b->window_bits);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && b->window_bits == 8 && n <= ((size_t)1 << 18)) {
+        const size_t entries = (n + 7) / 8 * 255;
+        e = hipMalloc(&m->ones_table, entries * frw::Grp<F>::PT_WORDS * 4);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(frw::msm_ones_table_kernel<F>, dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)n,
+                               (const uint32_t *)m->table, (uint32_t *)m->ones_table);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        frw_msm_free(m);
+        return frw::record_hip_error(e, "frw_groth16_setup: window tables");
+    }
+    m->dev.table = (const uint32_t *)m->table;
+    m->dev.ones_table = (const uint32_t *)m->ones_table;
+    frw_msm_free(b);
+    *pm = m;
+    return FRW_OK;
+}
+}  // namespace
+
 namespace frw {
+int msm_expand_tables(frw_msm **m) { return (*m)->group == 1 ? msm_expand_tables_t<FqField>(m) : msm_expand_tables_t<Fq2Field>(m); }
 // slice `rank` of `world` of `total` rows
 void groth16_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi)
 {
@@ -1973,14 +2072,21 @@ int fixed_base_gen_create(int device, FixedBaseGen *g)
 {
     g->g1 = g->g2 = nullptr;
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc((void **)&g->g1, (size_t)FB_WINDOWS * FB_DIGITS * Grp<FqField>::PT_WORDS * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&g->g2, (size_t)FB_WINDOWS * FB_DIGITS * Grp<Fq2Field>::PT_WORDS * 4);
+    void *gens1 = nullptr, *gens2 = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void **)&g->g1, (size_t)FBW_WINDOWS * FBW_DIGITS * Grp<FqField>::PT_WORDS * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->g2, (size_t)FBW_WINDOWS * FBW_DIGITS * Grp<Fq2Field>::PT_WORDS * 4);
+    if (e == hipSuccess) e = hipMalloc(&gens1, (size_t)FBW_WINDOWS * Grp<FqField>::PT_WORDS * 4);
+    if (e == hipSuccess) e = hipMalloc(&gens2, (size_t)FBW_WINDOWS * Grp<Fq2Field>::PT_WORDS * 4);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(fixed_base_table_kernel<FqField>, dim3(FB_WINDOWS * FB_DIGITS / 64), dim3(64), 0, nullptr, g->g1);
-        hipLaunchKernelGGL(fixed_base_table_kernel<Fq2Field>, dim3(FB_WINDOWS * FB_DIGITS / 64), dim3(64), 0, nullptr, g->g2);
+        hipLaunchKernelGGL(fixed_base_window_gens_kernel<FqField>, dim3(1), dim3(64), 0, nullptr, (uint32_t *)gens1);
+        hipLaunchKernelGGL(fixed_base_window_gens_kernel<Fq2Field>, dim3(1), dim3(64), 0, nullptr, (uint32_t *)gens2);
+        hipLaunchKernelGGL(fixed_base_wide_table_kernel<FqField>, dim3(FBW_WINDOWS * FBW_DIGITS / 64), dim3(64), 0, nullptr, (const uint32_t *)gens1, g->g1);
+        hipLaunchKernelGGL(fixed_base_wide_table_kernel<Fq2Field>, dim3(FBW_WINDOWS * FBW_DIGITS / 64), dim3(64), 0, nullptr, (const uint32_t *)gens2, g->g2);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (gens1) (void)hipFree(gens1);
+    if (gens2) (void)hipFree(gens2);
     if (e != hipSuccess) { fixed_base_gen_free(g); return record_hip_error(e, "fixed-base tables"); }
     return FRW_OK;
 }
@@ -1995,28 +2101,30 @@ hipError_t msm_fill_fixed_base(frw_msm *m, const FixedBaseGen &g, size_t first_r
 {
     if (count == 0) return hipSuccess;
     if (!m->bare || first_row + count > m->dev.n) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((count + 63) / 64));
     if (m->group == 1)
-        hipLaunchKernelGGL(fixed_base_rows_kernel<FqField>, grid, dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g1,
+        hipLaunchKernelGGL((fixed_base_wide_kernel<FqField, false>), dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g1,
                            (uint32_t *)m->table + first_row * Grp<FqField>::PT_WORDS);
     else
-        hipLaunchKernelGGL(fixed_base_rows_kernel<Fq2Field>, grid, dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g2,
-                           (uint32_t *)m->table + first_row * Grp<Fq2Field>::PT_WORDS);
+        hipLaunchKernelGGL((fixed_base_wide_kernel<Fq2PairField, false>), dim3((unsigned)((count + 31) / 32)), dim3(64), 0, st, count, d_scalars,
+                           (const uint32_t *)g.g2, (uint32_t *)m->table + first_row * Grp<Fq2Field>::PT_WORDS);
     return hipGetLastError();
 }
 // ... as ark-ff's affine bytes in device memory (the verifying key's points)
 hipError_t fixed_base_ark_dev(const FixedBaseGen &g, int group, size_t count, const uint32_t *d_scalars, uint32_t *d_out, hipStream_t st)
 {
     if (count == 0) return hipSuccess;
-    const dim3 grid((unsigned)((count + 63) / 64));
-    if (group == 1) hipLaunchKernelGGL(fixed_base_kernel<FqField>, grid, dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g1, d_out);
-    else hipLaunchKernelGGL(fixed_base_kernel<Fq2Field>, grid, dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g2, d_out);
+    if (group == 1)
+        hipLaunchKernelGGL((fixed_base_wide_kernel<FqField, true>), dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, count, d_scalars, (const uint32_t *)g.g1, d_out);
+    else
+        hipLaunchKernelGGL((fixed_base_wide_kernel<Fq2PairField, true>), dim3((unsigned)((count + 31) / 32)), dim3(64), 0, st, count, d_scalars,
+                           (const uint32_t *)g.g2, d_out);
     return hipGetLastError();
 }
 // a key of bare handles from its five tables (ownership passes to the key, also on failure)
 int groth16_pk_assemble(int device, uint64_t ni, uint64_t nw, uint64_t n, uint32_t rank, uint32_t world, frw_msm *h, frw_msm *a, frw_msm *b1, frw_msm *l,
                         frw_msm *b2, frw_groth16_pk **out)
 {
+    const bool bare = h->bare;
     frw_groth16_pk *pk = nullptr;
     const int rc = pk_create(device, ni, nw, n, &pk);
     if (rc != FRW_OK) {
@@ -2024,7 +2132,7 @@ int groth16_pk_assemble(int device, uint64_t ni, uint64_t nw, uint64_t n, uint32
         return rc;
     }
     pk->h = h; pk->a = a; pk->b1 = b1; pk->l = l; pk->b2 = b2;
-    pk->bare = true;
+    pk->bare = bare;
     pk->rank = rank; pk->world = world < 1 ? 1 : world;
     groth16_shard_range(ni + nw + 3, rank, pk->world, &pk->z_lo, &pk->z_hi);
     groth16_shard_range(n - 1, rank, pk->world, &pk->h_lo, &pk->h_hi);

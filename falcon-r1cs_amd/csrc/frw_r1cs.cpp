@@ -6,6 +6,8 @@
 #include <stdint.h>
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -793,7 +795,7 @@ void hip_ok(hipError_t e, const char *what)
 }
 
 int groth16_setup_device(int device, const std::vector<DeviceRun> &runs, uint32_t statements, size_t ni, size_t nw, size_t nc, const uint64_t *toxic,
-                         uint32_t rank, uint32_t world, frw_groth16_pk **pk_out, uint64_t *vk_out)
+                         bool tables, uint32_t rank, uint32_t world, frw_groth16_pk **pk_out, uint64_t *vk_out)
 {
     using namespace frw::host;
     const size_t nv = ni + nw;
@@ -815,6 +817,16 @@ int groth16_setup_device(int device, const std::vector<DeviceRun> &runs, uint32_
     frw_msm *tab[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};                         // h, a, b1, l, b2
     frw::FixedBaseGen gen{nullptr, nullptr};
     int rc = FRW_OK;
+    // FRW_SETUP_TIMING in the environment: the phases' wall times on stderr (each after a device synchronisation)
+    const bool timing = std::getenv("FRW_SETUP_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "frw setup: %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     try {
         DeviceBuffers dev;
         auto pow_tab = [&](const Fr &base) {
@@ -824,7 +836,9 @@ int groth16_setup_device(int device, const std::vector<DeviceRun> &runs, uint32_
         // (1) L_i(t) = zt w^i / (n (t - w^i)) for the whole domain
         uint32_t *lag = (uint32_t *)dev.get(n * 32);
         const frw::SetupPowTab wt = pow_tab(w);
+        mark("host constants");
         hip_ok(frw::launch_setup_lagrange(n, wt, setup_const(t), setup_const(zt * inverse(Fr::from(n))), setup_const(Fr::one()), lag, nullptr), "setup: Lagrange coefficients");
+        mark("Lagrange coefficients");
         // (2) u, v, w: the per-signature matrices by columns, a run of statements per launch
         std::vector<const ConstraintMatrices *> distinct;
         std::vector<std::array<frw::SetupCsc, 3>> csc;
@@ -853,21 +867,38 @@ int groth16_setup_device(int device, const std::vector<DeviceRun> &runs, uint32_
             }
             csc.push_back(three);
         }
+        // one launch per parameter set: the offsets of all its statements (a run of the aggregate is `count` consecutive ones)
         std::vector<frw::SetupRun> druns;
-        for (const DeviceRun &run : runs) {
-            const size_t which = std::find(distinct.begin(), distinct.end(), run.m) - distinct.begin();
-            frw::SetupRun d{};
-            for (int k = 0; k < 3; k++) d.m[k] = csc[which][k];
-            d.num_inst = (uint32_t)run.m->num_instance_variables;
-            d.num_vars = (uint32_t)(run.m->num_instance_variables + run.m->num_witness_variables);
-            d.num_constraints = (uint32_t)run.m->num_constraints;
-            d.first = run.first; d.count = run.count;
-            d.wit_off = run.wit_off; d.pub_off = run.pub_off; d.row_off = run.row_off;
-            druns.push_back(d);
+        for (size_t which = 0; which < distinct.size(); which++) {
+            const ConstraintMatrices &m = *distinct[which];
+            std::vector<uint64_t> offs;
+            for (const DeviceRun &run : runs) {
+                if (run.m != distinct[which]) continue;
+                for (uint32_t k = 0; k < run.count; k++) {
+                    offs.push_back(run.wit_off + (uint64_t)k * m.num_witness_variables);
+                    offs.push_back(run.pub_off + (uint64_t)k * (m.num_instance_variables - 1));
+                    offs.push_back(run.row_off + (uint64_t)k * m.num_constraints);
+                    offs.push_back(run.first + k);
+                }
+            }
+            void *d_offs = dev.put(offs.data(), offs.size() * 8);
+            csc_bufs.push_back(d_offs);
+            for (size_t lo = 0; lo < offs.size() / 4; lo += 65535) {           // grid.y
+                frw::SetupRun d{};
+                for (int k = 0; k < 3; k++) d.m[k] = csc[which][k];
+                d.num_inst = (uint32_t)m.num_instance_variables;
+                d.num_vars = (uint32_t)(m.num_instance_variables + m.num_witness_variables);
+                d.num_constraints = (uint32_t)m.num_constraints;
+                d.count = (uint32_t)std::min<size_t>(65535, offs.size() / 4 - lo);
+                d.offs = (const uint64_t *)d_offs + 4 * lo;
+                druns.push_back(d);
+            }
         }
+        mark("matrices by columns (host)");
         uint32_t *uvw = (uint32_t *)dev.get(3 * nv * 32), *col0 = (uint32_t *)dev.get((size_t)statements * 3 * 32);
         hip_ok(frw::launch_setup_columns(druns.data(), druns.size(), statements, ni, nc, nv, lag, uvw, col0, nullptr), "setup: the QAP at t");
         hip_ok(hipDeviceSynchronize(), "setup: the QAP at t");
+        mark("u, v, w at t");
         dev.drop(lag);
         for (void *p : csc_bufs) dev.drop(p);
         // (3) the five tables, row by row in place
@@ -897,19 +928,25 @@ int groth16_setup_device(int device, const std::vector<DeviceRun> &runs, uint32_
         const Fr tail_a[3] = {alpha, delta, zero}, tail_b1[3] = {beta, zero, zero}, tail_b2[3] = {beta, zero, delta};
         var_scalars(0, 0, 0);
         tails(tail_a);
+        mark("tables allocated, generators");
         hip_ok(frw::msm_fill_fixed_base(tab[1], gen, 0, zrows, scal, nullptr), "setup: a_query");
+        mark("a_query");
         var_scalars(0, 1, 0);
         tails(tail_b1);
         hip_ok(frw::msm_fill_fixed_base(tab[2], gen, 0, zrows, scal, nullptr), "setup: b_g1_query");
+        mark("b_g1_query");
         tails(tail_b2);                                             // the same scalars but for the tail: b_g2_query ++ [beta2, O, delta2]
         hip_ok(frw::msm_fill_fixed_base(tab[4], gen, 0, zrows, scal, nullptr), "setup: b_g2_query");
+        mark("b_g2_query");
         var_scalars(1, 0, ni);                                      // l_query: the witness variables; the instance rows stay the point at infinity
         hip_ok(frw::msm_fill_fixed_base(tab[3], gen, 0, zrows, scal, nullptr), "setup: l_query");
+        mark("l_query");
         {
             const frw::SetupPowTab tt = pow_tab(t);
             hip_ok(frw::launch_setup_h_scalars(h_lo, hrows, tt, setup_const(zt * dinv), scal, nullptr), "setup: scalars");
             hip_ok(frw::msm_fill_fixed_base(tab[0], gen, 0, hrows, scal, nullptr), "setup: h_query");
         }
+        mark("h_query");
         // (4) the verifying key: alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | gamma_abc_g1 [ni]
         if (vk_out) {
             uint32_t *pts = (uint32_t *)dev.get(std::max<size_t>(ni * 96, 4 * 192));
@@ -925,6 +962,14 @@ int groth16_setup_device(int device, const std::vector<DeviceRun> &runs, uint32_
             hip_ok(hipMemcpy(vk_out + 12, pts, 3 * 192, hipMemcpyDeviceToHost), "setup: the verifying key's G2 points");
         }
         hip_ok(hipDeviceSynchronize(), "setup");
+        mark("verifying key");
+        // a key of window tables: grown from the rows, table by table (the rows go as their table comes)
+        if (tables) {
+            dev.drop(uvw);
+            dev.drop(scal);
+            for (int k = 0; k < 5 && rc == FRW_OK; k++) rc = frw::msm_expand_tables(&tab[k]);
+            if (rc != FRW_OK) throw std::runtime_error("window tables");
+        }
     } catch (const std::bad_alloc &) {
         rc = FRW_E_OUT_OF_MEMORY;
     } catch (const std::exception &) {
@@ -971,25 +1016,28 @@ extern "C" int frw_groth16_setup_r1cs_opts(const frw_r1cs *r, const uint64_t *to
     const size_t nv = (size_t)r->dev.num_instance + r->dev.num_witness;
     if (mode == FRW_KEY_AUTO) mode = world > 1 || nv > FRW_KEY_AUTO_TABLE_VARIABLES ? FRW_KEY_BARE : FRW_KEY_TABLES;
     if (mode == FRW_KEY_TABLES && world > 1) return FRW_E_INVALID_ARG;
+    // either kind of key is made on the device (groth16_setup_device; window tables are grown from the rows); FRW_SETUP_ON_HOST in the
+    // environment keeps round 4's host-side evaluation of the QAP for keys of window tables -- the tests hold the two against each other
+    const bool on_host = mode == FRW_KEY_TABLES && std::getenv("FRW_SETUP_ON_HOST") != nullptr;
     try {
         if (!r->dev.agg) {
             if (!r->host_matrices) return FRW_E_INVALID_ARG;
             const ConstraintMatrices &m = *r->host_matrices;
-            if (mode == FRW_KEY_TABLES)
+            if (on_host)
                 return groth16_setup_blocks(r->device, {SetupBlock{&m, 0, 0, 0}}, m.num_instance_variables, m.num_witness_variables, m.num_constraints,
                                             toxic, pk_out, vk_out);
             return groth16_setup_device(r->device, {DeviceRun{&m, 0, 1, 0, 0, 0}}, 1, m.num_instance_variables, m.num_witness_variables,
-                                        m.num_constraints, toxic, rank, world, pk_out, vk_out);
+                                        m.num_constraints, toxic, mode == FRW_KEY_TABLES, rank, world, pk_out, vk_out);
         }
         const ConstraintMatrices *mats[2] = {nullptr, nullptr};
         for (int g = 0; g < 2; g++)
             if (r->base[g]) mats[g] = r->base[g]->host_matrices.get();
-        if (mode == FRW_KEY_BARE) {
+        if (!on_host) {
             std::vector<DeviceRun> runs;
             for (const frw::R1csAggRun &run : r->runs)
                 runs.push_back(DeviceRun{mats[r->statement_logn[run.first] - 9], run.first, run.count, run.wit_off, run.pub_off, run.row_off});
             return groth16_setup_device(r->device, runs, r->agg.num_statements, r->dev.num_instance, r->dev.num_witness, r->dev.num_constraints, toxic,
-                                        rank, world, pk_out, vk_out);
+                                        mode == FRW_KEY_TABLES, rank, world, pk_out, vk_out);
         }
         std::vector<SetupBlock> blocks;
         for (const frw::R1csAggRun &run : r->runs) {

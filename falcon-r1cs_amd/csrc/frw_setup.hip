@@ -115,13 +115,17 @@ hipError_t launch_setup_lagrange(uint64_t n, const SetupPowTab &wt, const SetupC
 }
 
 // ---- u, v, w: the QAP's polynomials at t, variable by variable -----------------------------------------------------------------------
-// grid.y = the statements of a run; a thread per variable of the per-signature system
+// grid.y = the statements of one parameter set (wherever they sit in the aggregate: offs[s] = where statement s finds its witness
+// variables, its public inputs and its rows); a thread per variable of the per-signature system -- but for variable 0, the constant one:
+// it stands in 150,000 rows of A (every booleanity constraint (1 - b) b = 0), a chain no thread should walk alone (it was 0.2 s per
+// launch: 94 s for the 516 runs of the 1,024-statement mix); setup_column0_kernel gives it a workgroup per (statement, matrix).
 __global__ __launch_bounds__(256) void setup_columns_kernel(SetupRun run, uint64_t num_instance_all, size_t num_vars_all, const uint32_t *__restrict__ lag,
-                                                            uint32_t *__restrict__ uvw /* [3][num_vars_all][8] */, uint32_t *__restrict__ col0 /* [statements][3][8] */)
+                                                            uint32_t *__restrict__ uvw /* [3][num_vars_all][8] */)
 {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
-    if (c >= run.num_vars) return;
-    const uint32_t *rows = lag + (size_t)(run.row_off + (uint64_t)s * run.num_constraints) * 8;
+    if (c == 0 || c >= run.num_vars) return;
+    const uint64_t wit_off = run.offs[4 * (size_t)s], pub_off = run.offs[4 * (size_t)s + 1], row_off = run.offs[4 * (size_t)s + 2];
+    const uint32_t *rows = lag + (size_t)row_off * 8;
     for (int k = 0; k < 3; k++) {
         const SetupCsc &m = run.m[k];
         F29 acc;
@@ -131,11 +135,36 @@ __global__ __launch_bounds__(256) void setup_columns_kernel(SetupRun run, uint64
         for (uint32_t j = lo; j < hi; j++)
             acc = f29_reduce_4p(f29_add(acc, f29_mul(ld29(rows + (size_t)m.row[j] * 8), ld29(m.val + (size_t)j * 8))));
         uint32_t *dst;
-        if (c == 0) dst = col0 + ((size_t)(run.first + s) * 3 + k) * 8;
-        else if (c < run.num_inst) dst = uvw + ((size_t)k * num_vars_all + run.pub_off + (uint64_t)s * (run.num_inst - 1) + c) * 8;
-        else dst = uvw + ((size_t)k * num_vars_all + num_instance_all + run.wit_off + (uint64_t)s * (run.num_vars - run.num_inst) + (c - run.num_inst)) * 8;
+        if (c < run.num_inst) dst = uvw + ((size_t)k * num_vars_all + pub_off + c) * 8;
+        else dst = uvw + ((size_t)k * num_vars_all + num_instance_all + wit_off + (c - run.num_inst)) * 8;
         st29(dst, acc);
     }
+}
+// the constant one's column: grid (3 matrices, statements), the non-zeros dealt to 256 threads, a tree through LDS
+__global__ __launch_bounds__(256) void setup_column0_kernel(SetupRun run, const uint32_t *__restrict__ lag, uint32_t *__restrict__ col0 /* [statements][3][8] */)
+{
+    __shared__ uint32_t lds[256 * NL29];
+    const uint32_t k = blockIdx.x, s = blockIdx.y;
+    const uint64_t row_off = run.offs[4 * (size_t)s + 2], stmt = run.offs[4 * (size_t)s + 3];
+    const uint32_t *rows = lag + (size_t)row_off * 8;
+    const SetupCsc &m = run.m[k];
+    F29 acc;
+#pragma unroll
+    for (int j = 0; j < NL29; j++) acc.l[j] = 0;
+    for (uint32_t j = m.col_ptr[0] + threadIdx.x; j < m.col_ptr[1]; j += 256)
+        acc = f29_reduce_4p(f29_add(acc, f29_mul(ld29(rows + (size_t)m.row[j] * 8), ld29(m.val + (size_t)j * 8))));
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        if ((int)threadIdx.x >= stride && (int)threadIdx.x < 2 * stride)
+            for (int j = 0; j < NL29; j++) lds[(threadIdx.x - stride) * NL29 + j] = acc.l[j];
+        __syncthreads();
+        if ((int)threadIdx.x < stride) {
+            F29 o;
+            for (int j = 0; j < NL29; j++) o.l[j] = lds[threadIdx.x * NL29 + j];
+            acc = f29_reduce_4p(f29_add(acc, o));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st29(col0 + ((size_t)stmt * 3 + k) * 8, acc);
 }
 // column 0 = the statements' sums; u_i += L_(C + i)(t) for the instance variables (r1cs_to_qap.rs: the input rows of A)
 __global__ __launch_bounds__(256) void setup_columns_finish_kernel(uint32_t statements, uint64_t num_instance_all, uint64_t num_constraints_all, size_t num_vars_all,
@@ -164,7 +193,8 @@ hipError_t launch_setup_columns(const SetupRun *runs, size_t num_runs, uint32_t 
     for (size_t r = 0; r < num_runs; r++) {
         const SetupRun &run = runs[r];
         if (run.count == 0 || run.count > 65535) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(setup_columns_kernel, dim3((run.num_vars + 255) / 256, run.count), dim3(256), 0, st, run, num_instance_all, num_vars_all, lag, uvw, col0);
+        hipLaunchKernelGGL(setup_columns_kernel, dim3((run.num_vars + 255) / 256, run.count), dim3(256), 0, st, run, num_instance_all, num_vars_all, lag, uvw);
+        hipLaunchKernelGGL(setup_column0_kernel, dim3(3, run.count), dim3(256), 0, st, run, lag, col0);
     }
     hipLaunchKernelGGL(setup_columns_finish_kernel, dim3((unsigned)((num_instance_all + 255) / 256)), dim3(256), 0, st, statements, num_instance_all,
                        num_constraints_all, num_vars_all, lag, col0, uvw);

@@ -119,6 +119,107 @@ def aggregate_leg_bytes(statements, n, num_witness, num_instance):
     return int(key + tables + 2 * 32 * nv + proof)
 
 
+# ---- BASELINE configs[4] as written: ONE proof for an aggregate of mixed statements, its key in slices over the ranks --------------------
+BENCH_SEED = 0x46414C434F4E31            # bench.py SEED
+
+
+def aggregate_mix(total=1024, seed=BENCH_SEED):
+    """The parameter sets of the statements of the benchmark's mixed aggregate, in order (drawn from the seed: 513 Falcon-512 and
+    511 Falcon-1024 for the 1,024 of BASELINE configs[4])."""
+    import random
+    rng = random.Random(seed)
+    return [rng.choice([9, 10]) for _ in range(total)]
+
+
+def circuit_counts(logn):
+    """(I, W, C) of FalconNTTVerificationCircuit (README.md:44,55 of the reference; frw_layout)."""
+    n = 1 << logn
+    nb = 50 if logn == 9 else 52
+    return 2 * n + 1, 153 * n + nb, 159 * n + nb + 2
+
+
+def qap_pass_count(log_n):
+    return (log_n + 5) // 6
+
+
+def sharded_aggregate_plan(world, rank, logns):
+    """One proof for the aggregate of `logns`, the key of bare handles in `world` slices (frw_groth16_setup_r1cs_opts): what rank `rank`
+    holds and sums, as plain arithmetic -- the statement's sizes, this rank's rows of the witness-side tables ([z_lo, z_hi) of nv + 3) and
+    of h_query ([h_lo, h_hi) of domain - 1: frw.h's split, equal counts with the first `total mod world` slices one longer), and the
+    bytes of what it keeps in HBM while the leg runs: the transform tables of the domain (every rank runs the whole witness map), its
+    slices of the five tables, the statements' witnesses and the aggregate's assignment, and the workspace of one proof."""
+    if world < 1 or not 0 <= rank < world or not logns:
+        raise ValueError("sharded_aggregate_plan: bad arguments")
+    ni, nw, nc = 1, 0, 0
+    for g in logns:
+        i, w, c = circuit_counts(g)
+        ni, nw, nc = ni + i - 1, nw + w, nc + c
+    log_n = 14
+    while (1 << log_n) < nc + ni:
+        log_n += 1
+    n, nv = 1 << log_n, ni + nw
+    z_lo, z_hi = shard_range(nv + 3, rank, world)
+    h_lo, h_hi = shard_range(n - 1, rank, world)
+    nz, nh = z_hi - z_lo, h_hi - h_lo
+    passes = qap_pass_count(log_n)
+    items = min(65536, max(2048, (nz // 128 + 2047) // 2048 * 2048)) + 256          # frw_msm.hip nmsm_max_items
+    ones_groups = 1024 if nz > (1 << 18) else 64
+    buffers = {
+        "transform tables of the domain (2 (K - 1) twists + 5 scales, 32 n bytes each)": (2 * (passes - 1) + 5) * 32 * n,
+        "per-signature matrices (flattened rows, long rows, CSR)": 1300 * sum(circuit_counts(g)[2] for g in set(logns)),
+        "key: rows of a_query, b_g1_query, l_query (112 B) and b_g2_query (224 B)": (3 * 112 + 224) * nz,
+        "key: rows of h_query (112 B)": 112 * nh,
+        "statements' witnesses and instances as the witness kernel wrote them": 32 * (nv + len(logns)),
+        "the aggregate's assignment": 32 * nv,
+        "proof: A z, B z, C z and three working arrays": 3 * 32 * nc + 3 * 32 * n + 64,
+        "proof: h": 32 * n,
+        "proof: z ++ [1, r, s]": 32 * (nv + 3),
+        "proof: the sum over h_query, sixteen window rows": 16 * (4 * 32768 * 4 + 131072 * (8 + 240) + (32768 + 4096 + 1) * 240 + 4 * nh) + 4096,
+        "proof: one sort of the slice's scalars (32 n entries at worst) + the G1 tables' own arrays": (
+            32 * (128 if nz > (1 << 18) else 16) * 128 * 4 + 32 * (3 * 128 + items + 8) * 4 + 4 * 33 * nz
+            + (3 * 32 * (items + 128 + 1) + 3 * (ones_groups + 64)) * 240 + 4096),
+        "proof: the G2 table's own arrays": (32 * (items + 128 + 1) + ones_groups + 64) * 464 + 4096,
+    }
+    return {"world": world, "rank": rank, "statements": len(logns), "falcon512": list(logns).count(9), "falcon1024": list(logns).count(10),
+            "num_instance": ni, "num_witness": nw, "num_constraints": nc, "log_domain_size": log_n,
+            "z_lo": z_lo, "z_hi": z_hi, "h_lo": h_lo, "h_hi": h_hi,
+            "bucket_additions_h_query": 16 * nh,
+            "partial_sum_bytes_per_rank": 72 * 8,
+            "buffers": buffers, "hbm_plan_bytes": int(sum(buffers.values())),
+            "hbm_limit_bytes": int(HBM_PLAN_FRACTION * HBM_BYTES_PER_GPU),
+            "fits": int(sum(buffers.values())) <= int(HBM_PLAN_FRACTION * HBM_BYTES_PER_GPU)}
+
+
+def check_sharded_aggregate_plans(plans):
+    """The slices of the ranks tile both row ranges in rank order, every rank proves the same statement, and every plan fits HBM."""
+    world = plans[0]["world"]
+    assert len(plans) == world and [p["rank"] for p in plans] == list(range(world))
+    nv3 = plans[0]["num_instance"] + plans[0]["num_witness"] + 3
+    assert plans[0]["z_lo"] == 0 and plans[-1]["z_hi"] == nv3 and plans[0]["h_lo"] == 0 and plans[-1]["h_hi"] == (1 << plans[0]["log_domain_size"]) - 1
+    for a, b in zip(plans, plans[1:]):
+        assert a["z_hi"] == b["z_lo"] and a["h_hi"] == b["h_lo"], "slices must be contiguous"
+    for p in plans:
+        assert p["z_hi"] > p["z_lo"] and p["h_hi"] > p["h_lo"], "more ranks than rows"
+        for k in ("statements", "num_instance", "num_witness", "num_constraints", "log_domain_size"):
+            assert p[k] == plans[0][k]
+        assert p["fits"], "rank %d plans %.1f GB of HBM for the sharded aggregate, limit %.1f GB" % (p["rank"], p["hbm_plan_bytes"] / 1e9, p["hbm_limit_bytes"] / 1e9)
+    return True
+
+
+def all_gather_bytes(local, world, rank):
+    """All-gather a small 1-D uint8/int64 tensor of the same shape on every rank (a rank's partial sums of a sharded proof: 576 bytes):
+    returns [world, *local.shape] on local's device.  RCCL when the group is `nccl` (device tensors), staged through the host for gloo."""
+    if not is_dist() or world == 1:
+        return local.clone().unsqueeze(0)
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    host = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)]
+    dist.all_gather(host, local.cpu())
+    return torch.stack(host).to(local.device)
+
+
 def step_plan(world, rank, batch_per_gpu, chunk, allgather_chunk, n, num_witness, num_instance, compact_bytes,
               with_gather_legs=True, with_prove_leg=False, aggregate_statements=0):
     """Everything bench.py derives from (world, rank, per-GPU batch, launch size): this rank's global index range, the

@@ -9,6 +9,7 @@ system; the proof: the flow of examples/pok_sig.rs:30-47 on that system.  Checke
       laid end to end -- which (1) and the CPU test pin as the right system: h against the oracle's witness map (oracle/
       qap_oracle.c) and the FFT-free identity, (A, B, C) against oracle/bls12_381.py::prove_exponents_from_products, and the
       product's and the oracle's pairing verifiers on the result."""
+import os
 import random
 
 import numpy as np
@@ -248,6 +249,23 @@ def _bare_and_sliced_keys_give_the_same_bytes(engine, agg, toxic, vk, r, s, want
     lim = T.ints_to_limbs
     tox = [toxic[k] for k in ("alpha", "beta", "gamma", "delta", "t")]
     rs = np.array([lim([r, s])])
+    # window tables grown on the device from device-made rows: the host-made key's proof, byte for byte
+    key, vk_dev = engine.groth16_setup_r1cs(agg.handle, *tox, mode=EN.KEY_TABLES)
+    try:
+        assert engine.groth16_pk_info(key).mode == EN.KEY_TABLES
+        for k in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1"):
+            assert np.array_equal(vk_dev[k], vk[k]), "the device-made verifying key differs from the host-made one: " + k
+        ws_bytes = engine.groth16_workspace_bytes(key, agg.handle, 1)
+        pws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        proof = torch.full((1, 48), -1, dtype=torch.int64, device=dev)
+        bad = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        engine.groth16_prove_dev(key, agg.handle, 1, agg.wit, agg.inst, rs, proof, pws, ws_bytes, bad, s0)
+        torch.cuda.synchronize()
+        assert bad.tolist() == [0]
+        assert proof.cpu().numpy().view(np.uint64)[0].tolist() == want_proof.tolist(), "device-made window tables: another proof than the host-made key's"
+        del pws
+    finally:
+        engine.groth16_pk_free(key)
     key, vk_bare = engine.groth16_setup_r1cs(agg.handle, *tox, mode=EN.KEY_BARE)
     try:
         info = engine.groth16_pk_info(key)
@@ -314,7 +332,12 @@ def _prove_and_check(engine, oracle, tmp_path, logns, seed, python_pairing, slic
         dev, s0 = agg.dev, agg.s0
         rng = random.Random(seed)
         toxic = {k: rng.randrange(2, E.R) for k in ("alpha", "beta", "gamma", "delta", "t")}
-        key, vk = engine.groth16_setup_r1cs(agg.handle, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["t"], mode=EN.KEY_TABLES)
+        # this key through round 4's HOST-side evaluation of the QAP at t (FRW_SETUP_ON_HOST); the keys below are made on the device
+        os.environ["FRW_SETUP_ON_HOST"] = "1"
+        try:
+            key, vk = engine.groth16_setup_r1cs(agg.handle, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["t"], mode=EN.KEY_TABLES)
+        finally:
+            del os.environ["FRW_SETUP_ON_HOST"]
         try:
             q = engine.qap_info(agg.handle)
             n = int(q.domain_size)
