@@ -911,6 +911,7 @@ def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True, wor
            "verify": {"seconds": round(verify_s, 4), "public_inputs": ni - 1, "pairings": 3,
                       "what": "frw_groth16_verify: prepare_inputs over %d public inputs (a few host threads beyond 16,384) + 3 Miller loops + "
                               "1 final exponentiation" % (ni - 1)},
+           "proof_sha256": __import__("hashlib").sha256(proof_h.tobytes()).hexdigest(),
            "roofline": rates,
            "checked": "constraint system satisfied (0 violated rows of %d); deg h <= n - 2; %sproof accepted by frw_groth16_verify for its "
                       "%d public inputs and rejected with one input of the last statement changed; bit-exactness of (A, B, C) against the "
@@ -1781,12 +1782,26 @@ def main():
         elif "e" in box:
             gather_info["error"] = box["e"]
 
+    if args.dump_digests:
+        # one extra, untimed pass with every launch digested: per-signature (global index, status, digest) of this rank
+        dd = torch.zeros(batch, dtype=torch.int64, device=dev)
+        for c in range(nchunks):
+            a = c * chunk
+            cnt = min(chunk, batch - a)
+            launch(logn, cnt, d_sig[a:a + cnt], d_pk[a:a + cnt], d_hm[a:a + cnt], d_wit, d_inst, d_st[a:a + cnt],
+                   frw.ENC_MONTGOMERY, stream.cuda_stream)
+            eng.digest_dev(d_wit, L.num_witness * 4, cnt, dd[a:a + cnt], stream.cuda_stream)
+        torch.cuda.synchronize()
+        np.save("%s.rank%d.npy" % (args.dump_digests, rank),
+                np.stack([np.arange(lo, hi, dtype=np.uint64), d_st.cpu().numpy().astype(np.uint64),
+                          dd.cpu().numpy().view(np.uint64)]))
+
     # ---- third curve (N > 1): BASELINE configs[4] as written -- ONE proof for the 1,024 mixed statements, its key in N slices ----------
     # The witness buffer has served its purpose (digests, checks, gather legs): its 164 GB go back first -- the leg keeps the transform tables
     # of the 2^27 domain, this rank's slices of the key and one proof's workspace (sharding.sharded_aggregate_plan).  One collective on its
     # data path (an all-gather of 576 bytes per rank), so it runs under a deadline like the gather legs.
     sharded_info = None
-    if use_pg and not dual and args.aggregate_sharded and logn == 10 and not legs_hung and not args.dump_digests:
+    if use_pg and not dual and args.aggregate_sharded and logn == 10 and not legs_hung:
         import threading
         mix = sharding.aggregate_mix(args.aggregate_sharded)
         splan = sharding.sharded_aggregate_plan(world, rank, mix)
@@ -1814,20 +1829,6 @@ def main():
             sharded_info["error"] = "no result within %d s (a collective did not complete)" % args.allgather_deadline
         elif "e" in sbox:
             sharded_info["error"] = sbox["e"]
-
-    if args.dump_digests:
-        # one extra, untimed pass with every launch digested: per-signature (global index, status, digest) of this rank
-        dd = torch.zeros(batch, dtype=torch.int64, device=dev)
-        for c in range(nchunks):
-            a = c * chunk
-            cnt = min(chunk, batch - a)
-            launch(logn, cnt, d_sig[a:a + cnt], d_pk[a:a + cnt], d_hm[a:a + cnt], d_wit, d_inst, d_st[a:a + cnt],
-                   frw.ENC_MONTGOMERY, stream.cuda_stream)
-            eng.digest_dev(d_wit, L.num_witness * 4, cnt, dd[a:a + cnt], stream.cuda_stream)
-        torch.cuda.synchronize()
-        np.save("%s.rank%d.npy" % (args.dump_digests, rank),
-                np.stack([np.arange(lo, hi, dtype=np.uint64), d_st.cpu().numpy().astype(np.uint64),
-                          dd.cpu().numpy().view(np.uint64)]))
 
     result = None
     traffic = None if dual else measured_traffic(logn, chunk)
@@ -1891,8 +1892,6 @@ def main():
                 torch.cuda.empty_cache()
                 result["secondary"]["aggregate_proof_16_falcon1024"] = time_aggregate_proof(eng, dev, (10,) * 16, 10, groth16_result)
                 torch.cuda.empty_cache()
-                result["secondary"]["configs4_as_64_proofs_of_16"] = time_configs4_as_aggregates_of_16(eng, dev)
-                torch.cuda.empty_cache()
             if not args.no_aggregate:
                 result["secondary"]["host_call_one_signature_falcon%d" % n] = time_host_call(eng, logn)
                 result["secondary"]["aggregate_1024_mixed"] = time_aggregate(eng, dev, 1024, 50, threads)
@@ -1902,6 +1901,10 @@ def main():
                 # the device first -- the proof keeps 208 GB of its own (sharding.sharded_aggregate_plan).
                 d_wit = d_inst = None
                 torch.cuda.empty_cache()
+                if args.aggregate_sharded == 1024:
+                    # ... and the same 1,024 signatures as 64 proofs of 16 (three keys of window tables: 130 GB)
+                    result["secondary"]["configs4_as_64_proofs_of_16"] = time_configs4_as_aggregates_of_16(eng, dev)
+                    torch.cuda.empty_cache()
                 mix = sharding.aggregate_mix(args.aggregate_sharded)
                 assert sharding.sharded_aggregate_plan(1, 0, mix)["fits"]
                 result["secondary"]["aggregate_proof_%d_mixed" % len(mix)] = time_aggregate_proof(eng, dev, mix, 3, None)

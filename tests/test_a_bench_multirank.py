@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--aggregate-leg", "0"]
+COMMON = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--aggregate-sharded", "0", "--aggregate-leg", "0"]
 
 
 def _run(cmd, timeout=600):
@@ -120,3 +120,31 @@ def test_a_failed_gather_leg_reaches_the_caller_as_exit_code_3():
     assert "injected gather-leg failure on rank 1" in run.stderr and "Traceback" in run.stderr
     lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["value"] > 0           # the primary line is still printed
+
+
+@pytest.mark.gpu
+def test_one_proof_with_its_key_in_slices_over_two_and_four_ranks():
+    """BASELINE configs[4]'s shape on the "node", as far as one card allows: ONE proof for a mixed aggregate (the first 4 statements of the
+    benchmark's mix, two of each parameter set: the 2^19 domain)
+    whose key lies in slices over the ranks -- every rank: the whole witness map and its slices of the five sums
+    (frw_groth16_prove_partial_dev), one all-gather of 576 bytes per rank over the process group (gloo here, RCCL on a node),
+    frw_groth16_prove_combine_dev on every rank.  The leg itself asserts that all ranks hold the same 384 bytes and that the product's
+    pairing verifier accepts them (and rejects them for another statement); here: two and four ranks reproduce the ONE-rank proof
+    (the whole key, frw_groth16_prove_dev) byte for byte."""
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-allgather", "--no-prove", "--aggregate-leg", "0",
+              "--batch", "256", "--chunk", "128", "--backend", "gloo", "--aggregate-sharded", "4"]
+    shas = {}
+    for world in (1, 2, 4):
+        run = subprocess.run([sys.executable, "bench.py", "--gpus", str(world)] + (["--force-pg"] if world == 1 else []) + common,
+                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=_plain_env())
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+        lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, run.stdout
+        a = json.loads(lines[0])["scaling_curves"]["aggregate_proof_sharded"]
+        assert "error" not in a, a
+        assert "QAP domain 2^19" in a["workload"] and a["proving_key"]["slices"] == world and a["signatures_per_s"] > 0
+        assert a["proving_key"]["kind"].startswith("bare" if world > 1 else "window")
+        lo, hi = a["proving_key"]["rows_this_rank"]["h_query"]
+        assert lo == 0 and hi == ((1 << 19) - 1 + world - 1) // world
+        shas[world] = a["proof_sha256"]
+    assert shas[2] == shas[1] and shas[4] == shas[1], shas
