@@ -218,11 +218,15 @@ __device__ __forceinline__ void round_high(F29 (&x)[8], const uint32_t *roots, i
         }
     } else if (T == 6) {
         if (!DIF) {
+            // (the fences: as in the other direction below -- every stage's twiddles fetched in its stage, not all seven up front)
             { const F29 w = root_get(roots, g << 2);                                         // stage 4
               dit_mul(x[0], x[1], w); dit_mul(x[2], x[3], w); dit_mul(x[4], x[5], w); dit_mul(x[6], x[7], w); }
+            __builtin_amdgcn_sched_barrier(0);
             { const F29 w0 = root_get(roots, g << 1), w1 = root_get(roots, (g + 8) << 1);    // stage 5
               dit_mul(x[0], x[2], w0); dit_mul(x[1], x[3], w1); dit_mul(x[4], x[6], w0); dit_mul(x[5], x[7], w1); }
+            __builtin_amdgcn_sched_barrier(0);
             dit_mul(x[0], x[4], root_get(roots, g)); dit_mul(x[1], x[5], root_get(roots, g + 8));                  // stage 6
+            __builtin_amdgcn_sched_barrier(0);
             dit_mul(x[2], x[6], root_get(roots, g + 16)); dit_mul(x[3], x[7], root_get(roots, g + 24));
         } else {
             // the scheduler would fetch all seven twiddles up front (63 registers on top of the 72 of x and the 45 of a
@@ -473,6 +477,7 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
     }
 }
 
+#if !defined(FRW_QAP_PROBE)     // (tools/kernel_resources.sh compiles single instantiations of the pass kernel through a probe unit)
 namespace {
 template <int MODE, int T, int LOAD, int STORE>
 hipError_t launch_pass(const NttPass &p, unsigned arrays, hipStream_t st)
@@ -763,5 +768,7 @@ hipError_t launch_qap_quotient(const R1csDev &r, const QapDev &q, size_t batch, 
 {
     return qap_run(QAP_SIX, r, q, batch, witness, instance, h, num_unsatisfied, workspace, workspace_bytes, st);
 }
+
+#endif   // FRW_QAP_PROBE
 
 }  // namespace frw
