@@ -141,6 +141,12 @@ struct R1csView {
     const uint32_t *one;  size_t one_stride;
     uint32_t *abc;        size_t abc_sig_stride, abc_mat_stride;
     unsigned int *flags;  size_t flag_stride;
+    // Statements that are NOT evenly spaced -- all the statements of one parameter set inside a MIXED aggregate, in ONE launch (round 5:
+    // the 1,024-statement mix of BASELINE configs[4] is 516 runs of two statements; a launch sequence per run was 1,548 launches of 70
+    // microseconds at the head of every proof): offs[3 s ..] = the elements before statement s's witness variables, before its public
+    // inputs (its instance variable j >= 1 at inst + 8 (offs + j)) and the rows before its first row, in device memory; the strides
+    // above are then unused (but for the matrices' stride).
+    const uint64_t *offs;
 };
 // An aggregate statement: FalconNTTVerificationCircuit::generate_constraints run once per statement on ONE constraint system
 // (host/frw_host.hpp FalconAggregateVerificationCircuit).  Its instance vector is [1, public inputs of statement 0, of
@@ -154,10 +160,17 @@ struct R1csAggRun {
     uint64_t pub_off;           // public inputs before the run's first one (its instance variable j >= 1 is aggregate variable pub_off + j)
     uint64_t row_off;           // constraint rows before the run's first one
 };
+// all the statements of one parameter set, wherever they stand in the aggregate: one launch of that set's kernels
+struct R1csAggSet {
+    const R1csDev *base;
+    uint32_t count;
+    const uint64_t *offs;       // device memory, [count][3]: R1csView::offs
+};
 struct R1csAgg {
     uint32_t num_statements;
     uint32_t num_runs;
     const R1csAggRun *runs;     // host memory
+    R1csAggSet set[2];          // Falcon-512, Falcon-1024 (count 0: none)
 };
 size_t r1cs_check_scratch_bytes(const R1csDev &r, size_t batch, bool with_abc);
 hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *witness, const uint64_t *instance,

@@ -303,6 +303,58 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(uint32_t n, const uint32
     for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) out[b] = hist[b];
 }
 
+// A bare handle's sixteen window rows would each turn the scalars into digits again -- sixteen times the 32-byte reads and the
+// Montgomery products, and of the 2^27-point sum over h_query's 446 ms the counting sort took 95 (profiles/r05_aggregate1024_timeline.txt).
+// So: ONE pass writes the digits, window-major (int16[16][n]: two bytes per scalar and window), and the rows' histogram and scatter
+// read their own window's.
+__global__ __launch_bounds__(256) void msm_digits_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery, int16_t *__restrict__ digits)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int d[MSM_W];
+    (void)scalar_digits(scalars + (size_t)i * 8, montgomery, d, false);
+#pragma unroll
+    for (int j = 0; j < MSM_W; j++) digits[(size_t)j * n + i] = (int16_t)(d[j] == (1 << 15) ? -32768 : d[j]);     // (+2^15 does not fit: stored as its negative's code, told apart below)
+}
+// digits are in [-2^15 + 1, 2^15]: the one value outside int16, +2^15, travels as -32768 (which no digit is)
+__device__ __forceinline__ int msm_digit_load(const int16_t *digits, size_t at)
+{
+    const int v = digits[at];
+    return v == -32768 ? 1 << 15 : v;
+}
+__global__ __launch_bounds__(1024) void msm_hist_digits_kernel(uint32_t n, const int16_t *__restrict__ digits, uint32_t *__restrict__ slice_hist)
+{
+    __shared__ uint32_t hist[MSM_BUCKETS];
+    const size_t row = blockIdx.y;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        const int v = msm_digit_load(digits, row * n + i);
+        if (v) atomicAdd(&hist[(v < 0 ? -v : v) - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = slice_hist + (row * slices + slice) * MSM_BUCKETS;
+    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) out[b] = hist[b];
+}
+__global__ __launch_bounds__(1024) void msm_scatter_digits_kernel(uint32_t n, const int16_t *__restrict__ digits, const uint32_t *__restrict__ offsets,
+                                                                  const uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ entries)
+{
+    __shared__ uint32_t cursor[MSM_BUCKETS];
+    const size_t row = blockIdx.y;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    const uint32_t *first = slice_hist + (row * slices + slice) * MSM_BUCKETS, *off = offsets + row * MSM_BUCKETS;
+    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) cursor[b] = off[b] + first[b];
+    __syncthreads();
+    uint32_t *ent = entries + row * (size_t)n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        const int v = msm_digit_load(digits, row * n + i);
+        if (v) ent[atomicAdd(&cursor[(uint32_t)(v < 0 ? -v : v) - 1u], 1u)] = i | (v < 0 ? 0x80000000u : 0u);
+    }
+}
+
 // per bucket: its size (counts) and, in place of every slice's count, the slice's first position inside the bucket
 __global__ __launch_bounds__(256) void msm_slice_offsets_kernel(uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ counts, int slices)
 {
@@ -1163,6 +1215,7 @@ __global__ __launch_bounds__(64) void fixed_base_wide_kernel(size_t count, const
 
 }  // namespace frw
 
+#if !defined(FRW_MSM_PROBE)     // (tools/kernel_resources.py compiles single instantiations of the kernels above through a probe unit)
 // ---- C ABI ------------------------------------------------------------------------------------------------------------------------
 struct frw_msm {
     int device;
@@ -1182,6 +1235,7 @@ using frw::Fq2Field;
 // four words per row, so that whatever the number of points everything before them is 16-byte aligned (the items are read two words at a time)
 template <class F> struct MsmBufs {
     uint32_t *counts, *offsets, *order, *item_first, *item_count, *ones_count, *items, *buckets, *partial, *partial_items, *entries, *ones_list, *end;
+    int16_t *digits;            // a bare handle: int16[16][n], the windows' digits of the scalar vector being summed
     uint32_t max_items;
     size_t ent_stride, ones_stride;
 };
@@ -1207,6 +1261,11 @@ template <class F> MsmBufs<F> msm_carve(void *ws, size_t rows, uint32_t n, bool 
     b.entries = b.partial_items + rows * (size_t)b.max_items * BW;
     b.ones_list = b.entries + rows * b.ent_stride;
     b.end = b.ones_list + rows * b.ones_stride;
+    b.digits = nullptr;
+    if (bare) {
+        b.digits = (int16_t *)b.end;
+        b.end += ((size_t)frw::MSM_W * n * 2 + 3) / 4;
+    }
     return b;
 }
 // a bare handle: sixteen rows (windows) and their sixteen sums
@@ -1391,7 +1450,12 @@ hipError_t msm_rows(const frw_msm *m, size_t rows, const uint32_t *sc, size_t st
     const dim3 sgrid((unsigned)slices, (unsigned)rows);
     hipError_t e = hipMemsetAsync(b.ones_count, 0, rows * 16, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, b.ones_count, b.ones_list, bare ? 1 : 0);
+    if (bare) {
+        hipLaunchKernelGGL(frw::msm_digits_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, sc, montgomery, b.digits);
+        hipLaunchKernelGGL(frw::msm_hist_digits_kernel, sgrid, dim3(1024), 0, st, n, (const int16_t *)b.digits, slice_hist);
+    } else {
+        hipLaunchKernelGGL(frw::msm_hist_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, slice_hist, b.ones_count, b.ones_list, 0);
+    }
     hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, (unsigned)rows), dim3(256), 0, st, slice_hist, b.counts, slices);
     hipLaunchKernelGGL(frw::msm_scan_kernel, dim3((unsigned)rows), dim3(1024), 0, st, b.counts, b.offsets);
     // (four at a time: 12.6 ms with the finer split, 12.1 without); beyond 2^18 points: see MSM_MAX_ITEMS_LARGE
@@ -1401,7 +1465,8 @@ hipError_t msm_rows(const frw_msm *m, size_t rows, const uint32_t *sc, size_t st
     const uint32_t finer = bare ? 1u : rows <= 2 ? (n > (1u << 18) ? 24u : 4u) : 1u;
     hipLaunchKernelGGL(frw::msm_order_kernel, dim3((unsigned)rows), dim3(1024), 0, st, b.counts, b.offsets, b.order, b.item_first, b.items, b.item_count, finer,
                        b.max_items);
-    hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.offsets, slice_hist, b.entries, bare ? 1 : 0);
+    if (bare) hipLaunchKernelGGL(frw::msm_scatter_digits_kernel, sgrid, dim3(1024), 0, st, n, (const int16_t *)b.digits, b.offsets, slice_hist, b.entries);
+    else hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.offsets, slice_hist, b.entries, 0);
     hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(b.max_items / 64, (unsigned)rows), dim3(64), 0, st, m->dev, b.offsets,
                        b.counts, b.items, b.item_count, b.entries, b.partial_items, finer, b.max_items, b.ent_stride);
     hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, (unsigned)rows), dim3(64), 0, st, b.offsets, b.counts, b.item_first,
@@ -2364,13 +2429,15 @@ int groth16_prove_bare(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t ba
         e = hipEventRecord(pk->sorted, st);
         for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
         if (e != hipSuccess) break;
-        rc = frw_qap_witness_map_dev(r1cs, 1, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + b : nullptr, qap_ws, sz.qap, pk->main);
-        if (rc != FRW_OK) break;
+        // (the witness-side sums first: the witness map of a mixed aggregate is hundreds of launches, and what the one host thread enqueues
+        // behind them starts that much later -- 50 ms of an idle chip at the head of the 1,024-statement proof, profiles/r05_aggregate1024_timeline.txt)
         const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
         e = nmsm_accumulate_bare<FqField, true>(g1s, 3, g1, pA, pk->side[0], true);
         if (e != hipSuccess) break;
         e = nmsm_accumulate_bare<Fq2Field, false>(&pk->b2, 1, g2, (uint32_t *)pB2, pk->side[2], false);
         if (e != hipSuccess) break;
+        rc = frw_qap_witness_map_dev(r1cs, 1, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + b : nullptr, qap_ws, sz.qap, pk->main);
+        if (rc != FRW_OK) break;
         // h's coefficients [h_lo, h_hi) against this slice of h_query
         rc = msm_run<FqField, true>(pk->h, 1, h + pk->h_lo * 4, n, 1, (uint64_t *)pH, h_ws, sz.msm[0], pk->main, true);
         if (rc != FRW_OK) break;
@@ -2570,3 +2637,4 @@ extern "C" int frw_groth16_prove_combine_dev(const frw_groth16_pk *pk, size_t wo
     e = hipGetLastError();
     return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_groth16_prove_combine_dev");
 }
+#endif   // FRW_MSM_PROBE

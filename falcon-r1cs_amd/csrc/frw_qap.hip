@@ -71,6 +71,14 @@ struct NttPass {
 #define QAP_MUL(a, b) f29_mul(a, b)
 #endif
 
+// -DFRW_QAP_NO_LAUNDER (tools/ab_qap.py): the indices of stores and LDS slots are NOT derived afresh where they are used (round 4's
+// code: the compiler keeps them from where the elements were loaded, in scratch memory) -- the A/B of round 5's removal of that scratch
+#if defined(FRW_QAP_NO_LAUNDER)
+#define QAP_LAUNDER(v) ((void)0)
+#else
+#define QAP_LAUNDER(v) asm volatile("" : "+v"(v))
+#endif
+
 // compile-time loop: `#pragma unroll` is a request, and a loop over a thread's eight elements that stays a loop puts the
 // register array into scratch memory (it did, for the loop that multiplies by the factor and stores)
 template <int N, class F>
@@ -210,11 +218,16 @@ __device__ __forceinline__ void round_high(F29 (&x)[8], const uint32_t *roots, i
             { const F29 w = root_get(roots, g << 2);
               dif_mul_lazy<8>(x[0], x[1], w); dif_mul_lazy<8>(x[2], x[3], w); dif_mul_lazy<8>(x[4], x[5], w); dif_mul_lazy<8>(x[6], x[7], w); }
         } else {
-            const F29 wa = root_get(roots, g << 2), wb = root_get(roots, (g + 4) << 2);
-            const F29 wa0 = root_get(roots, g << 1), wa1 = root_get(roots, (g + 8) << 1);
-            const F29 wb0 = root_get(roots, (g + 4) << 1), wb1 = root_get(roots, (g + 12) << 1);
-            dif_mul_lazy<2>(x[0], x[2], wa0); dif_mul_lazy<2>(x[1], x[3], wa1); dif_mul_lazy<2>(x[4], x[6], wb0); dif_mul_lazy<2>(x[5], x[7], wb1);
-            dif_mul_lazy<4>(x[0], x[1], wa); dif_mul_lazy<4>(x[2], x[3], wa); dif_mul_lazy<4>(x[4], x[5], wb); dif_mul_lazy<4>(x[6], x[7], wb);
+            // (each stage's twiddles fetched in its stage: six of them held at once were 54 registers)
+            { const F29 wa0 = root_get(roots, g << 1), wa1 = root_get(roots, (g + 8) << 1);
+              dif_mul_lazy<2>(x[0], x[2], wa0); dif_mul_lazy<2>(x[1], x[3], wa1); }
+            { const F29 wb0 = root_get(roots, (g + 4) << 1), wb1 = root_get(roots, (g + 12) << 1);
+              dif_mul_lazy<2>(x[4], x[6], wb0); dif_mul_lazy<2>(x[5], x[7], wb1); }
+            __builtin_amdgcn_sched_barrier(0);
+            { const F29 wa = root_get(roots, g << 2);
+              dif_mul_lazy<4>(x[0], x[1], wa); dif_mul_lazy<4>(x[2], x[3], wa); }
+            { const F29 wb = root_get(roots, (g + 4) << 2);
+              dif_mul_lazy<4>(x[4], x[5], wb); dif_mul_lazy<4>(x[6], x[7], wb); }
         }
     } else if (T == 6) {
         if (!DIF) {
@@ -242,15 +255,27 @@ __device__ __forceinline__ void round_high(F29 (&x)[8], const uint32_t *roots, i
               dif_mul(x[0], x[1], w); dif_mul(x[2], x[3], w); dif_mul(x[4], x[5], w); dif_mul(x[6], x[7], w); }
         }
     } else {
-        const F29 wa = root_get(roots, g << 2), wb = root_get(roots, (g + 4) << 2);                   // stage 4, the two groups
-        const F29 wa0 = root_get(roots, g << 1), wa1 = root_get(roots, (g + 8) << 1);                 // stage 5
-        const F29 wb0 = root_get(roots, (g + 4) << 1), wb1 = root_get(roots, (g + 12) << 1);
+        // stage 4: the two groups' twiddles wa, wb; stage 5: wa0, wa1, wb0, wb1 -- each fetched in its stage
         if (!DIF) {
-            dit_mul(x[0], x[1], wa); dit_mul(x[2], x[3], wa); dit_mul(x[4], x[5], wb); dit_mul(x[6], x[7], wb);
-            dit_mul(x[0], x[2], wa0); dit_mul(x[1], x[3], wa1); dit_mul(x[4], x[6], wb0); dit_mul(x[5], x[7], wb1);
+            { const F29 wa = root_get(roots, g << 2);
+              dit_mul(x[0], x[1], wa); dit_mul(x[2], x[3], wa); }
+            { const F29 wb = root_get(roots, (g + 4) << 2);
+              dit_mul(x[4], x[5], wb); dit_mul(x[6], x[7], wb); }
+            __builtin_amdgcn_sched_barrier(0);
+            { const F29 wa0 = root_get(roots, g << 1), wa1 = root_get(roots, (g + 8) << 1);
+              dit_mul(x[0], x[2], wa0); dit_mul(x[1], x[3], wa1); }
+            { const F29 wb0 = root_get(roots, (g + 4) << 1), wb1 = root_get(roots, (g + 12) << 1);
+              dit_mul(x[4], x[6], wb0); dit_mul(x[5], x[7], wb1); }
         } else {
-            dif_mul(x[0], x[2], wa0); dif_mul(x[1], x[3], wa1); dif_mul(x[4], x[6], wb0); dif_mul(x[5], x[7], wb1);
-            dif_mul(x[0], x[1], wa); dif_mul(x[2], x[3], wa); dif_mul(x[4], x[5], wb); dif_mul(x[6], x[7], wb);
+            { const F29 wa0 = root_get(roots, g << 1), wa1 = root_get(roots, (g + 8) << 1);
+              dif_mul(x[0], x[2], wa0); dif_mul(x[1], x[3], wa1); }
+            { const F29 wb0 = root_get(roots, (g + 4) << 1), wb1 = root_get(roots, (g + 12) << 1);
+              dif_mul(x[4], x[6], wb0); dif_mul(x[5], x[7], wb1); }
+            __builtin_amdgcn_sched_barrier(0);
+            { const F29 wa = root_get(roots, g << 2);
+              dif_mul(x[0], x[1], wa); dif_mul(x[2], x[3], wa); }
+            { const F29 wb = root_get(roots, (g + 4) << 2);
+              dif_mul(x[4], x[5], wb); dif_mul(x[6], x[7], wb); }
         }
     }
 }
@@ -347,10 +372,15 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
     //   T == 5: ((4 g + j) 16 + c) with bit 4 XOR-ed by g: writers (two g, all c) differ in g & 1, readers (they read
     //           g' = e & 3, j' = g) in j' & 1
     //   T == 4: ((2 j + g) 32 + c): a 32-lane group is one g and all c
-    auto xslot = [&](int j, int gg) {
-        return T == 6 ? (((8 * j + gg) * 8 + c) ^ (j << 3)) : T == 5 ? (((4 * gg + j) * 16 + c) ^ ((gg & 1) << 4)) : ((2 * j + gg) * 32 + c);
-    };
     auto exchange = [&](F29 (&x)[8]) {
+        // (the slots from a laundered thread index: the fused pass exchanges twice, and slot addresses kept from the first exchange for
+        // the second were four registers in scratch memory for the nine thousand instructions in between)
+        uint32_t tid_x = (uint32_t)tid;
+        QAP_LAUNDER(tid_x);
+        const int c = (int)(tid_x & (COLS - 1)), g = (int)(tid_x >> CB);
+        auto xslot = [&](int j, int gg) {
+            return T == 6 ? (((8 * j + gg) * 8 + c) ^ (j << 3)) : T == 5 ? (((4 * gg + j) * 16 + c) ^ ((gg & 1) << 4)) : ((2 * j + gg) * 32 + c);
+        };
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (T == 6) {
@@ -461,17 +491,34 @@ __global__ __launch_bounds__(QAP_THREADS, 3) void ntt_pass_kernel(const NttPass 
     // ---- out ---------------------------------------------------------------------------------------------------------------------
     if (MODE == PASS_FIRST || MEMORDER) {
         // rows of the last round -> LDS -> memory order, four columns at a time
+        // (the stores' indices from a laundered thread index: see the other branch)
+        uint32_t tid_st = (uint32_t)tid;
+        QAP_LAUNDER(tid_st);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if ((c >> 2) == h)
                 static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; lds_put(mslot(DIF ? row_low(e) : row_high(e), c & 3), x[e]); });
             wave_sync();
 #pragma unroll
-            for (int k = 0; k < 4; k++) store_elem(widx(tid, 4 * h + k), lds_get(mslot(tid, k)));
+            for (int k = 0; k < 4; k++) store_elem(widx((int)tid_st, 4 * h + k), lds_get(mslot((int)tid_st, k)));
             wave_sync();
         }
     } else {
-        static_for<8>([&](auto ec) { constexpr int e = decltype(ec)::value; store_elem(widx(DIF || FUSED ? row_low(e) : row_high(e), c), x[e]); });
+        // The indices of the eight elements are a handful of integer operations on (tile, thread) -- but computed once, where the elements
+        // are loaded, the compiler keeps the eight 64-bit addresses alive across the whole pass for these stores (an in-place pass
+        // stores where it loaded): sixteen registers the butterflies do not have at three wavefronts per SIMD -- they went to scratch
+        // memory (round 4: 28 - 112 bytes per lane in the upper passes).  The thread index is laundered through an empty asm, so the
+        // indices are derived again here, from scratch only in the other sense.
+        uint32_t tid_out = (uint32_t)tid;
+        QAP_LAUNDER(tid_out);
+        const int c_out = (int)(tid_out & (COLS - 1)), g_out = (int)(tid_out >> CB);
+        auto row_low_out = [&](int e) { return g_out * 8 + e; };
+        auto row_high_out = [&](int e) { return T == 6 ? e * 8 + g_out : T == 5 ? (e & 3) * 8 + g_out + 4 * (e >> 2) : (e & 1) * 8 + g_out + 2 * (e >> 1); };
+        static_for<8>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const int row = DIF || FUSED ? row_low_out(e) : row_high_out(e);
+            store_elem(high | ((uint32_t)row << p.sh) | lowmid | (uint32_t)c_out, x[e]);
+        });
     }
     if (LIST) wave_sync();                                           // the next turn reuses the LDS
     }

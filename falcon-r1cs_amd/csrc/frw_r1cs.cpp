@@ -427,6 +427,25 @@ extern "C" int frw_r1cs_load_aggregate(int device, size_t count, const int32_t *
             r->agg.num_statements = (uint32_t)count;
             r->agg.num_runs = (uint32_t)r->runs.size();
             r->agg.runs = r->runs.data();
+            // per parameter set: where each of its statements sits (R1csView::offs), for the evaluation kernels' one launch per set
+            for (int g = 0; g < 2; g++) {
+                std::vector<uint64_t> offs;
+                for (const frw::R1csAggRun &run : r->runs) {
+                    if (run.base != (r->base[g] ? &r->base[g]->dev : nullptr)) continue;
+                    for (uint32_t k = 0; k < run.count; k++) {
+                        offs.push_back(run.wit_off + (uint64_t)k * run.base->num_witness);
+                        offs.push_back(run.pub_off + (uint64_t)k * (run.base->num_instance - 1));
+                        offs.push_back(run.row_off + (uint64_t)k * run.base->num_constraints);
+                    }
+                }
+                r->agg.set[g] = frw::R1csAggSet{r->base[g] ? &r->base[g]->dev : nullptr, (uint32_t)(offs.size() / 3), nullptr};
+                if (offs.empty()) continue;
+                void *d = nullptr;
+                if (hipMalloc(&d, offs.size() * 8) != hipSuccess) throw std::bad_alloc();
+                r->allocs.push_back(d);
+                if (hipMemcpy(d, offs.data(), offs.size() * 8, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy");
+                r->agg.set[g].offs = (const uint64_t *)d;
+            }
             r->dev.agg = &r->agg;
             r->dev.num_instance = (uint32_t)(pub + 1);
             r->dev.num_witness = (uint32_t)wit;

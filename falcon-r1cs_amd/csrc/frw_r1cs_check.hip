@@ -48,11 +48,12 @@ struct StatementVars {
 };
 __device__ __forceinline__ StatementVars statement_vars(const R1csDev &r, const R1csView &v, size_t sig)
 {
+    if (v.offs) return StatementVars{v.wit + (size_t)v.offs[3 * sig] * 8, v.inst + (size_t)v.offs[3 * sig + 1] * 8, v.one, r.num_instance};
     return StatementVars{v.wit + sig * v.wit_stride, v.inst + sig * v.inst_stride, v.one + sig * v.one_stride, r.num_instance};
 }
 __device__ __forceinline__ uint32_t *product_ptr(const R1csView &v, size_t sig, uint32_t matrix, uint32_t row)
 {
-    return v.abc + (sig * v.abc_sig_stride + (size_t)matrix * v.abc_mat_stride + row) * 8;
+    return v.abc + ((v.offs ? (size_t)v.offs[3 * sig + 2] : sig * v.abc_sig_stride) + (size_t)matrix * v.abc_mat_stride + row) * 8;
 }
 
 // The fast path of frw_r1cs_eval_dev (abc != nullptr): thread per row in nine-limb arithmetic (frw_fr29.h).
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(BLOCK) void r1cs_check_kernel(R1csDev r, size_t bat
 {
     const size_t sig = blockIdx.y;
     if (sig >= batch) return;
-    const uint32_t *wit = view.wit + sig * view.wit_stride, *inst = view.inst + sig * view.inst_stride, *one = view.one + sig * view.one_stride;
+    const StatementVars sv = statement_vars(r, view, sig);
+    const uint32_t *wit = sv.wit, *inst = sv.inst, *one = sv.one;
     unsigned bad = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < r.num_constraints; i += gridDim.x * BLOCK) {
         const uint32_t row = r.order[i];
@@ -430,8 +432,9 @@ size_t r1cs_check_scratch_bytes(const R1csDev &r, size_t batch, bool with_abc)
 {
     if (r.agg) {
         size_t need = 0;
-        for (uint32_t k = 0; k < r.agg->num_runs; k++) {
-            const size_t b = r1cs_check_scratch_bytes(*r.agg->runs[k].base, r.agg->runs[k].count, with_abc);
+        for (int g = 0; g < 2; g++) {
+            if (!r.agg->set[g].count) continue;
+            const size_t b = r1cs_check_scratch_bytes(*r.agg->set[g].base, r.agg->set[g].count, with_abc);
             need = b > need ? b : need;
         }
         return need;
@@ -505,20 +508,18 @@ hipError_t launch_r1cs_check(const R1csDev &r, size_t batch, const uint64_t *wit
     const uint32_t *wit = (const uint32_t *)witness, *inst = (const uint32_t *)instance;
     const size_t W = r.num_witness, I = r.num_instance, C = r.num_constraints;
     if (!r.agg) {
-        const R1csView v{wit, W * 8, inst, I * 8, inst, I * 8, (uint32_t *)abc, 3 * C, C, num_unsatisfied, 1};
+        const R1csView v{wit, W * 8, inst, I * 8, inst, I * 8, (uint32_t *)abc, 3 * C, C, num_unsatisfied, 1, nullptr};
         return launch_view(r, batch, v, st, caller_scratch);
     }
     for (size_t b = 0; b < batch; b++) {
         const uint32_t *bw = wit + b * W * 8, *bi = inst + b * I * 8;
         uint32_t *ba = abc ? (uint32_t *)abc + b * 3 * C * 8 : nullptr;
-        for (uint32_t k = 0; k < r.agg->num_runs; k++) {
-            const R1csAggRun &run = r.agg->runs[k];
-            const size_t pub = (size_t)run.base->num_instance - 1;        // public inputs per statement
-            const R1csView v{bw + run.wit_off * 8, (size_t)run.base->num_witness * 8,
-                             bi + run.pub_off * 8, pub * 8, bi, 0,
-                             ba ? ba + run.row_off * 8 : nullptr, run.base->num_constraints, C,
-                             num_unsatisfied ? num_unsatisfied + b : nullptr, 0};
-            const hipError_t e = launch_view(*run.base, run.count, v, st, caller_scratch);
+        // one launch sequence per PARAMETER SET: its statements found through their offsets, wherever they stand
+        for (int g = 0; g < 2; g++) {
+            const R1csAggSet &set = r.agg->set[g];
+            if (!set.count) continue;
+            const R1csView v{bw, 0, bi, 0, bi, 0, ba, 0, C, num_unsatisfied ? num_unsatisfied + b : nullptr, 0, set.offs};
+            const hipError_t e = launch_view(*set.base, set.count, v, st, caller_scratch);
             if (e != hipSuccess) return e;
         }
     }

@@ -174,7 +174,7 @@ def sharded_aggregate_plan(world, rank, logns):
         "proof: A z, B z, C z and three working arrays": 3 * 32 * nc + 3 * 32 * n + 64,
         "proof: h": 32 * n,
         "proof: z ++ [1, r, s]": 32 * (nv + 3),
-        "proof: the sum over h_query, sixteen window rows": 16 * (4 * 32768 * 4 + 131072 * (8 + 240) + (32768 + 4096 + 1) * 240 + 4 * nh) + 4096,
+        "proof: the sum over h_query, sixteen window rows (entries 4 B and digits 2 B per point and window)": 16 * (4 * 32768 * 4 + 131072 * (8 + 240) + (32768 + 4096 + 1) * 240 + 6 * nh) + 4096,
         "proof: one sort of the slice's scalars (32 n entries at worst) + the G1 tables' own arrays": (
             32 * (128 if nz > (1 << 18) else 16) * 128 * 4 + 32 * (3 * 128 + items + 8) * 4 + 4 * 33 * nz
             + (3 * 32 * (items + 128 + 1) + 3 * (ones_groups + 64)) * 240 + 4096),

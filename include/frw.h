@@ -270,7 +270,11 @@ int frw_r1cs_eval_scratch_dev(const frw_r1cs *r, size_t batch, const uint64_t *d
  *                       signatures as fit.
  * Returns FRW_E_INVALID_ARG for a null pointer, a workspace smaller than one signature's, or a domain outside 2^14 .. 2^30
  * (the transforms run as passes of six, five or four radix-2 stages: 2^17 = 6 + 6 + 5 and 2^18 = 6 + 6 + 6 for the Falcon
- * circuits, 2^19 = 6 + 5 + 4 + 4 .. 2^24 = 6 + 6 + 6 + 6 for aggregate statements).  Stream-ordered: everything is enqueued on
+ * circuits, 2^19 = 6 + 5 + 4 + 4 .. 2^24 = 6 + 6 + 6 + 6, 2^25 = 6 + 5 + 5 + 5 + 4 .. 2^27 = 6 + 6 + 5 + 5 + 5 for aggregate statements.
+ * RUN AND TESTED: every domain 2^17 .. 2^27 (tests/test_gpu_qap.py, tests/test_gpu_aggregate.py) -- 2^27 is the 1,024-statement
+ * aggregate of BASELINE configs[4], whose thirteen per-index factor tables (56 GB) are made on the device; the schedules of
+ * 2^28 .. 2^30 come from the same rule and are checked by the exact-integer model of tests/test_qap_schedule.py only: a 2^28 domain's
+ * tables alone are 120 GB, and the smallest statement that needs it is 1,600 Falcon-1024 verifications).  Stream-ordered: everything is enqueued on
  * `stream` and NOTHING is allocated -- the sparse products borrow the working arrays, idle at that point, as their
  * scratch -- so a call may be captured in a HIP graph.  A HIP failure is recorded for frw_last_error().
  * Precondition: every witness / instance element is canonical Montgomery form (limbs < p), which is what arkworks and
@@ -323,9 +327,11 @@ int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
  * are the per-signature systems' blocks, and a run of consecutive statements of one parameter set is one launch of that set's
  * kernels reading the aggregate vectors in place.  d_num_unsatisfied counts the violated rows of the whole statement.
  * frw_groth16_setup_r1cs is frw_groth16_setup for the system behind any handle; the proving key of an aggregate has one query
- * point per variable of the whole statement (Falcon-1024: 3.6 KB of G1 window tables x 3 and 7.2 KB of G2 per variable, 1.8 KB
- * per domain point for h_query: 53 GB for sixteen statements).  A 1,024-signature statement needs the 2^28 domain: 268 M
- * points of h_query alone are 480 GB of window tables -- not one GPU's; it is proved as aggregates of <= 64 statements. */
+ * point per variable of the whole statement.  As window tables that is 3.6 KB of G1 tables x 3 and 7.2 KB of G2 per variable and
+ * 1.8 KB per domain point of h_query: 53 GB for sixteen Falcon-1024 statements -- the fastest proofs, up to there.  Beyond, the key
+ * keeps the points alone (FRW_KEY_BARE below: 112 / 224 bytes a point) and the sums run window by window over them: the 1,024 mixed
+ * statements of BASELINE configs[4] (513 Falcon-512 + 511 Falcon-1024: C + I = 126.6 M, the 2^27 domain -- round 4 had written 2^28
+ * and 480 GB here, both wrong) are 121.9 M variables, 83 GB of points, ONE proof in 0.7 s on one MI355X. */
 typedef struct {
     uint64_t num_statements;                    /* 1 for the handles of frw_r1cs_load */
     uint64_t count_logn9, count_logn10;

@@ -491,6 +491,13 @@ def test_one_proof_for_sixty_four_falcon1024_statements(engine, oracle):
     _prove_large_and_check_by_properties(engine, oracle, (10,) * 64, seed=64, log_domain=24, vouch_for_vk=False)
 
 
+@pytest.mark.parametrize("count,log_domain", [(128, 25), (256, 26)], ids=["2^25", "2^26"])
+def test_one_proof_on_the_five_pass_domains(engine, oracle, count, log_domain):
+    """The transform schedules between the two above: 2^25 = 6 + 5 + 5 + 5 + 4 stages (128 Falcon-1024 statements), 2^26 = 6 + 5 + 5 + 5 + 5
+    (256) -- with the 2^27 of the next test, every domain frw.h says has run."""
+    _prove_large_and_check_by_properties(engine, oracle, (10,) * count, seed=count, log_domain=log_domain, vouch_for_vk=count > 128)
+
+
 def test_configs4_one_proof_for_1024_mixed_statements(engine, oracle):
     """BASELINE configs[4] as written: ONE Groth16 proof for 1,024 mixed statements -- the mix bench.py draws (513 Falcon-512 + 511
     Falcon-1024), C + I = 126.6 M: the 2^27 domain (6 + 6 + 5 + 5 + 5 stages), 121.9 M variables, 83 GB of key."""

@@ -22,15 +22,21 @@ import falcon_r1cs_amd as frw  # noqa: E402
 from falcon_r1cs_amd._lib import QapInfoStruct  # noqa: E402
 
 CSRC = os.path.join(ROOT, "falcon-r1cs_amd", "csrc")
-SRC = ("frw_kernels.hip", "frw_prepare.hip", "frw_r1cs_check.hip", "frw_qap.hip", "frw_msm.hip", "frw_capi.cpp", "frw_synth.cpp", "frw_r1cs.cpp", "frw_verify.cpp")
+SRC = ("frw_kernels.hip", "frw_prepare.hip", "frw_r1cs_check.hip", "frw_qap.hip", "frw_setup.hip", "frw_msm.hip", "frw_capi.cpp", "frw_synth.cpp", "frw_r1cs.cpp", "frw_verify.cpp")
 
 
 def build(name, flags, logn):
     out_dir = os.path.join(ROOT, "gpurun_out", "variants")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libfrw_qap_%s.so" % name)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-o", so] +
-                          flags.split() + [os.path.join(CSRC, f) for f in SRC])
+    prebuilt = os.path.join(ROOT, "tools", "variants", "libfrw_qap_%s.so" % name)
+    if os.path.exists(prebuilt):
+        # built where the sources are (tools/build_qap_variant.sh NAME FLAGS: only frw_qap.hip is compiled again, the other objects are
+        # the library's own) and sent along: no minutes of the GPU box go into compiling
+        so = prebuilt
+    else:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-o", so] +
+                              flags.split() + [os.path.join(CSRC, f) for f in SRC])
     lib = C.CDLL(so)
     lib.frw_r1cs_load.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.frw_qap_info.argtypes = [C.c_void_p, C.POINTER(QapInfoStruct)]

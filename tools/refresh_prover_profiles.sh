@@ -21,6 +21,9 @@ trace msm "$R/tools/time_msm.py" 10 64 5
 trace groth16 "$R/tools/time_groth16.py" 10 64 5
 trace groth16_batch1 "$R/tools/time_groth16.py" 10 1 5
 trace aggregate16 "$R/bench.py" --workload aggregate --aggregate 10x16 --steps 5
+# BASELINE configs[4] as written: ONE proof for the 1,024 mixed statements (bare key, the 2^27 domain): setup, three proofs, verification
+trace aggregate1024 "$R/tools/time_aggregate_large.py" 1024 2
+python3 "$R/tools/kernel_timeline.py" "$(find "$R/gpurun_out/p_${TAG}_aggregate1024" -name "aggregate1024_kernel_trace.csv" | head -1)" 5 > "$O/${TAG}_aggregate1024_timeline.txt"
 python3 "$R/tools/kernel_timeline.py" "$(find "$R/gpurun_out/p_${TAG}_groth16" -name "groth16_kernel_trace.csv" | head -1)" 0.3 > "$O/${TAG}_groth16_timeline_64.txt"
 python3 "$R/tools/kernel_timeline.py" "$(find "$R/gpurun_out/p_${TAG}_groth16_batch1" -name "groth16_batch1_kernel_trace.csv" | head -1)" 0.08 > "$O/${TAG}_groth16_batch1_latency.txt"
 python3 "$R/tools/kernel_timeline.py" "$(find "$R/gpurun_out/p_${TAG}_aggregate16" -name "aggregate16_kernel_trace.csv" | head -1)" 0.15 > "$O/${TAG}_aggregate16_timeline.txt"
