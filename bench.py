@@ -51,7 +51,12 @@ def launch_ranks(argv, n, grace_s=30.0):
     torch.distributed's env:// rendezvous reads (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free
     MASTER_PORT), let them write to this process's stdout / stderr (rank 0 prints the one JSON line), and return the
     largest exit code.  Nothing is exec'ed.  When a rank fails the others get `grace_s` seconds to leave by themselves
-    (their own deadlines end a collective whose peer is gone) and are then terminated by PID."""
+    (their own deadlines end a collective whose peer is gone) and are then terminated by PID.
+    The ranks do not outlive this process: SIGTERM / SIGINT arriving here are passed on to them, whatever ends the wait (an
+    exception, a signal) terminates those still running, and every rank asks the kernel for SIGTERM on its parent's death
+    (PR_SET_PDEATHSIG) -- a harness that times this process out does not leave GPUs and a rendezvous port held."""
+    import ctypes
+    import signal
     import socket
     import subprocess
     if any(a == "--plan" for a in argv):
@@ -67,12 +72,44 @@ def launch_ranks(argv, n, grace_s=30.0):
     # the host's cores are shared by the ranks (what torch.distributed.run's OMP_NUM_THREADS=1 default is about; the
     # synthetic-input threads are sized by bench.py itself)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    def die_with_parent():
+        # in the child, before its program starts: SIGTERM when the launcher goes (prctl(PR_SET_PDEATHSIG = 1, SIGTERM))
+        try:
+            ctypes.CDLL(None).prctl(1, int(signal.SIGTERM), 0, 0, 0)
+        except Exception:                        # noqa: BLE001 -- not Linux: the finally below still covers the orderly ways out
+            pass
     procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+
+    def pass_on(signum, _frame):
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signum)
+    previous = {sg: signal.signal(sg, pass_on) for sg in (signal.SIGTERM, signal.SIGINT)}
     codes = [None] * n
     first_failure = None
+    try:
+        for r in range(n):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e, preexec_fn=die_with_parent))
+        codes = _wait_for_ranks(procs, codes, first_failure, grace_s)
+    finally:
+        for sg, h in previous.items():
+            signal.signal(sg, h)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    # a rank killed by a signal reports -SIG: any non-zero code is a failed run
+    return max(abs(c) for c in codes)
+
+
+def _wait_for_ranks(procs, codes, first_failure, grace_s):
+    import subprocess
     while any(c is None for c in codes):
         for r, p in enumerate(procs):
             if codes[r] is None:
@@ -93,8 +130,7 @@ def launch_ranks(argv, n, grace_s=30.0):
                         codes[r] = p.wait()
             break
         time.sleep(0.05)
-    # a rank killed by a signal reports -SIG: any non-zero code is a failed run
-    return max(abs(c) for c in codes)
+    return codes
 
 
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1:

@@ -496,8 +496,10 @@ extern "C" int frw_aggregate_assign_dev(const frw_r1cs *r, const uint64_t *d_wit
         if (r->base[g] && (!wsrc[g] || !isrc[g])) return FRW_E_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSetDevice(r->device);
-    static const uint64_t one[4] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};   // R mod p
-    if (e == hipSuccess) e = hipMemcpyAsync(d_instance, one, 32, hipMemcpyHostToDevice, st);
+    // the aggregate's ONE constant: the leading element of any statement's own instance vector (the witness entry points write it in the
+    // batches' encoding) -- a device-to-device copy, so the call stays on the stream and may be captured
+    const uint64_t *first_one = r->base[0] ? isrc[0] : isrc[1];
+    if (e == hipSuccess) e = hipMemcpyAsync(d_instance, first_one, 32, hipMemcpyDeviceToDevice, st);
     size_t used[2] = {0, 0};
     for (const frw::R1csAggRun &run : r->runs) {
         if (e != hipSuccess) break;

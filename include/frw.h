@@ -326,6 +326,10 @@ int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
  * ones (either pair may be NULL if the aggregate has no such statement).  The aggregate's matrices are never materialised: they
  * are the per-signature systems' blocks, and a run of consecutive statements of one parameter set is one launch of that set's
  * kernels reading the aggregate vectors in place.  d_num_unsatisfied counts the violated rows of the whole statement.
+ * frw_aggregate_assign_dev -- preconditions it cannot check: the Falcon-512 batch holds at least count_logn9 signatures and the
+ * Falcon-1024 batch count_logn10 (frw_r1cs_info), both written with the SAME encoding (the aggregate's constant one is copied from the
+ * first statement's own instance vector) and none of them rejected (FRW_ST_COEFF_RANGE zero-fills a slot: its leading one too).
+ * Device-to-device copies on `stream` only -- two per run of consecutive statements of one parameter set --, capture-safe.
  * frw_groth16_setup_r1cs is frw_groth16_setup for the system behind any handle; the proving key of an aggregate has one query
  * point per variable of the whole statement.  As window tables that is 3.6 KB of G1 tables x 3 and 7.2 KB of G2 per variable and
  * 1.8 KB per domain point of h_query: 53 GB for sixteen Falcon-1024 statements -- the fastest proofs, up to there.  Beyond, the key

@@ -37,10 +37,13 @@ sys.argv = ["bench.py", "--gpus=4", "--steps", "1"]
 import subprocess
 started = []
 class FakeProc:
-    def __init__(self, cmd, env=None):
+    def __init__(self, cmd, env=None, preexec_fn=None):
+        assert callable(preexec_fn)                    # the ranks ask for SIGTERM on the launcher's death (PR_SET_PDEATHSIG)
         started.append((cmd, env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"], env["MASTER_PORT"]))
         self.pid = 1
     def poll(self):
+        return 0
+    def wait(self, timeout=None):
         return 0
 subprocess.Popen = FakeProc
 try:
@@ -63,3 +66,35 @@ def test_under_a_launcher_nothing_is_started():
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1"], cwd=ROOT, capture_output=True, text=True,
                          timeout=600, env=env)
     assert out.returncode == 1 and "launcher" not in out.stderr and "no HIP device visible" in out.stderr, out.stderr[-2000:]
+
+
+def test_ranks_do_not_outlive_an_interrupted_launcher(tmp_path):
+    """a launcher that is terminated (a harness timeout, Ctrl-C) must take its ranks with it -- the signal is passed on, and
+    whatever ends the wait terminates those still running.  The "ranks" here are bench.py itself started under a name that makes it sleep:
+    a stand-in script, so no GPU is involved."""
+    import signal
+    import time
+    stub = tmp_path / "bench_stub.py"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("import numpy as np")]
+    # the launcher part of bench.py verbatim; as a RANK (WORLD_SIZE set) the stub records its pid and sleeps
+    stub.write_text(head.replace('if __name__ == "__main__" and "WORLD_SIZE" not in os.environ',
+                                 'if "WORLD_SIZE" in os.environ:\n    open(%r + os.environ["RANK"], "w").write(str(os.getpid()))\n    time.sleep(120)\n    sys.exit(0)\n'
+                                 'if __name__ == "__main__" and "WORLD_SIZE" not in os.environ' % str(tmp_path / "pid")))
+    p = subprocess.Popen([sys.executable, str(stub), "--gpus", "2"], cwd=ROOT, env=_env_without_launcher())
+    deadline = time.time() + 30
+    while time.time() < deadline and not all(os.path.exists(str(tmp_path / ("pid%d" % r))) for r in range(2)):
+        time.sleep(0.1)
+    pids = [int(open(str(tmp_path / ("pid%d" % r))).read()) for r in range(2)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(30) != 0
+    time.sleep(0.5)
+    for pid in pids:
+        alive = True
+        try:
+            os.kill(pid, 0)
+            # a zombie of a reparented child counts as gone once it has been reaped; give init a moment
+            alive = open("/proc/%d/stat" % pid).read().split()[2] not in ("Z", "X")
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, "rank %d outlived its launcher" % pid

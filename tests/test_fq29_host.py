@@ -20,6 +20,8 @@ M29 = (1 << 29) - 1
 
 @pytest.fixture(scope="module")
 def lib():
+    if os.environ.get("FRW_TEST_FQ29_SO"):           # tools/sanitize_cpu.sh: its own ASan / UBSan build, at a path of its own
+        return C.CDLL(os.environ["FRW_TEST_FQ29_SO"])
     out = os.path.join(HERE, "cpp", "build")
     os.makedirs(out, exist_ok=True)
     so = os.path.join(out, "libtest_fq29.so")

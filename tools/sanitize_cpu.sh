@@ -33,11 +33,12 @@ done
 echo "host mirror: clean"
 # the field / curve headers of the prover (frw_fq29.h incl. the Euclidean inversion, frw_quad.h's level programmes) through their host
 # harness: the sanitized library takes the place of the test's own for one run of tests/test_fq29_host.py
-SO="$ROOT/tests/cpp/build/libtest_fq29.so"
-mkdir -p "$ROOT/tests/cpp/build"
+# (a path of its own, named to the test through FRW_TEST_FQ29_SO, and removed whatever happens: a sanitized library left where the
+# ordinary fixture looks would be newer than the sources and fail to load without the preload)
+SO=$(mktemp /tmp/libtest_fq29_asan.XXXXXX.so)
+trap 'rm -f "$SO"' EXIT
 g++ -O1 -g -std=c++17 -shared -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -Wno-unknown-pragmas -fno-strict-aliasing \
     -I "$ROOT/tests/cpp/hip_host" -I "$ROOT/falcon-r1cs_amd/csrc" -o "$SO" "$ROOT/tests/cpp/test_fq29.cpp"
-(cd "$ROOT" && ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
+(cd "$ROOT" && FRW_TEST_FQ29_SO="$SO" ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
     python -m pytest tests/test_fq29_host.py -x -q 2>&1 | tail -1)
-rm -f "$SO"                                    # the next ordinary test run rebuilds its own
 echo "fq29 / quad headers: clean"
