@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <new>
@@ -355,6 +356,152 @@ __global__ __launch_bounds__(1024) void msm_scatter_digits_kernel(uint32_t n, co
     }
 }
 
+// ---- WIDE windows for the largest bare sums (round 5) -------------------------------------------------------------------------------
+// A bare handle's windows cost no table, so their width is free: thirteen 20-bit windows instead of sixteen 16-bit ones are 19 % fewer
+// bucket additions (one per point and non-zero digit: 13 n instead of 16 n) -- what the 2^27-point sum over h_query of the 1,024-statement
+// aggregate spends 350 of its 430 ms on.  2^19 buckets per window do not fit the LDS histograms of the counting sort above; they need not:
+// bucket m = |d| - 1 of window j is bucket (m mod 2^15) of ROW j 16 + (m >> 15), and a row is to every kernel from the fine sort on what a
+// window (or a signature) was -- 32,768 buckets, work items, combine, the two-stage fold -- 208 rows of them.  Two sorts: a COARSE one of
+// all (window, point) pairs by row (208 counters per workgroup; 8-byte entries: point | sign, m mod 2^15), then per row the 15-bit LDS-
+// histogram sort as ever, reading the row's coarse entries.  A row's buckets fold to S1 = sum (lo + 1) B_lo AND S0 = sum B_lo; a window is
+// sum_hi S1_hi + 2^15 sum_hi hi S0_hi (msm_wide_window_kernel), the windows join by Horner's rule with 20 doublings each.
+// (Worth it from 2^23 points by the additions' count: below, the folds of 13 x 2^19 buckets cost more than three windows' additions save.
+// By the clock not even at 2^27 yet -- see MSM_WIDE_FROM -- so only handles loaded as wide run this.)
+constexpr int WIDE_C = 20, WIDE_W = 13, WIDE_H = 1 << (WIDE_C - MSM_C), WIDE_ROWS = WIDE_W * WIDE_H;
+constexpr uint32_t WIDE_MAX_ITEMS = 65536;       // >= 32,768 + (32,768 / 1.5) 33 / 32 (finer = 1)
+constexpr int WIDE_SLICES_COARSE = 512, WIDE_SLICES_FINE = 8;
+// signed 20-bit digits, d_j in [-2^19 + 1, 2^19], sum d_j 2^(20 j) = k; the top window (bits 240 ..) takes the last carry
+__device__ __forceinline__ void scalar_digits_wide(const uint32_t *src, int montgomery, int (&d)[WIDE_W])
+{
+    const Fr8 w = scalar_canonical(src, montgomery);
+    int carry = 0;
+#pragma unroll
+    for (int j = 0; j < WIDE_W; j++) {
+        const int bit = WIDE_C * j, k = bit >> 5, sh = bit & 31;
+        const uint64_t two = (uint64_t)w.l[k] | (k + 1 < 8 ? (uint64_t)w.l[k + 1] << 32 : 0ull);
+        int v = (int)((two >> sh) & ((1u << WIDE_C) - 1u)) + carry;
+        carry = 0;
+        if (j + 1 < WIDE_W && v > (1 << (WIDE_C - 1))) { v -= 1 << WIDE_C; carry = 1; }
+        d[j] = v;
+    }
+}
+__global__ __launch_bounds__(1024) void msm_wide_coarse_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery,
+                                                                    uint32_t *__restrict__ slice_hist /* [slice][208] */)
+{
+    __shared__ uint32_t hist[WIDE_ROWS];
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    if (threadIdx.x < WIDE_ROWS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int d[WIDE_W];
+        scalar_digits_wide(scalars + (size_t)i * 8, montgomery, d);
+#pragma unroll
+        for (int j = 0; j < WIDE_W; j++)
+            if (d[j]) atomicAdd(&hist[j * WIDE_H + (((uint32_t)(d[j] < 0 ? -d[j] : d[j]) - 1u) >> (MSM_C - 1))], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < WIDE_ROWS) slice_hist[(size_t)slice * WIDE_ROWS + threadIdx.x] = hist[threadIdx.x];
+}
+// every slice's first position inside its rows, the rows' sizes and where they start (one workgroup)
+__global__ __launch_bounds__(256) void msm_wide_coarse_offsets_kernel(uint32_t slices, uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ row_count,
+                                                                      unsigned long long *__restrict__ row_start)
+{
+    __shared__ unsigned long long total[WIDE_ROWS];
+    const uint32_t r = threadIdx.x;
+    if (r < WIDE_ROWS) {
+        uint32_t run = 0;
+        for (uint32_t s_ = 0; s_ < slices; s_++) {
+            const uint32_t c = slice_hist[(size_t)s_ * WIDE_ROWS + r];
+            slice_hist[(size_t)s_ * WIDE_ROWS + r] = run;
+            run += c;
+        }
+        row_count[r] = run;
+        total[r] = run;
+    }
+    __syncthreads();
+    if (r == 0) {
+        unsigned long long at = 0;
+        for (int k = 0; k < WIDE_ROWS; k++) { row_start[k] = at; at += total[k]; }
+    }
+}
+__global__ __launch_bounds__(1024) void msm_wide_coarse_scatter_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery,
+                                                                       const uint32_t *__restrict__ slice_hist, const unsigned long long *__restrict__ row_start,
+                                                                       uint2 *__restrict__ coarse /* point | sign << 31, bucket of the row */)
+{
+    __shared__ uint32_t cursor[WIDE_ROWS];
+    __shared__ unsigned long long base[WIDE_ROWS];
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
+    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+    if (threadIdx.x < WIDE_ROWS) {
+        cursor[threadIdx.x] = slice_hist[(size_t)slice * WIDE_ROWS + threadIdx.x];
+        base[threadIdx.x] = row_start[threadIdx.x];
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int d[WIDE_W];
+        scalar_digits_wide(scalars + (size_t)i * 8, montgomery, d);
+#pragma unroll
+        for (int j = 0; j < WIDE_W; j++) {
+            if (!d[j]) continue;
+            const uint32_t m = (uint32_t)(d[j] < 0 ? -d[j] : d[j]) - 1u, row = j * WIDE_H + (m >> (MSM_C - 1));
+            coarse[base[row] + atomicAdd(&cursor[row], 1u)] = make_uint2(i | (d[j] < 0 ? 0x80000000u : 0u), m & (MSM_BUCKETS - 1));
+        }
+    }
+}
+// per row: the 15-bit counting sort of its coarse entries (grid: slices of the row x rows)
+__global__ __launch_bounds__(1024) void msm_wide_fine_hist_kernel(const uint2 *__restrict__ coarse, const uint32_t *__restrict__ row_count,
+                                                                  const unsigned long long *__restrict__ row_start, uint32_t *__restrict__ slice_hist)
+{
+    __shared__ uint32_t hist[MSM_BUCKETS];
+    const size_t row = blockIdx.y;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, cnt = row_count[row], per = (cnt + slices - 1) / slices;
+    const uint32_t lo = slice * per < cnt ? slice * per : cnt, hi = lo + per < cnt ? lo + per : cnt;
+    const uint2 *src = coarse + row_start[row];
+    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) atomicAdd(&hist[src[i].y], 1u);
+    __syncthreads();
+    uint32_t *out = slice_hist + (row * slices + slice) * MSM_BUCKETS;
+    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) out[b] = hist[b];
+}
+__global__ __launch_bounds__(1024) void msm_wide_fine_scatter_kernel(const uint2 *__restrict__ coarse, const uint32_t *__restrict__ row_count,
+                                                                     const unsigned long long *__restrict__ row_start, const uint32_t *__restrict__ offsets,
+                                                                     const uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ entries)
+{
+    __shared__ uint32_t cursor[MSM_BUCKETS];
+    const size_t row = blockIdx.y;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, cnt = row_count[row], per = (cnt + slices - 1) / slices;
+    const uint32_t lo = slice * per < cnt ? slice * per : cnt, hi = lo + per < cnt ? lo + per : cnt;
+    const uint2 *src = coarse + row_start[row];
+    const uint32_t *first = slice_hist + (row * slices + slice) * MSM_BUCKETS, *off = offsets + row * MSM_BUCKETS;
+    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) cursor[b] = off[b] + first[b];
+    __syncthreads();
+    uint32_t *ent = entries + row_start[row];                     // a row's entries lie where its coarse entries do
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        const uint2 e = src[i];
+        ent[atomicAdd(&cursor[e.y], 1u)] = e.x;
+    }
+}
+// window j = sum_hi S1(j, hi) + 2^15 sum_hi hi S0(j, hi): one lane per window (F::LANES lanes)
+template <class F>
+__global__ __launch_bounds__(64) void msm_wide_window_kernel(const uint32_t *__restrict__ s1 /* [208][BK_WORDS] */, const uint32_t *__restrict__ s0,
+                                                             uint32_t *__restrict__ window_sums /* [13][BK_WORDS] */)
+{
+    __builtin_amdgcn_s_setprio(2);
+    constexpr int BW = Grp<F>::BK_WORDS;
+    if (threadIdx.x >= (unsigned)F::LANES) return;
+    const size_t j = blockIdx.x;
+    XyzzT<F> run = pt_identity<F>(), weighted = pt_identity<F>(), plain = load_bucket<F>(s1 + (j * WIDE_H) * BW);
+    for (int hi = WIDE_H - 1; hi >= 1; hi--) {
+        run = pt_add(run, load_bucket<F>(s0 + (j * WIDE_H + hi) * BW));
+        weighted = pt_add(weighted, run);                            // sum_(hi >= 1) hi S0_hi
+        plain = pt_add(plain, load_bucket<F>(s1 + (j * WIDE_H + hi) * BW));
+    }
+    for (int k = 0; k < MSM_C - 1; k++) weighted = pt_double(weighted);
+    store_bucket<F>(window_sums + j * BW, pt_add(plain, weighted));
+}
+
 // per bucket: its size (counts) and, in place of every slice's count, the slice's first position inside the bucket
 __global__ __launch_bounds__(256) void msm_slice_offsets_kernel(uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ counts, int slices)
 {
@@ -526,7 +673,8 @@ template <class F, bool PREFETCH>
 __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
                                                            const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items, uint32_t finer,
-                                                           uint32_t max_items, size_t ent_stride /* entries per row: 16 n, a bare handle's: n */)
+                                                           uint32_t max_items, size_t ent_stride /* entries per row: 16 n, a bare handle's: n */,
+                                                           const unsigned long long *__restrict__ row_base /* wide windows: where each row's entries start; else null */)
 {
     constexpr int PW = Grp<F>::PT_WORDS;
     const size_t sig = blockIdx.y;
@@ -538,7 +686,7 @@ __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint3
     const uint32_t total = offsets[sig * MSM_BUCKETS + MSM_BUCKETS - 1] + counts[sig * MSM_BUCKETS + MSM_BUCKETS - 1], split = msm_split_of(total, finer);
     const uint32_t k = c <= split ? 1u : (c + split - 1) / split;
     const uint32_t lo = (uint32_t)((uint64_t)c * chunk / k), cnt = (uint32_t)((uint64_t)c * (chunk + 1) / k) - lo;     // equal parts
-    const uint32_t *ent = entries + sig * ent_stride + offsets[sig * MSM_BUCKETS + b] + lo;
+    const uint32_t *ent = entries + (row_base ? (size_t)row_base[sig] : sig * ent_stride) + offsets[sig * MSM_BUCKETS + b] + lo;
     XyzzT<F> acc = pt_identity<F>();
     if (PREFETCH) {
         uint32_t e = cnt ? ent[0] : 0u;
@@ -623,7 +771,8 @@ __global__ __launch_bounds__(64, 2) void msm_ones_kernel(MsmDev m, const uint32_
 // `partial`.  CHUNK = 2^LOG_CHUNK is 8 for small batches (latency) and up to 64 for large ones (the multiples are a third of the
 // work at 8).
 template <class F, int LOG_CHUNK>
-__global__ __launch_bounds__(64, 2) void msm_fold1_kernel(const uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial)
+__global__ __launch_bounds__(64, 2) void msm_fold1_kernel(const uint32_t *__restrict__ buckets, uint32_t *__restrict__ partial,
+                                                          uint32_t *__restrict__ partial_plain /* wide windows: the chunk's UNWEIGHTED sum too; else null */)
 {
     __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
     constexpr int BW = Grp<F>::BK_WORDS, CHUNK = 1 << LOG_CHUNK;
@@ -646,6 +795,7 @@ __global__ __launch_bounds__(64, 2) void msm_fold1_kernel(const uint32_t *__rest
     uint32_t *mine = partial + (sig * MSM_FOLD1_THREADS + g) * (size_t)BW;
     sum = pt_add(sum, load_bucket<F>(mine));                           // the scalars that are one
     store_bucket<F>(mine, sum);
+    if (partial_plain) store_bucket<F>(partial_plain + (sig * MSM_FOLD1_THREADS + g) * (size_t)BW, run);
 }
 // Stage 2: 512 threads add `each` partial sums each, a tree through LDS, one inversion, ark-ff's bytes out
 template <class F>
@@ -673,6 +823,9 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
     }
 }
 
+// (launch bounds of the narrow kernels: two waves per SIMD for G1; the two-lane G2 policy is written for ONE -- its mixed addition holds an
+// accumulator, a row, the neighbour's copies of both operands of a product and 28 64-bit columns: 256 registers and then some, which at a
+// bound of two went to AGPR moves and scratch under a warning that the target was missed.  Said so, the compiler may use the AGPRs it has.)
 // ---- narrow windows: the witness-side sums ---------------------------------------------------------------------------------------
 // The sums over a_query, b_g1_query, b_g2_query and l_query take a WITNESS as scalars: 46 % zeros, 45 % ones, and of the rest
 // all but two thousand values are below 2^16 (Falcon-1024: 13 N values that are not boolean, 2 N of them ~146 bits).  Through
@@ -877,7 +1030,7 @@ __global__ __launch_bounds__(1024) void nmsm_scatter_bare_kernel(uint32_t n, con
 }
 // one thread per (signature, item): the sum of the item's table rows
 template <class F, bool PREFETCH>
-__global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(NmsmTables tables, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
+__global__ __launch_bounds__(64, F::LANES > 1 ? 1 : 2) void nmsm_bucket_kernel(NmsmTables tables, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                             const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count,
                                                             const uint32_t *__restrict__ entries, uint32_t *__restrict__ partial_items,
                                                             uint32_t target, uint32_t max_items,
@@ -922,7 +1075,7 @@ __global__ __launch_bounds__(64, 2) void nmsm_bucket_kernel(NmsmTables tables, c
 // workgroup are added up through LDS (six steps instead of the 64 / 128-fold serial addition they would cost the fold), and one
 // partial sum per workgroup goes out: gridDim.x <= 64 of them per signature
 template <class F>
-__global__ __launch_bounds__(64, 2) void nmsm_ones_kernel(NmsmTables tables, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
+__global__ __launch_bounds__(64, F::LANES > 1 ? 1 : 2) void nmsm_ones_kernel(NmsmTables tables, const uint32_t *__restrict__ ones_count, const uint32_t *__restrict__ ones_list,
                                                           uint32_t *__restrict__ partial_ones /* [blockIdx.y][groups_stride][BK_WORDS] */, uint32_t groups_stride,
                                                           uint32_t row_step /* 1; a bare handle's tables: 32 -- grid row y is (table y, window 0), the only window with ones */)
 {
@@ -963,7 +1116,7 @@ template <> struct BulkPolicy<Fq2Field> { typedef Fq2PairField type; };
 // more than 64 partial sums of ones (sums over more than 2^18 points): workgroup g of 64 adds up the partial sums g, g + 64, ... of its
 // signature -- one per lane, then a tree through LDS -- and leaves sum g of 64 in the first 64 slots of the second stage's array
 template <class F>
-__global__ __launch_bounds__(64, 2) void nmsm_ones_fold_kernel(const uint32_t *__restrict__ partial_ones, uint32_t groups, uint32_t groups_stride,
+__global__ __launch_bounds__(64, F::LANES > 1 ? 1 : 2) void nmsm_ones_fold_kernel(const uint32_t *__restrict__ partial_ones, uint32_t groups, uint32_t groups_stride,
                                                                uint32_t *__restrict__ folded /* [sig][64][BK_WORDS] */)
 {
     __builtin_amdgcn_s_setprio(2);                               // latency, not throughput: ahead of a chip-filling bucket kernel's waves on the same SIMD
@@ -985,7 +1138,7 @@ __global__ __launch_bounds__(64, 2) void nmsm_ones_fold_kernel(const uint32_t *_
 // bucket b = the sum of its items, by a workgroup of its own: the buckets of small digits hold many times the mean (the high
 // bytes of 14-bit values fall into 48 of them), and fifty items added up by one thread were the longest chain of the whole sum
 template <class F>
-__global__ __launch_bounds__(64, 2) void nmsm_combine_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+__global__ __launch_bounds__(64, F::LANES > 1 ? 1 : 2) void nmsm_combine_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
                                                              const uint32_t *__restrict__ item_first, const uint32_t *__restrict__ partial_items,
                                                              uint32_t *__restrict__ buckets /* [slot][128][BK_WORDS] */, uint32_t target, uint32_t max_items,
                                                              uint32_t sigs)
@@ -1222,6 +1375,7 @@ struct frw_msm {
     int group;                  // 1: G1, 2: G2
     int window_bits;            // 16: the dense pipeline (32,768 buckets), 8: the narrow one (128 buckets)
     bool bare = false;          // the table is the points themselves (one row each): the sums run window by window (round 5)
+    bool wide = false;          // ... a dense bare handle on thirteen 20-bit windows (frw::WIDE_*): from 2^23 points, or asked for at load time
     uint64_t row_lo = 0;        // a slice of a sharded key: the index of row 0 in the whole query (the caller offsets the scalars by it)
     frw::MsmDev dev;
     void *table;
@@ -1268,9 +1422,56 @@ template <class F> MsmBufs<F> msm_carve(void *ws, size_t rows, uint32_t n, bool 
     }
     return b;
 }
-// a bare handle: sixteen rows (windows) and their sixteen sums
-template <class F> size_t msm_workspace_per_signature(uint32_t n, bool bare = false)
+// Wide windows (frw::WIDE_*) are run by handles LOADED so (frw_msm_g1_load_bare(.., narrow = 2, ..): the tests do, on the small adversarial
+// vectors and on 2^18 points) -- no handle takes them by its size: measured on the 2^27-point sum of the 1,024-statement aggregate
+// (profiles/r05_wide_windows_ab.txt) the bucket kernel goes 350 -> 306 ms as it should, and the two-level sort gives 25 ms of it back (its fine
+// scatter, 4-byte writes into 208 x 32,768 open cache lines, is 76 ms -- as slow as the one-level scatter it replaces), with 13 GB more
+// workspace: 694 against 683 - 698 ms per proof.  What would make them pay is a sort whose every pass writes runs (<= 1,024 bins per pass).
+constexpr uint32_t MSM_WIDE_FROM = 0xffffffffu;
+template <class F> struct MsmWideBufs {
+    MsmBufs<F> rows;                    // the 208 rows' arrays (entries apart: below)
+    uint32_t *partial_plain, *slice_hist_coarse, *row_count, *s1, *s0, *window_sums, *entries, *end;
+    unsigned long long *row_start;
+    uint2 *coarse;
+};
+template <class F> MsmWideBufs<F> msm_carve_wide(void *ws, uint32_t n)
 {
+    constexpr size_t BW = frw::Grp<F>::BK_WORDS, R = frw::WIDE_ROWS;
+    static_assert((size_t)frw::WIDE_SLICES_FINE * 4 <= BW * 4, "the fine slice histograms borrow the buckets' memory");
+    MsmWideBufs<F> w;
+    MsmBufs<F> &b = w.rows;
+    b.max_items = frw::WIDE_MAX_ITEMS;
+    b.ent_stride = 0; b.ones_stride = 0; b.digits = nullptr;
+    b.counts = (uint32_t *)ws;
+    b.offsets = b.counts + R * frw::MSM_BUCKETS;
+    b.order = b.offsets + R * frw::MSM_BUCKETS;
+    b.item_first = b.order + R * frw::MSM_BUCKETS;
+    b.item_count = b.item_first + R * frw::MSM_BUCKETS;
+    b.ones_count = b.item_count + R * 4;
+    b.items = b.ones_count + R * 4;
+    b.buckets = b.items + R * (size_t)b.max_items * 2;
+    b.partial = b.buckets + R * (size_t)frw::MSM_BUCKETS * BW;
+    w.partial_plain = b.partial + R * (size_t)frw::MSM_FOLD1_THREADS * BW;
+    b.partial_items = w.partial_plain + R * (size_t)frw::MSM_FOLD1_THREADS * BW;
+    w.s1 = b.partial_items + R * (size_t)b.max_items * BW;
+    w.s0 = w.s1 + R * BW;
+    w.window_sums = w.s0 + R * BW;
+    w.row_start = (unsigned long long *)(w.window_sums + (size_t)frw::WIDE_W * BW);     // (every term so far a multiple of four words)
+    w.row_count = (uint32_t *)(w.row_start + R);
+    w.slice_hist_coarse = w.row_count + R;
+    w.coarse = (uint2 *)(w.slice_hist_coarse + (size_t)frw::WIDE_SLICES_COARSE * R);
+    w.entries = (uint32_t *)(w.coarse + (size_t)frw::WIDE_W * n);
+    w.end = w.entries + (size_t)frw::WIDE_W * n;
+    b.entries = w.entries; b.ones_list = w.end; b.end = w.end;
+    return w;
+}
+// a bare handle: sixteen rows (windows) and their sixteen sums
+template <class F> size_t msm_workspace_per_signature(uint32_t n, bool bare = false, bool wide = false)
+{
+    if (wide) {
+        char *const base0 = (char *)(uintptr_t)4096;
+        return ((size_t)((char *)msm_carve_wide<F>(base0, n).end - base0) + 15) & ~(size_t)15;
+    }
     const size_t rows = bare ? frw::MSM_W : 1;
     char *const base = (char *)(uintptr_t)4096;                       // (a carve of nothing: only the distance to its end is used)
     const size_t bytes = (size_t)((char *)msm_carve<F>(base, rows, n, bare).end - base) + (bare ? (size_t)frw::MSM_W * frw::Grp<F>::BK_WORDS * 4 : 0);
@@ -1356,7 +1557,7 @@ template <class F> size_t nmsm_workspace_per_signature(uint32_t n, bool bare = f
     return (((size_t)((char *)b.end - base) + 16) + 15) & ~(size_t)15;
 }
 
-template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, int window_bits, bool bare, frw_msm **out)
+template <class F> int msm_load(int device, int group, size_t num_points, const uint64_t *bases, int window_bits, bool bare, frw_msm **out, bool force_wide = false)
 {
     // (a table row index and its window share 31 bits of an entry: 2^26 points x 16 windows, 2^25 x 32; a bare handle's entries are point indices)
     if (!out || !bases || num_points == 0 || num_points > (bare ? ((size_t)1 << 31) - 1 : (size_t)1 << (window_bits == 8 ? 25 : 26))) return FRW_E_INVALID_ARG;
@@ -1371,6 +1572,7 @@ template <class F> int msm_load(int device, int group, size_t num_points, const 
     m->group = group;
     m->window_bits = window_bits;
     m->bare = bare;
+    m->wide = bare && window_bits == 16 && (force_wide || num_points >= MSM_WIDE_FROM);
     m->table = nullptr;
     m->ones_table = nullptr;
     m->dev.ones_table = nullptr;
@@ -1468,7 +1670,7 @@ hipError_t msm_rows(const frw_msm *m, size_t rows, const uint32_t *sc, size_t st
     if (bare) hipLaunchKernelGGL(frw::msm_scatter_digits_kernel, sgrid, dim3(1024), 0, st, n, (const int16_t *)b.digits, b.offsets, slice_hist, b.entries);
     else hipLaunchKernelGGL(frw::msm_scatter_kernel, sgrid, dim3(1024), 0, st, n, sc, stride_words, montgomery, b.offsets, slice_hist, b.entries, 0);
     hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(b.max_items / 64, (unsigned)rows), dim3(64), 0, st, m->dev, b.offsets,
-                       b.counts, b.items, b.item_count, b.entries, b.partial_items, finer, b.max_items, b.ent_stride);
+                       b.counts, b.items, b.item_count, b.entries, b.partial_items, finer, b.max_items, b.ent_stride, (const unsigned long long *)nullptr);
     hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, (unsigned)rows), dim3(64), 0, st, b.offsets, b.counts, b.item_first,
                        b.partial_items, b.buckets, finer, b.max_items);
     // first stage of the fold: enough threads to occupy the chip (~2^16), as few as that allows
@@ -1478,11 +1680,52 @@ hipError_t msm_rows(const frw_msm *m, size_t rows, const uint32_t *sc, size_t st
     frw::MsmDev ones_dev = m->dev;
     if (bare) ones_dev.n = 0;                                        // (no list: every row's count is zero and its slice of the list the same empty one)
     hipLaunchKernelGGL(frw::msm_ones_kernel<F>, dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, ones_dev, b.ones_count, b.ones_list, b.partial);
-    if (log_chunk == 6) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 6>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial);
-    else if (log_chunk == 5) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 5>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial);
-    else hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 3>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial);
+    if (log_chunk == 6) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 6>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial, (uint32_t *)nullptr);
+    else if (log_chunk == 5) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 5>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial, (uint32_t *)nullptr);
+    else hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 3>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial, (uint32_t *)nullptr);
     hipLaunchKernelGGL(frw::msm_fold2_kernel<F>, dim3((unsigned)rows), dim3(frw::MSM_FOLD_THREADS), 0, st, b.partial,
                        (int)(t1 / frw::MSM_FOLD_THREADS), out, xyzz_out ? 1 : 0);
+    return hipGetLastError();
+}
+// ONE scalar vector over a bare handle on wide windows (frw::WIDE_*): the coarse sort, the rows' fine sorts, work items, buckets, the
+// two-stage folds (weighted and plain), the windows, Horner's rule
+template <class F, bool PREFETCH>
+hipError_t msm_rows_wide(const frw_msm *m, const uint32_t *sc, int montgomery, uint32_t *out, bool xyzz_out, void *d_workspace, hipStream_t st)
+{
+    constexpr unsigned R = frw::WIDE_ROWS;
+    const uint32_t n = m->dev.n;
+    const MsmWideBufs<F> w = msm_carve_wide<F>(d_workspace, n);
+    const MsmBufs<F> &b = w.rows;
+    uint32_t *slice_hist = b.buckets;                                 // [208][8][32,768], dead before the first bucket is stored
+    hipError_t e = hipMemsetAsync(b.ones_count, 0, R * 16, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(frw::msm_wide_coarse_hist_kernel, dim3(frw::WIDE_SLICES_COARSE), dim3(1024), 0, st, n, sc, montgomery, w.slice_hist_coarse);
+    hipLaunchKernelGGL(frw::msm_wide_coarse_offsets_kernel, dim3(1), dim3(256), 0, st, (uint32_t)frw::WIDE_SLICES_COARSE, w.slice_hist_coarse, w.row_count, w.row_start);
+    hipLaunchKernelGGL(frw::msm_wide_coarse_scatter_kernel, dim3(frw::WIDE_SLICES_COARSE), dim3(1024), 0, st, n, sc, montgomery,
+                       (const uint32_t *)w.slice_hist_coarse, (const unsigned long long *)w.row_start, w.coarse);
+    const dim3 fgrid(frw::WIDE_SLICES_FINE, R);
+    hipLaunchKernelGGL(frw::msm_wide_fine_hist_kernel, fgrid, dim3(1024), 0, st, (const uint2 *)w.coarse, (const uint32_t *)w.row_count,
+                       (const unsigned long long *)w.row_start, slice_hist);
+    hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, R), dim3(256), 0, st, slice_hist, b.counts, (int)frw::WIDE_SLICES_FINE);
+    hipLaunchKernelGGL(frw::msm_scan_kernel, dim3(R), dim3(1024), 0, st, b.counts, b.offsets);
+    hipLaunchKernelGGL(frw::msm_order_kernel, dim3(R), dim3(1024), 0, st, b.counts, b.offsets, b.order, b.item_first, b.items, b.item_count, 1u, b.max_items);
+    hipLaunchKernelGGL(frw::msm_wide_fine_scatter_kernel, fgrid, dim3(1024), 0, st, (const uint2 *)w.coarse, (const uint32_t *)w.row_count,
+                       (const unsigned long long *)w.row_start, (const uint32_t *)b.offsets, (const uint32_t *)slice_hist, w.entries);
+    hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(b.max_items / 64, R), dim3(64), 0, st, m->dev, b.offsets, b.counts, b.items, b.item_count,
+                       w.entries, b.partial_items, 1u, b.max_items, (size_t)0, (const unsigned long long *)w.row_start);
+    hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, R), dim3(64), 0, st, b.offsets, b.counts, b.item_first, b.partial_items,
+                       b.buckets, 1u, b.max_items);
+    // the folds: 64 buckets per thread (208 rows x 512 threads fill the chip), weighted and plain; then 512 threads per row and sum
+    constexpr int LOG_CHUNK = 6;
+    const unsigned t1 = (unsigned)frw::MSM_BUCKETS >> LOG_CHUNK;
+    frw::MsmDev ones_dev = m->dev;
+    ones_dev.n = 0;
+    hipLaunchKernelGGL(frw::msm_ones_kernel<F>, dim3(t1 / 64, R), dim3(64), 0, st, ones_dev, b.ones_count, b.ones_list, b.partial);     // (no ones: the partial sums start as the identity)
+    hipLaunchKernelGGL((frw::msm_fold1_kernel<F, LOG_CHUNK>), dim3(t1 / 64, R), dim3(64), 0, st, b.buckets, b.partial, w.partial_plain);
+    hipLaunchKernelGGL(frw::msm_fold2_kernel<F>, dim3(R), dim3(frw::MSM_FOLD_THREADS), 0, st, b.partial, (int)(t1 / frw::MSM_FOLD_THREADS), w.s1, 1);
+    hipLaunchKernelGGL(frw::msm_fold2_kernel<F>, dim3(R), dim3(frw::MSM_FOLD_THREADS), 0, st, w.partial_plain, (int)(t1 / frw::MSM_FOLD_THREADS), w.s0, 1);
+    hipLaunchKernelGGL(frw::msm_wide_window_kernel<F>, dim3(frw::WIDE_W), dim3(64), 0, st, (const uint32_t *)w.s1, (const uint32_t *)w.s0, w.window_sums);
+    hipLaunchKernelGGL(frw::msm_horner_kernel<F>, dim3(1), dim3(64), 0, st, (const uint32_t *)w.window_sums, (int)frw::WIDE_W, (int)frw::WIDE_C, out, xyzz_out ? 1 : 0);
     return hipGetLastError();
 }
 // the whole call for one group; `d_out` rows are ARK_WORDS / 2 uint64_t
@@ -1491,12 +1734,18 @@ int msm_run(const frw_msm *m, size_t batch, const uint64_t *d_scalars, size_t sc
             void *d_workspace, size_t workspace_bytes, hipStream_t st, bool xyzz_out = false)
 {
     const uint32_t n = m->dev.n;
-    const size_t per = msm_workspace_per_signature<F>(n, m->bare);
+    const size_t per = msm_workspace_per_signature<F>(n, m->bare, m->wide);
     size_t chunk = workspace_bytes / per;
     if (chunk == 0 || ((uintptr_t)d_workspace & 15)) return FRW_E_INVALID_ARG;
     if (chunk > 32768) chunk = 32768;                                  // grid.y
     constexpr int BW = frw::Grp<F>::BK_WORDS;
     hipError_t e = hipSetDevice(m->device);
+    if (m->wide) {
+        for (size_t sig = 0; e == hipSuccess && sig < batch; sig++)
+            e = msm_rows_wide<F, PREFETCH>(m, (const uint32_t *)(d_scalars + sig * scalar_stride * 4), montgomery,
+                                           (uint32_t *)d_out + sig * (xyzz_out ? BW : frw::Grp<F>::ARK_WORDS), xyzz_out, d_workspace, st);
+        return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_msm_dev");
+    }
     if (m->bare) {
         // one scalar vector at a time: its sixteen windows fill the grid; the window sums wait at the end of the workspace for Horner's rule
         uint32_t *window_sums = (uint32_t *)((char *)d_workspace + per) - (size_t)frw::MSM_W * BW;
@@ -1571,7 +1820,9 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
     }
     const unsigned rows = (unsigned)(cnt * (size_t)tables);
     typedef typename frw::BulkPolicy<F>::type FB;
-    constexpr bool BULK_PREFETCH = PREFETCH || FB::LANES > 1;       // two lanes per point: the registers for the prefetch are there
+    // two lanes per point (G2): WITHOUT the prefetch of the next row the bucket kernel is 249 registers = two waves per SIMD; with it 256 + 26
+    // AGPRs = one (round 4 ran it that way).  FRW_G2_PREFETCH in the environment brings the prefetch back (the A/B of profiles/r05_g2_*).
+    static const bool g2_prefetch = std::getenv("FRW_G2_PREFETCH") != nullptr;
     // the ones' partial sums: enough threads to occupy the chip (~2^16 over the batch), between 256 and 4,096 per signature
     int ones_threads = 256;
     while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * rows < 65536) ones_threads <<= 1;
@@ -1589,9 +1840,14 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
         const hipError_t e = hipEventRecord(ones_done, ones_stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((sorted.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
-                       sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items,
-                       (const unsigned long long *)nullptr);
+    if (PREFETCH || (FB::LANES > 1 && g2_prefetch))
+        hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, true>), dim3((sorted.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
+                           sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items,
+                           (const unsigned long long *)nullptr);
+    else
+        hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, false>), dim3((sorted.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
+                           sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items,
+                           (const unsigned long long *)nullptr);
     // the items of a bucket: added up by a workgroup per bucket where latency counts (a lone proof: 12 ms -> 8.6), by the fold's own
     // thread where throughput does (the combine is nine times the wave-level additions: 3 % of a 64-proof call)
     const bool combine = cnt <= 16;
@@ -1624,7 +1880,7 @@ hipError_t nmsm_accumulate_bare(const frw_msm *const *ms, int tables, const Nmsm
     }
     const unsigned rows = (unsigned)tables * frw::NMSM_W;
     typedef typename frw::BulkPolicy<F>::type FB;
-    constexpr bool BULK_PREFETCH = PREFETCH || FB::LANES > 1;
+    static const bool g2_prefetch = std::getenv("FRW_G2_PREFETCH") != nullptr;       // (see nmsm_accumulate)
     const uint32_t ones_threads = frw::nmsm_ones_max(n);             // 4,096, or 65,536 beyond 2^18 points
     hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3(ones_threads / 64, (unsigned)tables), dim3(64), 0, st, dev, b.ones_count, b.ones_list, b.partial_ones,
                        b.ones_stride, (uint32_t)frw::NMSM_W);
@@ -1636,8 +1892,12 @@ hipError_t nmsm_accumulate_bare(const frw_msm *const *ms, int tables, const Nmsm
         ones_groups = 64;
         ones_finish_stride = 64;
     }
-    hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, BULK_PREFETCH>), dim3((b.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
-                       b.offsets, b.counts, b.items, b.item_count, b.entries, b.partial_items, b.target, b.max_items, (const unsigned long long *)b.entry_base);
+    if (PREFETCH || (FB::LANES > 1 && g2_prefetch))
+        hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, true>), dim3((b.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
+                           b.offsets, b.counts, b.items, b.item_count, b.entries, b.partial_items, b.target, b.max_items, (const unsigned long long *)b.entry_base);
+    else
+        hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, false>), dim3((b.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
+                           b.offsets, b.counts, b.items, b.item_count, b.entries, b.partial_items, b.target, b.max_items, (const unsigned long long *)b.entry_base);
     hipLaunchKernelGGL(frw::nmsm_combine_kernel<FB>, dim3(frw::NMSM_BUCKETS, rows), dim3(64), 0, st, b.counts, b.offsets, b.item_first,
                        b.partial_items, b.bucket_sums, b.target, b.max_items, (uint32_t)frw::NMSM_W);
     hipLaunchKernelGGL(frw::nmsm_finish_kernel<FB>, dim3(rows), dim3(64), 0, st, b.counts, b.offsets, b.item_first, b.partial_items,
@@ -1703,11 +1963,13 @@ extern "C" int frw_msm_g2_load(int device, size_t num_points, const uint64_t *ba
 }
 extern "C" int frw_msm_g1_load_bare(int device, size_t num_points, const uint64_t *bases, int narrow, frw_msm **out)
 {
-    return msm_load<FqField>(device, 1, num_points, bases, narrow ? 8 : 16, true, out);
+    if (narrow < 0 || narrow > 2) return FRW_E_INVALID_ARG;
+    return msm_load<FqField>(device, 1, num_points, bases, narrow == 1 ? 8 : 16, true, out, narrow == 2);
 }
 extern "C" int frw_msm_g2_load_bare(int device, size_t num_points, const uint64_t *bases, int narrow, frw_msm **out)
 {
-    return msm_load<Fq2Field>(device, 2, num_points, bases, narrow ? 8 : 16, true, out);
+    if (narrow < 0 || narrow > 2) return FRW_E_INVALID_ARG;
+    return msm_load<Fq2Field>(device, 2, num_points, bases, narrow == 1 ? 8 : 16, true, out, narrow == 2);
 }
 extern "C" int frw_g1_fixed_base(int device, size_t count, const uint64_t *scalars, uint64_t *out)
 {
@@ -1724,14 +1986,14 @@ extern "C" int frw_msm_info(const frw_msm *m, frw_msm_info_t *out)
     const bool g2 = m->group == 2;
     out->num_points = m->dev.n;
     const bool narrow = m->window_bits == 8;
-    out->window_bits = m->window_bits;
-    out->num_windows = 256 / m->window_bits;
+    out->window_bits = m->wide ? frw::WIDE_C : m->window_bits;
+    out->num_windows = m->wide ? frw::WIDE_W : 256 / m->window_bits;
     out->table_bytes = (uint64_t)(m->bare ? 1 : out->num_windows) * m->dev.n * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
     if (m->ones_table) out->table_bytes += (uint64_t)((m->dev.n + 7) / 8) * 255 * (g2 ? frw::Grp<Fq2Field>::PT_WORDS : frw::Grp<FqField>::PT_WORDS) * 4;
     const uint32_t n = m->dev.n;
     const bool bare = m->bare;
     out->workspace_bytes_per_signature = narrow ? (g2 ? nmsm_workspace_per_signature<Fq2Field>(n, bare) : nmsm_workspace_per_signature<FqField>(n, bare))
-                                                : (g2 ? msm_workspace_per_signature<Fq2Field>(n, bare) : msm_workspace_per_signature<FqField>(n, bare));
+                                                : (g2 ? msm_workspace_per_signature<Fq2Field>(n, bare, m->wide) : msm_workspace_per_signature<FqField>(n, bare, m->wide));
     return FRW_OK;
 }
 
@@ -2044,6 +2306,7 @@ template <class F> int msm_alloc_bare_t(int device, int group, int window_bits, 
     frw_msm *m = new (std::nothrow) frw_msm;
     if (!m) return FRW_E_OUT_OF_MEMORY;
     m->device = device; m->group = group; m->window_bits = window_bits; m->bare = true; m->row_lo = row_lo;
+    m->wide = window_bits == 16 && rows >= MSM_WIDE_FROM;
     m->table = nullptr; m->ones_table = nullptr;
     m->dev.n = (uint32_t)rows; m->dev.ones_table = nullptr;
     e = hipMalloc(&m->table, rows * frw::Grp<F>::PT_WORDS * 4);

@@ -444,14 +444,15 @@ class WitnessEngine:
                                                   C.c_void_p(stream)), "frw_r1cs_eval_scratch_dev")
 
     # ---- multi-scalar multiplication over BLS12-381 G1 (frw_msm.hip) --------------------------------------------------
-    def msm_g1_load(self, bases, narrow=False, bare=False):
+    def msm_g1_load(self, bases, narrow=False, bare=False, wide=False):
         """bases: uint64[n, 12] (ark-ff's bytes of n affine points, zeros = infinity) -> handle; free with msm_free.
         narrow: 8-bit windows (128 buckets) instead of 16-bit ones: for scalars that are mostly zero, one or small.
-        bare: the points only, no window table (the sums run window by window)."""
+        bare: the points only, no window table (the sums run window by window); wide: a dense bare handle on thirteen 20-bit windows
+        whatever its size (what handles of 2^23 points and more run on anyway)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 12)
         h = C.c_void_p()
         if bare:
-            check(self._lib.frw_msm_g1_load_bare(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), 1 if narrow else 0, C.byref(h)),
+            check(self._lib.frw_msm_g1_load_bare(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), 2 if wide else 1 if narrow else 0, C.byref(h)),
                   "frw_msm_g1_load_bare")
             return h
         fn = self._lib.frw_msm_g1_load_narrow if narrow else self._lib.frw_msm_g1_load
@@ -474,11 +475,11 @@ class WitnessEngine:
                                           out.ctypes.data_as(C.c_void_p)), "frw_g2_fixed_base")
         return out
 
-    def msm_g2_load(self, bases, narrow=False, bare=False):
+    def msm_g2_load(self, bases, narrow=False, bare=False, wide=False):
         bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 24)
         h = C.c_void_p()
         if bare:
-            check(self._lib.frw_msm_g2_load_bare(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), 1 if narrow else 0, C.byref(h)),
+            check(self._lib.frw_msm_g2_load_bare(self.device, bases.shape[0], bases.ctypes.data_as(C.c_void_p), 2 if wide else 1 if narrow else 0, C.byref(h)),
                   "frw_msm_g2_load_bare")
             return h
         fn = self._lib.frw_msm_g2_load_narrow if narrow else self._lib.frw_msm_g2_load

@@ -34,8 +34,9 @@ def _run(engine, handle, scalars, montgomery, chunk=None):
     return out.cpu().numpy().view(np.uint64)
 
 
-HANDLES = [(False, False), (True, False), (False, True), (True, True)]
-HANDLE_IDS = ["tables-16bit", "tables-8bit", "bare-16bit", "bare-8bit"]
+# (narrow, bare); bare == "wide": a dense bare handle on thirteen 20-bit windows (208 rows: the two-level sort, weighted and plain folds)
+HANDLES = [(False, False), (True, False), (False, True), (True, True), (False, "wide")]
+HANDLE_IDS = ["tables-16bit", "tables-8bit", "bare-16bit", "bare-8bit", "bare-20bit"]
 
 @pytest.mark.parametrize("narrow,bare", HANDLES, ids=HANDLE_IDS)
 def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle, narrow, bare):
@@ -58,16 +59,18 @@ def test_small_and_adversarial_inputs_equal_the_cpu_bucket_method(engine, oracle
         [0x0101010101010101010101010101010101010101010101010101010101010101] * n,      # one bucket, thirty-two windows (9,600 entries in it: cut into items)
         [(1 << 255) - 19 if i % 2 else 0x8000 for i in range(n)],  # digit exactly 2^15 (kept positive); top-window carry
         [0x80 if i % 3 else 0x7f81 for i in range(n)],             # digit exactly 2^7 (kept positive), 0x81 -> -0x7f with a carry into 0x7f -> 0x80
+        [0x80000 if i % 2 else (1 << 255) - (1 << 19) + 1 for i in range(n)],    # digit exactly 2^19 (kept positive) / twenty-bit windows full of carries
+        [sum(((j * 7 + i) % 16 * 32768 + 5) << (20 * j) for j in range(12)) for i in range(n)],     # every coarse class of the wide windows, bucket 5 of each
         [rng.randrange(1 << 16) for _ in range(n)],
         # out of contract for "canonical" scalars, but harmless: integers >= r are taken mod r (k P = (k mod r) P), never past the buckets
         [rng.choice([E.R, E.R + 5, (1 << 256) - 1, 2 * E.R + 7, (1 << 255) + rng.randrange(1 << 200)]) for _ in range(n)],
     ]
     vectors[0][3] = vectors[0][10]                                 # the duplicated base with the same scalar: doubling
     vectors[0][11] = vectors[0][4]                                 # the negated base with the same scalar: cancellation
-    handle = engine.msm_g1_load(bases, narrow=narrow, bare=bare)
+    handle = engine.msm_g1_load(bases, narrow=narrow, bare=bool(bare), wide=bare == "wide")
     try:
         info = engine.msm_info(handle)
-        assert info.num_points == n and (info.window_bits, info.num_windows) == ((8, 32) if narrow else (16, 16))
+        assert info.num_points == n and (info.window_bits, info.num_windows) == ((20, 13) if bare == "wide" else (8, 32) if narrow else (16, 16))
         assert info.table_bytes == n * 112 * (1 if bare else info.num_windows) + (0 if bare or not narrow else (n + 7) // 8 * 255 * 112)
         canon = np.stack([T.ints_to_limbs(v) for v in vectors])
         mont = np.stack([T.ints_to_limbs([x * FR_R % E.R for x in v]) for v in vectors])
@@ -215,7 +218,7 @@ def test_witness_scalars_mostly_zero_and_one_equal_the_cpu_bucket_method(engine,
     z = np.concatenate([z, np.zeros((2, n, 4), dtype=np.uint64)])
     z[batch, :, 0] = 1                                            # all ones
     z[batch + 1, 12345, 0] = 1                                    # a single one
-    handle = engine.msm_g1_load(bases, narrow=narrow, bare=bare)
+    handle = engine.msm_g1_load(bases, narrow=narrow, bare=bool(bare), wide=bare == "wide")
     try:
         got = _run(engine, handle, z, 0)
         for i in range(z.shape[0]):
@@ -245,7 +248,7 @@ def test_g2_fixed_base_and_msm_equal_python_integers(engine, narrow, bare):
                [rng.choice([0, 1, 1, rng.randrange(1 << 14), rng.randrange(1 << 146)]) for _ in range(n)]]
     vectors[0][3] = vectors[0][10]
     vectors[0][11] = vectors[0][4]
-    handle = engine.msm_g2_load(bases, narrow=narrow, bare=bare)
+    handle = engine.msm_g2_load(bases, narrow=narrow, bare=bool(bare), wide=bare == "wide")
     try:
         import torch
         dev = torch.device("cuda:0")
@@ -268,7 +271,7 @@ def test_g2_fixed_base_and_msm_equal_python_integers(engine, narrow, bare):
         engine.msm_free(handle)
 
 
-@pytest.mark.parametrize("bare", [False, True], ids=["tables", "bare"])
+@pytest.mark.parametrize("bare", [False, True, "wide"], ids=["tables", "bare", "bare-20bit"])
 def test_one_digit_in_every_window_of_a_large_sum(engine, oracle, bare):
     """More than 2^18 points (the finest split of the dense pipeline: a bucket of the mean size cut 16 ways) whose scalars are ALL the same
     value with one digit in every window: ONE bucket takes all 16 n entries and is cut into 2^18 work items -- which a work item packed
@@ -286,7 +289,7 @@ def test_one_digit_in_every_window_of_a_large_sum(engine, oracle, bare):
     extra = sum((int.from_bytes(vectors[1][i].tobytes(), "little") - k) * ks[i] for i in range(0, n, 4096))
     want = [oracle.g1_scalar_mul(oracle.g1_generator(), k * ksum % E.R).tolist(),
             oracle.g1_scalar_mul(oracle.g1_generator(), (k * ksum + extra) % E.R).tolist()]
-    handle = engine.msm_g1_load(bases, bare=bare)
+    handle = engine.msm_g1_load(bases, bare=bool(bare), wide=bare == "wide")
     try:
         # one signature at a time (the finest split: a chunk of one or two), then both in one chunk
         got1 = [_run(engine, handle, vectors[i:i + 1], 0)[0].tolist() for i in range(2)]
