@@ -361,15 +361,14 @@ __global__ __launch_bounds__(1024) void msm_scatter_digits_kernel(uint32_t n, co
 // bucket additions (one per point and non-zero digit: 13 n instead of 16 n) -- what the 2^27-point sum over h_query of the 1,024-statement
 // aggregate spends 350 of its 430 ms on.  2^19 buckets per window do not fit the LDS histograms of the counting sort above; they need not:
 // bucket m = |d| - 1 of window j is bucket (m mod 2^15) of ROW j 16 + (m >> 15), and a row is to every kernel from the fine sort on what a
-// window (or a signature) was -- 32,768 buckets, work items, combine, the two-stage fold -- 208 rows of them.  Two sorts: a COARSE one of
-// all (window, point) pairs by row (208 counters per workgroup; 8-byte entries: point | sign, m mod 2^15), then per row the 15-bit LDS-
-// histogram sort as ever, reading the row's coarse entries.  A row's buckets fold to S1 = sum (lo + 1) B_lo AND S0 = sum B_lo; a window is
-// sum_hi S1_hi + 2^15 sum_hi hi S0_hi (msm_wide_window_kernel), the windows join by Horner's rule with 20 doublings each.
-// (Worth it from 2^23 points by the additions' count: below, the folds of 13 x 2^19 buckets cost more than three windows' additions save.
-// By the clock not even at 2^27 yet -- see MSM_WIDE_FROM -- so only handles loaded as wide run this.)
+// window (or a signature) was -- 32,768 buckets, work items, combine, the two-stage fold -- 208 rows of them.  The sort is in two levels
+// (below: bins of 1,024 buckets, then the buckets of a bin), every pass writing runs.  A row's buckets fold to S1 = sum (lo + 1) B_lo AND
+// S0 = sum B_lo; a window is sum_hi S1_hi + 2^15 sum_hi hi S0_hi (msm_wide_window_kernel), the windows join by Horner's rule with 20
+// doublings each.  The folds of 13 x 2^19 buckets are a fixed 14 ms, three windows' additions 0.18 ns a point: handles of 2^26 points and
+// more take wide windows by themselves (MSM_WIDE_FROM_DEFAULT), smaller ones when loaded so.
 constexpr int WIDE_C = 20, WIDE_W = 13, WIDE_H = 1 << (WIDE_C - MSM_C), WIDE_ROWS = WIDE_W * WIDE_H;
 constexpr uint32_t WIDE_MAX_ITEMS = 65536;       // >= 32,768 + (32,768 / 1.5) 33 / 32 (finer = 1)
-constexpr int WIDE_SLICES_COARSE = 512, WIDE_SLICES_FINE = 8;
+constexpr int WIDE_SLICES = 128;                 // slices of a window in the bins' sort (whole tiles each)
 // signed 20-bit digits, d_j in [-2^19 + 1, 2^19], sum d_j 2^(20 j) = k; the top window (bits 240 ..) takes the last carry
 __device__ __forceinline__ void scalar_digits_wide(const uint32_t *src, int montgomery, int (&d)[WIDE_W])
 {
@@ -385,100 +384,183 @@ __device__ __forceinline__ void scalar_digits_wide(const uint32_t *src, int mont
         d[j] = v;
     }
 }
-__global__ __launch_bounds__(1024) void msm_wide_coarse_hist_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery,
-                                                                    uint32_t *__restrict__ slice_hist /* [slice][208] */)
+// The sort, every pass writing RUNS (the first version of it scattered 4-byte entries into 208 x 32,768 open cache lines: each such write a
+// read-modify-write of a line in HBM, 76 ms for 1.7 x 10^9 of them -- all that three windows' additions saved):
+//   digits     int32[13][n], written once
+//   bins       per window, its points by bin = m >> 10 (512 bins): a workgroup sorts a TILE of 4,096 entries by bin in LDS and copies the
+//              runs out (a bin's run of a tile to consecutive addresses: 8 entries = 64 bytes on average, whole lines)
+//   buckets    per bin (262,000 entries of 1,024 buckets: one workgroup, 4 KB of counters): the 4-byte entries of a bin go into a 1 MB region
+//              whose 1,024 open lines stay in the L2
+// A row's thirty-two bins lie one after the other, so rows and bins share one numbering: bin g = row (g >> 5), buckets [1,024 (g & 31), ..).
+constexpr int WIDE_BINS = 512, WIDE_BIN_BUCKETS = MSM_BUCKETS * WIDE_H / WIDE_BINS, WIDE_ALL_BINS = WIDE_W * WIDE_BINS, WIDE_TILE = 4096;
+static_assert(WIDE_BIN_BUCKETS == 1024 && WIDE_ALL_BINS == WIDE_ROWS * 32, "a row = 32 bins of 1,024 buckets");
+__global__ __launch_bounds__(256) void msm_wide_digits_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery, int32_t *__restrict__ digits)
 {
-    __shared__ uint32_t hist[WIDE_ROWS];
-    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
-    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
-    if (threadIdx.x < WIDE_ROWS) hist[threadIdx.x] = 0;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int d[WIDE_W];
+    scalar_digits_wide(scalars + (size_t)i * 8, montgomery, d);
+#pragma unroll
+    for (int j = 0; j < WIDE_W; j++) digits[(size_t)j * n + i] = d[j];
+}
+__global__ __launch_bounds__(1024) void msm_wide_bin_hist_kernel(uint32_t n, const int32_t *__restrict__ digits, uint32_t *__restrict__ slice_hist /* [window][slice][512] */)
+{
+    __shared__ uint32_t hist[WIDE_BINS];
+    const size_t j = blockIdx.y;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = ((n + slices - 1) / slices + WIDE_TILE - 1) / WIDE_TILE * WIDE_TILE;
+    const uint32_t lo = (uint64_t)slice * per < n ? slice * per : n, hi = (uint64_t)lo + per < n ? lo + per : n;
+    if (threadIdx.x < WIDE_BINS) hist[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
-        int d[WIDE_W];
-        scalar_digits_wide(scalars + (size_t)i * 8, montgomery, d);
-#pragma unroll
-        for (int j = 0; j < WIDE_W; j++)
-            if (d[j]) atomicAdd(&hist[j * WIDE_H + (((uint32_t)(d[j] < 0 ? -d[j] : d[j]) - 1u) >> (MSM_C - 1))], 1u);
+        const int v = digits[j * n + i];
+        if (v) atomicAdd(&hist[((uint32_t)(v < 0 ? -v : v) - 1u) >> 10], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < WIDE_ROWS) slice_hist[(size_t)slice * WIDE_ROWS + threadIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x < WIDE_BINS) slice_hist[(j * slices + slice) * WIDE_BINS + threadIdx.x] = hist[threadIdx.x];
 }
-// every slice's first position inside its rows, the rows' sizes and where they start (one workgroup)
-__global__ __launch_bounds__(256) void msm_wide_coarse_offsets_kernel(uint32_t slices, uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ row_count,
-                                                                      unsigned long long *__restrict__ row_start)
+// every slice's first position inside its bins; the bins' sizes and starts; the rows' (one workgroup)
+__global__ __launch_bounds__(1024) void msm_wide_bin_offsets_kernel(uint32_t slices, uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ bin_count,
+                                                                    unsigned long long *__restrict__ bin_start, uint32_t *__restrict__ row_count,
+                                                                    unsigned long long *__restrict__ row_start)
 {
-    __shared__ unsigned long long total[WIDE_ROWS];
-    const uint32_t r = threadIdx.x;
-    if (r < WIDE_ROWS) {
+    for (uint32_t g = threadIdx.x; g < (uint32_t)WIDE_ALL_BINS; g += 1024) {
+        const uint32_t j = g / WIDE_BINS, bin = g % WIDE_BINS;
         uint32_t run = 0;
         for (uint32_t s_ = 0; s_ < slices; s_++) {
-            const uint32_t c = slice_hist[(size_t)s_ * WIDE_ROWS + r];
-            slice_hist[(size_t)s_ * WIDE_ROWS + r] = run;
+            uint32_t *h = slice_hist + ((size_t)j * slices + s_) * WIDE_BINS + bin;
+            const uint32_t c = *h;
+            *h = run;
             run += c;
         }
-        row_count[r] = run;
-        total[r] = run;
+        bin_count[g] = run;
     }
     __syncthreads();
-    if (r == 0) {
+    if (threadIdx.x == 0) {
         unsigned long long at = 0;
-        for (int k = 0; k < WIDE_ROWS; k++) { row_start[k] = at; at += total[k]; }
-    }
-}
-__global__ __launch_bounds__(1024) void msm_wide_coarse_scatter_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery,
-                                                                       const uint32_t *__restrict__ slice_hist, const unsigned long long *__restrict__ row_start,
-                                                                       uint2 *__restrict__ coarse /* point | sign << 31, bucket of the row */)
-{
-    __shared__ uint32_t cursor[WIDE_ROWS];
-    __shared__ unsigned long long base[WIDE_ROWS];
-    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
-    const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
-    if (threadIdx.x < WIDE_ROWS) {
-        cursor[threadIdx.x] = slice_hist[(size_t)slice * WIDE_ROWS + threadIdx.x];
-        base[threadIdx.x] = row_start[threadIdx.x];
+        for (int g = 0; g < WIDE_ALL_BINS; g++) { bin_start[g] = at; at += bin_count[g]; }
     }
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
-        int d[WIDE_W];
-        scalar_digits_wide(scalars + (size_t)i * 8, montgomery, d);
+    if (threadIdx.x < (unsigned)WIDE_ROWS) {
+        const uint32_t r = threadIdx.x;
+        uint32_t c = 0;
+        for (int k = 0; k < 32; k++) c += bin_count[r * 32 + k];
+        row_count[r] = c;
+        row_start[r] = bin_start[r * 32];
+    }
+}
+__global__ __launch_bounds__(1024) void msm_wide_bin_scatter_kernel(uint32_t n, const int32_t *__restrict__ digits, const uint32_t *__restrict__ slice_hist,
+                                                                    const unsigned long long *__restrict__ bin_start,
+                                                                    uint2 *__restrict__ coarse /* point | sign << 31, bucket of the bin */)
+{
+    __shared__ uint2 stage[WIDE_TILE];
+    __shared__ uint16_t sbin[WIDE_TILE];
+    __shared__ uint32_t tcount[WIDE_BINS], tstart[WIDE_BINS], tfill[WIDE_BINS];
+    __shared__ unsigned long long gpos[WIDE_BINS];
+    const size_t j = blockIdx.y;
+    const uint32_t t = threadIdx.x;
+    const uint32_t slices = gridDim.x, slice = blockIdx.x, per = ((n + slices - 1) / slices + WIDE_TILE - 1) / WIDE_TILE * WIDE_TILE;
+    const uint32_t lo = (uint64_t)slice * per < n ? slice * per : n, hi = (uint64_t)lo + per < n ? lo + per : n;
+    if (t < WIDE_BINS) gpos[t] = bin_start[j * WIDE_BINS + t] + slice_hist[(j * slices + slice) * WIDE_BINS + t];
+    for (uint32_t tile0 = lo; tile0 < hi; tile0 += WIDE_TILE) {
+        if (t < WIDE_BINS) { tcount[t] = 0; tfill[t] = 0; }
+        __syncthreads();
+        int dv[WIDE_TILE / 1024];
 #pragma unroll
-        for (int j = 0; j < WIDE_W; j++) {
-            if (!d[j]) continue;
-            const uint32_t m = (uint32_t)(d[j] < 0 ? -d[j] : d[j]) - 1u, row = j * WIDE_H + (m >> (MSM_C - 1));
-            coarse[base[row] + atomicAdd(&cursor[row], 1u)] = make_uint2(i | (d[j] < 0 ? 0x80000000u : 0u), m & (MSM_BUCKETS - 1));
+        for (int k = 0; k < WIDE_TILE / 1024; k++) {
+            const uint32_t i = tile0 + t + 1024u * k;
+            dv[k] = i < hi ? digits[j * n + i] : 0;
+            if (dv[k]) atomicAdd(&tcount[((uint32_t)(dv[k] < 0 ? -dv[k] : dv[k]) - 1u) >> 10], 1u);
         }
+        __syncthreads();
+        // exclusive prefix sums of the 512 counts
+        if (t < WIDE_BINS) tstart[t] = tcount[t];
+        __syncthreads();
+        for (int off = 1; off < WIDE_BINS; off <<= 1) {
+            const uint32_t v = t < WIDE_BINS && t >= (uint32_t)off ? tstart[t - off] : 0u;
+            __syncthreads();
+            if (t < WIDE_BINS) tstart[t] += v;
+            __syncthreads();
+        }
+        if (t < WIDE_BINS) tstart[t] -= tcount[t];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WIDE_TILE / 1024; k++) {
+            if (!dv[k]) continue;
+            const uint32_t i = tile0 + t + 1024u * k, m = (uint32_t)(dv[k] < 0 ? -dv[k] : dv[k]) - 1u, bin = m >> 10;
+            const uint32_t pos = tstart[bin] + atomicAdd(&tfill[bin], 1u);
+            stage[pos] = make_uint2(i | (dv[k] < 0 ? 0x80000000u : 0u), m & (WIDE_BIN_BUCKETS - 1));
+            sbin[pos] = (uint16_t)bin;
+        }
+        __syncthreads();
+        const uint32_t total = tstart[WIDE_BINS - 1] + tcount[WIDE_BINS - 1];
+        for (uint32_t p = t; p < total; p += 1024) {
+            const uint32_t bin = sbin[p];
+            coarse[gpos[bin] + (p - tstart[bin])] = stage[p];
+        }
+        __syncthreads();
+        if (t < WIDE_BINS) gpos[t] += tcount[t];
+        __syncthreads();
     }
 }
-// per row: the 15-bit counting sort of its coarse entries (grid: slices of the row x rows)
-__global__ __launch_bounds__(1024) void msm_wide_fine_hist_kernel(const uint2 *__restrict__ coarse, const uint32_t *__restrict__ row_count,
-                                                                  const unsigned long long *__restrict__ row_start, uint32_t *__restrict__ slice_hist)
+// The buckets' sort: a bin's 4-byte entries go into its 1 MB of the entry array, 1,024 lines open at a time -- and with a workgroup per
+// bin, 512 bins in flight, those 512 MB of open lines left the L2 one dirty word at a time (33 ms: 77 bytes of HBM traffic per entry; with
+// cursors in global memory shared by the workgroups of a bin, 107 ms: device-wide atomics).  So a bin is cut into WIDE_PARTS parts by entry,
+// one workgroup each with its cursors in LDS (a part's own first positions come from the parts' histograms), and the parts of a bin run on
+// the SAME XCD at the same time (workgroups go to the XCDs round robin, w % 8): two bins in flight per XCD, their lines complete before
+// they leave its L2.  The order inside a bucket is what the LDS atomics make it within a part; parts in order.
+constexpr int WIDE_PARTS = 32;
+static_assert(WIDE_ALL_BINS % 8 == 0, "bins go to the XCDs eight at a time");
+struct WidePart { size_t g; uint32_t part, lo, hi; };
+__device__ __forceinline__ WidePart wide_part_of(uint32_t w, const uint32_t *__restrict__ bin_count)
 {
-    __shared__ uint32_t hist[MSM_BUCKETS];
-    const size_t row = blockIdx.y;
-    const uint32_t slices = gridDim.x, slice = blockIdx.x, cnt = row_count[row], per = (cnt + slices - 1) / slices;
-    const uint32_t lo = slice * per < cnt ? slice * per : cnt, hi = lo + per < cnt ? lo + per : cnt;
-    const uint2 *src = coarse + row_start[row];
-    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) hist[b] = 0;
-    __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) atomicAdd(&hist[src[i].y], 1u);
-    __syncthreads();
-    uint32_t *out = slice_hist + (row * slices + slice) * MSM_BUCKETS;
-    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) out[b] = hist[b];
+    WidePart p;
+    const uint32_t q = w >> 3;
+    p.part = q % WIDE_PARTS;
+    p.g = (size_t)(q / WIDE_PARTS) * 8 + (w & 7);
+    const uint32_t cnt = bin_count[p.g];
+    p.lo = (uint32_t)((uint64_t)cnt * p.part / WIDE_PARTS);
+    p.hi = (uint32_t)((uint64_t)cnt * (p.part + 1) / WIDE_PARTS);
+    return p;
 }
-__global__ __launch_bounds__(1024) void msm_wide_fine_scatter_kernel(const uint2 *__restrict__ coarse, const uint32_t *__restrict__ row_count,
-                                                                     const unsigned long long *__restrict__ row_start, const uint32_t *__restrict__ offsets,
-                                                                     const uint32_t *__restrict__ slice_hist, uint32_t *__restrict__ entries)
+// the sizes of the 1,024 buckets within every part (grid: bins x parts)
+__global__ __launch_bounds__(1024) void msm_wide_bucket_hist_kernel(const uint2 *__restrict__ coarse, const uint32_t *__restrict__ bin_count,
+                                                                    const unsigned long long *__restrict__ bin_start, uint32_t *__restrict__ part_hist)
 {
-    __shared__ uint32_t cursor[MSM_BUCKETS];
-    const size_t row = blockIdx.y;
-    const uint32_t slices = gridDim.x, slice = blockIdx.x, cnt = row_count[row], per = (cnt + slices - 1) / slices;
-    const uint32_t lo = slice * per < cnt ? slice * per : cnt, hi = lo + per < cnt ? lo + per : cnt;
-    const uint2 *src = coarse + row_start[row];
-    const uint32_t *first = slice_hist + (row * slices + slice) * MSM_BUCKETS, *off = offsets + row * MSM_BUCKETS;
-    for (int b = threadIdx.x; b < MSM_BUCKETS; b += 1024) cursor[b] = off[b] + first[b];
+    __shared__ uint32_t hist[WIDE_BIN_BUCKETS];
+    const WidePart p = wide_part_of(blockIdx.x, bin_count);
+    const uint2 *src = coarse + bin_start[p.g];
+    hist[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t *ent = entries + row_start[row];                     // a row's entries lie where its coarse entries do
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    for (uint32_t i = p.lo + threadIdx.x; i < p.hi; i += 1024) atomicAdd(&hist[src[i].y], 1u);
+    __syncthreads();
+    part_hist[(p.g * WIDE_PARTS + p.part) * WIDE_BIN_BUCKETS + threadIdx.x] = hist[threadIdx.x];
+}
+// per bin: a part's first position within each bucket, and the buckets' sizes straight into the rows' count arrays (grid: the 6,656 bins)
+__global__ __launch_bounds__(1024) void msm_wide_bucket_parts_kernel(uint32_t *__restrict__ part_hist, uint32_t *__restrict__ counts)
+{
+    const size_t g = blockIdx.x;
+    uint32_t run = 0;
+    for (int part = 0; part < WIDE_PARTS; part++) {
+        uint32_t *h = part_hist + (g * WIDE_PARTS + part) * WIDE_BIN_BUCKETS + threadIdx.x;
+        const uint32_t c = *h;
+        *h = run;
+        run += c;
+    }
+    counts[g * WIDE_BIN_BUCKETS + threadIdx.x] = run;
+}
+__global__ __launch_bounds__(1024) void msm_wide_bucket_scatter_kernel(const uint2 *__restrict__ coarse, const uint32_t *__restrict__ bin_count,
+                                                                       const unsigned long long *__restrict__ bin_start, const uint32_t *__restrict__ offsets,
+                                                                       const uint32_t *__restrict__ part_hist, const unsigned long long *__restrict__ row_start,
+                                                                       uint32_t *__restrict__ entries)
+{
+    __shared__ uint32_t cursor[WIDE_BIN_BUCKETS];
+    const WidePart p = wide_part_of(blockIdx.x, bin_count);
+    const uint2 *src = coarse + bin_start[p.g];
+    // (relative to the row: offsets are [row][32,768] = [bin][1,024])
+    cursor[threadIdx.x] = offsets[p.g * WIDE_BIN_BUCKETS + threadIdx.x] + part_hist[(p.g * WIDE_PARTS + p.part) * WIDE_BIN_BUCKETS + threadIdx.x];
+    __syncthreads();
+    uint32_t *ent = entries + row_start[p.g >> 5];
+    for (uint32_t i = p.lo + threadIdx.x; i < p.hi; i += 1024) {
         const uint2 e = src[i];
         ent[atomicAdd(&cursor[e.y], 1u)] = e.x;
     }
@@ -1422,22 +1504,30 @@ template <class F> MsmBufs<F> msm_carve(void *ws, size_t rows, uint32_t n, bool 
     }
     return b;
 }
-// Wide windows (frw::WIDE_*) are run by handles LOADED so (frw_msm_g1_load_bare(.., narrow = 2, ..): the tests do, on the small adversarial
-// vectors and on 2^18 points) -- no handle takes them by its size: measured on the 2^27-point sum of the 1,024-statement aggregate
-// (profiles/r05_wide_windows_ab.txt) the bucket kernel goes 350 -> 306 ms as it should, and the two-level sort gives 25 ms of it back (its fine
-// scatter, 4-byte writes into 208 x 32,768 open cache lines, is 76 ms -- as slow as the one-level scatter it replaces), with 13 GB more
-// workspace: 694 against 683 - 698 ms per proof.  What would make them pay is a sort whose every pass writes runs (<= 1,024 bins per pass).
-constexpr uint32_t MSM_WIDE_FROM = 0xffffffffu;
+// Wide windows (frw::WIDE_*): bare dense handles of 2^26 points and more, and those LOADED so (frw_msm_g1_load_bare(.., narrow = 2, ..): the
+// tests do, on the small adversarial vectors and on 2^18 points).  Measured on the 2^27-point sum of the 1,024-statement aggregate
+// (profiles/r05_wide_windows_ab.txt): the bucket kernel 350 -> 308 ms, the sort 65 -> 34 ms once every pass of it wrote runs (the first
+// version's scatter into 208 x 32,768 open cache lines took 76 ms and gave the gain back), the proof 683 - 698 -> 613 ms.
+constexpr uint32_t MSM_WIDE_FROM_DEFAULT = 1u << 26;
+static uint32_t msm_wide_from()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("FRW_BARE_WIDE_FROM_LOG2");             // (measurement switch: tools/time_aggregate_large.py)
+        const int lg = e ? atoi(e) : 0;
+        return lg >= 10 && lg <= 31 ? (uint32_t)1 << lg : MSM_WIDE_FROM_DEFAULT;
+    }();
+    return v;
+}
 template <class F> struct MsmWideBufs {
     MsmBufs<F> rows;                    // the 208 rows' arrays (entries apart: below)
-    uint32_t *partial_plain, *slice_hist_coarse, *row_count, *s1, *s0, *window_sums, *entries, *end;
-    unsigned long long *row_start;
+    uint32_t *partial_plain, *slice_hist, *bin_count, *row_count, *s1, *s0, *window_sums, *entries, *end;
+    unsigned long long *row_start, *bin_start;
     uint2 *coarse;
+    int32_t *digits;
 };
 template <class F> MsmWideBufs<F> msm_carve_wide(void *ws, uint32_t n)
 {
     constexpr size_t BW = frw::Grp<F>::BK_WORDS, R = frw::WIDE_ROWS;
-    static_assert((size_t)frw::WIDE_SLICES_FINE * 4 <= BW * 4, "the fine slice histograms borrow the buckets' memory");
     MsmWideBufs<F> w;
     MsmBufs<F> &b = w.rows;
     b.max_items = frw::WIDE_MAX_ITEMS;
@@ -1457,10 +1547,13 @@ template <class F> MsmWideBufs<F> msm_carve_wide(void *ws, uint32_t n)
     w.s0 = w.s1 + R * BW;
     w.window_sums = w.s0 + R * BW;
     w.row_start = (unsigned long long *)(w.window_sums + (size_t)frw::WIDE_W * BW);     // (every term so far a multiple of four words)
-    w.row_count = (uint32_t *)(w.row_start + R);
-    w.slice_hist_coarse = w.row_count + R;
-    w.coarse = (uint2 *)(w.slice_hist_coarse + (size_t)frw::WIDE_SLICES_COARSE * R);
+    w.bin_start = w.row_start + R;
+    w.row_count = (uint32_t *)(w.bin_start + frw::WIDE_ALL_BINS);
+    w.bin_count = w.row_count + R;
+    w.slice_hist = w.bin_count + frw::WIDE_ALL_BINS;
+    w.coarse = (uint2 *)(w.slice_hist + (size_t)frw::WIDE_W * frw::WIDE_SLICES * frw::WIDE_BINS);
     w.entries = (uint32_t *)(w.coarse + (size_t)frw::WIDE_W * n);
+    w.digits = (int32_t *)w.entries;                  // (the digits are dead once the bins are sorted; the entries are written after that)
     w.end = w.entries + (size_t)frw::WIDE_W * n;
     b.entries = w.entries; b.ones_list = w.end; b.end = w.end;
     return w;
@@ -1572,7 +1665,7 @@ template <class F> int msm_load(int device, int group, size_t num_points, const 
     m->group = group;
     m->window_bits = window_bits;
     m->bare = bare;
-    m->wide = bare && window_bits == 16 && (force_wide || num_points >= MSM_WIDE_FROM);
+    m->wide = bare && window_bits == 16 && (force_wide || num_points >= msm_wide_from());
     m->table = nullptr;
     m->ones_table = nullptr;
     m->dev.ones_table = nullptr;
@@ -1696,21 +1789,26 @@ hipError_t msm_rows_wide(const frw_msm *m, const uint32_t *sc, int montgomery, u
     const uint32_t n = m->dev.n;
     const MsmWideBufs<F> w = msm_carve_wide<F>(d_workspace, n);
     const MsmBufs<F> &b = w.rows;
-    uint32_t *slice_hist = b.buckets;                                 // [208][8][32,768], dead before the first bucket is stored
     hipError_t e = hipMemsetAsync(b.ones_count, 0, R * 16, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(frw::msm_wide_coarse_hist_kernel, dim3(frw::WIDE_SLICES_COARSE), dim3(1024), 0, st, n, sc, montgomery, w.slice_hist_coarse);
-    hipLaunchKernelGGL(frw::msm_wide_coarse_offsets_kernel, dim3(1), dim3(256), 0, st, (uint32_t)frw::WIDE_SLICES_COARSE, w.slice_hist_coarse, w.row_count, w.row_start);
-    hipLaunchKernelGGL(frw::msm_wide_coarse_scatter_kernel, dim3(frw::WIDE_SLICES_COARSE), dim3(1024), 0, st, n, sc, montgomery,
-                       (const uint32_t *)w.slice_hist_coarse, (const unsigned long long *)w.row_start, w.coarse);
-    const dim3 fgrid(frw::WIDE_SLICES_FINE, R);
-    hipLaunchKernelGGL(frw::msm_wide_fine_hist_kernel, fgrid, dim3(1024), 0, st, (const uint2 *)w.coarse, (const uint32_t *)w.row_count,
-                       (const unsigned long long *)w.row_start, slice_hist);
-    hipLaunchKernelGGL(frw::msm_slice_offsets_kernel, dim3(frw::MSM_BUCKETS / 256, R), dim3(256), 0, st, slice_hist, b.counts, (int)frw::WIDE_SLICES_FINE);
+    const dim3 sgrid(frw::WIDE_SLICES, frw::WIDE_W);
+    hipLaunchKernelGGL(frw::msm_wide_digits_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, sc, montgomery, w.digits);
+    hipLaunchKernelGGL(frw::msm_wide_bin_hist_kernel, sgrid, dim3(1024), 0, st, n, (const int32_t *)w.digits, w.slice_hist);
+    hipLaunchKernelGGL(frw::msm_wide_bin_offsets_kernel, dim3(1), dim3(1024), 0, st, (uint32_t)frw::WIDE_SLICES, w.slice_hist, w.bin_count, w.bin_start, w.row_count,
+                       w.row_start);
+    hipLaunchKernelGGL(frw::msm_wide_bin_scatter_kernel, sgrid, dim3(1024), 0, st, n, (const int32_t *)w.digits, (const uint32_t *)w.slice_hist,
+                       (const unsigned long long *)w.bin_start, w.coarse);
+    uint32_t *part_hist = b.buckets;                                  // [6,656][32][1,024]: 0.9 GB of the buckets' 1.5, dead before the first bucket is stored
+    static_assert((size_t)frw::WIDE_ALL_BINS * frw::WIDE_PARTS * frw::WIDE_BIN_BUCKETS <= (size_t)R * frw::MSM_BUCKETS * frw::Grp<F>::BK_WORDS, "the parts' histograms borrow the buckets");
+    const dim3 pgrid(frw::WIDE_ALL_BINS * frw::WIDE_PARTS);
+    hipLaunchKernelGGL(frw::msm_wide_bucket_hist_kernel, pgrid, dim3(1024), 0, st, (const uint2 *)w.coarse, (const uint32_t *)w.bin_count,
+                       (const unsigned long long *)w.bin_start, part_hist);
+    hipLaunchKernelGGL(frw::msm_wide_bucket_parts_kernel, dim3(frw::WIDE_ALL_BINS), dim3(1024), 0, st, part_hist, b.counts);
     hipLaunchKernelGGL(frw::msm_scan_kernel, dim3(R), dim3(1024), 0, st, b.counts, b.offsets);
     hipLaunchKernelGGL(frw::msm_order_kernel, dim3(R), dim3(1024), 0, st, b.counts, b.offsets, b.order, b.item_first, b.items, b.item_count, 1u, b.max_items);
-    hipLaunchKernelGGL(frw::msm_wide_fine_scatter_kernel, fgrid, dim3(1024), 0, st, (const uint2 *)w.coarse, (const uint32_t *)w.row_count,
-                       (const unsigned long long *)w.row_start, (const uint32_t *)b.offsets, (const uint32_t *)slice_hist, w.entries);
+    hipLaunchKernelGGL(frw::msm_wide_bucket_scatter_kernel, pgrid, dim3(1024), 0, st, (const uint2 *)w.coarse, (const uint32_t *)w.bin_count,
+                       (const unsigned long long *)w.bin_start, (const uint32_t *)b.offsets, (const uint32_t *)part_hist, (const unsigned long long *)w.row_start,
+                       w.entries);
     hipLaunchKernelGGL((frw::msm_bucket_kernel<F, PREFETCH>), dim3(b.max_items / 64, R), dim3(64), 0, st, m->dev, b.offsets, b.counts, b.items, b.item_count,
                        w.entries, b.partial_items, 1u, b.max_items, (size_t)0, (const unsigned long long *)w.row_start);
     hipLaunchKernelGGL(frw::msm_combine_kernel<F>, dim3(frw::MSM_BUCKETS / 64, R), dim3(64), 0, st, b.offsets, b.counts, b.item_first, b.partial_items,
@@ -2306,7 +2404,7 @@ template <class F> int msm_alloc_bare_t(int device, int group, int window_bits, 
     frw_msm *m = new (std::nothrow) frw_msm;
     if (!m) return FRW_E_OUT_OF_MEMORY;
     m->device = device; m->group = group; m->window_bits = window_bits; m->bare = true; m->row_lo = row_lo;
-    m->wide = window_bits == 16 && rows >= MSM_WIDE_FROM;
+    m->wide = window_bits == 16 && rows >= msm_wide_from();
     m->table = nullptr; m->ones_table = nullptr;
     m->dev.n = (uint32_t)rows; m->dev.ones_table = nullptr;
     e = hipMalloc(&m->table, rows * frw::Grp<F>::PT_WORDS * 4);
@@ -2613,7 +2711,10 @@ Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
         s.msm[1] = ((size_t)((char *)g1.end - base) + 255) & ~(size_t)255;
         const NmsmBufs g2 = nmsm_carve_bare<Fq2Field>(base, 1, nz, &g1);
         s.msm[4] = ((size_t)((char *)g2.end - base) + 255) & ~(size_t)255;
-        s.msm_all = s.msm[0] + s.msm[1] + s.msm[4];
+        // (the witness map's workspace and the sum over h_query's are ONE region: the sum starts, on the same stream, when the map is
+        // through and has left h -- 30 GB of the 2^27 domain's workspace)
+        s.qap = (s.qap + 255) & ~(size_t)255;
+        s.msm_all = std::max(s.msm[0], s.qap) - s.qap + s.msm[1] + s.msm[4];
         s.pts = 6 * (size_t)frw::Grp<FqField>::BK_WORDS * 4 + 192 + 64 + 64;
         s.per = ((s.qap + s.h + s.zext + s.msm_all + s.pts) + 255) & ~(size_t)255;
         return s;
@@ -2658,10 +2759,10 @@ int groth16_prove_bare(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t ba
     for (size_t b = 0; e == hipSuccess && rc == FRW_OK && b < batch; b++) {
         if (lock.owns_lock()) lock.unlock();
         char *base = (char *)d_workspace;
-        void *qap_ws = base;                          base += sz.qap;
+        void *qap_ws = base;
+        char *h_ws = base;                            base += std::max(sz.qap, sz.msm[0]);        // one region, one stream: groth16_sizes
         uint64_t *h = (uint64_t *)base;               base += sz.h;
         uint64_t *zext = (uint64_t *)base;            base += sz.zext;
-        char *h_ws = base;                            base += sz.msm[0];
         char *g1_ws = base;                           base += sz.msm[1];
         char *g2_ws = base;                           base += sz.msm[4];
         constexpr size_t XW = frw::Grp<FqField>::BK_WORDS;

@@ -416,8 +416,9 @@ int frw_msm_g2_dev(const frw_msm *m, size_t batch, const uint64_t *d_scalars, si
  * the bucket additions of the table path, one per point and non-zero digit, plus 255 point operations.  Results are the same affine
  * points, bit for bit.  frw_msm_info: table_bytes = num_points x 112 (224); one scalar vector is summed at a time, whatever the workspace.
  * narrow == 2: a dense bare handle on WIDE windows -- thirteen of 20 bits instead of sixteen of 16: 19 % fewer bucket additions (a bare
- * handle's windows cost no memory), a two-level counting sort; frw_msm_info then says 20 and 13.  Correct and tested, and on the 2^27-point
- * sum no faster than the sixteen windows yet (the sort gives back what the additions save: DESIGN 5.8), so nothing selects it by itself. */
+ * handle's windows cost no memory), a two-level counting sort whose passes write runs; frw_msm_info then says 20 and 13.  A dense bare
+ * handle of 2^26 points and more takes wide windows by itself (the folds of 13 x 2^19 buckets are a fixed 14 ms: below that size they cost
+ * more than three windows' additions save); on the 2^27-point sum of the 1,024-statement aggregate 423 -> 356 ms. */
 int frw_msm_g1_load_bare(int device, size_t num_points, const uint64_t *bases, int narrow, frw_msm **out);
 int frw_msm_g2_load_bare(int device, size_t num_points, const uint64_t *bases, int narrow, frw_msm **out);
 
