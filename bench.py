@@ -753,12 +753,14 @@ def aggregate_statements(eng, dev, logns, first_index=0):
     return batches
 
 
-def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s):
+def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s, h_windows=16):
     """groth16_roofline for one proof of an aggregate statement: the point additions of the four witness-side sums counted from ONE
     statement of each parameter set (every statement of a set has the same structure: a few hundred additions either way) times the
     number of such statements; a key of window tables sums the ones of eight points in one addition (byte-pattern tables) up to 2^18
-    points, a key of bare handles adds every one; the sum over h_query is 16 (n - 1) mixed additions either way, its buckets' folds
-    once per call (tables) or once per window (bare: 16 x), plus Horner's 255 operations per sum."""
+    points, a key of bare handles adds every one; the sum over h_query is one mixed addition per point and window -- 16 (n - 1), or
+    13 (n - 1) when the bare handle runs 20-bit windows (frw_msm_info of the key's h_query says which: `h_windows`) -- its buckets' folds
+    once per call (tables) or once per 32,768-bucket row (bare: 16 rows; wide windows: 13 x 16 rows, each bucket in a weighted and a
+    plain running sum as ever), plus Horner's 255 operations per sum."""
     rates = eng.valu_rates()
     (mm, mo), (am, ao) = point_op_instructions(MADD_OPS), point_op_instructions(ADD_OPS)
     n = 1 << log_n
@@ -774,9 +776,9 @@ def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s):
         g1_madds += cnt * (2 * (ones + digits) + (ones_w + digits_w))
         g2_madds += cnt * (ones + digits)
     bare = key_mode == frw.KEY_BARE
-    windows_h, windows_w = (16, 32) if bare else (1, 1)
+    rows_h, windows_w = ((16 if h_windows == 16 else h_windows * 16), 32) if bare else (1, 1)
     G2_FACTOR = 3
-    h_madds, h_adds = 16 * (n - 1), windows_h * 2 * 32768 + (255 if bare else 0)
+    h_madds, h_adds = h_windows * (n - 1), rows_h * 2 * 32768 + (255 if bare else 0)
     g1_adds = 3 * (windows_w * (2 * 128 + 64) + (255 if bare else 0))
     g2_adds = windows_w * (2 * 128 + 64) + (255 if bare else 0)
     madds = h_madds + g1_madds + G2_FACTOR * g2_madds
@@ -797,7 +799,8 @@ def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s):
                        "product %d + %d; multiplies at %.1f, the others at %.1f wave-instructions/SIMD/us, measured in this process)"
                        % (rates["simds"], FQ_MUL_MULTIPLY, FQ_MUL_OTHER, F29_MUL_MAD64, F29_MUL_OTHER, rates["v_mad_u64_u32"], rates["v_add_u32"]),
             "kernel": "frw_groth16_prove_dev on the aggregate handle: ntt_pass_kernel + r1cs_eval (witness map), msm_bucket_kernel (h_query, %s), "
-                      "nmsm_bucket_kernel / nmsm_ones_kernel (witness-side sums), folds" % ("sixteen window rows over the bare points" if bare else "window tables")}
+                      "nmsm_bucket_kernel / nmsm_ones_kernel (witness-side sums), folds"
+                      % (("%d window rows over the bare points" % rows_h) if bare else "window tables")}
 
 
 def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True, world=1, rank=0, cdev=None):
@@ -901,7 +904,8 @@ def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True, wor
         c = (pow(t, n, R_FR) - 1) * pow(delta, -1, R_FR) % R_FR
         want = eng.g1_fixed_base(np.frombuffer((h_t * c % R_FR).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4))[0]
         assert np.array_equal(hacc[0].cpu().numpy().view(np.uint64), want), "h_acc differs from (h(t) zt / delta) G1"
-    rates = aggregate_roofline(eng, logns, int(info.log_domain_size), batches, key_mode, 1e3 / ms) if rank == 0 else None
+    h_windows = int(eng.msm_info(eng.groth16_pk_query(pk_h, 0)).num_windows)       # 16 windows of 16 bits, or 13 of 20 (bare handles from 2^26 points)
+    rates = aggregate_roofline(eng, logns, int(info.log_domain_size), batches, key_mode, 1e3 / ms, h_windows) if rank == 0 else None
     hbm_in_use = torch.cuda.mem_get_info(dev)
     eng.groth16_pk_free(pk_h)
     del ws, h

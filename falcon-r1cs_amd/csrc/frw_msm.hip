@@ -1508,13 +1508,13 @@ template <class F> MsmBufs<F> msm_carve(void *ws, size_t rows, uint32_t n, bool 
 // tests do, on the small adversarial vectors and on 2^18 points).  Measured on the 2^27-point sum of the 1,024-statement aggregate
 // (profiles/r05_wide_windows_ab.txt): the bucket kernel 350 -> 308 ms, the sort 65 -> 34 ms once every pass of it wrote runs (the first
 // version's scatter into 208 x 32,768 open cache lines took 76 ms and gave the gain back), the proof 683 - 698 -> 613 ms.
-constexpr uint32_t MSM_WIDE_FROM_DEFAULT = 1u << 26;
+constexpr uint32_t MSM_WIDE_FROM_DEFAULT = (1u << 26) - 1;           // (h_query of the 2^26 domain has 2^26 - 1 points)
 static uint32_t msm_wide_from()
 {
     static const uint32_t v = [] {
         const char *e = getenv("FRW_BARE_WIDE_FROM_LOG2");             // (measurement switch: tools/time_aggregate_large.py)
         const int lg = e ? atoi(e) : 0;
-        return lg >= 10 && lg <= 31 ? (uint32_t)1 << lg : MSM_WIDE_FROM_DEFAULT;
+        return lg >= 10 && lg <= 31 ? ((uint32_t)1 << lg) - 1 : MSM_WIDE_FROM_DEFAULT;
     }();
     return v;
 }

@@ -163,6 +163,17 @@ def sharded_aggregate_plan(world, rank, logns):
     nz, nh = z_hi - z_lo, h_hi - h_lo
     passes = qap_pass_count(log_n)
     items = min(65536, max(2048, (nz // 128 + 2047) // 2048 * 2048)) + 256          # frw_msm.hip nmsm_max_items
+    # the sum over this rank's rows of h_query: thirteen 20-bit windows from 2^26 - 1 points (208 rows of 32,768 buckets, the two-level
+    # sort's 8-byte and 4-byte entries), sixteen 16-bit windows below (entries 4 B and digits 2 B per point and window): frw_msm.hip
+    # msm_carve_wide / msm_carve.  Its workspace and the witness map's are ONE region (same stream, one after the other: groth16_sizes).
+    wide = nh >= (1 << 26) - 1
+    if wide:
+        h_windows = 13
+        h_sum = 208 * (4 * 32768 * 4 + 65536 * 8 + 32768 * 240 + 2 * 4096 * 240 + 65536 * 240 + 3 * 240) + 13 * (8 + 4) * nh + 13 * 128 * 512 * 4 + 4096
+    else:
+        h_windows = 16
+        h_sum = 16 * (4 * 32768 * 4 + 131072 * (8 + 240) + (32768 + 4096 + 1) * 240 + 6 * nh) + 4096
+    qap = 3 * 32 * nc + 3 * 32 * n + 64
     ones_groups = 1024 if nz > (1 << 18) else 64
     buffers = {
         "transform tables of the domain (2 (K - 1) twists + 5 scales, 32 n bytes each)": (2 * (passes - 1) + 5) * 32 * n,
@@ -171,10 +182,9 @@ def sharded_aggregate_plan(world, rank, logns):
         "key: rows of h_query (112 B)": 112 * nh,
         "statements' witnesses and instances as the witness kernel wrote them": 32 * (nv + len(logns)),
         "the aggregate's assignment": 32 * nv,
-        "proof: A z, B z, C z and three working arrays": 3 * 32 * nc + 3 * 32 * n + 64,
+        "proof: A z, B z, C z and three working arrays of the witness map | the sum over h_query, %d windows (one region: the larger)" % h_windows: max(qap, h_sum),
         "proof: h": 32 * n,
         "proof: z ++ [1, r, s]": 32 * (nv + 3),
-        "proof: the sum over h_query, sixteen window rows (entries 4 B and digits 2 B per point and window)": 16 * (4 * 32768 * 4 + 131072 * (8 + 240) + (32768 + 4096 + 1) * 240 + 6 * nh) + 4096,
         "proof: one sort of the slice's scalars (32 n entries at worst) + the G1 tables' own arrays": (
             32 * (128 if nz > (1 << 18) else 16) * 128 * 4 + 32 * (3 * 128 + items + 8) * 4 + 4 * 33 * nz
             + (3 * 32 * (items + 128 + 1) + 3 * (ones_groups + 64)) * 240 + 4096),
@@ -183,7 +193,7 @@ def sharded_aggregate_plan(world, rank, logns):
     return {"world": world, "rank": rank, "statements": len(logns), "falcon512": list(logns).count(9), "falcon1024": list(logns).count(10),
             "num_instance": ni, "num_witness": nw, "num_constraints": nc, "log_domain_size": log_n,
             "z_lo": z_lo, "z_hi": z_hi, "h_lo": h_lo, "h_hi": h_hi,
-            "bucket_additions_h_query": 16 * nh,
+            "windows_h_query": h_windows, "bucket_additions_h_query": h_windows * nh,
             "partial_sum_bytes_per_rank": 72 * 8,
             "buffers": buffers, "hbm_plan_bytes": int(sum(buffers.values())),
             "hbm_limit_bytes": int(HBM_PLAN_FRACTION * HBM_BYTES_PER_GPU),

@@ -335,7 +335,7 @@ int frw_r1cs_diag_host_allocations(const frw_r1cs *r, uint64_t *count);
  * 1.8 KB per domain point of h_query: 53 GB for sixteen Falcon-1024 statements -- the fastest proofs, up to there.  Beyond, the key
  * keeps the points alone (FRW_KEY_BARE below: 112 / 224 bytes a point) and the sums run window by window over them: the 1,024 mixed
  * statements of BASELINE configs[4] (513 Falcon-512 + 511 Falcon-1024: C + I = 126.6 M, the 2^27 domain -- round 4 had written 2^28
- * and 480 GB here, both wrong) are 121.9 M variables, 83 GB of points, ONE proof in 0.7 s on one MI355X. */
+ * and 480 GB here, both wrong) are 121.9 M variables, 83 GB of points, ONE proof in 0.6 s on one MI355X. */
 typedef struct {
     uint64_t num_statements;                    /* 1 for the handles of frw_r1cs_load */
     uint64_t count_logn9, count_logn10;

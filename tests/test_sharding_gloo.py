@@ -160,8 +160,10 @@ def test_sharded_aggregate_plan_of_configs4(world):
         assert (q["z_lo"], q["z_hi"]) == sharding.shard_range(nv3, r, world) and (q["h_lo"], q["h_hi"]) == sharding.shard_range((1 << 27) - 1, r, world)
     key = sum(v for k, v in p["buffers"].items() if k.startswith("key:"))
     if world == 1:
-        assert abs(key - 83.3e9) < 0.2e9 and 205e9 < p["hbm_plan_bytes"] < 220e9          # 83 GB of points; the leg as measured on one GPU: 216 GB in use
-    assert sum(q["bucket_additions_h_query"] for q in plans) == 16 * ((1 << 27) - 1)
+        assert abs(key - 83.3e9) < 0.2e9 and 195e9 < p["hbm_plan_bytes"] < 212e9          # 83 GB of points; the leg as measured on one GPU: 209 GB in use
+    # a handle of 2^26 - 1 points and more runs thirteen 20-bit windows, a smaller one sixteen 16-bit windows (frw_msm.hip MSM_WIDE_FROM_DEFAULT)
+    assert all(q["windows_h_query"] == (13 if world <= 2 else 16) for q in plans)
+    assert sum(q["bucket_additions_h_query"] for q in plans) == (13 if world <= 2 else 16) * ((1 << 27) - 1)
     # a mix that does not fit is refused by the check
     with pytest.raises(AssertionError):
         sharding.check_sharded_aggregate_plans([sharding.sharded_aggregate_plan(1, 0, [10] * 2048)])

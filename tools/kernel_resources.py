@@ -29,7 +29,7 @@ QAP_PASSES = [("PASS_FIRST", 6, "LOAD_PLAIN", "STORE_FACTOR"), ("PASS_FIRST", 6,
 HOT = {
     "frw_qap.hip": ("FRW_QAP_PROBE", ["template __global__ void ntt_pass_kernel<%s, %d, %s, %s, false>(const NttPass);" % p for p in QAP_PASSES], 0, 3),
     "frw_msm.hip": ("FRW_MSM_PROBE", ["template __global__ void msm_bucket_kernel<FqField, true>(MsmDev, const uint32_t *, const uint32_t *, const uint32_t *, "
-                                      "const uint32_t *, const uint32_t *, uint32_t *, uint32_t, uint32_t, size_t);",
+                                      "const uint32_t *, const uint32_t *, uint32_t *, uint32_t, uint32_t, size_t, const unsigned long long *);",
                                       "template __global__ void nmsm_bucket_kernel<FqField, true>(NmsmTables, const uint32_t *, const uint32_t *, const uint32_t *, "
                                       "const uint32_t *, const uint32_t *, uint32_t *, uint32_t, uint32_t, const unsigned long long *);"], 0, 2),
 }

@@ -1,5 +1,6 @@
 """Phase times of ONE proof for a large aggregate (default: BASELINE configs[4]'s 1,024 mixed statements, the 2^27 domain):
-witnesses, handle (transform tables on the device), key (device setup), proof (repeated), verification.  Prints JSON."""
+witnesses, handle (transform tables on the device), key (device setup), proof (repeated), verification.  Prints JSON.
+    python tools/time_aggregate_large.py [statements=1024] [proofs=3] [1024: Falcon-1024 only | mixed] [auto | tables | bare]"""
 import json
 import os
 import random
@@ -57,7 +58,8 @@ def main():
     torch.cuda.synchronize()
     toxic = [rng.randrange(2, R_FR) for _ in range(5)]
     t0 = time.perf_counter()
-    key, vk = eng.groth16_setup_r1cs(handle, *toxic)
+    mode = {"auto": frw.KEY_AUTO, "tables": frw.KEY_TABLES, "bare": frw.KEY_BARE}[sys.argv[4] if len(sys.argv) > 4 else "auto"]
+    key, vk = eng.groth16_setup_r1cs(handle, *toxic, mode=mode)
     out["key_s"] = round(time.perf_counter() - t0, 3)
     pi = eng.groth16_pk_info(key)
     out["key_mode"], out["key_bytes"] = int(pi.mode), int(pi.key_bytes)
