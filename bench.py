@@ -753,18 +753,20 @@ def aggregate_statements(eng, dev, logns, first_index=0):
     return batches
 
 
-def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s, h_windows=16):
+def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s, h_windows=16, side_counts=None):
     """groth16_roofline for one proof of an aggregate statement: the point additions of the four witness-side sums counted from ONE
     statement of each parameter set (every statement of a set has the same structure: a few hundred additions either way) times the
     number of such statements; a key of window tables sums the ones of eight points in one addition (byte-pattern tables) up to 2^18
     points, a key of bare handles adds every one; the sum over h_query is one mixed addition per point and window -- 16 (n - 1), or
     13 (n - 1) when the bare handle runs 20-bit windows (frw_msm_info of the key's h_query says which: `h_windows`) -- its buckets' folds
     once per call (tables) or once per 32,768-bucket row (bare: 16 rows; wide windows: 13 x 16 rows, each bucket in a weighted and a
-    plain running sum as ever), plus Horner's 255 operations per sum."""
+    plain running sum as ever), plus Horner's 255 operations per sum.
+    side_counts (a key of bare handles: frw_diag_groth16_side_counts on the proof's own scalars): the sums over b_g1_query / b_g2_query
+    run over the rows that hold a point there -- their additions are what the device counted, not an estimate."""
     rates = eng.valu_rates()
     (mm, mo), (am, ao) = point_op_instructions(MADD_OPS), point_op_instructions(ADD_OPS)
     n = 1 << log_n
-    g1_madds = g2_madds = 0
+    g1_madds = g2_madds = l_madds = 0
     for g in (9, 10):
         cnt = list(logns).count(g)
         if not cnt:
@@ -775,7 +777,12 @@ def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s, h_win
         ones_w, digits_w, _ = witness_side_additions(inst_row[:0], wit_row)
         g1_madds += cnt * (2 * (ones + digits) + (ones_w + digits_w))
         g2_madds += cnt * (ones + digits)
+        l_madds += cnt * (ones_w + digits_w)
     bare = key_mode == frw.KEY_BARE
+    if bare and side_counts is not None:
+        _, digits_all, ones_all, digits_b, ones_b = side_counts
+        g1_madds = (digits_all + ones_all) + l_madds + (digits_b + ones_b)          # a_query, l_query (no instance rows), b_g1_query
+        g2_madds = digits_b + ones_b
     rows_h, windows_w = ((16 if h_windows == 16 else h_windows * 16), 32) if bare else (1, 1)
     G2_FACTOR = 3
     h_madds, h_adds = h_windows * (n - 1), rows_h * 2 * 32768 + (255 if bare else 0)
@@ -793,7 +800,8 @@ def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s, h_win
             "achieved": round(total * proofs_per_s / 1e9, 2), "peak": round(total * peak_proofs / 1e9, 2),
             "frac": round(proofs_per_s / peak_proofs, 4),
             "per_proof": {"fq_products": fq_products, "fr_products": fr_products,
-                          "mixed_additions": {"h_query": h_madds, "a_query + b_g1_query + l_query": g1_madds, "b_g2_query (Fq2)": g2_madds},
+                          "mixed_additions": {"h_query": h_madds, "a_query + b_g1_query + l_query": g1_madds, "b_g2_query (Fq2)": g2_madds,
+                                              "rows_of_b_queries_holding_a_point": None if side_counts is None else side_counts[0]},
                           "g2_priced_as_g1_times": G2_FACTOR, "transform_passes": qap_pass_stages(log_n)},
             "peak_is": "%d SIMDs x 64 lanes issuing only the instructions of these products (an Fq product %d multiplies + %d others, an Fr "
                        "product %d + %d; multiplies at %.1f, the others at %.1f wave-instructions/SIMD/us, measured in this process)"
@@ -905,7 +913,13 @@ def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True, wor
         want = eng.g1_fixed_base(np.frombuffer((h_t * c % R_FR).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4))[0]
         assert np.array_equal(hacc[0].cpu().numpy().view(np.uint64), want), "h_acc differs from (h(t) zt / delta) G1"
     h_windows = int(eng.msm_info(eng.groth16_pk_query(pk_h, 0)).num_windows)       # 16 windows of 16 bits, or 13 of 20 (bare handles from 2^26 points)
-    rates = aggregate_roofline(eng, logns, int(info.log_domain_size), batches, key_mode, 1e3 / ms, h_windows) if rank == 0 else None
+    side_counts = None
+    if rank == 0 and key_mode == frw.KEY_BARE:
+        # z ++ [1, r, s] of this key's slice (the three tail scalars as zeros: three additions in 10^8)
+        z = torch.cat([d_inst[0], d_wit[0], torch.zeros((3, 4), dtype=torch.int64, device=dev)])[int(pinfo.z_lo):int(pinfo.z_hi)].contiguous()
+        side_counts = eng.diag_groth16_side_counts(pk_h, z, ws, ws_bytes, s0)
+        del z
+    rates = aggregate_roofline(eng, logns, int(info.log_domain_size), batches, key_mode, 1e3 / ms, h_windows, side_counts) if rank == 0 else None
     hbm_in_use = torch.cuda.mem_get_info(dev)
     eng.groth16_pk_free(pk_h)
     del ws, h

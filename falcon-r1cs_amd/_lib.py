@@ -111,6 +111,7 @@ PROTOTYPES = {
     "frw_groth16_prove_combine_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "frw_groth16_vk_load_opts": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "frw_diag_poly_eval_dev": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frw_diag_groth16_side_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "frw_msm_g2_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),
     "frw_msm_info": (C.c_int, [C.c_void_p, C.POINTER(MsmInfoStruct)]),

@@ -797,7 +797,8 @@ __global__ __launch_bounds__(64, 2) void msm_bucket_kernel(MsmDev m, const uint3
 // Grid: one workgroup per sum (the three G1 tables of a proof side by side); sums: [sum][windows][BK_WORDS].
 template <class F>
 __global__ __launch_bounds__(64) void msm_horner_kernel(const uint32_t *__restrict__ sums, int windows, int window_bits,
-                                                        uint32_t *__restrict__ out /* [sum][ARK_WORDS], or [sum][BK_WORDS] */, int xyzz_out)
+                                                        uint32_t *__restrict__ out /* [sum][ARK_WORDS], or [sum][BK_WORDS] */, int xyzz_out,
+                                                        uint32_t out_step = 1 /* XYZZ rows: sum i goes to row i out_step */)
 {
     __builtin_amdgcn_s_setprio(2);
     constexpr int BW = Grp<F>::BK_WORDS;
@@ -808,8 +809,47 @@ __global__ __launch_bounds__(64) void msm_horner_kernel(const uint32_t *__restri
         for (int k = 0; k < window_bits; k++) acc = pt_double(acc);
         acc = pt_add(acc, load_bucket<F>(src + (size_t)j * BW));
     }
-    if (xyzz_out) store_bucket<F>(out + (size_t)blockIdx.x * BW, acc);
+    if (xyzz_out) store_bucket<F>(out + (size_t)blockIdx.x * out_step * BW, acc);
     else store_ark_point<F>(out + (size_t)blockIdx.x * Grp<F>::ARK_WORDS, pt_to_affine(acc));
+}
+// the rows of a table that hold a point (not all words zero), in order: per block of 1,024 rows their number, then -- the blocks' running
+// totals in between, one workgroup -- their indices
+template <int PT_WORDS_>
+__global__ __launch_bounds__(1024) void live_rows_kernel(const uint32_t *__restrict__ rows, uint32_t n, uint32_t *__restrict__ block_counts /* in: null or the blocks' first positions */,
+                                                         uint32_t *__restrict__ index /* null: count only */)
+{
+    __shared__ uint32_t wave_total[16];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t any = 0;
+    if (i < n) {
+        const uint4 *v = (const uint4 *)(rows + (size_t)i * PT_WORDS_);
+#pragma unroll
+        for (int k = 0; k < PT_WORDS_ / 4; k++) { const uint4 w = v[k]; any |= w.x | w.y | w.z | w.w; }
+    }
+    const unsigned long long ballot = __builtin_amdgcn_ballot_w64(any != 0);
+    if (lane == 0) wave_total[wave] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < 16; w++) { before += w < wave ? wave_total[w] : 0u; total += wave_total[w]; }
+    if (!index) {
+        if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+        return;
+    }
+    if (any) index[block_counts[blockIdx.x] + before + (uint32_t)__popcll(ballot & ((1ull << lane) - 1))] = i;
+}
+__global__ __launch_bounds__(1024) void live_rows_scan_kernel(uint32_t *__restrict__ block_counts, uint32_t blocks, uint32_t *__restrict__ total)
+{
+    // one workgroup: every thread a run of blocks, the runs' totals scanned through LDS
+    __shared__ uint32_t run_total[1024];
+    const uint32_t per = (blocks + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < blocks ? lo + per : blocks;
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += block_counts[b];
+    run_total[threadIdx.x] = sum;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t t = 0; t < threadIdx.x; t++) before += run_total[t];
+    for (uint32_t b = lo; b < hi; b++) { const uint32_t c = block_counts[b]; block_counts[b] = before; before += c; }
+    if (threadIdx.x == 1023) *total = before;
 }
 
 // bucket b = the sum of its items (one for almost every bucket: a copy)
@@ -918,7 +958,7 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
 constexpr int NMSM_C = 8, NMSM_W = 32, NMSM_BUCKETS = 128;
 // slices of the counting sort (a workgroup of 1,024 threads each): 16 per signature, 128 beyond 2^18 scalars (an aggregate statement is
 // one "signature": 16 workgroups for 2.5 M scalars were 1.2 ms at the head of every other kernel of its proof)
-__host__ __device__ constexpr uint32_t nmsm_slices(uint32_t n) { return n > (1u << 18) ? 128u : 16u; }
+__host__ __device__ constexpr uint32_t nmsm_slices(uint32_t n) { return n > (1u << 23) ? 1024u : n > (1u << 18) ? 128u : 16u; }
 // Work items per signature: 2,048 for the per-signature circuits (n < 2^18 points), n / 128 rounded up to a multiple of 2,048 beyond
 // (an aggregate statement is ONE "signature" with sixteen times the points: 2,048 items would be 32 wavefronts on 1,024 SIMDs, each
 // a chain of 550 additions); items <= buckets + total / split <= 128 + target, rounded up to whole wavefronts.
@@ -1052,16 +1092,21 @@ __global__ __launch_bounds__(1024) void nmsm_scatter_kernel(uint32_t n, const ui
 // entry_base[w] (the windows' totals differ by orders of magnitude: the low two hold every 14-bit value of a witness, the upper
 // thirteen nothing), and msm_horner_kernel puts the thirty-two window sums of every table together.  Scalars equal to one: a list,
 // summed with window 0.
+// `index` (or null): element k of the sum is scalar -- and table row -- index[k]: the rows of a table that are not the point at infinity
+// (frw_groth16_pk.b_index: b_g1_query / b_g2_query hold a point for 59 % of the variables of a Falcon circuit, and of those variables'
+// values four in five of a witness's ones and every full-size value are elsewhere).
 __global__ __launch_bounds__(1024) void nmsm_hist_bare_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery,
                                                               uint32_t *__restrict__ slice_hist /* [window][slice][128] */,
-                                                              uint32_t *__restrict__ ones_count /* [0] */, uint32_t *__restrict__ ones_list /* [n] */)
+                                                              uint32_t *__restrict__ ones_count /* [0] */, uint32_t *__restrict__ ones_list /* [n] */,
+                                                              const uint32_t *__restrict__ index)
 {
     __shared__ uint32_t hist[NMSM_W * NMSM_BUCKETS];
     const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
     const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
     for (int b = threadIdx.x; b < NMSM_W * NMSM_BUCKETS; b += 1024) hist[b] = 0;
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 1024) {
+        const uint32_t i = index ? index[k] : k;
         int d[NMSM_W];
         if (scalar_digits8(scalars + (size_t)i * 8, montgomery, d)) {
             ones_list[atomicAdd(&ones_count[0], 1u)] = i;
@@ -1089,7 +1134,8 @@ __global__ __launch_bounds__(64) void nmsm_entry_base_kernel(const uint32_t *__r
 __global__ __launch_bounds__(1024) void nmsm_scatter_bare_kernel(uint32_t n, const uint32_t *__restrict__ scalars, int montgomery,
                                                                  const uint32_t *__restrict__ offsets /* [window][128] */,
                                                                  const uint32_t *__restrict__ slice_hist,
-                                                                 const unsigned long long *__restrict__ entry_base, uint32_t *__restrict__ entries)
+                                                                 const unsigned long long *__restrict__ entry_base, uint32_t *__restrict__ entries,
+                                                                 const uint32_t *__restrict__ index)
 {
     __shared__ uint32_t cursor[NMSM_W * NMSM_BUCKETS];
     __shared__ unsigned long long base[NMSM_W];
@@ -1099,7 +1145,8 @@ __global__ __launch_bounds__(1024) void nmsm_scatter_bare_kernel(uint32_t n, con
         cursor[b] = offsets[b] + slice_hist[((size_t)(b / NMSM_BUCKETS) * slices + slice) * NMSM_BUCKETS + (b % NMSM_BUCKETS)];
     if (threadIdx.x < NMSM_W) base[threadIdx.x] = entry_base[threadIdx.x];
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 1024) {
+        const uint32_t i = index ? index[k] : k;
         int d[NMSM_W];
         if (scalar_digits8(scalars + (size_t)i * 8, montgomery, d)) continue;
 #pragma unroll
@@ -1576,6 +1623,7 @@ struct NmsmBufs {
     uint32_t *slice_hist, *counts, *offsets, *item_first, *items, *item_count, *ones_count, *ones_list, *entries;      // the sort's
     uint32_t *partial_items, *partial_ones, *folded_ones, *bucket_sums;                                              // a table's own
     uint32_t target, max_items, ones_stride;
+    uint32_t n = 0;             // (bare) how many scalars the sort is over: a table's rows, or the rows its index names
     // a bare handle's sort (rows = the thirty-two windows of one scalar vector): where every window's entries start, and its tables'
     // window sums [table][32]
     unsigned long long *entry_base = nullptr;
@@ -1617,6 +1665,7 @@ template <class F> NmsmBufs nmsm_carve_bare(void *d_workspace, size_t tables, ui
         b = *sorted;
     } else {
         b.target = frw::nmsm_target_items(n); b.max_items = frw::nmsm_max_items(n); b.ones_stride = frw::nmsm_ones_max(n) / 64;
+        b.n = n;
         b.entry_base = (unsigned long long *)d_workspace;                  // [32]
         b.slice_hist = (uint32_t *)(b.entry_base + WIN);
         b.counts = b.slice_hist + WIN * (size_t)frw::nmsm_slices(n) * frw::NMSM_BUCKETS;
@@ -1884,16 +1933,18 @@ hipError_t nmsm_sort(const NmsmBufs &b, uint32_t n, size_t cnt, const uint32_t *
     return hipGetLastError();
 }
 // ... of ONE scalar vector for bare handles: all thirty-two windows in one pass (`b` from nmsm_carve_bare)
-hipError_t nmsm_sort_bare(const NmsmBufs &b, uint32_t n, const uint32_t *sc, int montgomery, hipStream_t st)
+// `index`: the sum is over the scalars (and rows) index[0 .. n) of `sc` (null: over 0 .. n)
+hipError_t nmsm_sort_bare(const NmsmBufs &b, uint32_t n, const uint32_t *sc, int montgomery, hipStream_t st, const uint32_t *index = nullptr)
 {
     const uint32_t slices = frw::nmsm_slices(n);
     hipError_t e = hipMemsetAsync(b.ones_count, 0, 16, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(frw::nmsm_hist_bare_kernel, dim3(slices), dim3(1024), 0, st, n, sc, montgomery, b.slice_hist, b.ones_count, b.ones_list);
+    hipLaunchKernelGGL(frw::nmsm_hist_bare_kernel, dim3(slices), dim3(1024), 0, st, n, sc, montgomery, b.slice_hist, b.ones_count, b.ones_list, index);
     hipLaunchKernelGGL(frw::nmsm_plan_kernel, dim3(frw::NMSM_W), dim3(frw::NMSM_BUCKETS), 0, st, b.slice_hist, b.counts, b.offsets, b.item_first, b.items,
                        b.item_count, b.target, b.max_items, slices);
     hipLaunchKernelGGL(frw::nmsm_entry_base_kernel, dim3(1), dim3(64), 0, st, b.counts, b.offsets, b.entry_base);
-    hipLaunchKernelGGL(frw::nmsm_scatter_bare_kernel, dim3(slices), dim3(1024), 0, st, n, sc, montgomery, b.offsets, b.slice_hist, b.entry_base, b.entries);
+    hipLaunchKernelGGL(frw::nmsm_scatter_bare_kernel, dim3(slices), dim3(1024), 0, st, n, sc, montgomery, b.offsets, b.slice_hist, b.entry_base, b.entries,
+                       index);
     return hipGetLastError();
 }
 // `sorted`: whose sort arrays to read; `own`: where the tables' partial sums go -- carved for `tables * cnt` signatures when there is
@@ -1967,9 +2018,9 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
 // (table, window); the scalars equal to one -- a list -- are summed by up to 65,536 threads per table and join window 0; Horner's rule
 // over the thirty-two window sums.  d_out: [tables] results.
 template <class F, bool PREFETCH>
-hipError_t nmsm_accumulate_bare(const frw_msm *const *ms, int tables, const NmsmBufs &b, uint32_t *d_out, hipStream_t st, bool xyzz_out)
+hipError_t nmsm_accumulate_bare(const frw_msm *const *ms, int tables, const NmsmBufs &b, uint32_t *d_out, hipStream_t st, bool xyzz_out, uint32_t out_step = 1)
 {
-    const uint32_t n = ms[0]->dev.n;
+    const uint32_t n = b.n;                                          // (the sort's: the tables' rows, or those an index names)
     frw::NmsmTables dev;
     dev.n = n; dev.sigs = frw::NMSM_W;
     for (int t = 0; t < 3; t++) {
@@ -2001,7 +2052,8 @@ hipError_t nmsm_accumulate_bare(const frw_msm *const *ms, int tables, const Nmsm
     hipLaunchKernelGGL(frw::nmsm_finish_kernel<FB>, dim3(rows), dim3(64), 0, st, b.counts, b.offsets, b.item_first, b.partial_items,
                        b.bucket_sums, ones_for_finish, (int)ones_groups, ones_finish_stride, b.target, b.max_items,
                        b.window_sums, 1, (uint32_t)frw::NMSM_W, 1);
-    hipLaunchKernelGGL(frw::msm_horner_kernel<FB>, dim3((unsigned)tables), dim3(64), 0, st, b.window_sums, frw::NMSM_W, frw::NMSM_C, d_out, xyzz_out ? 1 : 0);
+    hipLaunchKernelGGL(frw::msm_horner_kernel<FB>, dim3((unsigned)tables), dim3(64), 0, st, b.window_sums, frw::NMSM_W, frw::NMSM_C, d_out, xyzz_out ? 1 : 0,
+                       out_step);
     return hipGetLastError();
 }
 // the narrow pipeline for one group
@@ -2334,6 +2386,11 @@ struct frw_groth16_pk {
     bool bare = false;
     uint32_t rank = 0, world = 1;
     uint64_t z_lo = 0, z_hi = 0, h_lo = 0, h_hi = 0;
+    // (bare) the rows of b_g2_query -- and with them of b_g1_query -- that hold a point, in order: the sums over these two tables are over
+    // those rows only.  A variable that no constraint has on its B side has the point at infinity there: 41 % of a Falcon circuit's, and
+    // with them four fifths of a witness's ones and all its full-size values -- 207,000 additions per statement against 48,000.
+    uint32_t *b_index = nullptr;
+    uint32_t b_rows = 0;
     // FOUR streams of the key's own, created one after the other -- as many as the device has hardware queues (HIP's default), so
     // that no two of them wait in line for the same queue.  `main`: the witness map + the sum over h_query; side[0]: the three G1
     // witness-side sums as one chain of kernels, then both scalar multiplications; side[2]: the sum over b_g2_query; side[1]: the G1
@@ -2354,6 +2411,7 @@ extern "C" void frw_groth16_pk_free(frw_groth16_pk *pk)
     if (!pk) return;
     for (frw_msm *m : {pk->h, pk->a, pk->b1, pk->l, pk->b2}) frw_msm_free(m);
     (void)hipSetDevice(pk->device);
+    if (pk->b_index) (void)hipFree(pk->b_index);
     for (int i = 0; i < 4; i++) {
         if (i < 3 && pk->side[i]) (void)hipStreamDestroy(pk->side[i]);
         if (pk->join[i]) (void)hipEventDestroy(pk->join[i]);
@@ -2562,6 +2620,32 @@ int groth16_pk_assemble(int device, uint64_t ni, uint64_t nw, uint64_t n, uint32
     pk->rank = rank; pk->world = world < 1 ? 1 : world;
     groth16_shard_range(ni + nw + 3, rank, pk->world, &pk->z_lo, &pk->z_hi);
     groth16_shard_range(n - 1, rank, pk->world, &pk->h_lo, &pk->h_hi);
+    if (bare) {
+        // the rows of b_g2_query that hold a point (b_g1_query's are the same variables': row nv + 2 -- delta_2 -- is the one more G2 has)
+        const uint32_t rows = b2->dev.n, blocks = (rows + 1023) / 1024;
+        uint32_t *counts = nullptr, live = 0;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipMalloc((void **)&counts, ((size_t)blocks + 1) * 4);
+        if (e == hipSuccess) {
+            constexpr int PW2 = Grp<Fq2Field>::PT_WORDS;
+            hipLaunchKernelGGL(live_rows_kernel<PW2>, dim3(blocks), dim3(1024), 0, nullptr, (const uint32_t *)b2->dev.table, rows, counts, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(live_rows_scan_kernel, dim3(1), dim3(1024), 0, nullptr, counts, blocks, counts + blocks);
+            e = hipMemcpy(&live, counts + blocks, 4, hipMemcpyDeviceToHost);
+            // (a slice without a single point in these tables still sums something: row 0, the point at infinity)
+            if (e == hipSuccess) e = hipMalloc((void **)&pk->b_index, (size_t)(live ? live : 1) * 4);
+            if (e == hipSuccess) e = hipMemset(pk->b_index, 0, 4);
+            if (e == hipSuccess && live) {
+                hipLaunchKernelGGL(live_rows_kernel<PW2>, dim3(blocks), dim3(1024), 0, nullptr, (const uint32_t *)b2->dev.table, rows, counts, pk->b_index);
+                e = hipDeviceSynchronize();
+            }
+            pk->b_rows = live ? live : 1;
+        }
+        if (counts) (void)hipFree(counts);
+        if (e != hipSuccess) {
+            frw_groth16_pk_free(pk);
+            return record_hip_error(e, "frw_groth16_pk_load (the rows of b_g2_query that hold a point)");
+        }
+    }
     *out = pk;
     return FRW_OK;
 }
@@ -2701,20 +2785,23 @@ Groth16Sizes groth16_sizes(const frw_groth16_pk *pk, const frw_r1cs *r)
     s.h = (size_t)pk->domain_size * 32;
     s.zext = (nv + 3) * 32;
     if (pk->bare) {
-        // msm[0]: the sum over h_query (sixteen window rows); msm[1]: ONE sort of the slice's scalars and the three G1 tables' own
-        // arrays; msm[4]: the G2 table's own arrays (it reads msm[1]'s sort)
+        // msm[0]: the sum over h_query (its window rows); msm[1]: the sort of the slice's scalars and the own arrays of a_query and
+        // l_query; msm[2]: the sort of the scalars of the rows b_g1_query / b_g2_query hold a point in (pk->b_index) and b_g1_query's own
+        // arrays; msm[4]: b_g2_query's own arrays (it reads msm[2]'s sort)
         const uint32_t nz = pk->a->dev.n;
         char *const base = (char *)(uintptr_t)4096;
         frw_msm_info(pk->h, &mi);
         s.msm[0] = (mi.workspace_bytes_per_signature + 255) & ~(size_t)255;
-        const NmsmBufs g1 = nmsm_carve_bare<FqField>(base, 3, nz);
+        const NmsmBufs g1 = nmsm_carve_bare<FqField>(base, 2, nz);
         s.msm[1] = ((size_t)((char *)g1.end - base) + 255) & ~(size_t)255;
-        const NmsmBufs g2 = nmsm_carve_bare<Fq2Field>(base, 1, nz, &g1);
+        const NmsmBufs gb = nmsm_carve_bare<FqField>(base, 1, pk->b_rows);
+        s.msm[2] = ((size_t)((char *)gb.end - base) + 255) & ~(size_t)255;
+        const NmsmBufs g2 = nmsm_carve_bare<Fq2Field>(base, 1, pk->b_rows, &gb);
         s.msm[4] = ((size_t)((char *)g2.end - base) + 255) & ~(size_t)255;
         // (the witness map's workspace and the sum over h_query's are ONE region: the sum starts, on the same stream, when the map is
         // through and has left h -- 30 GB of the 2^27 domain's workspace)
         s.qap = (s.qap + 255) & ~(size_t)255;
-        s.msm_all = std::max(s.msm[0], s.qap) - s.qap + s.msm[1] + s.msm[4];
+        s.msm_all = std::max(s.msm[0], s.qap) - s.qap + s.msm[1] + s.msm[2] + s.msm[4];
         s.pts = 6 * (size_t)frw::Grp<FqField>::BK_WORDS * 4 + 192 + 64 + 64;
         s.per = ((s.qap + s.h + s.zext + s.msm_all + s.pts) + 255) & ~(size_t)255;
         return s;
@@ -2736,6 +2823,36 @@ extern "C" size_t frw_groth16_workspace_bytes(const frw_groth16_pk *pk, const fr
 {
     if (!pk || !r) return 0;
     return groth16_sizes(pk, r).per * (pk->bare ? (batch_in_flight ? 1 : 0) : batch_in_flight);     // a bare key proves one statement at a time
+}
+
+// (diagnostic: what the witness-side sums of a key of bare handles add up for the scalars z -- the benchmark prices its roofline with these)
+extern "C" int frw_diag_groth16_side_counts(const frw_groth16_pk *pk, const uint64_t *d_z, void *d_workspace, size_t workspace_bytes, void *stream,
+                                            uint64_t *out)
+{
+    if (!pk || !pk->bare || !d_z || !d_workspace || !out || ((uintptr_t)d_workspace & 255)) return FRW_E_INVALID_ARG;
+    const uint32_t nz = pk->a->dev.n;
+    const NmsmBufs g1 = nmsm_carve_bare<FqField>(d_workspace, 2, nz);
+    const size_t first = ((size_t)((char *)g1.end - (char *)d_workspace) + 255) & ~(size_t)255;
+    const NmsmBufs gb = nmsm_carve_bare<FqField>((char *)d_workspace + first, 1, pk->b_rows);
+    if ((size_t)((char *)gb.end - (char *)d_workspace) > workspace_bytes) return FRW_E_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(pk->device);
+    if (e == hipSuccess) e = nmsm_sort_bare(g1, nz, (const uint32_t *)d_z, 1, st);
+    if (e == hipSuccess) e = nmsm_sort_bare(gb, pk->b_rows, (const uint32_t *)d_z, 1, st, pk->b_index);
+    out[0] = pk->b_rows;
+    for (int k = 0; k < 2 && e == hipSuccess; k++) {
+        const NmsmBufs &b = k ? gb : g1;
+        std::vector<uint32_t> counts((size_t)frw::NMSM_W * frw::NMSM_BUCKETS);
+        uint32_t ones = 0;
+        e = hipMemcpyAsync(counts.data(), b.counts, counts.size() * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&ones, b.ones_count, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        uint64_t total = 0;
+        for (uint32_t c : counts) total += c;
+        out[1 + 2 * k] = total;
+        out[2 + 2 * k] = ones;
+    }
+    return e == hipSuccess ? FRW_OK : frw::record_hip_error(e, "frw_diag_groth16_side_counts");
 }
 
 namespace {
@@ -2764,6 +2881,7 @@ int groth16_prove_bare(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t ba
         uint64_t *h = (uint64_t *)base;               base += sz.h;
         uint64_t *zext = (uint64_t *)base;            base += sz.zext;
         char *g1_ws = base;                           base += sz.msm[1];
+        char *gb_ws = base;                           base += sz.msm[2];
         char *g2_ws = base;                           base += sz.msm[4];
         constexpr size_t XW = frw::Grp<FqField>::BK_WORDS;
         uint32_t *pA = (uint32_t *)base, *pH = pA + 3 * XW, *pSA = pH + XW, *pRB1 = pSA + XW;      // [A | B1' | L] [H] [s A | r B1']
@@ -2785,30 +2903,39 @@ int groth16_prove_bare(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t ba
         forked = true;
         if (e == hipSuccess) e = hipStreamWaitEvent(pk->main, pk->fork, 0);
         if (e != hipSuccess) break;
-        // the sort first, on the caller's stream (workgroups of 1,024 threads: they would not start under the bucket kernels)
-        const NmsmBufs g1 = nmsm_carve_bare<FqField>(g1_ws, 3, nz);
-        const NmsmBufs g2 = nmsm_carve_bare<Fq2Field>(g2_ws, 1, nz, &g1);
-        e = nmsm_sort_bare(g1, nz, (const uint32_t *)(zext + pk->z_lo * 4), 1, st);
+        // the sorts first, on the caller's stream (workgroups of 1,024 threads: they would not start under the bucket kernels): one over
+        // all the slice's scalars for a_query and l_query, one over the rows that b_g1_query / b_g2_query hold a point in
+        const NmsmBufs g1 = nmsm_carve_bare<FqField>(g1_ws, 2, nz);
+        const NmsmBufs gb = nmsm_carve_bare<FqField>(gb_ws, 1, pk->b_rows);
+        const NmsmBufs g2 = nmsm_carve_bare<Fq2Field>(g2_ws, 1, pk->b_rows, &gb);
+        // (the short one first: the sums over b_g1_query and b_g2_query -- side[1], side[2] -- start while the long one runs; `ones_done`
+        // is a spare event in this path)
+        e = nmsm_sort_bare(gb, pk->b_rows, (const uint32_t *)(zext + pk->z_lo * 4), 1, st, pk->b_index);
+        if (e == hipSuccess) e = hipEventRecord(pk->ones_done, st);
+        for (int i = 1; i < 3 && e == hipSuccess; i++) e = hipStreamWaitEvent(pk->side[i], pk->ones_done, 0);
+        if (e == hipSuccess) e = nmsm_sort_bare(g1, nz, (const uint32_t *)(zext + pk->z_lo * 4), 1, st);
         if (e != hipSuccess) break;
         e = hipEventRecord(pk->sorted, st);
-        for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pk->side[0], pk->sorted, 0);
         if (e != hipSuccess) break;
         // (the witness-side sums first: the witness map of a mixed aggregate is hundreds of launches, and what the one host thread enqueues
         // behind them starts that much later -- 50 ms of an idle chip at the head of the 1,024-statement proof, profiles/r05_aggregate1024_timeline.txt)
-        const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
-        e = nmsm_accumulate_bare<FqField, true>(g1s, 3, g1, pA, pk->side[0], true);
+        // pA: [A | B1' | L]: a_query and l_query share a chain of kernels (rows 0 and 2), b_g1_query has the key's spare stream
+        const frw_msm *g1s[2] = {pk->a, pk->l};
+        e = nmsm_accumulate_bare<FqField, true>(g1s, 2, g1, pA, pk->side[0], true, 2);
         if (e != hipSuccess) break;
         e = nmsm_accumulate_bare<Fq2Field, false>(&pk->b2, 1, g2, (uint32_t *)pB2, pk->side[2], false);
+        if (e != hipSuccess) break;
+        e = nmsm_accumulate_bare<FqField, true>(&pk->b1, 1, gb, pA + XW, pk->side[1], true);
         if (e != hipSuccess) break;
         rc = frw_qap_witness_map_dev(r1cs, 1, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + b : nullptr, qap_ws, sz.qap, pk->main);
         if (rc != FRW_OK) break;
         // h's coefficients [h_lo, h_hi) against this slice of h_query
         rc = msm_run<FqField, true>(pk->h, 1, h + pk->h_lo * 4, n, 1, (uint64_t *)pH, h_ws, sz.msm[0], pk->main, true);
         if (rc != FRW_OK) break;
-        for (int i = 0; i < 3 && e == hipSuccess; i += 2) e = hipEventRecord(pk->join[i], pk->side[i]);
+        for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventRecord(pk->join[i], pk->side[i]);
         if (e == hipSuccess) e = hipEventRecord(pk->join[3], pk->main);
-        for (int i = 0; i < 4 && e == hipSuccess; i++)
-            if (i != 1) e = hipStreamWaitEvent(st, pk->join[i], 0);
+        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st, pk->join[i], 0);
         if (e != hipSuccess) break;
         if (d_partial) {
             hipLaunchKernelGGL(frw::groth16_partial_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)pA, (const uint32_t *)pB2,

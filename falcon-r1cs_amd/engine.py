@@ -551,6 +551,14 @@ class WitnessEngine:
         check(self._lib.frw_groth16_prove_combine_dev(pk, world, self._ptr(d_partials), rs.ctypes.data_as(C.c_void_p), self._ptr(d_proof),
                                                       self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream)), "frw_groth16_prove_combine_dev")
 
+    def diag_groth16_side_counts(self, pk, d_z, d_workspace, workspace_bytes, stream=0):
+        """(rows of b_g1_query / b_g2_query that hold a point, digits and ones over all rows, digits and ones over those rows): the point
+        additions of the witness-side sums of a key of bare handles for the scalars d_z (z ++ [1, r, s] of the key's slice)."""
+        out = np.zeros(5, dtype=np.uint64)
+        check(self._lib.frw_diag_groth16_side_counts(pk, self._ptr(d_z), self._ptr(d_workspace), workspace_bytes, C.c_void_p(stream),
+                                                     out.ctypes.data_as(C.c_void_p)), "frw_diag_groth16_side_counts")
+        return [int(v) for v in out]
+
     def diag_poly_eval_dev(self, d_coeffs, n, t):
         """p(t) for the polynomial whose n coefficients (ark-ff's Montgomery form) are in device memory; t, result: Python integers."""
         tt = np.frombuffer(int(t).to_bytes(32, "little"), dtype=np.uint64).copy()

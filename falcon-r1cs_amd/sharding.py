@@ -142,6 +142,11 @@ def qap_pass_count(log_n):
     return (log_n + 5) // 6
 
 
+# variables (other than the constant one) that some constraint of FalconNTTVerificationCircuit has on its B side: the columns of B in the
+# matrices frw_r1cs_export writes (tests/test_gpu_aggregate.py holds the device's count to them)
+B_SIDE_VARIABLES = {9: 46630, 10: 93222}
+
+
 def sharded_aggregate_plan(world, rank, logns):
     """One proof for the aggregate of `logns`, the key of bare handles in `world` slices (frw_groth16_setup_r1cs_opts): what rank `rank`
     holds and sums, as plain arithmetic -- the statement's sizes, this rank's rows of the witness-side tables ([z_lo, z_hi) of nv + 3) and
@@ -162,7 +167,23 @@ def sharded_aggregate_plan(world, rank, logns):
     h_lo, h_hi = shard_range(n - 1, rank, world)
     nz, nh = z_hi - z_lo, h_hi - h_lo
     passes = qap_pass_count(log_n)
-    items = min(65536, max(2048, (nz // 128 + 2047) // 2048 * 2048)) + 256          # frw_msm.hip nmsm_max_items
+    # the rows in which b_g1_query / b_g2_query hold a point: the variables some constraint has on its B side (B_SIDE_VARIABLES per
+    # statement, the constant one, beta_2 and delta_2) -- the sums over those two tables run over them only (frw_groth16_pk.b_index);
+    # a rank's share of them taken as its share of the rows
+    nb_all = 1 + sum(B_SIDE_VARIABLES[g] for g in logns) + 2
+    nb = max(1, -(-nb_all * nz // (nv + 3)))
+
+    def narrow(n_):                                                                  # frw_msm.hip nmsm_max_items, nmsm_ones_max, nmsm_slices
+        return (min(65536, max(2048, (n_ // 128 + 2047) // 2048 * 2048)) + 256, 1024 if n_ > (1 << 18) else 64,
+                1024 if n_ > (1 << 23) else 128 if n_ > (1 << 18) else 16)
+
+    def sort_bytes(n_):                                                              # nmsm_carve_bare: 32 n entries at worst + the list of ones
+        items, _, slices = narrow(n_)
+        return 32 * slices * 128 * 4 + 32 * (3 * 128 + items + 8) * 4 + 4 * 33 * n_ + 4096
+
+    def own_bytes(n_, tables, bucket_bytes):                                         # a table's partial sums: work items, buckets, ones
+        items, ones_groups, _ = narrow(n_)
+        return tables * (32 * (items + 128 + 1) + ones_groups + 64) * bucket_bytes + 4096
     # the sum over this rank's rows of h_query: thirteen 20-bit windows from 2^26 - 1 points (208 rows of 32,768 buckets, the two-level
     # sort's 8-byte and 4-byte entries), sixteen 16-bit windows below (entries 4 B and digits 2 B per point and window): frw_msm.hip
     # msm_carve_wide / msm_carve.  Its workspace and the witness map's are ONE region (same stream, one after the other: groth16_sizes).
@@ -174,7 +195,6 @@ def sharded_aggregate_plan(world, rank, logns):
         h_windows = 16
         h_sum = 16 * (4 * 32768 * 4 + 131072 * (8 + 240) + (32768 + 4096 + 1) * 240 + 6 * nh) + 4096
     qap = 3 * 32 * nc + 3 * 32 * n + 64
-    ones_groups = 1024 if nz > (1 << 18) else 64
     buffers = {
         "transform tables of the domain (2 (K - 1) twists + 5 scales, 32 n bytes each)": (2 * (passes - 1) + 5) * 32 * n,
         "per-signature matrices (flattened rows, long rows, CSR)": 1300 * sum(circuit_counts(g)[2] for g in set(logns)),
@@ -185,15 +205,14 @@ def sharded_aggregate_plan(world, rank, logns):
         "proof: A z, B z, C z and three working arrays of the witness map | the sum over h_query, %d windows (one region: the larger)" % h_windows: max(qap, h_sum),
         "proof: h": 32 * n,
         "proof: z ++ [1, r, s]": 32 * (nv + 3),
-        "proof: one sort of the slice's scalars (32 n entries at worst) + the G1 tables' own arrays": (
-            32 * (128 if nz > (1 << 18) else 16) * 128 * 4 + 32 * (3 * 128 + items + 8) * 4 + 4 * 33 * nz
-            + (3 * 32 * (items + 128 + 1) + 3 * (ones_groups + 64)) * 240 + 4096),
-        "proof: the G2 table's own arrays": (32 * (items + 128 + 1) + ones_groups + 64) * 464 + 4096,
+        "proof: the sort of the slice's scalars (32 n entries at worst) + the own arrays of a_query and l_query": sort_bytes(nz) + own_bytes(nz, 2, 240),
+        "proof: the sort over the rows b_g1_query / b_g2_query hold a point in + b_g1_query's own arrays": sort_bytes(nb) + own_bytes(nb, 1, 240),
+        "proof: b_g2_query's own arrays": own_bytes(nb, 1, 464),
     }
     return {"world": world, "rank": rank, "statements": len(logns), "falcon512": list(logns).count(9), "falcon1024": list(logns).count(10),
             "num_instance": ni, "num_witness": nw, "num_constraints": nc, "log_domain_size": log_n,
             "z_lo": z_lo, "z_hi": z_hi, "h_lo": h_lo, "h_hi": h_hi,
-            "windows_h_query": h_windows, "bucket_additions_h_query": h_windows * nh,
+            "windows_h_query": h_windows, "bucket_additions_h_query": h_windows * nh, "rows_of_b_queries_holding_a_point": nb,
             "partial_sum_bytes_per_rank": 72 * 8,
             "buffers": buffers, "hbm_plan_bytes": int(sum(buffers.values())),
             "hbm_limit_bytes": int(HBM_PLAN_FRACTION * HBM_BYTES_PER_GPU),

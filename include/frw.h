@@ -667,6 +667,15 @@ int frw_diag_valu_rates(frw_ctx *ctx, double out[4]);
  * domains of 2^27 coefficients.  Synchronous; allocates its own small scratch. */
 int frw_diag_poly_eval_dev(int device, uint64_t n, const uint64_t *d_coeffs, const uint64_t *t, uint64_t *out);
 
+/* What the four witness-side sums of a key of BARE handles add up for the scalars d_z (device, uint64_t[rows of this key's slice][4],
+ * Montgomery: z ++ [1, r, s] from row z_lo on): out[0] = the rows in which b_g1_query / b_g2_query hold a point (a variable that no
+ * constraint has on its B side has the point at infinity there, and the sums over those two tables skip it: frw_groth16_pk.b_index);
+ * out[1], out[2] = non-zero 8-bit digits of the scalars that are not one, and scalars equal to one, over all rows (a_query, l_query);
+ * out[3], out[4] = the same over the rows of out[0] (b_g1_query, b_g2_query).  One point addition each.  The benchmark prices the
+ * aggregate proof's roofline with these.  d_workspace: 256-byte aligned, frw_groth16_workspace_bytes(pk, r, 1) is enough.  Synchronous. */
+int frw_diag_groth16_side_counts(const frw_groth16_pk *pk, const uint64_t *d_z, void *d_workspace, size_t workspace_bytes, void *stream,
+                                 uint64_t *out);
+
 /* Page-locked host memory.  Output buffers of the host-buffer entry points allocated here are filled by
  * asynchronous DMA that overlaps with the kernels of the next chunk (pageable buffers work too, slower). */
 int frw_host_alloc(frw_ctx *ctx, size_t bytes, void **ptr);

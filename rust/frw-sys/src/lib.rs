@@ -256,6 +256,8 @@ extern "C" {
     pub fn frw_msm_g1_load_bare(device: c_int, num_points: usize, bases: *const u64, narrow: c_int, out: *mut *mut frw_msm) -> c_int;
     pub fn frw_msm_g2_load_bare(device: c_int, num_points: usize, bases: *const u64, narrow: c_int, out: *mut *mut frw_msm) -> c_int;
     pub fn frw_diag_poly_eval_dev(device: c_int, n: u64, d_coeffs: *const u64, t: *const u64, out: *mut u64) -> c_int;
+    pub fn frw_diag_groth16_side_counts(pk: *const frw_groth16_pk, d_z: *const u64, d_workspace: *mut c_void, workspace_bytes: usize,
+                                        stream: *mut c_void, out: *mut u64) -> c_int;
     pub fn frw_groth16_pk_free(pk: *mut frw_groth16_pk);
     pub fn frw_groth16_setup(device: c_int, circuit: c_int, logn: c_int, toxic: *const u64, pk_out: *mut *mut frw_groth16_pk,
                              vk_out: *mut u64) -> c_int;

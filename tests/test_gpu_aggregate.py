@@ -238,7 +238,47 @@ def test_witness_map_on_the_other_domains(engine, oracle, tmp_path, logns):
         agg.close()
 
 
-def _bare_and_sliced_keys_give_the_same_bytes(engine, agg, toxic, vk, r, s, want_proof, slices):
+def _digits8(v):
+    """non-zero signed 8-bit digits of a scalar that is not one (frw_msm.hip scalar_digits8: a byte above 128 borrows from the next)"""
+    cnt = carry = 0
+    for j in range(32):
+        d = ((v >> (8 * j)) & 0xff) + carry
+        carry = 0
+        if j < 31 and d > 128:
+            d -= 256
+            carry = 1
+        cnt += d != 0
+    return cnt
+
+
+def _witness_side_counts(tmp_path, agg, z_ints):
+    """What frw_diag_groth16_side_counts must say for the scalars z_ints = z ++ [1, r, s]: the rows in which b_g2_query holds a point are
+    the variables with a non-zero column in B (the matrices the product exports per parameter set: tests/test_r1cs_export.py holds them to
+    the oracle's) plus beta_2's and delta_2's; digits and ones over all rows and over those."""
+    from test_r1cs_export import export, read_r1cs
+    cols = {}
+    for g in set(agg.logns):
+        export(0, g, tmp_path / ("c%d.r1cs" % g))
+        ni, nw, nc, m = read_r1cs(tmp_path / ("c%d.r1cs" % g))
+        cols[g] = (ni, nw, np.unique(m[1][1]))
+    live = np.zeros(agg.ni + agg.nw + 3, dtype=bool)
+    pub, wit = 0, 0
+    for g in agg.logns:
+        ni, nw, c = cols[g]
+        live[0] |= bool((c == 0).any())
+        inst_c, wit_c = c[(c > 0) & (c < ni)], c[c >= ni]
+        live[pub + inst_c] = True
+        live[agg.ni + wit + (wit_c - ni)] = True
+        pub += ni - 1
+        wit += nw
+    live[agg.ni + agg.nw] = live[agg.ni + agg.nw + 2] = True              # beta_2 (scalar 1), delta_2 (scalar s); row nv + 1 holds no point
+    zs = np.array(z_ints, dtype=object)
+    count = lambda sel: (sum(_digits8(int(v)) for v in zs[sel] if v not in (0, 1)), int(sum(1 for v in zs[sel] if v == 1)))
+    everything = np.ones(len(zs), dtype=bool)
+    return [int(live.sum())] + list(count(everything)) + list(count(live))
+
+
+def _bare_and_sliced_keys_give_the_same_bytes(engine, agg, toxic, vk, r, s, want_proof, slices, tmp_path=None, z_ints=None):
     """The key of BARE handles (the points only, made on the device end to end: frw_groth16_setup_r1cs_opts) must give the proof of the
     window tables byte for byte -- and so must a key in slices: every rank's partial sums over its slices of the five queries, put
     together by frw_groth16_prove_combine_dev (here the ranks are handles on one card, one after the other)."""
@@ -282,6 +322,14 @@ def _bare_and_sliced_keys_give_the_same_bytes(engine, agg, toxic, vk, r, s, want
         torch.cuda.synchronize()
         assert bad.tolist() == [0]
         assert proof.cpu().numpy().view(np.uint64)[0].tolist() == want_proof.tolist(), "bare key: another proof than the window tables'"
+        if z_ints is not None:
+            # what the sums add up: the sums over b_g1_query / b_g2_query run over the rows that hold a point -- the variables of B's columns
+            R = 1 << 256
+            zext = z_ints + [1, r, s]
+            d_z = torch.from_numpy(np.array(lim([v * R % E.R for v in zext])).view(np.int64)).to(dev)
+            got = engine.diag_groth16_side_counts(key, d_z, pws, ws_bytes, s0)
+            assert got == _witness_side_counts(tmp_path, agg, zext), got
+            assert got[0] < 0.7 * len(zext) and got[3] + got[4] < 0.5 * (got[1] + got[2])     # (why the index exists)
         # a whole key through the partial / combine pair
         part = torch.full((1, EN.GROTH16_PARTIAL_WORDS), -1, dtype=torch.int64, device=dev)
         cws = torch.empty(EN.GROTH16_COMBINE_WORKSPACE, dtype=torch.uint8, device=dev)
@@ -388,7 +436,8 @@ def _prove_and_check(engine, oracle, tmp_path, logns, seed, python_pairing, slic
         finally:
             engine.groth16_pk_free(key)
         del pws, ws, h
-        _bare_and_sliced_keys_give_the_same_bytes(engine, agg, toxic, vk, r, s, got_p, slices)
+        _bare_and_sliced_keys_give_the_same_bytes(engine, agg, toxic, vk, r, s, got_p, slices, tmp_path,
+                                                  zi + T.limbs_to_ints(z_wit) if len(agg.logns) <= 4 else None)
     finally:
         agg.close()
 

@@ -84,8 +84,24 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     assert bad.tolist() == [0]
+    # the order of a bucket's entries is whatever the sorts' atomics made it; the proof must not depend on it: every repetition's bytes
+    first = proof.clone()
+    same = 0
+    for _ in range(int(os.environ.get("FRW_TOOL_SOAK", "0"))):
+        proof.zero_()
+        run()
+        torch.cuda.synchronize()
+        assert torch.equal(proof, first), "the proof's bytes changed between two runs on the same inputs"
+        same += 1
+    if same:
+        out["soak_identical_proofs"] = same + 1
     out["ms_per_proof"] = round(ms, 2)
     out["signatures_per_s"] = round(total / (ms * 1e-3), 1)
+    if int(pi.mode) == frw.KEY_BARE:
+        z = torch.cat([d_inst[0], d_wit[0], torch.zeros((3, 4), dtype=torch.int64, device=dev)]).contiguous()
+        c = eng.diag_groth16_side_counts(key, z, ws, ws_bytes, s0)
+        out["witness_side"] = {"rows_of_b_queries_holding_a_point": c[0], "of_rows": ni + nw + 3, "digits_all": c[1], "ones_all": c[2], "digits_b": c[3], "ones_b": c[4]}
+        del z
     # the witness map on its own
     q = eng.qap_info(handle)
     h = torch.empty((1, n, 4), dtype=torch.int64, device=dev)
