@@ -958,7 +958,22 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
 constexpr int NMSM_C = 8, NMSM_W = 32, NMSM_BUCKETS = 128;
 // slices of the counting sort (a workgroup of 1,024 threads each): 16 per signature, 128 beyond 2^18 scalars (an aggregate statement is
 // one "signature": 16 workgroups for 2.5 M scalars were 1.2 ms at the head of every other kernel of its proof)
-__host__ __device__ constexpr uint32_t nmsm_slices(uint32_t n) { return n > (1u << 23) ? 1024u : n > (1u << 18) ? 128u : 16u; }
+// (1,024 slices for the 2^27-scalar sums were tried: the histogram no faster -- it waited for ONE global counter, see wave_append -- and the
+// scatter three times slower: a slice's run inside a bucket is a 1,024th of it, and the entry array's lines left the L2 half written)
+__host__ __device__ constexpr uint32_t nmsm_slices(uint32_t n) { return n > (1u << 18) ? 128u : 16u; }
+// list[(*count)++] = value for the lanes of a wavefront that ask for it: ONE atomic per wavefront (the scalars equal to one are 55 % of a
+// witness: 65 M increments of one address in the 1,024-statement proof, 20 ms of a histogram pass that computes for two)
+__device__ __forceinline__ void wave_append(bool want, uint32_t *__restrict__ count, uint32_t *__restrict__ list, uint32_t value)
+{
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
+    if (!mask) return;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));   // wanting lanes below this one
+    const int leader = __builtin_ctzll(mask);
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (want) list[base + lane] = value;
+}
 // Work items per signature: 2,048 for the per-signature circuits (n < 2^18 points), n / 128 rounded up to a multiple of 2,048 beyond
 // (an aggregate statement is ONE "signature" with sixteen times the points: 2,048 items would be 32 wavefronts on 1,024 SIMDs, each
 // a chain of 550 additions); items <= buckets + total / split <= 128 + target, rounded up to whole wavefronts.
@@ -1108,10 +1123,9 @@ __global__ __launch_bounds__(1024) void nmsm_hist_bare_kernel(uint32_t n, const 
     for (uint32_t k = lo + threadIdx.x; k < hi; k += 1024) {
         const uint32_t i = index ? index[k] : k;
         int d[NMSM_W];
-        if (scalar_digits8(scalars + (size_t)i * 8, montgomery, d)) {
-            ones_list[atomicAdd(&ones_count[0], 1u)] = i;
-            continue;
-        }
+        const bool one = scalar_digits8(scalars + (size_t)i * 8, montgomery, d);
+        wave_append(one, ones_count, ones_list, i);
+        if (one) continue;
 #pragma unroll
         for (int j = 0; j < NMSM_W; j++)
             if (d[j]) atomicAdd(&hist[j * NMSM_BUCKETS + (d[j] < 0 ? -d[j] : d[j]) - 1], 1u);

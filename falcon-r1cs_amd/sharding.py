@@ -175,7 +175,7 @@ def sharded_aggregate_plan(world, rank, logns):
 
     def narrow(n_):                                                                  # frw_msm.hip nmsm_max_items, nmsm_ones_max, nmsm_slices
         return (min(65536, max(2048, (n_ // 128 + 2047) // 2048 * 2048)) + 256, 1024 if n_ > (1 << 18) else 64,
-                1024 if n_ > (1 << 23) else 128 if n_ > (1 << 18) else 16)
+                128 if n_ > (1 << 18) else 16)
 
     def sort_bytes(n_):                                                              # nmsm_carve_bare: 32 n entries at worst + the list of ones
         items, _, slices = narrow(n_)
