@@ -1115,21 +1115,48 @@ __global__ __launch_bounds__(1024) void nmsm_hist_bare_kernel(uint32_t n, const 
                                                               uint32_t *__restrict__ ones_count /* [0] */, uint32_t *__restrict__ ones_list /* [n] */,
                                                               const uint32_t *__restrict__ index)
 {
+    // The scalars equal to one (55 % of a witness) go to ONE list with ONE counter: appended a wavefront at a time that was an atomic of
+    // one address per wavefront and round of the loop -- 1.5 M of them in a row, 8 ns each: the whole 12 - 21 ms of this kernel, its waves
+    // waiting 95 % of their cycles (SQ counters, tools/dev/pmc_sort.sh).  So a workgroup collects its ones in LDS (a counter there costs
+    // nothing) and moves them out 3,072 at least at a time: one global atomic per flush, and the list is written in whole lines.
+    constexpr uint32_t ONES_CAP = 4096;
     __shared__ uint32_t hist[NMSM_W * NMSM_BUCKETS];
+    __shared__ uint32_t ones_buf[ONES_CAP];
+    __shared__ uint32_t ones_fill, ones_base;
     const uint32_t slices = gridDim.x, slice = blockIdx.x, per = (n + slices - 1) / slices;
     const uint32_t lo = slice * per, hi = lo + per < n ? lo + per : n;
     for (int b = threadIdx.x; b < NMSM_W * NMSM_BUCKETS; b += 1024) hist[b] = 0;
+    if (threadIdx.x == 0) ones_fill = 0;
     __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += 1024) {
-        const uint32_t i = index ? index[k] : k;
-        int d[NMSM_W];
-        const bool one = scalar_digits8(scalars + (size_t)i * 8, montgomery, d);
-        wave_append(one, ones_count, ones_list, i);
-        if (one) continue;
+    auto flush = [&](uint32_t fill) {                                  // (every thread of the workgroup with the same `fill`; nobody appends meanwhile)
+        if (threadIdx.x == 0 && fill) ones_base = atomicAdd(&ones_count[0], fill);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < fill; t += 1024) ones_list[ones_base + t] = ones_buf[t];
+        __syncthreads();
+        if (threadIdx.x == 0) ones_fill = 0;
+        __syncthreads();
+    };
+    for (uint32_t k0 = lo; k0 < hi; k0 += 1024) {                      // (the same number of rounds for every thread: barriers inside)
+        const uint32_t k = k0 + threadIdx.x;
+        bool one = false;
+        if (k < hi) {
+            const uint32_t i = index ? index[k] : k;
+            int d[NMSM_W];
+            one = scalar_digits8(scalars + (size_t)i * 8, montgomery, d);
+            if (one) {
+                ones_buf[atomicAdd(&ones_fill, 1u)] = i;               // (at most 1,024 a round, and a round starts with 3,072 free)
+            } else {
 #pragma unroll
-        for (int j = 0; j < NMSM_W; j++)
-            if (d[j]) atomicAdd(&hist[j * NMSM_BUCKETS + (d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
+                for (int j = 0; j < NMSM_W; j++)
+                    if (d[j]) atomicAdd(&hist[j * NMSM_BUCKETS + (d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t fill = ones_fill;                               // (read between two barriers: the same value in every thread)
+        __syncthreads();
+        if (fill > ONES_CAP - 1024) flush(fill);
     }
+    flush(ones_fill);
     __syncthreads();
     for (int b = threadIdx.x; b < NMSM_W * NMSM_BUCKETS; b += 1024)
         slice_hist[((size_t)(b / NMSM_BUCKETS) * slices + slice) * NMSM_BUCKETS + (b % NMSM_BUCKETS)] = hist[b];
@@ -2922,15 +2949,13 @@ int groth16_prove_bare(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t ba
         const NmsmBufs g1 = nmsm_carve_bare<FqField>(g1_ws, 2, nz);
         const NmsmBufs gb = nmsm_carve_bare<FqField>(gb_ws, 1, pk->b_rows);
         const NmsmBufs g2 = nmsm_carve_bare<Fq2Field>(g2_ws, 1, pk->b_rows, &gb);
-        // (the short one first: the sums over b_g1_query and b_g2_query -- side[1], side[2] -- start while the long one runs; `ones_done`
-        // is a spare event in this path)
-        e = nmsm_sort_bare(gb, pk->b_rows, (const uint32_t *)(zext + pk->z_lo * 4), 1, st, pk->b_index);
-        if (e == hipSuccess) e = hipEventRecord(pk->ones_done, st);
-        for (int i = 1; i < 3 && e == hipSuccess; i++) e = hipStreamWaitEvent(pk->side[i], pk->ones_done, 0);
-        if (e == hipSuccess) e = nmsm_sort_bare(g1, nz, (const uint32_t *)(zext + pk->z_lo * 4), 1, st);
+        // (both before any sum starts: a sort's workgroups are 1,024 threads of 70 - 128 registers -- a whole CU's register file -- and
+        // with the G2 sum's kernels already on the chip the long sort's scatter took 39 ms instead of 7: profiles/r05_witness_sorts.txt)
+        e = nmsm_sort_bare(g1, nz, (const uint32_t *)(zext + pk->z_lo * 4), 1, st);
+        if (e == hipSuccess) e = nmsm_sort_bare(gb, pk->b_rows, (const uint32_t *)(zext + pk->z_lo * 4), 1, st, pk->b_index);
         if (e != hipSuccess) break;
         e = hipEventRecord(pk->sorted, st);
-        if (e == hipSuccess) e = hipStreamWaitEvent(pk->side[0], pk->sorted, 0);
+        for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
         if (e != hipSuccess) break;
         // (the witness-side sums first: the witness map of a mixed aggregate is hundreds of launches, and what the one host thread enqueues
         // behind them starts that much later -- 50 ms of an idle chip at the head of the 1,024-statement proof, profiles/r05_aggregate1024_timeline.txt)
