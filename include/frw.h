@@ -459,7 +459,7 @@ int frw_groth16_pk_load(int device, const frw_groth16_pk_desc_t *desc, frw_groth
  * 513 Falcon-512 + 511 Falcon-1024, 121.9 M variables, the 2^27 domain) and its sums run window by window over the same rows: the same
  * number of bucket additions (one per point and non-zero digit), plus 255 point operations per sum to put the windows together.  Such a
  * key also knows in which rows b_g1_query / b_g2_query hold a point -- the variables some constraint has on its B side: 59 % of a Falcon
- * circuit's, with a fifth of a witness's ones and none of its full-size values -- and sums those two tables over them alone (an index
+ * circuit's, with half of a witness's ones and none of its full-size values: a third of the additions -- and sums those two tables over them alone (an index
  * made when the key is put together, a second, short sort per proof: frw_diag_groth16_side_counts has the numbers).
  *   FRW_KEY_TABLES  window tables (the fastest proofs; what frw_groth16_pk_load and frw_groth16_setup make)
  *   FRW_KEY_BARE    the points only
