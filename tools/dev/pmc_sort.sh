@@ -1,3 +1,9 @@
+#!/bin/bash
+# SQ counters of every kernel of ONE proof for the 1,024-statement aggregate (and of its key's setup), kernels serialised by the profiler:
+# two rocprofv3 --pmc passes over tools/time_aggregate_large.py 1024 1, counters only (no tracing domains).  On the GPU box, from anywhere:
+#   bash tools/dev/pmc_sort.sh     -> gpurun_out/pmc_sort_mix/, gpurun_out/pmc_sort_act/ (*_counter_collection.csv)
+# What it answered in round 5 (profiles/r05_witness_sorts.txt): nmsm_hist_bare_kernel's waves waited 95 % of their cycles -- for the one
+# global counter of the list of ones.
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
