@@ -753,7 +753,7 @@ def aggregate_statements(eng, dev, logns, first_index=0):
     return batches
 
 
-def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s, h_windows=16, side_counts=None):
+def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s, h_windows=16, side_counts=None, h_points=None):
     """groth16_roofline for one proof of an aggregate statement: the point additions of the four witness-side sums counted from ONE
     statement of each parameter set (every statement of a set has the same structure: a few hundred additions either way) times the
     number of such statements; a key of window tables sums the ones of eight points in one addition (byte-pattern tables) up to 2^18
@@ -762,7 +762,9 @@ def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s, h_win
     once per call (tables) or once per 32,768-bucket row (bare: 16 rows; wide windows: 13 x 16 rows, each bucket in a weighted and a
     plain running sum as ever), plus Horner's 255 operations per sum.
     side_counts (a key of bare handles: frw_diag_groth16_side_counts on the proof's own scalars): the sums over b_g1_query / b_g2_query
-    run over the rows that hold a point there -- their additions are what the device counted, not an estimate."""
+    run over the rows that hold a point there -- their additions are what the device counted, not an estimate.
+    h_points: the rows of h_query this key holds (a key in slices: the line is then THIS RANK's work -- its slices of the five sums and
+    the whole witness map -- against one chip's peak)."""
     rates = eng.valu_rates()
     (mm, mo), (am, ao) = point_op_instructions(MADD_OPS), point_op_instructions(ADD_OPS)
     n = 1 << log_n
@@ -785,7 +787,7 @@ def aggregate_roofline(eng, logns, log_n, batches, key_mode, proofs_per_s, h_win
         g2_madds = digits_b + ones_b
     rows_h, windows_w = ((16 if h_windows == 16 else h_windows * 16), 32) if bare else (1, 1)
     G2_FACTOR = 3
-    h_madds, h_adds = h_windows * (n - 1), rows_h * 2 * 32768 + (255 if bare else 0)
+    h_madds, h_adds = h_windows * (n - 1 if h_points is None else h_points), rows_h * 2 * 32768 + (255 if bare else 0)
     g1_adds = 3 * (windows_w * (2 * 128 + 64) + (255 if bare else 0))
     g2_adds = windows_w * (2 * 128 + 64) + (255 if bare else 0)
     madds = h_madds + g1_madds + G2_FACTOR * g2_madds
@@ -919,7 +921,10 @@ def time_aggregate_proof(eng, dev, logns, reps, separate=None, check_h=True, wor
         z = torch.cat([d_inst[0], d_wit[0], torch.zeros((3, 4), dtype=torch.int64, device=dev)])[int(pinfo.z_lo):int(pinfo.z_hi)].contiguous()
         side_counts = eng.diag_groth16_side_counts(pk_h, z, ws, ws_bytes, s0)
         del z
-    rates = aggregate_roofline(eng, logns, int(info.log_domain_size), batches, key_mode, 1e3 / ms, h_windows, side_counts) if rank == 0 else None
+    rates = aggregate_roofline(eng, logns, int(info.log_domain_size), batches, key_mode, 1e3 / ms, h_windows, side_counts,
+                               int(pinfo.h_hi) - int(pinfo.h_lo)) if rank == 0 else None
+    if rates is not None and world > 1:
+        rates["of"] = "rank 0's share of the proof (its slices of the five sums, the whole witness map) against one chip's peak"
     hbm_in_use = torch.cuda.mem_get_info(dev)
     eng.groth16_pk_free(pk_h)
     del ws, h
