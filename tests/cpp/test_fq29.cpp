@@ -29,6 +29,15 @@ extern "C" void t_fq(int op, const uint32_t *a, const uint32_t *b, uint32_t *out
     case 13: fq_pack(load(a), out); break;
     case 14: store(fq_sqr(load(a)), out); break;
     case 15: store(fq_inv_fermat(load(a)), out); break;
+    case 16: store(fq_inv_binary(load(a)), out); break;         // the one-round-at-a-time inverse (fq_inv's fallback)
+    case 17: {                                                  // a: 12 canonical words; out[0..12): 1 / a mod q, out[12]: did the 31-round path finish
+        uint32_t y[12], x[12];
+        std::memcpy(y, a, sizeof y);
+        out[12] = fq_inv_words31(y, x) ? 1u : 0u;
+        std::memcpy(out, x, sizeof x);
+        break;
+    }
+    case 18: out[0] = Q_NEG_INV31; break;
     }
 }
 // a b - c d with one reduction; which = 0: c < 4 q, 1: c < 16 q

@@ -149,6 +149,30 @@ def test_conversions_and_inverse(lib):
             assert got % Q == pow(x, -1, Q) * RQ % Q and got < 2 * Q, (x, k)
 
 
+def test_inverse_thirty_one_rounds_at_a_time(lib):
+    """fq_inv's fast path (frw_fq29.h fq_inv_words31: Pornin's batched binary GCD) on canonical words: the inverse, and that the path
+    FINISHES (b == 1 after 25 x 31 rounds) -- for the values whose Euclidean rounds are extreme, for values around the word boundaries of
+    the stand-ins, and for a few thousand random ones; zero is refused (the caller falls back and returns zero); its constant."""
+    assert fq(lib, 18, limbs(0))[0] == (-pow(Q, -1, 1 << 31)) % (1 << 31)
+    rng = random.Random(4343)
+    special = [1, 2, 3, Q - 1, Q - 2, (Q - 1) // 2, (Q + 1) // 2, 1 << 380, (1 << 380) - 1, (1 << 64) - 1, 1 << 64, (1 << 64) + 1,
+               (1 << 31) - 1, 1 << 31, (1 << 32) + 1, (1 << 96) - 1, Q >> 1, Q >> 33, (Q >> 64) + 1]
+    special += [(1 << k) % Q for k in range(1, 381, 7)] + [Q - (1 << k) for k in range(0, 380, 11)]
+    for x in special + [rng.randrange(1, Q) for _ in range(3000)] + [rng.randrange(1, 1 << rng.randrange(1, 381)) for _ in range(1000)]:
+        out = (C.c_uint32 * 14)()
+        lib.t_fq(17, words(x), None, out)
+        assert out[12] == 1, "the batched rounds did not end in b == 1 for %x" % x
+        assert value(list(out)[:12], 32) == pow(x, -1, Q), hex(x)
+    out = (C.c_uint32 * 14)()
+    lib.t_fq(17, words(0), None, out)
+    assert out[12] == 0
+    # the fallback is still the inverse, and fq_inv agrees with it whatever path it took
+    for x in [1, Q - 1] + [rng.randrange(1, Q) for _ in range(20)]:
+        mont = limbs(x * RQ % Q)
+        assert value(fq(lib, 16, mont)) % Q == value(fq(lib, 9, mont)) % Q == pow(x, -1, Q) * RQ % Q
+    assert value(fq(lib, 9, limbs(0))) % Q == 0
+
+
 def _pt(p):
     return (C.c_uint32 * 24)(*[(l >> (32 * h)) & 0xFFFFFFFF for l in E.to_limbs(p) for h in range(2)])
 
