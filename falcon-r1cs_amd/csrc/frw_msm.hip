@@ -959,37 +959,6 @@ __global__ __launch_bounds__(MSM_FOLD_THREADS) void msm_fold2_kernel(const uint3
         else store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(sum));
     }
 }
-// The second stage for a few sums at a time (latency): a tree of point additions across the 64 lanes of a wavefront by shuffles -- no LDS,
-// no barrier (msm_fold2_kernel's nine levels through LDS with two barriers each cost as much as its additions) -- 64 slots per workgroup,
-// so 4,096 partial sums are two launches of depth six each instead of eight additions in a row and nine levels.
-template <class F> __device__ __forceinline__ XyzzT<F> pt_shfl_down(const XyzzT<F> &p, int delta)
-{
-    static_assert(sizeof(XyzzT<F>) % 4 == 0, "a point is whole words");
-    XyzzT<F> r;
-    uint32_t w[sizeof(XyzzT<F>) / 4];
-    __builtin_memcpy(w, &p, sizeof p);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(XyzzT<F>) / 4); k++) w[k] = __shfl_down(w[k], delta, 64);
-    __builtin_memcpy(&r, w, sizeof r);
-    return r;
-}
-template <class F>
-__global__ __launch_bounds__(64) void msm_tree_kernel(const uint32_t *__restrict__ in /* [sum][in_stride][BK_WORDS] */, uint32_t in_stride, uint32_t count,
-                                                      uint32_t *__restrict__ out /* [sum][out_stride][BK_WORDS]; the last stage: [sum][ARK_WORDS] or [sum][BK_WORDS] */,
-                                                      uint32_t out_stride, int last, int xyzz_out)
-{
-    __builtin_amdgcn_s_setprio(2);
-    constexpr int BW = Grp<F>::BK_WORDS;
-    const size_t sig = blockIdx.y;
-    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
-    XyzzT<F> acc = slot < count ? load_bucket<F>(in + (sig * in_stride + slot) * (size_t)BW) : pt_identity<F>();
-#pragma unroll 1
-    for (int off = 32; off >= 1; off >>= 1) acc = pt_add(acc, pt_shfl_down<F>(acc, off));
-    if (threadIdx.x) return;
-    if (!last) store_bucket<F>(out + (sig * out_stride + blockIdx.x) * (size_t)BW, acc);
-    else if (xyzz_out) store_bucket<F>(out + sig * BW, acc);
-    else store_ark_point<F>(out + sig * Grp<F>::ARK_WORDS, pt_to_affine(acc));
-}
 
 // (launch bounds of the narrow kernels: two waves per SIMD for G1; the two-lane G2 policy is written for ONE -- its mixed addition holds an
 // accumulator, a row, the neighbour's copies of both operands of a product and 28 64-bit columns: 256 registers and then some, which at a
@@ -1912,16 +1881,8 @@ hipError_t msm_rows(const frw_msm *m, size_t rows, const uint32_t *sc, size_t st
     if (log_chunk == 6) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 6>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial, (uint32_t *)nullptr);
     else if (log_chunk == 5) hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 5>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial, (uint32_t *)nullptr);
     else hipLaunchKernelGGL((frw::msm_fold1_kernel<F, 3>), dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, b.buckets, b.partial, (uint32_t *)nullptr);
-    if (log_chunk == 3) {
-        // latency: 4,096 partial sums as two trees of shuffles (64 x 64); the first tree's 64 results go where the buckets were (dead now)
-        hipLaunchKernelGGL(frw::msm_tree_kernel<F>, dim3(t1 / 64, (unsigned)rows), dim3(64), 0, st, (const uint32_t *)b.partial, (uint32_t)frw::MSM_FOLD1_THREADS, t1,
-                           b.buckets, (uint32_t)frw::MSM_BUCKETS, 0, 0);
-        hipLaunchKernelGGL(frw::msm_tree_kernel<F>, dim3(1, (unsigned)rows), dim3(64), 0, st, (const uint32_t *)b.buckets, (uint32_t)frw::MSM_BUCKETS, t1 / 64,
-                           out, 0u, 1, xyzz_out ? 1 : 0);
-    } else {
-        hipLaunchKernelGGL(frw::msm_fold2_kernel<F>, dim3((unsigned)rows), dim3(frw::MSM_FOLD_THREADS), 0, st, b.partial,
-                           (int)(t1 / frw::MSM_FOLD_THREADS), out, xyzz_out ? 1 : 0);
-    }
+    hipLaunchKernelGGL(frw::msm_fold2_kernel<F>, dim3((unsigned)rows), dim3(frw::MSM_FOLD_THREADS), 0, st, b.partial,
+                       (int)(t1 / frw::MSM_FOLD_THREADS), out, xyzz_out ? 1 : 0);
     return hipGetLastError();
 }
 // ONE scalar vector over a bare handle on wide windows (frw::WIDE_*): the coarse sort, the rows' fine sorts, work items, buckets, the
@@ -2050,12 +2011,8 @@ hipError_t nmsm_sort_bare(const NmsmBufs &b, uint32_t n, const uint32_t *sc, int
 // to spare) gives it here: the ones are summed there, `st` waits for them before the fold (a quarter of a millisecond off the chain of
 // a proof made alone).
 template <class F, bool PREFETCH>
-// phase: 0 the whole chain; 1 its head (the ones' sums and the bucket kernel: the launches that have work for the whole chip) and 2 its tail
-// (combine, fold) -- for a caller that has other things to enqueue in between (frw_groth16_prove_dev for a proof made alone: the one host
-// thread takes 0.6 ms to enqueue the witness map's thirty launches, and a chain enqueued behind them starts that much later)
 hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs &sorted, const NmsmBufs &own, size_t cnt, uint32_t *d_out, bool ones_as_mask,
-                           hipStream_t st, bool xyzz_out = false, bool ones_elsewhere = false, hipStream_t ones_stream = nullptr, hipEvent_t ones_done = nullptr,
-                           int phase = 0)
+                           hipStream_t st, bool xyzz_out = false, bool ones_elsewhere = false, hipStream_t ones_stream = nullptr, hipEvent_t ones_done = nullptr)
 {
     if (!ones_elsewhere) ones_stream = st;                          // (a caller's stream may be the null stream: the flag says whether it was given)
     const uint32_t n = ms[0]->dev.n;
@@ -2074,25 +2031,21 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
     // the ones' partial sums: enough threads to occupy the chip (~2^16 over the batch), between 256 and 4,096 per signature
     int ones_threads = 256;
     while (ones_threads < (int)frw::nmsm_ones_max(n) && (size_t)ones_threads * rows < 65536) ones_threads <<= 1;
-    const bool head = phase != 2, tail = phase != 1;
-    if (head)
-        hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, rows), dim3(64), 0, ones_stream, dev, sorted.ones_count, sorted.ones_list,
-                           own.partial_ones, own.ones_stride, 1u);
+    hipLaunchKernelGGL(frw::nmsm_ones_kernel<FB>, dim3((unsigned)ones_threads / 64, rows), dim3(64), 0, ones_stream, dev, sorted.ones_count, sorted.ones_list,
+                       own.partial_ones, own.ones_stride, 1u);
     const uint32_t *ones_for_finish = own.partial_ones;
     uint32_t ones_groups = (uint32_t)ones_threads / 64, ones_finish_stride = own.ones_stride;
     if (ones_groups > 64) {
-        if (head)
-            hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<FB>, dim3(64, rows), dim3(64), 0, ones_stream, own.partial_ones, ones_groups, own.ones_stride, own.folded_ones);
+        hipLaunchKernelGGL(frw::nmsm_ones_fold_kernel<FB>, dim3(64, rows), dim3(64), 0, ones_stream, own.partial_ones, ones_groups, own.ones_stride, own.folded_ones);
         ones_for_finish = own.folded_ones;
         ones_groups = 64;
         ones_finish_stride = 64;
     }
-    if (ones_elsewhere && head) {
+    if (ones_elsewhere) {
         const hipError_t e = hipEventRecord(ones_done, ones_stream);
         if (e != hipSuccess) return e;
     }
-    if (!head) {
-    } else if (PREFETCH || (FB::LANES > 1 && g2_prefetch))
+    if (PREFETCH || (FB::LANES > 1 && g2_prefetch))
         hipLaunchKernelGGL((frw::nmsm_bucket_kernel<FB, true>), dim3((sorted.max_items * FB::LANES + 63) / 64, rows), dim3(64), 0, st, dev,
                            sorted.offsets, sorted.counts, sorted.items, sorted.item_count, sorted.entries, own.partial_items, sorted.target, sorted.max_items,
                            (const unsigned long long *)nullptr);
@@ -2102,7 +2055,6 @@ hipError_t nmsm_accumulate(const frw_msm *const *ms, int tables, const NmsmBufs 
                            (const unsigned long long *)nullptr);
     // the items of a bucket: added up by a workgroup per bucket where latency counts (a lone proof: 12 ms -> 8.6), by the fold's own
     // thread where throughput does (the combine is nine times the wave-level additions: 3 % of a 64-proof call)
-    if (!tail) return hipGetLastError();
     const bool combine = cnt <= 16;
     if (combine)
         hipLaunchKernelGGL(frw::nmsm_combine_kernel<FB>, dim3(frw::NMSM_BUCKETS, rows), dim3(64), 0, st, sorted.counts, sorted.offsets, sorted.item_first,
@@ -3144,17 +3096,11 @@ int groth16_prove(const frw_groth16_pk *pk, const frw_r1cs *r1cs, size_t batch, 
         for (int i = 0; i < 3 && e == hipSuccess; i++)
             if (i != 1 || lone) e = hipStreamWaitEvent(pk->side[i], pk->sorted, 0);
         if (e != hipSuccess) break;
-        // (a proof made alone: the head of the G1 sums' chain -- the ones, the bucket kernel: three launches -- goes in ahead of the witness
-        // map's thirty; behind them the chain started 0.5 ms late and both k P ended the proof's longest path)
-        const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
-        const NmsmBufs own_g1 = nmsm_carve<FqField>(msm_ws[1], 3 * cnt, (uint32_t)stride);
-        if (lone) {
-            e = nmsm_accumulate<FqField, true>(g1s, 3, sorted, own_g1, cnt, pA, ones_as_mask, pk->side[0], true, lone, pk->side[1], pk->ones_done, 1);
-            if (e != hipSuccess) break;
-        }
         rc = frw_qap_witness_map_dev(r1cs, cnt, wit, inst, h, d_num_unsatisfied ? d_num_unsatisfied + lo : nullptr, qap_ws, cnt * sz.qap, pk->main);
         if (rc != FRW_OK) break;
-        e = nmsm_accumulate<FqField, true>(g1s, 3, sorted, own_g1, cnt, pA, ones_as_mask, pk->side[0], true, lone, pk->side[1], pk->ones_done, lone ? 2 : 0);
+        const frw_msm *g1s[3] = {pk->a, pk->b1, pk->l};
+        e = nmsm_accumulate<FqField, true>(g1s, 3, sorted, nmsm_carve<FqField>(msm_ws[1], 3 * cnt, (uint32_t)stride), cnt, pA, ones_as_mask, pk->side[0], true,
+                                           lone, pk->side[1], pk->ones_done);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(frw::groth16_scale_quad_kernel, dim3((unsigned)(2 * cnt)), dim3(4), 0, pk->side[0], cnt, (const uint32_t *)d_split,
                            (const uint32_t *)pA, pSA);
